@@ -1,0 +1,240 @@
+/*
+ * swimsim.h -- C ABI of the MI355X-native SWIM tick simulator (libswimsim.so).
+ *
+ * This is the drop-in boundary for ONE path of jpfuentes2/swim: the gossip /
+ * failure-detection round (probe -> ack -> k-indirect ping-req -> suspicion
+ * timer -> piggyback dissemination), stepped as a bulk-synchronous tick over
+ * N simulated members.  The reference has no FFI of its own:
+ * its seams are three conduit-typed Haskell functions.  Each entry point below
+ * names the reference interface it replaces (paths relative to the reference
+ * checkout).  The Haskell-side binding a maintainer would add is shown in
+ * INTEGRATION.md and shipped as source in haskell/Swim/Sim.hs.
+ *
+ * Conventions
+ *   - plain C, fixed-width integers, no C++ and no torch types in signatures;
+ *   - every call returns SWIMSIM_OK (0) or a negative swimsim_status; the text
+ *     is available from swimsim_last_error();  no C++ exception crosses the ABI
+ *     (reference style: `configure :: IO (Either Error Store)`, src/Util.hs:103);
+ *   - the caller allocates every output buffer and passes its capacity;
+ *   - one handle = one logical thread of control (guard with an MVar on the
+ *     Haskell side); different handles are independent;
+ *   - member names of the reference (`memberName :: String`, src/Types.hs:62)
+ *     are rendered as "m<id>", id in [0, n_members).
+ *
+ * The library is the HIP/gfx950 implementation only.  There is NO CPU fallback:
+ * creating a handle without a usable GPU fails with SWIMSIM_ERR_DEVICE.
+ */
+#ifndef SWIMSIM_H
+#define SWIMSIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWIMSIM_ABI_VERSION 1u
+
+/* ---- status codes ------------------------------------------------------ */
+typedef enum swimsim_status {
+  SWIMSIM_OK = 0,
+  SWIMSIM_ERR_INVALID = -1,   /* bad argument / config                          */
+  SWIMSIM_ERR_DEVICE = -2,    /* no GPU, HIP error                              */
+  SWIMSIM_ERR_NOMEM = -3,     /* host or device allocation failed               */
+  SWIMSIM_ERR_CAPACITY = -4,  /* a bounded table overflowed (max_subjects,
+                                 timer_cap, inbox overflow list, incarnation
+                                 bits); the handle is poisoned afterwards       */
+  SWIMSIM_ERR_STATE = -5,     /* call not valid in this state (poisoned handle) */
+  SWIMSIM_ERR_BUFFER = -6     /* caller buffer too small (n_out has the need)   */
+} swimsim_status;
+
+/* ---- Liveness (src/Types.hs:76 `data Liveness = IsAliveC | IsSuspectC | IsDeadC`) */
+enum { SWIMSIM_ALIVE = 0, SWIMSIM_SUSPECT = 1, SWIMSIM_DEAD = 2 };
+
+/* Causes of a membership event (which rule of the reference produced it). */
+enum {
+  SWIMSIM_CAUSE_PROBE = 0,   /* own probe + k indirect probes failed: src/Core.hs:253-254 */
+  SWIMSIM_CAUSE_TIMER = 1,   /* suspicion timeout -> Dead: the FIXME at src/Core.hs:141    */
+  SWIMSIM_CAUSE_GOSSIP = 2,  /* piggybacked Suspect/Alive/Dead accepted: src/Core.hs:110-117 */
+  SWIMSIM_CAUSE_REFUTE = 3,  /* rumour about self refuted: src/Core.hs:155-166          */
+  SWIMSIM_CAUSE_JOIN = 4     /* member came (back) up and announced Alive              */
+};
+#define SWIMSIM_EVMASK_ALL 0x1Fu
+#define SWIMSIM_EVMASK_DEFAULT \
+  ((1u << SWIMSIM_CAUSE_PROBE) | (1u << SWIMSIM_CAUSE_REFUTE) | (1u << SWIMSIM_CAUSE_JOIN))
+
+/* ---- configuration ------------------------------------------------------
+ * First block = the reference's `Config` (src/Types.hs:46-51) as far as the hot
+ * path reads it (numToGossip, gossipInterval: src/Core.hs:237,239,249,258).
+ * bindHost / joinHosts / udpBufferSize are dead fields in the reference and live
+ * only in the host-language mirror (swim_amd.types.Config, haskell/Swim/Sim.hs).
+ * Second block = simulator-only knobs ("SimConfig").
+ * A field left 0 takes the documented default.
+ */
+typedef struct swimsim_config {
+  uint32_t struct_size;        /* = sizeof(swimsim_config_t)                          */
+  uint32_t abi_version;        /* = SWIMSIM_ABI_VERSION                               */
+  /* -- reference Config -- */
+  int32_t  num_to_gossip;      /* numToGossip: probes per period AND proxies per failed
+                                  probe (one field for both, src/Core.hs:239,249)     */
+  int64_t  gossip_interval_us; /* gossipInterval; 1 tick == 1 interval (D1)           */
+  /* -- simulator -- */
+  uint32_t n_members;          /* N >= 2                                              */
+  uint64_t seed;               /* counter-based RNG seed (replaces global StdGen, F7) */
+  int32_t  probes_per_tick;    /* 0 -> num_to_gossip (D14)                            */
+  int32_t  indirect_k;         /* 0 -> num_to_gossip (D7)                             */
+  uint32_t loss_ppm;           /* per-message loss probability, parts per million     */
+  uint32_t suspicion_ticks;    /* Suspect -> Dead timeout (D4); 0 -> 3*ceil(log2 N)   */
+  uint32_t retransmit_mult;    /* piggyback budget L = mult*ceil(log2(N+1)) (D5); 0->3 */
+  uint32_t max_subjects;       /* capacity of the rumour-subject table; 0 -> default  */
+  uint32_t timer_cap;          /* pending suspicion timers per member; 0 -> 64        */
+  uint32_t event_cap;          /* event ring capacity; 0 -> 1<<20                     */
+  uint32_t event_mask;         /* bit per SWIMSIM_CAUSE_*; 0 -> SWIMSIM_EVMASK_DEFAULT */
+  int32_t  device;             /* HIP device ordinal                                  */
+  uint32_t shard_index;        /* this handle owns members [lo,hi) of the population  */
+  uint32_t n_shards;           /* 0/1 -> unsharded                                    */
+} swimsim_config_t;
+
+typedef struct swimsim swimsim_t; /* opaque; owned by the library */
+
+/* Membership event = the `Broadcast (Suspect|Alive|Dead ...)` gossip a node of the
+ * reference would enqueue (src/Types.hs:42-44,135-145; src/Core.hs:119-121,254). */
+typedef struct swimsim_event {
+  uint64_t tick;
+  uint32_t observer;     /* whose view changed (for REFUTE/JOIN == subject)            */
+  uint32_t subject;      /* `node`                                                     */
+  uint32_t incarnation;  /* `incarnation`                                              */
+  uint8_t  state;        /* SWIMSIM_ALIVE / SUSPECT / DEAD                             */
+  uint8_t  cause;        /* SWIMSIM_CAUSE_*                                            */
+  uint16_t _pad;
+} swimsim_event_t;
+
+/* One non-default entry of a member's view = `Member` (src/Types.hs:62-68). */
+typedef struct swimsim_view_entry {
+  uint32_t subject;      /* memberName = "m<subject>"                                  */
+  uint32_t incarnation;  /* memberIncarnation                                          */
+  uint32_t since_tick;   /* memberLastChange, in ticks                                 */
+  uint8_t  state;        /* memberAlive                                                */
+  uint8_t  _pad[3];
+} swimsim_view_entry_t;
+
+typedef struct swimsim_rumor {
+  uint32_t subject;
+  uint32_t incarnation;
+  uint8_t  state;
+  uint8_t  tx_left;      /* remaining piggyback transmissions                          */
+  uint16_t _pad;
+} swimsim_rumor_t;
+
+/* Per-member summary: the parts of `Store` (src/Types.hs:53-60) that survive in a
+ * tick model: storeIncarnation, plus the piggyback queue the reference leaves as
+ * a FIXME (src/Core.hs:136-138). */
+typedef struct swimsim_member {
+  uint32_t id;
+  uint32_t incarnation;       /* storeIncarnation                                      */
+  uint8_t  up;                /* ground truth (fault schedule), not protocol state     */
+  uint8_t  n_rumors;
+  uint16_t n_timers;          /* pending suspicion timers                              */
+  swimsim_rumor_t rumors[8];  /* piggyback buffer, order unspecified                   */
+} swimsim_member_t;
+
+/* Counter indices for swimsim_counters(). */
+enum {
+  SWIMSIM_CTR_PINGS = 0,          /* direct Pings sent (src/Core.hs:246)                 */
+  SWIMSIM_CTR_DIRECT_FAILED = 1,  /* f: direct probes not acked                          */
+  SWIMSIM_CTR_PING_REQS = 2,      /* IndirectPings sent (src/Core.hs:250)                */
+  SWIMSIM_CTR_SUSPECTS = 3,       /* probes that ended in Suspect (src/Core.hs:253)      */
+  SWIMSIM_CTR_FALSE_SUSPECTS = 4, /* ... of a member that was actually up                */
+  SWIMSIM_CTR_PAYLOADS = 5,       /* d: non-empty piggyback payloads delivered           */
+  SWIMSIM_CTR_RUMORS_SEEN = 6,    /* rumours examined by receivers                       */
+  SWIMSIM_CTR_CHANGES = 7,        /* r: (observer,subject) view entries changed          */
+  SWIMSIM_CTR_PB_WRITES = 8,      /* c: piggyback buffers rewritten                      */
+  SWIMSIM_CTR_TIMERS_FIRED = 9,   /* Suspect -> Dead by timeout                          */
+  SWIMSIM_CTR_REFUTES = 10,       /* incarnation bumps (src/Core.hs:155-166)             */
+  SWIMSIM_CTR_EVENTS_DROPPED = 11,/* events lost to a full ring                          */
+  SWIMSIM_CTR_ACTIVE_MEMBERS = 12,/* up-member ticks actually processed                  */
+  SWIMSIM_CTR_EVDIGEST = 13,      /* running digest of every view / incarnation change   */
+  SWIMSIM_CTR_COUNT = 16
+};
+
+#define SWIMSIM_TICK_NONE UINT64_MAX
+
+/* ---- lifecycle ---------------------------------------------------------- */
+
+/* Defaults = `parseConfig` (src/Util.hs:44-50): numToGossip 10, gossipInterval
+ * 200 000 us; simulator fields zero (n_members must be set by the caller). */
+int swimsim_default_config(swimsim_config_t* cfg);
+
+/* Replaces `configure` + `makeStore` + `makeSelf` for all N members at once
+ * (src/Util.hs:76-107): every member up, incarnation 0, every view "all Alive@0",
+ * empty piggyback buffers, tick 0.  On failure *out is NULL and the message is
+ * available via swimsim_last_error(NULL). */
+int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out);
+void swimsim_destroy(swimsim_t* h);
+const char* swimsim_last_error(const swimsim_t* h);
+
+/* ---- fault injection (the simulator owns ground truth) */
+
+/* Member `member` is down (up=0) / up again (up=1) FOR tick `tick` and after.
+ * `tick` must be >= the current tick.  Coming back up bumps the member's
+ * incarnation and announces Alive (cause JOIN). */
+int swimsim_schedule_fault(swimsim_t* h, uint64_t tick, uint32_t member, uint8_t up);
+
+/* ---- the hot path -------------------------------------------------------- */
+
+/* Runs `nticks` protocol periods for every member: replaces the body of
+ * `failureDetector`'s forever-loop (src/Core.hs:236-240), `probeNode'`
+ * (:243-269), the receive side `handleUDPMessage.process` (:89-117), the state
+ * rules `suspectOrDeadNode'`/`aliveNode` (:142-218) and `disseminate`'s
+ * piggyback queue (:127-138), for all members at once.  Blocking. */
+int swimsim_step(swimsim_t* h, uint32_t nticks);
+
+int swimsim_tick(const swimsim_t* h, uint64_t* tick);
+
+/* ---- results -------------------------------------------------------------- */
+
+/* Membership events since the last drain, sorted by (tick, observer, subject);
+ * several changes of one (tick, observer, subject) are collapsed to the final
+ * one.  Replaces reading `Broadcast` values off `storeGossip` (src/Core.hs:280). */
+int swimsim_drain_events(swimsim_t* h, swimsim_event_t* buf, size_t cap, size_t* n_out);
+
+/* Non-default entries of `observer`'s member map, sorted by subject: replaces
+ * `members` (src/Core.hs:76-77) / `readTVar storeMembers`. */
+int swimsim_read_view(swimsim_t* h, uint32_t observer, swimsim_view_entry_t* buf,
+                      size_t cap, size_t* n_out);
+
+int swimsim_read_member(swimsim_t* h, uint32_t member, swimsim_member_t* out);
+
+/* out[j] = first tick at which some live member's probe of j ended in Suspect
+ * while j was down (SWIMSIM_TICK_NONE if never); n must be n_members. */
+int swimsim_first_detect(swimsim_t* h, uint64_t* out, size_t n);
+
+/* 64-bit digest of the complete semantic state (all views, incarnations,
+ * piggyback buffers, live timers, first-detection ticks, tick counter).
+ * Independent of internal slot assignment and processing order. */
+int swimsim_digest(swimsim_t* h, uint64_t* out);
+
+int swimsim_counters(swimsim_t* h, uint64_t* out, size_t n);
+
+/* ---- unit-level hooks (what test/Spec.hs exercises directly) --------------- */
+
+/* `kRandomMembers store n excludes` (src/Core.hs:69-74; test/Spec.hs:108-139)
+ * evaluated for `observer` on the device with the current tick's selection
+ * stream.  Writes min(n, eligible) distinct member ids. */
+int swimsim_k_random_members(swimsim_t* h, uint32_t observer, uint32_t n,
+                             const uint32_t* excludes, size_t n_excludes,
+                             uint32_t* out, size_t cap, size_t* n_out);
+
+/* Overwrite one view entry (test fixture: the reference's tests swap a hand-built
+ * map into `storeMembers`, test/Spec.hs:45-56,101). */
+int swimsim_set_view(swimsim_t* h, uint32_t observer, uint32_t subject, uint8_t state,
+                     uint32_t incarnation);
+
+/* Resolved configuration (defaults filled in). */
+int swimsim_get_config(const swimsim_t* h, swimsim_config_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWIMSIM_H */

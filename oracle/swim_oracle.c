@@ -1,0 +1,880 @@
+/*
+ * swim_oracle.c -- CPU ORACLE (test infrastructure, not product; see swim_oracle.h).
+ *
+ * Message-level restatement of jpfuentes2/swim's gossip / failure-detection
+ * round as a bulk-synchronous tick.  Every function cites the reference lines it
+ * follows; "Dn" refers to the defect/divergence register in DESIGN.md section 3
+ * (= SURVEY.md appendix A).  Paths are relative to the reference checkout.
+ *
+ * Tick semantics, for tick t:
+ *   0. faults scheduled for t are applied (ground truth up[]).
+ *   1. every up member runs one period of `failureDetector` (src/Core.hs:233-241):
+ *      picks P targets (`kRandomMembers`), probes each (`probeNode'`), and on a
+ *      missing ack asks K proxies (`IndirectPing`).  Messages are delivered
+ *      in-memory through `process` (src/Core.hs:89-117) subject to the loss hash
+ *      and to up[dst].  Every message carries the sender's START-OF-TICK
+ *      piggyback buffer as a compound envelope (src/Types.hs:96-119).
+ *   2. all state changes land at the end of the tick (Jacobi): per member, in
+ *      this phase order: suspicion timers, own failed probes, received rumours;
+ *      each applied with the commutative merge `max (incarnation, state)`.
+ *   3. changed entries become rumours in the member's piggyback buffer.
+ * The outcome of a tick does not depend on the order in which members or
+ * messages are processed (property-tested via swimoracle_set_shuffle).
+ */
+#include "swim_oracle.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------- */
+/* spec constants                                                             */
+/* ------------------------------------------------------------------------- */
+#define PB_SLOTS 8          /* piggyback buffer slots per member (D5)              */
+#define SEL_ATTEMPTS 8      /* rejection-sampling attempts per pick (H4)           */
+#define INC_MAX 0x3FFFFFu   /* incarnation must fit 22 bits (key = inc<<2|state)   */
+
+enum { P_SELECT = 1, P_PROXY = 2, P_L_PING = 3, P_L_ACK = 4, P_L_REQ = 5,
+       P_L_FWD = 6, P_L_BACK = 7, P_L_RELAY = 8 };
+
+enum { TAG_SELF = 0x53454c46u, TAG_VIEW = 0x56494557u, TAG_PB = 0x50425546u,
+       TAG_TIMER = 0x54494d52u, TAG_FD = 0x46444554u, TAG_EV = 0x45564e54u,
+       TAG_INC = 0x494e4352u, TAG_TICK = 0x5449434bu, TAG_MEMBER = 0x4d454d42u };
+
+#define NONE32 0xFFFFFFFFu
+
+static inline uint32_t key_make(uint32_t inc, uint32_t st) { return (inc << 2) | st; }
+static inline uint32_t key_inc(uint32_t k) { return k >> 2; }
+static inline uint32_t key_state(uint32_t k) { return k & 3u; }
+
+/* ------------------------------------------------------------------------- */
+/* hashes.  Replaces the global StdGen of src/Util.hs:40 (F7).  */
+/* ------------------------------------------------------------------------- */
+static inline uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+static inline uint32_t tick_key(uint64_t seed, uint32_t t) {
+  return mix32((uint32_t)seed + mix32((uint32_t)(seed >> 32) + mix32(t + 0x9E3779B9u)));
+}
+static inline uint32_t hash_h(uint32_t tk, uint32_t a, uint32_t b, uint32_t c) {
+  return mix32(mix32(mix32(tk ^ a) + b) ^ c);
+}
+uint32_t swimoracle_hash(uint64_t seed, uint32_t tick, uint32_t a, uint32_t b, uint32_t c) {
+  return hash_h(tick_key(seed, tick), a, b, c);
+}
+static inline uint64_t mix64(uint64_t x) {
+  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull;
+  x ^= x >> 31;
+  return x;
+}
+static inline uint64_t h4(uint64_t tag, uint64_t a, uint64_t b, uint64_t c) {
+  return mix64(mix64(mix64(mix64(tag) + a) + b) + c);
+}
+
+/* ------------------------------------------------------------------------- */
+/* state                                                                      */
+/* ------------------------------------------------------------------------- */
+typedef struct { uint32_t subject, key; uint8_t tx; } orumor_t;
+typedef struct { int n; orumor_t r[PB_SLOTS]; } opb_t;           /* disseminate's queue */
+typedef struct { uint32_t subject, deadline; } otimer_t;
+typedef struct { otimer_t* v; uint32_t head, n, cap; } otimerq_t; /* FIFO               */
+typedef struct { uint32_t key, since1; } oentry_t;  /* Member: state+inc, lastChange+1 */
+typedef struct { uint32_t dst, subject, key; } opend_t;
+typedef struct { uint32_t i, j; } ofail_t;
+typedef struct { uint32_t tick, member; uint8_t up; uint32_t order; } ofault_t;
+
+/* internal message = public message + routing context the tick model needs     */
+typedef struct {
+  swimoracle_msg_t m;
+  uint32_t relay_to;  /* proxy must relay the ack to this requester (D9)           */
+  uint32_t lidx;      /* probe index (p, or p<<8|k) keying the loss hash           */
+  int via_proxy;      /* hop class: 0 = direct ping/ack, 1 = proxied               */
+} omsg_t;
+
+struct swimoracle {
+  swimsim_config_t cfg;     /* resolved */
+  uint32_t N, P, K, S, L, loss_thr;
+  uint64_t tick;
+  uint32_t tk;              /* tick key of the running tick */
+  uint8_t* up;
+  uint32_t* self_inc;       /* storeIncarnation (src/Types.hs:54) */
+  opb_t* pb;
+  otimerq_t* timers;
+  uint8_t* nsent;
+  /* sparse views: slot-major columns over the subjects anyone ever gossiped about */
+  uint32_t* slot_of;        /* subject -> slot+1, 0 = none (view entry = Alive@0)  */
+  uint32_t* subject_of;
+  oentry_t** cols;
+  uint32_t nslots, slots_cap;
+  /* fault schedule */
+  ofault_t* faults; size_t nfaults, faults_cap; uint32_t fault_order;
+  uint32_t* first_suspect;  /* NONE32 = never */
+  uint32_t* crash_tick;
+  /* per-tick scratch */
+  opend_t* pend; size_t npend, pend_cap;
+  opend_t* pend_sorted; size_t pend_sorted_cap;
+  uint32_t* pend_off;       /* N+1 */
+  ofail_t* fails; size_t nfails, fails_cap;
+  /* events */
+  swimsim_event_t* events; size_t nevents, events_cap_alloc;
+  uint64_t counters[SWIMSIM_CTR_COUNT];
+  uint64_t shuffle_seed;
+  /* probe / capture context (processing is synchronous, depth first) */
+  int ctx_acked;
+  int capture; int capture_literal_d8;
+  swimoracle_msg_t* cap_out; size_t cap_cap, cap_n;
+  int poisoned;
+  char err[256];
+};
+
+static char g_create_err[256];
+
+static int fail(swimoracle_t* o, int code, const char* msg) {
+  if (o) { snprintf(o->err, sizeof o->err, "%s", msg); if (code == SWIMSIM_ERR_CAPACITY) o->poisoned = 1; }
+  else snprintf(g_create_err, sizeof g_create_err, "%s", msg);
+  return code;
+}
+
+const char* swimoracle_last_error(const swimoracle_t* h) { return h ? h->err : g_create_err; }
+
+static uint32_t ceil_log2(uint64_t x) { uint32_t r = 0; while ((1ull << r) < x) r++; return r; }
+
+/* `parseConfig` (src/Util.hs:44-50) */
+int swimoracle_default_config(swimsim_config_t* cfg) {
+  if (!cfg) return SWIMSIM_ERR_INVALID;
+  memset(cfg, 0, sizeof *cfg);
+  cfg->struct_size = (uint32_t)sizeof *cfg;
+  cfg->abi_version = SWIMSIM_ABI_VERSION;
+  cfg->num_to_gossip = 10;            /* src/Util.hs:48 */
+  cfg->gossip_interval_us = 200000;   /* src/Util.hs:49 `milliseconds 200` */
+  return SWIMSIM_OK;
+}
+
+/* ------------------------------------------------------------------------- */
+/* views                                                                      */
+/* ------------------------------------------------------------------------- */
+static inline oentry_t view_get(const swimoracle_t* o, uint32_t i, uint32_t s) {
+  oentry_t z = {0, 0};
+  uint32_t sl = o->slot_of[s];
+  return sl ? o->cols[sl - 1][i] : z;
+}
+
+static oentry_t* view_ref(swimoracle_t* o, uint32_t i, uint32_t s) {
+  uint32_t sl = o->slot_of[s];
+  if (!sl) {
+    if (o->nslots >= o->cfg.max_subjects) { fail(o, SWIMSIM_ERR_CAPACITY, "max_subjects exceeded"); return NULL; }
+    if (o->nslots == o->slots_cap) {
+      uint32_t nc = o->slots_cap ? o->slots_cap * 2 : 16;
+      o->cols = (oentry_t**)realloc(o->cols, nc * sizeof *o->cols);
+      o->subject_of = (uint32_t*)realloc(o->subject_of, nc * sizeof *o->subject_of);
+      o->slots_cap = nc;
+    }
+    o->cols[o->nslots] = (oentry_t*)calloc(o->N, sizeof(oentry_t));
+    if (!o->cols[o->nslots]) { fail(o, SWIMSIM_ERR_NOMEM, "out of memory (view column)"); return NULL; }
+    o->subject_of[o->nslots] = s;
+    o->slot_of[s] = ++o->nslots;
+    sl = o->nslots;
+  }
+  return &o->cols[sl - 1][i];
+}
+
+/* `isAlive` (src/Core.hs:33-34) on member i's view of s */
+static inline int is_alive_in_view(const swimoracle_t* o, uint32_t i, uint32_t s) {
+  return key_state(view_get(o, i, s).key) == SWIMSIM_ALIVE;
+}
+
+/* ------------------------------------------------------------------------- */
+/* kRandomMembers (src/Core.hs:69-74) + shuffle (src/Util.hs:37-42)            */
+/*                                                                             */
+/* Reference: n first elements of a uniform shuffle of the members that are    */
+/* alive IN THE LOCAL VIEW and not in `excludes`.  Equivalent in distribution: */
+/* n draws without replacement.  Here: rejection sampling with the counter     */
+/* RNG (H4): per pick SEL_ATTEMPTS draws, then a deterministic cyclic scan so  */
+/* that "fewer than n candidates => all of them" holds exactly                 */
+/* (test/Spec.hs:117-128).  Self is never eligible (D15).                      */
+/* ------------------------------------------------------------------------- */
+static int eligible(const swimoracle_t* o, uint32_t i, uint32_t c, const uint32_t* excl,
+                    size_t nexcl, const uint32_t* picks, uint32_t npicks) {
+  if (c == i) return 0;                                   /* D15 */
+  for (size_t e = 0; e < nexcl; e++) if (excl[e] == c) return 0;  /* notElem m excludes */
+  for (uint32_t e = 0; e < npicks; e++) if (picks[e] == c) return 0;
+  return is_alive_in_view(o, i, c);                       /* isAlive m */
+}
+
+static uint32_t k_random_members(const swimoracle_t* o, uint32_t i, uint32_t n,
+                                 const uint32_t* excl, size_t nexcl, uint32_t purpose,
+                                 uint32_t hi_idx, uint32_t* out) {
+  uint32_t np = 0;
+  for (uint32_t p = 0; p < n; p++) {
+    uint32_t c = 0; int found = 0;
+    uint32_t base = (purpose == P_SELECT) ? (p << 8) : ((hi_idx << 16) | (p << 8));
+    for (uint32_t a = 0; a < SEL_ATTEMPTS; a++) {
+      uint32_t r = hash_h(o->tk, i, (purpose << 24) | base | a, 0);
+      c = (uint32_t)(((uint64_t)r * o->N) >> 32);
+      if (eligible(o, i, c, excl, nexcl, out, np)) { found = 1; break; }
+    }
+    if (!found) {
+      uint32_t c0 = c + 1 == o->N ? 0 : c + 1;
+      for (uint32_t d = 0; d < o->N; d++) {
+        c = c0 + d; if (c >= o->N) c -= o->N;
+        if (eligible(o, i, c, excl, nexcl, out, np)) { found = 1; break; }
+      }
+    }
+    if (!found) break;      /* fewer than n candidates: take what exists */
+    out[np++] = c;
+  }
+  return np;
+}
+
+/* ------------------------------------------------------------------------- */
+/* network: loss + delivery + process                                         */
+/* ------------------------------------------------------------------------- */
+static inline int lost(const swimoracle_t* o, uint32_t purpose, uint32_t src, uint32_t dst, uint32_t idx) {
+  if (!o->loss_thr) return 0;
+  return hash_h(o->tk, src, (purpose << 24) | idx, dst) < o->loss_thr;
+}
+
+static void pend_add(swimoracle_t* o, uint32_t dst, uint32_t subject, uint32_t key) {
+  if (o->npend == o->pend_cap) {
+    o->pend_cap = o->pend_cap ? o->pend_cap * 2 : 1024;
+    o->pend = (opend_t*)realloc(o->pend, o->pend_cap * sizeof *o->pend);
+  }
+  o->pend[o->npend].dst = dst; o->pend[o->npend].subject = subject; o->pend[o->npend].key = key;
+  o->npend++;
+}
+
+static void process(swimoracle_t* o, uint32_t self, uint32_t sender, const omsg_t* msg);
+
+/* A datagram src -> dst: the control message plus the sender's start-of-tick
+ * piggyback buffer as a compound envelope (src/Types.hs:96-119; D5, D11). */
+static int deliver(swimoracle_t* o, uint32_t purpose, uint32_t src, uint32_t dst, const omsg_t* msg) {
+  if (lost(o, purpose, src, dst, msg->lidx)) return 0;
+  if (!o->up[dst]) return 0;                      /* nobody listening */
+  const opb_t* pb = &o->pb[src];
+  if (pb->n > 0) {
+    o->counters[SWIMSIM_CTR_PAYLOADS]++;
+    for (int s = 0; s < pb->n; s++) {             /* handleUDPMessage: CC.concat over the envelope */
+      omsg_t r; memset(&r, 0, sizeof r);
+      uint32_t st = key_state(pb->r[s].key);
+      r.m.type = st == SWIMSIM_SUSPECT ? SWIMO_MSG_SUSPECT : st == SWIMSIM_DEAD ? SWIMO_MSG_DEAD : SWIMO_MSG_ALIVE;
+      r.m.incarnation = key_inc(pb->r[s].key);
+      r.m.node = pb->r[s].subject;
+      r.relay_to = NONE32;
+      o->counters[SWIMSIM_CTR_RUMORS_SEEN]++;
+      process(o, dst, src, &r);
+    }
+  }
+  process(o, dst, src, msg);
+  return 1;
+}
+
+static void emit(swimoracle_t* o, const swimoracle_msg_t* m) {
+  if (o->cap_n < o->cap_cap) o->cap_out[o->cap_n] = *m;
+  o->cap_n++;
+}
+
+static int accept_key(swimoracle_t* o, uint32_t i, uint32_t s, uint32_t key, uint8_t cause,
+                      uint32_t* refute_inc, opb_t* cand, uint32_t self_inc_start);
+
+/* `process sender msg` (src/Core.hs:89-117) */
+static void process(swimoracle_t* o, uint32_t self, uint32_t sender, const omsg_t* msg) {
+  switch (msg->m.type) {
+    case SWIMO_MSG_ACK:                                    /* src/Core.hs:92-94 */
+      if (o->capture) return;                              /* `return []` */
+      if (msg->relay_to != NONE32) {                       /* proxy relays the ack (D9) */
+        omsg_t a = *msg; a.relay_to = NONE32;
+        deliver(o, P_L_RELAY, self, msg->relay_to, &a);
+      } else {
+        o->ctx_acked = 1;                                  /* invokeAckHandler (src/Core.hs:220-221) */
+      }
+      return;
+    case SWIMO_MSG_PING:                                   /* src/Core.hs:97-101 */
+      if (msg->m.node == self) {
+        omsg_t a; memset(&a, 0, sizeof a);
+        a.m.type = SWIMO_MSG_ACK; a.m.seq_no = msg->m.seq_no; a.m.to = sender;
+        a.relay_to = msg->relay_to; a.lidx = msg->lidx; a.via_proxy = msg->via_proxy;
+        if (o->capture) { emit(o, &a.m); return; }
+        deliver(o, msg->via_proxy ? P_L_BACK : P_L_ACK, self, sender, &a);
+      }
+      return;                                              /* not for us: [] */
+    case SWIMO_MSG_INDIRECT_PING: {                        /* src/Core.hs:105-108 */
+      omsg_t p; memset(&p, 0, sizeof p);
+      p.m.type = SWIMO_MSG_PING; p.m.node = msg->m.node; p.m.to = msg->m.target;
+      if (o->capture && o->capture_literal_d8) {
+        /* literal: `nextIncarnation store >>= \next -> Ping (fromIntegral next)` (D8) */
+        o->self_inc[self] += 1;
+        p.m.seq_no = o->self_inc[self];
+      } else {
+        p.m.seq_no = msg->m.seq_no;                        /* D8: relay the requester's seqNo */
+      }
+      p.relay_to = sender; p.lidx = msg->lidx; p.via_proxy = 1;
+      if (o->capture) { emit(o, &p.m); return; }
+      deliver(o, P_L_FWD, self, msg->m.target, &p);
+      return;
+    }
+    case SWIMO_MSG_SUSPECT:                                /* src/Core.hs:110-117 */
+    case SWIMO_MSG_DEAD:
+    case SWIMO_MSG_ALIVE: {
+      uint32_t st = msg->m.type == SWIMO_MSG_SUSPECT ? SWIMSIM_SUSPECT
+                  : msg->m.type == SWIMO_MSG_DEAD ? SWIMSIM_DEAD : SWIMSIM_ALIVE;
+      uint32_t key = key_make(msg->m.incarnation, st);
+      if (o->capture) {                                    /* maybeBroadcast, applied now */
+        uint32_t refute = NONE32; opb_t cand = o->pb[self];
+        int ch = accept_key(o, self, msg->m.node, key, SWIMSIM_CAUSE_GOSSIP, &refute, &cand, o->self_inc[self]);
+        if (refute != NONE32) {                            /* src/Core.hs:155-166 */
+          o->self_inc[self] = refute + 1;
+          swimoracle_msg_t a; memset(&a, 0, sizeof a);
+          a.type = SWIMO_MSG_ALIVE; a.incarnation = o->self_inc[self]; a.node = self; a.broadcast = 1;
+          emit(o, &a);
+        } else if (ch) {
+          swimoracle_msg_t b = msg->m; b.broadcast = 1; emit(o, &b);
+        }
+        o->pb[self] = cand;
+        return;
+      }
+      pend_add(o, self, msg->m.node, key);                 /* lands at end of tick */
+      return;
+    }
+    default: return;
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* active side: failureDetector / probeNode' (src/Core.hs:233-269)             */
+/* ------------------------------------------------------------------------- */
+static void fails_add(swimoracle_t* o, uint32_t i, uint32_t j) {
+  if (o->nfails == o->fails_cap) {
+    o->fails_cap = o->fails_cap ? o->fails_cap * 2 : 256;
+    o->fails = (ofail_t*)realloc(o->fails, o->fails_cap * sizeof *o->fails);
+  }
+  o->fails[o->nfails].i = i; o->fails[o->nfails].j = j; o->nfails++;
+}
+
+/* probeNode' store currSeqNo m (src/Core.hs:243-254) */
+static void probe_node(swimoracle_t* o, uint32_t i, uint32_t p, uint32_t j) {
+  omsg_t ping; memset(&ping, 0, sizeof ping);
+  ping.m.type = SWIMO_MSG_PING; ping.m.seq_no = (uint32_t)o->tick + 1; ping.m.node = j; ping.m.to = j;
+  ping.relay_to = NONE32; ping.lidx = p; ping.via_proxy = 0;
+  o->counters[SWIMSIM_CTR_PINGS]++;
+  o->ctx_acked = 0;
+  deliver(o, P_L_PING, i, j, &ping);                       /* yield Direct (Ping ...) :246 */
+  if (o->ctx_acked) return;                                /* unlessAck (D2, D3)          */
+  o->counters[SWIMSIM_CTR_DIRECT_FAILED]++;
+  /* kRandomMembers store (numToGossip cfg) [] :249 -- D7: exclude the target */
+  uint32_t qs[256];
+  uint32_t nq = k_random_members(o, i, o->K, &j, 1, P_PROXY, p, qs);
+  int acked = 0;
+  for (uint32_t k = 0; k < nq; k++) {                      /* yieldMany ... indirectPing :250 */
+    omsg_t ip; memset(&ip, 0, sizeof ip);
+    ip.m.type = SWIMO_MSG_INDIRECT_PING; ip.m.seq_no = (uint32_t)o->tick + 1;
+    ip.m.target = j; ip.m.node = j;                        /* D12: node = member id        */
+    ip.relay_to = NONE32; ip.lidx = (p << 8) | k; ip.via_proxy = 1;
+    o->counters[SWIMSIM_CTR_PING_REQS]++;
+    o->ctx_acked = 0;
+    deliver(o, P_L_REQ, i, qs[k], &ip);
+    acked |= o->ctx_acked;                                 /* any of the k relays (D9)     */
+  }
+  if (acked) return;                                       /* second unlessAck :251        */
+  /* suspectNode store (Suspect (memberIncarnation m) name) :253 -- lands at end of tick */
+  fails_add(o, i, j);
+  o->counters[SWIMSIM_CTR_SUSPECTS]++;
+  if (o->up[j]) o->counters[SWIMSIM_CTR_FALSE_SUSPECTS]++;
+  else if (o->first_suspect[j] == NONE32 || (uint32_t)o->tick < o->first_suspect[j])
+    o->first_suspect[j] = (uint32_t)o->tick;
+}
+
+/* one period of failureDetector for member i (src/Core.hs:236-240; D14) */
+static void failure_detector(swimoracle_t* o, uint32_t i) {
+  uint32_t ms[256];
+  uint32_t n = k_random_members(o, i, o->P, NULL, 0, P_SELECT, 0, ms);   /* :239 */
+  o->nsent[i] = (uint8_t)n;
+  for (uint32_t p = 0; p < n; p++) probe_node(o, i, p, ms[p]);           /* mapM_ :240 */
+}
+
+/* ------------------------------------------------------------------------- */
+/* end of tick: timers, state rules, piggyback queue                          */
+/* ------------------------------------------------------------------------- */
+static void timer_push(swimoracle_t* o, uint32_t i, uint32_t s, uint32_t deadline) {
+  otimerq_t* q = &o->timers[i];
+  if (q->n >= o->cfg.timer_cap) { fail(o, SWIMSIM_ERR_CAPACITY, "timer_cap exceeded"); return; }
+  if (q->n == q->cap) {
+    uint32_t nc = q->cap ? q->cap * 2 : 4;
+    otimer_t* nv = (otimer_t*)malloc(nc * sizeof *nv);
+    for (uint32_t x = 0; x < q->n; x++) nv[x] = q->v[(q->head + x) % q->cap];
+    free(q->v); q->v = nv; q->head = 0; q->cap = nc;
+  }
+  q->v[(q->head + q->n) % q->cap].subject = s;
+  q->v[(q->head + q->n) % q->cap].deadline = deadline;
+  q->n++;
+}
+
+/* priority of a rumour in the piggyback queue: fewest transmissions first, then
+ * lowest subject id (total order => deterministic; H3, D5) */
+static inline int rumor_better(const orumor_t* a, const orumor_t* b) {
+  if (a->tx != b->tx) return a->tx > b->tx;
+  return a->subject < b->subject;
+}
+
+/* insert-or-replace into the candidate set, keeping the PB_SLOTS best */
+static void cand_insert(opb_t* c, uint32_t subject, uint32_t key, uint8_t tx) {
+  orumor_t r; r.subject = subject; r.key = key; r.tx = tx;
+  for (int s = 0; s < c->n; s++)
+    if (c->r[s].subject == subject) { c->r[s] = r; return; }   /* newer rumour supersedes */
+  if (c->n < PB_SLOTS) { c->r[c->n++] = r; return; }
+  int worst = 0;
+  for (int s = 1; s < c->n; s++) if (rumor_better(&c->r[worst], &c->r[s])) worst = s;
+  if (rumor_better(&r, &c->r[worst])) c->r[worst] = r;
+}
+
+static void event_add(swimoracle_t* o, uint32_t t, uint32_t i, uint32_t s, uint32_t key, uint8_t cause) {
+  if (!(o->cfg.event_mask & (1u << cause))) return;
+  if (o->nevents >= o->cfg.event_cap) { o->counters[SWIMSIM_CTR_EVENTS_DROPPED]++; return; }
+  if (o->nevents == o->events_cap_alloc) {
+    o->events_cap_alloc = o->events_cap_alloc ? o->events_cap_alloc * 2 : 1024;
+    o->events = (swimsim_event_t*)realloc(o->events, o->events_cap_alloc * sizeof *o->events);
+  }
+  swimsim_event_t* e = &o->events[o->nevents++];
+  memset(e, 0, sizeof *e);
+  e->tick = t; e->observer = i; e->subject = s; e->incarnation = key_inc(key);
+  e->state = (uint8_t)key_state(key); e->cause = cause;
+}
+
+/* The state rule.  Reference: suspectOrDeadNode' (src/Core.hs:142-187) and the
+ * unwritten aliveNode (src/Core.hs:197-218, D6).  Oracle: commutative merge
+ * `entry := max(entry, (incarnation,state))` with Alive < Suspect < Dead (H3, D13).
+ *   - unknown subject        : reference ignores (:147-148); here every member is
+ *                              known from the start (bootstrap assumption).
+ *   - i < inc  => ignore      : same (:151).
+ *   - about self => refute    : same (:155-166), with D10's counter fix.
+ * Returns 1 if i's entry for s changed. */
+static int accept_key(swimoracle_t* o, uint32_t i, uint32_t s, uint32_t key, uint8_t cause,
+                      uint32_t* refute_inc, opb_t* cand, uint32_t self_inc_start) {
+  uint32_t t = (uint32_t)o->tick;
+  if (s == i) {
+    /* `name == memberName storeSelf` -> refute (:155); old incarnations ignored (:151) */
+    if (key_state(key) != SWIMSIM_ALIVE && key_inc(key) >= self_inc_start)
+      if (*refute_inc == NONE32 || key_inc(key) > *refute_inc) *refute_inc = key_inc(key);
+    return 0;
+  }
+  oentry_t* e = view_ref(o, i, s);
+  if (!e) return 0;
+  if (key <= e->key) return 0;                     /* old incarnation / weaker state: ignore */
+  o->counters[SWIMSIM_CTR_EVDIGEST] += h4(TAG_EV, ((uint64_t)t << 32) | i, s, key)
+                                     - h4(TAG_EV, ((uint64_t)t << 32) | i, s, e->key);
+  if (e->since1 != t + 1) o->counters[SWIMSIM_CTR_CHANGES]++;
+  e->key = key; e->since1 = t + 1;                 /* memberLastChange = now (:176) */
+  if (cause == SWIMSIM_CAUSE_TIMER) o->counters[SWIMSIM_CTR_TIMERS_FIRED]++;
+  if (key_state(key) == SWIMSIM_SUSPECT) timer_push(o, i, s, t + o->S);   /* D4 */
+  cand_insert(cand, s, key, (uint8_t)o->L);        /* `Just msg` -> Broadcast -> enqueue (D5) */
+  event_add(o, t, i, s, key, cause);
+  return 1;
+}
+
+static void end_of_tick(swimoracle_t* o, uint32_t i, const opend_t* pend, uint32_t npend,
+                        const ofail_t* fails, uint32_t nfails) {
+  uint32_t t = (uint32_t)o->tick;
+  const opb_t* old = &o->pb[i];
+  uint32_t self_inc_start = o->self_inc[i];
+  uint32_t refute = NONE32;
+  /* age the queue: every ping sent this tick carried every slot (D5) */
+  opb_t cand; cand.n = 0;
+  for (int s = 0; s < old->n; s++)
+    if (old->r[s].tx > o->nsent[i]) { cand.r[cand.n] = old->r[s]; cand.r[cand.n].tx = (uint8_t)(old->r[s].tx - o->nsent[i]); cand.n++; }
+  /* phase 1: suspicion timers (the FIXME at src/Core.hs:141; D4), evaluated on the
+   * start-of-tick view */
+  otimerq_t* q = &o->timers[i];
+  uint32_t tprop[64]; uint32_t tkey[64]; uint32_t ntp = 0;
+  while (q->n && q->v[q->head].deadline <= t) {
+    otimer_t tm = q->v[q->head]; q->head = (q->head + 1) % q->cap; q->n--;
+    oentry_t e = view_get(o, i, tm.subject);
+    if (key_state(e.key) == SWIMSIM_SUSPECT && e.since1 - 1 + o->S == tm.deadline) {
+      if (ntp == 64) { /* flush */
+        for (uint32_t x = 0; x < ntp; x++) accept_key(o, i, tprop[x], tkey[x], SWIMSIM_CAUSE_TIMER, &refute, &cand, self_inc_start);
+        ntp = 0;
+      }
+      tprop[ntp] = tm.subject; tkey[ntp] = key_make(key_inc(e.key), SWIMSIM_DEAD); ntp++;
+    }
+  }
+  for (uint32_t x = 0; x < ntp; x++) accept_key(o, i, tprop[x], tkey[x], SWIMSIM_CAUSE_TIMER, &refute, &cand, self_inc_start);
+  /* phase 2: own probes that ended without any ack: suspectNode (src/Core.hs:253) with
+   * the incarnation of the start-of-tick view entry (`memberIncarnation m`) */
+  for (uint32_t f = 0; f < nfails; f++) {
+    uint32_t j = fails[f].j;
+    uint32_t key = key_make(key_inc(view_get(o, i, j).key), SWIMSIM_SUSPECT);
+    accept_key(o, i, j, key, SWIMSIM_CAUSE_PROBE, &refute, &cand, self_inc_start);
+  }
+  /* phase 3: rumours received this tick (any order: the merge is commutative) */
+  if (o->shuffle_seed && npend > 1) {
+    uint32_t* perm = (uint32_t*)malloc(npend * sizeof *perm);
+    for (uint32_t x = 0; x < npend; x++) perm[x] = x;
+    for (uint32_t x = npend - 1; x > 0; x--) {
+      uint32_t r = (uint32_t)(mix64(o->shuffle_seed + ((uint64_t)t << 32) + (uint64_t)i * 0x9E3779B97F4A7C15ull + x) % (x + 1));
+      uint32_t tmp = perm[x]; perm[x] = perm[r]; perm[r] = tmp;
+    }
+    for (uint32_t x = 0; x < npend; x++)
+      accept_key(o, i, pend[perm[x]].subject, pend[perm[x]].key, SWIMSIM_CAUSE_GOSSIP, &refute, &cand, self_inc_start);
+    free(perm);
+  } else {
+    for (uint32_t x = 0; x < npend; x++)
+      accept_key(o, i, pend[x].subject, pend[x].key, SWIMSIM_CAUSE_GOSSIP, &refute, &cand, self_inc_start);
+  }
+  /* refutation: bump own incarnation past the rumour's (src/Core.hs:155-166; D10) */
+  if (refute != NONE32) {
+    uint32_t ni = refute + 1;
+    if (ni > INC_MAX) { fail(o, SWIMSIM_ERR_CAPACITY, "incarnation overflow"); return; }
+    o->self_inc[i] = ni;
+    o->counters[SWIMSIM_CTR_EVDIGEST] += h4(TAG_INC, ((uint64_t)t << 32) | i, ni, 0);
+    o->counters[SWIMSIM_CTR_REFUTES]++;
+    cand_insert(&cand, i, key_make(ni, SWIMSIM_ALIVE), (uint8_t)o->L);   /* Just Alive{..} :163 */
+    event_add(o, t, i, i, key_make(ni, SWIMSIM_ALIVE), SWIMSIM_CAUSE_REFUTE);
+  }
+  if (old->n > 0 || cand.n > 0) o->counters[SWIMSIM_CTR_PB_WRITES]++;
+  o->pb[i] = cand;
+}
+
+/* ------------------------------------------------------------------------- */
+/* faults                                                                     */
+/* ------------------------------------------------------------------------- */
+static int fault_cmp(const void* a, const void* b) {
+  const ofault_t* x = (const ofault_t*)a; const ofault_t* y = (const ofault_t*)b;
+  if (x->tick != y->tick) return x->tick < y->tick ? -1 : 1;
+  return x->order < y->order ? -1 : x->order > y->order;
+}
+
+static void apply_faults(swimoracle_t* o, uint32_t t) {
+  size_t k = 0;
+  while (k < o->nfaults && o->faults[k].tick <= t) {
+    ofault_t f = o->faults[k++];
+    uint32_t m = f.member;
+    if (f.up == o->up[m]) continue;
+    o->up[m] = f.up;
+    if (!f.up) { o->crash_tick[m] = t; o->first_suspect[m] = NONE32; }
+    else {
+      /* (re)join: new incarnation + announce Alive (memberlist-style; the reference's
+       * joinHosts is dead config, src/Util.hs:46) */
+      uint32_t ni = o->self_inc[m] + 1;
+      if (ni > INC_MAX) { fail(o, SWIMSIM_ERR_CAPACITY, "incarnation overflow"); return; }
+      o->self_inc[m] = ni;
+      o->counters[SWIMSIM_CTR_EVDIGEST] += h4(TAG_INC, ((uint64_t)t << 32) | m, ni, 0);
+      cand_insert(&o->pb[m], m, key_make(ni, SWIMSIM_ALIVE), (uint8_t)o->L);
+      event_add(o, t, m, m, key_make(ni, SWIMSIM_ALIVE), SWIMSIM_CAUSE_JOIN);
+      o->first_suspect[m] = NONE32;
+    }
+  }
+  if (k) { memmove(o->faults, o->faults + k, (o->nfaults - k) * sizeof *o->faults); o->nfaults -= k; }
+}
+
+int swimoracle_schedule_fault(swimoracle_t* o, uint64_t tick, uint32_t member, uint8_t up) {
+  if (!o) return SWIMSIM_ERR_INVALID;
+  if (member >= o->N || up > 1) return fail(o, SWIMSIM_ERR_INVALID, "schedule_fault: bad member/up");
+  if (tick < o->tick || tick >= 0xFFFFFFFEull) return fail(o, SWIMSIM_ERR_INVALID, "schedule_fault: tick in the past");
+  if (o->nfaults == o->faults_cap) {
+    o->faults_cap = o->faults_cap ? o->faults_cap * 2 : 64;
+    o->faults = (ofault_t*)realloc(o->faults, o->faults_cap * sizeof *o->faults);
+  }
+  ofault_t f; f.tick = (uint32_t)tick; f.member = member; f.up = up; f.order = o->fault_order++;
+  o->faults[o->nfaults++] = f;
+  qsort(o->faults, o->nfaults, sizeof *o->faults, fault_cmp);
+  return SWIMSIM_OK;
+}
+
+/* ------------------------------------------------------------------------- */
+/* the tick                                                                   */
+/* ------------------------------------------------------------------------- */
+static int one_tick(swimoracle_t* o) {
+  uint32_t t = (uint32_t)o->tick;
+  uint32_t N = o->N;
+  apply_faults(o, t);
+  if (o->poisoned) return SWIMSIM_ERR_CAPACITY;
+  o->tk = tick_key(o->cfg.seed, t);
+  o->npend = 0; o->nfails = 0;
+  for (uint32_t i = 0; i < N; i++) {
+    o->nsent[i] = 0;
+    if (o->up[i]) { failure_detector(o, i); o->counters[SWIMSIM_CTR_ACTIVE_MEMBERS]++; }
+  }
+  /* bucket the pending rumours by receiver (stable: arrival order kept) */
+  memset(o->pend_off, 0, (N + 1) * sizeof *o->pend_off);
+  for (size_t x = 0; x < o->npend; x++) o->pend_off[o->pend[x].dst + 1]++;
+  for (uint32_t i = 0; i < N; i++) o->pend_off[i + 1] += o->pend_off[i];
+  if (o->npend > o->pend_sorted_cap) {
+    o->pend_sorted_cap = o->npend * 2;
+    o->pend_sorted = (opend_t*)realloc(o->pend_sorted, o->pend_sorted_cap * sizeof *o->pend_sorted);
+  }
+  {
+    uint32_t* cur = (uint32_t*)malloc(N * sizeof *cur);
+    memcpy(cur, o->pend_off, N * sizeof *cur);
+    for (size_t x = 0; x < o->npend; x++) o->pend_sorted[cur[o->pend[x].dst]++] = o->pend[x];
+    free(cur);
+  }
+  size_t fc = 0;
+  for (uint32_t i = 0; i < N; i++) {
+    size_t f0 = fc;
+    while (fc < o->nfails && o->fails[fc].i == i) fc++;
+    if (!o->up[i]) continue;
+    end_of_tick(o, i, o->pend_sorted + o->pend_off[i], o->pend_off[i + 1] - o->pend_off[i],
+                o->fails + f0, (uint32_t)(fc - f0));
+    if (o->poisoned) return SWIMSIM_ERR_CAPACITY;
+  }
+  o->tick++;
+  return SWIMSIM_OK;
+}
+
+int swimoracle_step(swimoracle_t* o, uint32_t nticks) {
+  if (!o) return SWIMSIM_ERR_INVALID;
+  if (o->poisoned) return fail(o, SWIMSIM_ERR_STATE, "handle is poisoned by an earlier capacity error");
+  for (uint32_t k = 0; k < nticks; k++) {
+    int rc = one_tick(o);
+    if (rc) return rc;
+  }
+  return SWIMSIM_OK;
+}
+
+int swimoracle_tick(const swimoracle_t* o, uint64_t* tick) {
+  if (!o || !tick) return SWIMSIM_ERR_INVALID;
+  *tick = o->tick; return SWIMSIM_OK;
+}
+
+/* ------------------------------------------------------------------------- */
+/* create / destroy                                                           */
+/* ------------------------------------------------------------------------- */
+static int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, char* err, size_t errn) {
+  if (!in) { snprintf(err, errn, "config is NULL"); return SWIMSIM_ERR_INVALID; }
+  if (in->struct_size != sizeof *in || in->abi_version != SWIMSIM_ABI_VERSION) {
+    snprintf(err, errn, "config struct_size/abi_version mismatch"); return SWIMSIM_ERR_INVALID; }
+  *c = *in;
+  if (c->n_members < 2 || c->n_members > 0x7FFFFFFFu) { snprintf(err, errn, "n_members must be in [2, 2^31)"); return SWIMSIM_ERR_INVALID; }
+  if (c->num_to_gossip < 0) { snprintf(err, errn, "num_to_gossip must be >= 0"); return SWIMSIM_ERR_INVALID; }
+  if (c->probes_per_tick == 0) c->probes_per_tick = c->num_to_gossip;
+  if (c->indirect_k == 0) c->indirect_k = c->num_to_gossip;
+  if (c->probes_per_tick < 0 || c->probes_per_tick > 16 || c->indirect_k < 0 || c->indirect_k > 16) {
+    snprintf(err, errn, "probes_per_tick / indirect_k must be in [0,16]"); return SWIMSIM_ERR_INVALID; }
+  if (c->loss_ppm > 1000000u) { snprintf(err, errn, "loss_ppm must be <= 1000000"); return SWIMSIM_ERR_INVALID; }
+  if (c->suspicion_ticks == 0) c->suspicion_ticks = 3 * ceil_log2(c->n_members);
+  if (c->suspicion_ticks == 0) c->suspicion_ticks = 1;
+  if (c->retransmit_mult == 0) c->retransmit_mult = 3;
+  if ((uint64_t)c->retransmit_mult * ceil_log2((uint64_t)c->n_members + 1) > 255) {
+    snprintf(err, errn, "retransmit budget exceeds 255"); return SWIMSIM_ERR_INVALID; }
+  if (c->max_subjects == 0) c->max_subjects = c->n_members < 1024 ? c->n_members : 1024;
+  if (c->max_subjects > 65534u) { snprintf(err, errn, "max_subjects must be <= 65534"); return SWIMSIM_ERR_INVALID; }
+  if (c->timer_cap == 0) c->timer_cap = 64;
+  if (c->timer_cap > 32768u) { snprintf(err, errn, "timer_cap must be <= 32768"); return SWIMSIM_ERR_INVALID; }
+  if (c->event_cap == 0) c->event_cap = 1u << 20;
+  if (c->event_mask == 0) c->event_mask = SWIMSIM_EVMASK_DEFAULT;
+  if (c->n_shards == 0) c->n_shards = 1;
+  if (c->n_shards != 1 || c->shard_index != 0) { snprintf(err, errn, "oracle: sharding is driven from outside (n_shards must be 1)"); return SWIMSIM_ERR_INVALID; }
+  return SWIMSIM_OK;
+}
+
+/* makeStore / makeSelf for every member (src/Util.hs:76-101): incarnation 0, seqNo 0,
+ * empty gossip queue; bootstrap assumption: everyone knows everyone as Alive@0. */
+int swimoracle_create(const swimsim_config_t* cfg, swimoracle_t** out) {
+  if (!out) return SWIMSIM_ERR_INVALID;
+  *out = NULL;
+  swimsim_config_t c;
+  int rc = resolve_config(cfg, &c, g_create_err, sizeof g_create_err);
+  if (rc) return rc;
+  swimoracle_t* o = (swimoracle_t*)calloc(1, sizeof *o);
+  if (!o) return fail(NULL, SWIMSIM_ERR_NOMEM, "out of memory");
+  o->cfg = c; o->N = c.n_members; o->P = (uint32_t)c.probes_per_tick; o->K = (uint32_t)c.indirect_k;
+  o->S = c.suspicion_ticks; o->L = c.retransmit_mult * ceil_log2((uint64_t)c.n_members + 1);
+  {
+    uint64_t thr = ((uint64_t)c.loss_ppm << 32) / 1000000ull;
+    o->loss_thr = thr > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)thr;
+  }
+  uint32_t N = o->N;
+  o->up = (uint8_t*)malloc(N); o->self_inc = (uint32_t*)calloc(N, 4);
+  o->pb = (opb_t*)calloc(N, sizeof(opb_t)); o->timers = (otimerq_t*)calloc(N, sizeof(otimerq_t));
+  o->nsent = (uint8_t*)calloc(N, 1); o->slot_of = (uint32_t*)calloc(N, 4);
+  o->first_suspect = (uint32_t*)malloc((size_t)N * 4); o->crash_tick = (uint32_t*)malloc((size_t)N * 4);
+  o->pend_off = (uint32_t*)calloc((size_t)N + 1, 4);
+  if (!o->up || !o->self_inc || !o->pb || !o->timers || !o->nsent || !o->slot_of || !o->first_suspect || !o->crash_tick || !o->pend_off) {
+    swimoracle_destroy(o); return fail(NULL, SWIMSIM_ERR_NOMEM, "out of memory");
+  }
+  memset(o->up, 1, N);
+  memset(o->first_suspect, 0xFF, (size_t)N * 4); memset(o->crash_tick, 0xFF, (size_t)N * 4);
+  *out = o;
+  return SWIMSIM_OK;
+}
+
+void swimoracle_destroy(swimoracle_t* o) {
+  if (!o) return;
+  for (uint32_t s = 0; s < o->nslots; s++) free(o->cols[s]);
+  if (o->timers) for (uint32_t i = 0; i < o->N; i++) free(o->timers[i].v);
+  free(o->cols); free(o->subject_of); free(o->slot_of); free(o->up); free(o->self_inc); free(o->pb);
+  free(o->timers); free(o->nsent); free(o->faults); free(o->first_suspect); free(o->crash_tick);
+  free(o->pend); free(o->pend_sorted); free(o->pend_off); free(o->fails); free(o->events);
+  free(o);
+}
+
+int swimoracle_get_config(const swimoracle_t* o, swimsim_config_t* out) {
+  if (!o || !out) return SWIMSIM_ERR_INVALID;
+  *out = o->cfg; return SWIMSIM_OK;
+}
+
+/* ------------------------------------------------------------------------- */
+/* results                                                                    */
+/* ------------------------------------------------------------------------- */
+static int event_cmp(const void* a, const void* b) {
+  const swimsim_event_t* x = (const swimsim_event_t*)a; const swimsim_event_t* y = (const swimsim_event_t*)b;
+  if (x->tick != y->tick) return x->tick < y->tick ? -1 : 1;
+  if (x->observer != y->observer) return x->observer < y->observer ? -1 : 1;
+  if (x->subject != y->subject) return x->subject < y->subject ? -1 : 1;
+  uint32_t kx = key_make(x->incarnation, x->state), ky = key_make(y->incarnation, y->state);
+  if (kx != ky) return kx < ky ? -1 : 1;
+  return 0;
+}
+
+int swimoracle_drain_events(swimoracle_t* o, swimsim_event_t* buf, size_t cap, size_t* n_out) {
+  if (!o || !n_out) return SWIMSIM_ERR_INVALID;
+  qsort(o->events, o->nevents, sizeof *o->events, event_cmp);
+  size_t w = 0;
+  for (size_t x = 0; x < o->nevents; x++) {            /* collapse (tick,observer,subject) to the final key */
+    if (x + 1 < o->nevents && o->events[x + 1].tick == o->events[x].tick &&
+        o->events[x + 1].observer == o->events[x].observer && o->events[x + 1].subject == o->events[x].subject) continue;
+    o->events[w++] = o->events[x];
+  }
+  o->nevents = w;
+  *n_out = w;
+  if (w > cap || (w && !buf)) return SWIMSIM_ERR_BUFFER;
+  if (w) memcpy(buf, o->events, w * sizeof *buf);
+  o->nevents = 0;
+  return SWIMSIM_OK;
+}
+
+static int ventry_cmp(const void* a, const void* b) {
+  uint32_t x = ((const swimsim_view_entry_t*)a)->subject, y = ((const swimsim_view_entry_t*)b)->subject;
+  return x < y ? -1 : x > y;
+}
+
+/* `members` (src/Core.hs:76-77): the non-default part of observer's map */
+int swimoracle_read_view(swimoracle_t* o, uint32_t observer, swimsim_view_entry_t* buf, size_t cap, size_t* n_out) {
+  if (!o || !n_out || observer >= o->N) return SWIMSIM_ERR_INVALID;
+  size_t n = 0;
+  for (uint32_t s = 0; s < o->nslots; s++) {
+    oentry_t e = o->cols[s][observer];
+    if (e.key == 0 || o->subject_of[s] == observer) continue;
+    if (n < cap && buf) {
+      memset(&buf[n], 0, sizeof buf[n]);
+      buf[n].subject = o->subject_of[s]; buf[n].incarnation = key_inc(e.key);
+      buf[n].state = (uint8_t)key_state(e.key); buf[n].since_tick = e.since1 - 1;
+    }
+    n++;
+  }
+  *n_out = n;
+  if (n > cap || (n && !buf)) return SWIMSIM_ERR_BUFFER;
+  qsort(buf, n, sizeof *buf, ventry_cmp);
+  return SWIMSIM_OK;
+}
+
+int swimoracle_read_member(swimoracle_t* o, uint32_t m, swimsim_member_t* out) {
+  if (!o || !out || m >= o->N) return SWIMSIM_ERR_INVALID;
+  memset(out, 0, sizeof *out);
+  out->id = m; out->incarnation = o->self_inc[m]; out->up = o->up[m];
+  out->n_rumors = (uint8_t)o->pb[m].n;
+  for (int s = 0; s < o->pb[m].n; s++) {
+    out->rumors[s].subject = o->pb[m].r[s].subject; out->rumors[s].incarnation = key_inc(o->pb[m].r[s].key);
+    out->rumors[s].state = (uint8_t)key_state(o->pb[m].r[s].key); out->rumors[s].tx_left = o->pb[m].r[s].tx;
+  }
+  /* live timers = entries currently Suspect */
+  uint32_t nt = 0;
+  for (uint32_t s = 0; s < o->nslots; s++)
+    if (o->subject_of[s] != m && key_state(o->cols[s][m].key) == SWIMSIM_SUSPECT) nt++;
+  out->n_timers = (uint16_t)nt;
+  return SWIMSIM_OK;
+}
+
+int swimoracle_first_detect(swimoracle_t* o, uint64_t* out, size_t n) {
+  if (!o || !out || n != o->N) return SWIMSIM_ERR_INVALID;
+  for (uint32_t j = 0; j < o->N; j++) out[j] = o->first_suspect[j] == NONE32 ? SWIMSIM_TICK_NONE : o->first_suspect[j];
+  return SWIMSIM_OK;
+}
+
+int swimoracle_digest(swimoracle_t* o, uint64_t* out) {
+  if (!o || !out) return SWIMSIM_ERR_INVALID;
+  uint64_t D = mix64((uint64_t)TAG_TICK + o->tick);
+  for (uint32_t i = 0; i < o->N; i++) {
+    uint64_t mh = h4(TAG_SELF, i, o->self_inc[i], o->up[i]);
+    for (uint32_t s = 0; s < o->nslots; s++) {
+      oentry_t e = o->cols[s][i];
+      if (e.key == 0 || o->subject_of[s] == i) continue;
+      mh += h4(TAG_VIEW, o->subject_of[s], e.key, e.since1);
+      if (key_state(e.key) == SWIMSIM_SUSPECT) mh += h4(TAG_TIMER, o->subject_of[s], (uint64_t)e.since1 - 1 + o->S, 0);
+    }
+    for (int s = 0; s < o->pb[i].n; s++) mh += h4(TAG_PB, o->pb[i].r[s].subject, o->pb[i].r[s].key, o->pb[i].r[s].tx);
+    D += mix64(mh + mix64((uint64_t)TAG_MEMBER + i));
+    if (o->first_suspect[i] != NONE32) D += h4(TAG_FD, i, o->first_suspect[i], 0);
+  }
+  *out = D;
+  return SWIMSIM_OK;
+}
+
+int swimoracle_counters(swimoracle_t* o, uint64_t* out, size_t n) {
+  if (!o || !out || n < SWIMSIM_CTR_COUNT) return SWIMSIM_ERR_INVALID;
+  memcpy(out, o->counters, sizeof o->counters);
+  return SWIMSIM_OK;
+}
+
+/* ------------------------------------------------------------------------- */
+/* unit-level hooks                                                           */
+/* ------------------------------------------------------------------------- */
+int swimoracle_k_random_members(swimoracle_t* o, uint32_t observer, uint32_t n, const uint32_t* excludes,
+                                size_t n_excludes, uint32_t* out, size_t cap, size_t* n_out) {
+  if (!o || !n_out || observer >= o->N || n > 255) return SWIMSIM_ERR_INVALID;
+  uint32_t tmp[256];
+  o->tk = tick_key(o->cfg.seed, (uint32_t)o->tick);
+  uint32_t np = k_random_members(o, observer, n, excludes, n_excludes, P_SELECT, 0, tmp);
+  *n_out = np;
+  if (np > cap || (np && !out)) return SWIMSIM_ERR_BUFFER;
+  memcpy(out, tmp, np * sizeof *out);
+  return SWIMSIM_OK;
+}
+
+int swimoracle_set_view(swimoracle_t* o, uint32_t observer, uint32_t subject, uint8_t state, uint32_t incarnation) {
+  if (!o || observer >= o->N || subject >= o->N || state > 2 || incarnation > INC_MAX || observer == subject)
+    return SWIMSIM_ERR_INVALID;
+  oentry_t* e = view_ref(o, observer, subject);
+  if (!e) return SWIMSIM_ERR_CAPACITY;
+  e->key = key_make(incarnation, state); e->since1 = (uint32_t)o->tick + 1;
+  if (state == SWIMSIM_SUSPECT) timer_push(o, observer, subject, (uint32_t)o->tick + o->S);
+  return o->poisoned ? SWIMSIM_ERR_CAPACITY : SWIMSIM_OK;
+}
+
+int swimoracle_process(swimoracle_t* o, uint32_t self, uint32_t sender, const swimoracle_msg_t* msg,
+                       int literal_d8, swimoracle_msg_t* out, size_t cap, size_t* n_out) {
+  if (!o || !msg || !n_out || self >= o->N) return SWIMSIM_ERR_INVALID;
+  omsg_t m; memset(&m, 0, sizeof m);
+  m.m = *msg; m.relay_to = NONE32;
+  o->capture = 1; o->capture_literal_d8 = literal_d8; o->cap_out = out; o->cap_cap = out ? cap : 0; o->cap_n = 0;
+  process(o, self, sender, &m);
+  o->capture = 0;
+  *n_out = o->cap_n;
+  return o->cap_n > o->cap_cap ? SWIMSIM_ERR_BUFFER : SWIMSIM_OK;
+}
+
+/* literal suspectOrDeadNode' on one entry (src/Core.hs:142-187), subject != self, known */
+uint32_t swimoracle_reference_rule(uint32_t cur_key, uint32_t msg_key) {
+  uint32_t i = key_inc(msg_key), st = key_state(msg_key);
+  uint32_t inc = key_inc(cur_key), cs = key_state(cur_key);
+  if (st == SWIMSIM_ALIVE) return cur_key;                    /* aliveNode is unwritten (D6) */
+  if (i < inc) return cur_key;                                /* :151 `i < memberIncarnation m` */
+  if (st == SWIMSIM_SUSPECT && cs != SWIMSIM_ALIVE) return cur_key;   /* livenessCheck IsSuspect :183 */
+  if (st == SWIMSIM_DEAD && cs == SWIMSIM_DEAD) return cur_key;       /* livenessCheck IsDead :184 */
+  return key_make(i, st);                                     /* :169-176 */
+}
+
+uint32_t swimoracle_merge_rule(uint32_t cur_key, uint32_t msg_key) {
+  return msg_key > cur_key ? msg_key : cur_key;
+}
+
+/* removeDeadNodes (src/Core.hs:65-67): Map.filter (not . isDead) */
+size_t swimoracle_remove_dead_nodes(swimsim_view_entry_t* entries, size_t n) {
+  size_t w = 0;
+  for (size_t x = 0; x < n; x++) if (entries[x].state != SWIMSIM_DEAD) entries[w++] = entries[x];
+  return w;
+}
+
+int swimoracle_set_shuffle(swimoracle_t* o, uint64_t shuffle_seed) {
+  if (!o) return SWIMSIM_ERR_INVALID;
+  o->shuffle_seed = shuffle_seed; return SWIMSIM_OK;
+}

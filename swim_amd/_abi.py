@@ -1,0 +1,109 @@
+"""ctypes declarations for the C ABI in include/swimsim.h.
+
+`bind(lib, prefix)` attaches argtypes/restypes for every entry point of the header
+under the given symbol prefix and returns a namespace of callables.  The product
+uses prefix ``swimsim_`` on libswimsim.so (see _lib.py).  The parity tests reuse
+the same declarations with prefix ``swimoracle_`` on the CPU oracle library --
+that loading happens in tests/ only, never in this package.
+"""
+import ctypes as C
+
+ABI_VERSION = 1
+
+OK = 0
+ERR_INVALID, ERR_DEVICE, ERR_NOMEM, ERR_CAPACITY, ERR_STATE, ERR_BUFFER = -1, -2, -3, -4, -5, -6
+ALIVE, SUSPECT, DEAD = 0, 1, 2
+CAUSE_PROBE, CAUSE_TIMER, CAUSE_GOSSIP, CAUSE_REFUTE, CAUSE_JOIN = 0, 1, 2, 3, 4
+EVMASK_ALL = 0x1F
+EVMASK_DEFAULT = (1 << CAUSE_PROBE) | (1 << CAUSE_REFUTE) | (1 << CAUSE_JOIN)
+TICK_NONE = 0xFFFFFFFFFFFFFFFF
+
+CTR_NAMES = [
+    "pings", "direct_failed", "ping_reqs", "suspects", "false_suspects", "payloads",
+    "rumors_seen", "changes", "pb_writes", "timers_fired", "refutes", "events_dropped",
+    "active_members", "evdigest", "_14", "_15",
+]
+CTR_COUNT = 16
+
+
+class Config(C.Structure):
+    """swimsim_config_t"""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("abi_version", C.c_uint32),
+        ("num_to_gossip", C.c_int32), ("gossip_interval_us", C.c_int64),
+        ("n_members", C.c_uint32), ("seed", C.c_uint64),
+        ("probes_per_tick", C.c_int32), ("indirect_k", C.c_int32),
+        ("loss_ppm", C.c_uint32), ("suspicion_ticks", C.c_uint32),
+        ("retransmit_mult", C.c_uint32), ("max_subjects", C.c_uint32),
+        ("timer_cap", C.c_uint32), ("event_cap", C.c_uint32), ("event_mask", C.c_uint32),
+        ("device", C.c_int32), ("shard_index", C.c_uint32), ("n_shards", C.c_uint32),
+    ]
+
+
+class Event(C.Structure):
+    """swimsim_event_t"""
+    _fields_ = [("tick", C.c_uint64), ("observer", C.c_uint32), ("subject", C.c_uint32),
+                ("incarnation", C.c_uint32), ("state", C.c_uint8), ("cause", C.c_uint8),
+                ("_pad", C.c_uint16)]
+
+
+class ViewEntry(C.Structure):
+    """swimsim_view_entry_t"""
+    _fields_ = [("subject", C.c_uint32), ("incarnation", C.c_uint32), ("since_tick", C.c_uint32),
+                ("state", C.c_uint8), ("_pad", C.c_uint8 * 3)]
+
+
+class Rumor(C.Structure):
+    """swimsim_rumor_t"""
+    _fields_ = [("subject", C.c_uint32), ("incarnation", C.c_uint32), ("state", C.c_uint8),
+                ("tx_left", C.c_uint8), ("_pad", C.c_uint16)]
+
+
+class Member(C.Structure):
+    """swimsim_member_t"""
+    _fields_ = [("id", C.c_uint32), ("incarnation", C.c_uint32), ("up", C.c_uint8),
+                ("n_rumors", C.c_uint8), ("n_timers", C.c_uint16), ("rumors", Rumor * 8)]
+
+
+# name -> (restype, argtypes); the handle is an opaque void*
+_H = C.c_void_p
+_SIGS = {
+    "default_config": (C.c_int, [C.POINTER(Config)]),
+    "create": (C.c_int, [C.POINTER(Config), C.POINTER(_H)]),
+    "destroy": (None, [_H]),
+    "last_error": (C.c_char_p, [_H]),
+    "schedule_fault": (C.c_int, [_H, C.c_uint64, C.c_uint32, C.c_uint8]),
+    "step": (C.c_int, [_H, C.c_uint32]),
+    "tick": (C.c_int, [_H, C.POINTER(C.c_uint64)]),
+    "drain_events": (C.c_int, [_H, C.POINTER(Event), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "read_view": (C.c_int, [_H, C.c_uint32, C.POINTER(ViewEntry), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "read_member": (C.c_int, [_H, C.c_uint32, C.POINTER(Member)]),
+    "first_detect": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_size_t]),
+    "digest": (C.c_int, [_H, C.POINTER(C.c_uint64)]),
+    "counters": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_size_t]),
+    "k_random_members": (C.c_int, [_H, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_size_t,
+                                   C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "set_view": (C.c_int, [_H, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint32]),
+    "get_config": (C.c_int, [_H, C.POINTER(Config)]),
+}
+
+ENTRY_POINTS = tuple(_SIGS)
+
+
+class Namespace:
+    pass
+
+
+def bind(lib, prefix):
+    """Resolve every entry point of swimsim.h as `prefix + name` in `lib`.
+
+    Raises AttributeError naming the first missing symbol (fail loudly)."""
+    ns = Namespace()
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, prefix + name)
+        fn.restype = res
+        fn.argtypes = args
+        setattr(ns, name, fn)
+    ns.lib = lib
+    ns.prefix = prefix
+    return ns

@@ -1,0 +1,24 @@
+"""Loads the product library libswimsim.so (HIP / gfx950).  No fallback: if the
+library is missing or a symbol of include/swimsim.h is absent this raises."""
+import ctypes as C
+import os
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libswimsim.so")
+
+_cached = None
+
+
+def load():
+    """Return the bound ABI namespace of libswimsim.so (prefix swimsim_)."""
+    global _cached
+    if _cached is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libswimsim.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        _cached = _abi.bind(lib, "swimsim_")
+    return _cached
