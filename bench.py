@@ -1,0 +1,168 @@
+#!/usr/bin/env python
+"""bench.py -- member-ticks/sec of the SWIM tick on MI355X (BASELINE.json metric).
+
+A "step" is one protocol period (tick) of the hot path over the whole simulated population.
+Workload at N=1 = BASELINE config "1 048 576 members, k=3, on 1 MI355X" in the
+dissemination-saturated regime: ~1 member crashes per tick, so
+every Ping/Ack carries a full 8-rumour piggyback payload and each member accepts ~2 view
+changes per tick.  State is resident in HBM before the timed region; faults are pre-scheduled.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     : dominant kernel (merge_kernel) algorithmic bytes / HIP-event duration vs 8 TB/s
+  cpu_baseline : the CPU oracle (a "port": the Haskell reference cannot be built here, no GHC)
+                 timed on a bounded sample of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_MEMBERS = 1 << 20
+
+
+def algorithmic_bytes(c0, c1, n_members, ticks, P, K):
+    """A = 16 + P + 64 d + 16 r + 128 c + f k  bytes per member-tick, from the
+    semantic event counters kept by the kernels (d payloads delivered, r view entries changed,
+    c piggyback lines rewritten, f failed direct probes).  Returns (A_total, A_merge, A_probe):
+    the probe kernel owns the P + f k liveness gathers, the merge kernel everything else."""
+    mt = float(n_members) * ticks
+    d = (c1["payloads"] - c0["payloads"]) / mt
+    r = (c1["changes"] - c0["changes"]) / mt
+    c = (c1["pb_writes"] - c0["pb_writes"]) / mt
+    f = (c1["direct_failed"] - c0["direct_failed"]) / mt
+    a_probe = P + f * K
+    a_merge = 16.0 + 64.0 * d + 16.0 * r + 128.0 * c
+    return a_probe + a_merge, a_merge, a_probe, {"d": d, "r": r, "c": c, "f": f}
+
+
+def first_detection_latency(sim, crashes, lo_tick, hi_tick):
+    fd = sim.firstDetectionArray()
+    lat = [int(fd[m]) - t + 1 for (t, m) in crashes if lo_tick <= t < hi_tick and int(fd[m]) != 0xFFFFFFFFFFFFFFFF]
+    return (sum(lat) / len(lat), len(lat)) if lat else (None, 0)
+
+
+def cpu_baseline(budget_ticks=60, warm_ticks=150, n_members=65536):
+    """The oracle (oracle/swim_oracle.c, single thread) on a 65 536-member slice of the workload at
+    the same per-member rumour load (~1 crash per tick), warm-up excluded."""
+    from swim_amd import Sim, workloads
+    from tests import oracle_binding          # checker only: never the thing shipped
+    total = warm_ticks + budget_ticks
+    sc, crashes, _ = workloads.saturated(n_members, total)
+    s = Sim.create(oracle_binding.load(), sc)
+    workloads.apply_crashes(s, crashes)
+    s.step(warm_ticks)
+    t0 = time.perf_counter()
+    s.step(budget_ticks)
+    dt = time.perf_counter() - t0
+    s.close()
+    return {"value": n_members * budget_ticks / dt, "unit": "member-ticks/s", "cores": 1, "kind": "port",
+            "sample": "%d-member slice, same per-member load (~1 crash/tick), ticks %d-%d, oracle/swim_oracle.c "
+                      "single thread; reference Haskell not timed: no GHC in image" % (n_members, warm_ticks, total),
+            "host_cores_available": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=150)
+    ap.add_argument("--members", type=int, default=N_MEMBERS, help="members per GPU")
+    ap.add_argument("--regime", default="saturated", choices=["saturated", "quiescent"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from swim_amd import Sim, _lib, workloads
+    total = args.warmup + args.steps
+    n = args.members
+    if args.regime == "saturated":
+        sc, crashes, _ = workloads.saturated(n, total, seed=1 + rank)
+    else:
+        sc, crashes, _ = workloads.quiescent(n, total, seed=1 + rank)
+    sc.device = local_rank
+    sim = Sim.create(_lib.load(), sc)
+    workloads.apply_crashes(sim, crashes)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sim.step(args.warmup)
+    c0 = sim.counters()
+    sim.kernelTimingEnable(True)
+    barrier()
+    t0 = time.perf_counter()
+    sim.step(args.steps)                      # blocking: returns after the stream has drained
+    barrier()
+    dt = time.perf_counter() - t0
+    kt = sim.kernelTiming()
+    c1 = sim.counters()
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        P = sim.resolved.probes_per_tick
+        K = sim.resolved.indirect_k
+        a_tot, a_merge, a_probe, rates = algorithmic_bytes(c0, c1, n, args.steps, P, K)
+        merge_s = kt["merge_ms"] / 1e3 / max(1, kt["ticks"])
+        probe_s = kt["probe_ms"] / 1e3 / max(1, kt["ticks"])
+        achieved = a_merge * n / merge_s / 1e9 if merge_s > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("regime") == args.regime and tj.get("members") == n:
+                traffic = tj.get("merge_kernel_hbm_bytes_per_launch")
+        lat, nlat = first_detection_latency(sim, crashes, args.warmup, total - 2)
+        out = {
+            "metric": "member-ticks/sec at N=1M simulated members; mean first-detection latency (ticks)",
+            "value": n * world * args.steps / dt,
+            "unit": "member-ticks/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "config3(%s): %d members/GPU, k=3, ~1 crash per tick (hashed schedule), "
+                                   "suspicion %d ticks, retransmit %dx log2 N" % (
+                                       args.regime, n, sim.resolved.suspicion_ticks, sim.resolved.retransmit_mult),
+                       "members_per_gpu": n, "num_to_gossip": sim.resolved.num_to_gossip,
+                       "parallelism": "1 GPU" if world == 1 else "%d independent replica clusters (cross-shard exchange: see DESIGN.md)" % world},
+            "ticks_per_s": args.steps / dt,
+            "mean_first_detection_latency_ticks": lat, "crashes_measured": nlat,
+            "per_member_tick": rates,
+            "roofline": {"bound": "hbm", "kernel": "merge_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_member_tick": a_merge,
+                         "avg_launch_us": merge_s * 1e6,
+                         "whole_tick": {"algorithmic_bytes_per_member_tick": a_tot,
+                                        "probe_kernel_us": probe_s * 1e6,
+                                        "achieved_GBs": a_tot * n / (merge_s + probe_s) / 1e9 if merge_s + probe_s > 0 else 0.0}},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    sim.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -91,6 +91,9 @@ typedef struct swimsim_config {
   uint32_t timer_cap;          /* pending suspicion timers per member; 0 -> 64        */
   uint32_t event_cap;          /* event ring capacity; 0 -> 1<<20                     */
   uint32_t event_mask;         /* bit per SWIMSIM_CAUSE_*; 0 -> SWIMSIM_EVMASK_DEFAULT */
+  uint32_t inbox_cap;          /* per-member delivery slots per tick; 0 -> sized from the
+                                  expected fan-in (2P + 4PK*P[direct probe fails]); rarer
+                                  excess goes through an exact overflow list             */
   int32_t  device;             /* HIP device ordinal                                  */
   uint32_t shard_index;        /* this handle owns members [lo,hi) of the population  */
   uint32_t n_shards;           /* 0/1 -> unsharded                                    */
@@ -233,6 +236,15 @@ int swimsim_set_view(swimsim_t* h, uint32_t observer, uint32_t subject, uint8_t 
 
 /* Resolved configuration (defaults filled in). */
 int swimsim_get_config(const swimsim_t* h, swimsim_config_t* out);
+
+/* ---- measurement ------------------------------------------------------------ */
+
+/* When enabled, swimsim_step brackets every tick-kernel launch with HIP events on the
+ * library's own stream (torch.cuda.Event would not see it) and accumulates the elapsed
+ * times.  out[0] = total ms in probe_kernel, out[1] = total ms in merge_kernel,
+ * out[2] = number of ticks measured; reading resets nothing, enabling resets. */
+int swimsim_kernel_timing_enable(swimsim_t* h, int enable);
+int swimsim_kernel_timing(swimsim_t* h, double* out, size_t n);
 
 #ifdef __cplusplus
 }

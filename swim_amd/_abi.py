@@ -36,6 +36,7 @@ class Config(C.Structure):
         ("loss_ppm", C.c_uint32), ("suspicion_ticks", C.c_uint32),
         ("retransmit_mult", C.c_uint32), ("max_subjects", C.c_uint32),
         ("timer_cap", C.c_uint32), ("event_cap", C.c_uint32), ("event_mask", C.c_uint32),
+        ("inbox_cap", C.c_uint32),
         ("device", C.c_int32), ("shard_index", C.c_uint32), ("n_shards", C.c_uint32),
     ]
 
@@ -87,7 +88,13 @@ _SIGS = {
     "get_config": (C.c_int, [_H, C.POINTER(Config)]),
 }
 
-ENTRY_POINTS = tuple(_SIGS)
+# entry points only the product library has (measurement plumbing; no oracle counterpart)
+_PRODUCT_ONLY = {
+    "kernel_timing_enable": (C.c_int, [_H, C.c_int]),
+    "kernel_timing": (C.c_int, [_H, C.POINTER(C.c_double), C.c_size_t]),
+}
+
+ENTRY_POINTS = tuple(_SIGS) + tuple(_PRODUCT_ONLY)
 
 
 class Namespace:
@@ -99,7 +106,10 @@ def bind(lib, prefix):
 
     Raises AttributeError naming the first missing symbol (fail loudly)."""
     ns = Namespace()
-    for name, (res, args) in _SIGS.items():
+    sigs = dict(_SIGS)
+    if prefix == "swimsim_":
+        sigs.update(_PRODUCT_ONLY)
+    for name, (res, args) in sigs.items():
         fn = getattr(lib, prefix + name)
         fn.restype = res
         fn.argtypes = args

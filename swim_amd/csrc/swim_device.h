@@ -1,0 +1,173 @@
+// swim_device.h -- device-side data layout and spec arithmetic for the SWIM tick (gfx950).
+//
+// Spec: DESIGN.md section 2.  Reference rules cited per function (paths relative to the
+// jpfuentes2/swim checkout).  This header is the PRODUCT's own statement of the spec hashes
+// and packings; the CPU oracle under oracle/ restates them independently.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace swim {
+
+// ---- spec constants -------------------------------------------------------------------
+constexpr int PB_SLOTS = 8;           // piggyback buffer slots per member (D5): one 64-B line
+constexpr int SEL_ATTEMPTS = 8;       // rejection-sampling attempts per pick (H4)
+constexpr uint32_t INC_MAX = 0x3FFFFFu;
+constexpr uint32_t NONE32 = 0xFFFFFFFFu;
+constexpr int BLOCK = 256;
+
+enum { ST_ALIVE = 0, ST_SUSPECT = 1, ST_DEAD = 2 };
+enum { P_SELECT = 1, P_PROXY = 2, P_L_PING = 3, P_L_ACK = 4, P_L_REQ = 5, P_L_FWD = 6, P_L_BACK = 7,
+       P_L_RELAY = 8 };
+enum : uint64_t { TAG_SELF = 0x53454c46u, TAG_VIEW = 0x56494557u, TAG_PB = 0x50425546u,
+                  TAG_TIMER = 0x54494d52u, TAG_FD = 0x46444554u, TAG_EV = 0x45564e54u,
+                  TAG_INC = 0x494e4352u, TAG_TICK = 0x5449434bu, TAG_MEMBER = 0x4d454d42u };
+
+// globals word indices (DevState::g)
+enum { G_NSLOTS = 0, G_ERR = 1, G_EVCUR = 2, G_OVF0 = 3, G_OVF1 = 4, G_WORDS = 8 };
+enum { ERRF_SUBJECTS = 1, ERRF_TIMERS = 2, ERRF_OVF = 4, ERRF_INC = 8 };
+
+// counter slots (same order as SWIMSIM_CTR_* in include/swimsim.h)
+enum { C_PINGS = 0, C_DIRECT_FAILED, C_PING_REQS, C_SUSPECTS, C_FALSE_SUSPECTS, C_PAYLOADS,
+       C_RUMORS_SEEN, C_CHANGES, C_PB_WRITES, C_TIMERS_FIRED, C_REFUTES, C_EVENTS_DROPPED,
+       C_ACTIVE, C_EVDIGEST, C_COUNT = 16 };
+
+// ---- hashes (replace the global StdGen of src/Util.hs:40, F7) -----------
+__host__ __device__ inline uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ inline uint32_t tick_key(uint64_t seed, uint32_t t) {
+  return mix32((uint32_t)seed + mix32((uint32_t)(seed >> 32) + mix32(t + 0x9E3779B9u)));
+}
+// H(tk, a, b, c); mk = mix32(tk ^ a) is hoisted per member
+__host__ __device__ inline uint32_t hash_mk(uint32_t mk, uint32_t b, uint32_t c) {
+  return mix32(mix32(mk + b) ^ c);
+}
+__host__ __device__ inline uint64_t mix64(uint64_t x) {
+  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
+  return x;
+}
+__host__ __device__ inline uint64_t h4(uint64_t tag, uint64_t a, uint64_t b, uint64_t c) {
+  return mix64(mix64(mix64(mix64(tag) + a) + b) + c);
+}
+
+// ---- device state (struct of arrays) -----------------------------------------------------
+// Per-member arrays are indexed by member id so that a wave of 64 consecutive members
+// issues coalesced loads.  View entries are member-major [member][slot]: slots are handed out
+// in time order, so the rumours circulating in one tick occupy ADJACENT slots and all of a
+// member's lookups in that tick fall into 2-3 64-B sectors of its own row.
+struct DevState {
+  uint32_t N, P, K, S, L, loss_thr, R_max, timer_cap, event_cap, event_mask, nblocks;
+  uint32_t inbox_cap, ovf_cap;  // per-member delivery slots; exact overflow list capacity
+  uint32_t* minfo;         // per member, ONE gather per probe target:
+                           //   bits 0-15 rumour slot+1 of this member as a subject (0 none,
+                           //   0xFFFF being allocated), 16-19 valid piggyback slots,
+                           //   20 which pb buffer is current, 21 up (ground truth)
+  uint16_t* probe_out;     // nsent | nfail<<5 | n own-ack sources<<10, probe -> merge kernel
+  uint32_t* ackfrom;       // [N][P] sources whose Ack reached this member with a payload
+  uint32_t* inbox_cnt;     // deliveries to this member this tick
+  uint32_t* inbox;         // [N][inbox_cap] source ids (bit31 = source's pb buffer)
+  uint4* hot;              // {storeIncarnation, timer ring head, timer ring count, next deadline}
+  uint32_t* subject_of;    // slot -> subject
+  uint32_t* fail;          // [N][P] targets whose probe ended without ack
+  uint2* ring;             // [N][timer_cap] {slot, deadline}: FIFO of suspicion timers
+  uint2* V;                // [N][R_max] {key = inc<<2|state, lastChange+1}
+  uint64_t* pb;            // [2][N][PB_SLOTS] {lo: slot | tx<<16, hi: key}
+  uint32_t* first_suspect;
+  uint32_t* crash_tick;
+  uint32_t* g;             // globals (G_*)
+  uint2* ovf;              // [2][ovf_cap] inbox overflow (dst, src)
+  uint4* events;           // {tick, observer, subject, key<<8|cause}
+  uint64_t* blk;           // [nblocks+1][C_COUNT] per-block counter rows (no atomics)
+};
+
+__device__ inline size_t vidx(const DevState& s, uint32_t i, uint32_t slot) {
+  return (size_t)i * s.R_max + slot;
+}
+
+__device__ inline bool lost(const DevState& s, uint32_t tk, uint32_t purpose, uint32_t src, uint32_t dst,
+                            uint32_t idx) {
+  if (!s.loss_thr) return false;
+  return hash_mk(mix32(tk ^ src), (purpose << 24) | idx, dst) < s.loss_thr;
+}
+
+// minfo fields
+constexpr uint32_t MI_SLOT = 0xFFFFu, MI_PBN_SHIFT = 16, MI_PBN = 0xFu << 16, MI_BUF = 1u << 20,
+                   MI_UP = 1u << 21, MI_PB = MI_PBN | MI_BUF;
+__device__ inline uint32_t mi_pbn(uint32_t mi) { return (mi >> MI_PBN_SHIFT) & 0xFu; }
+__device__ inline uint32_t mi_buf(uint32_t mi) { return (mi >> 20) & 1u; }
+__device__ inline bool mi_up(uint32_t mi) { return (mi & MI_UP) != 0; }
+// source word for "merge this member's current piggyback line": id | buffer<<31
+__device__ inline uint32_t mi_src(uint32_t id, uint32_t mi) { return id | (mi_buf(mi) << 31); }
+
+// `isAlive` on member i's view of c (src/Core.hs:33-34, 72-74); mc = minfo[c]
+__device__ inline bool view_alive(const DevState& s, uint32_t i, uint32_t mc) {
+  const uint32_t sl = mc & MI_SLOT;
+  if (sl == 0 || sl == MI_SLOT) return true;       // nobody ever gossiped about c: Alive@0
+  return (s.V[vidx(s, i, sl - 1)].x & 3u) == ST_ALIVE;
+}
+
+// kRandomMembers (src/Core.hs:69-74) + shuffle (src/Util.hs:37-42) as n draws without
+// replacement: rejection sampling on the counter RNG, then a cyclic scan so that "fewer than
+// n candidates => all of them" holds exactly (test/Spec.hs:117-128).  Self never eligible (D15).
+template <int MAXN>
+__device__ inline uint32_t select_members(const DevState& s, uint32_t mk, uint32_t i, uint32_t n,
+                                          uint32_t purpose, uint32_t hi_idx, const uint32_t* excl,
+                                          uint32_t nexcl, uint32_t (&out)[MAXN],
+                                          uint32_t (&info)[MAXN]) {
+  uint32_t np = 0;
+  const uint32_t N = s.N;
+  // Issue the first-attempt gathers of all picks together (independent loads); eligibility is
+  // then decided pick by pick in order, exactly as the sequential definition does.
+  uint32_t c0[MAXN <= 16 ? MAXN : 1], m0[MAXN <= 16 ? MAXN : 1];
+  if (MAXN <= 16) {
+#pragma unroll
+    for (int p = 0; p < (MAXN <= 16 ? MAXN : 1); ++p) {
+      c0[p] = 0; m0[p] = 0;
+      if ((uint32_t)p < n) {
+        const uint32_t base = (purpose << 24) | (purpose == P_SELECT ? ((uint32_t)p << 8) : ((hi_idx << 16) | ((uint32_t)p << 8)));
+        c0[p] = __umulhi(hash_mk(mk, base, 0), N);
+        m0[p] = s.minfo[c0[p]];
+      }
+    }
+  }
+  for (uint32_t p = 0; p < (uint32_t)MAXN; ++p) {
+    if (p >= n) break;
+    uint32_t c = 0, mc = 0;
+    bool found = false;
+    const uint32_t base = (purpose << 24) | (purpose == P_SELECT ? (p << 8) : ((hi_idx << 16) | (p << 8)));
+    auto eligible = [&](uint32_t cand, bool have, uint32_t mhave) -> bool {
+      if (cand == i) return false;
+      for (uint32_t e = 0; e < nexcl; ++e) if (excl[e] == cand) return false;
+      bool dup = false;
+      for (int e = 0; e < MAXN; ++e) dup |= ((uint32_t)e < np) && (out[e] == cand);
+      if (dup) return false;
+      mc = have ? mhave : s.minfo[cand];
+      return view_alive(s, i, mc);
+    };
+    for (uint32_t a = 0; a < SEL_ATTEMPTS; ++a) {
+      bool have = false; uint32_t mh = 0;
+      if (MAXN <= 16 && a == 0) {
+        have = true;
+        for (int e = 0; e < (MAXN <= 16 ? MAXN : 1); ++e) if ((uint32_t)e == p) { c = c0[e]; mh = m0[e]; }
+      } else {
+        c = __umulhi(hash_mk(mk, base | a, 0), N);
+      }
+      if (eligible(c, have, mh)) { found = true; break; }
+    }
+    if (!found) {
+      uint32_t cs = (c + 1 == N) ? 0 : c + 1;
+      for (uint32_t d = 0; d < N; ++d) {
+        c = cs + d; if (c >= N) c -= N;
+        if (eligible(c, false, 0)) { found = true; break; }
+      }
+    }
+    if (!found) break;
+    for (int e = 0; e < MAXN; ++e) if ((uint32_t)e == np) { out[e] = c; info[e] = mc; }
+    ++np;
+  }
+  return np;
+}
+
+}  // namespace swim

@@ -1,0 +1,505 @@
+// swimsim.hip -- C ABI (include/swimsim.h) over the gfx950 tick kernels.
+//
+// Host side of libswimsim.so: owns device memory, the fault schedule and the launch
+// sequence (per tick: [fault_kernel] -> probe_kernel -> merge_kernel on one HIP stream).
+// There is no CPU implementation behind this ABI: without a HIP device swimsim_create fails.
+#include "../../include/swimsim.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "swim_kernels.h"
+
+using namespace swim;
+
+namespace {
+
+struct Fault { uint32_t tick, member, up, order; };
+
+thread_local std::string g_create_err;
+
+uint32_t ceil_log2(uint64_t x) { uint32_t r = 0; while ((1ull << r) < x) r++; return r; }
+
+}  // namespace
+
+struct swimsim {
+  swimsim_config_t cfg{};
+  DevState d{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  uint64_t tick = 0;
+  std::vector<Fault> faults;      // sorted by (tick, order)
+  uint32_t fault_order = 0;
+  FaultRec* d_faults = nullptr; size_t d_faults_cap = 0;
+  unsigned long long* d_scratch64 = nullptr;   // digest accumulator
+  uint32_t* d_sel = nullptr;                   // [0..255] picks, [256] count, [257..] excludes
+  size_t d_sel_cap = 0;
+  std::vector<void*> allocs;
+  std::vector<swimsim_event_t> host_events;    // drained from the device ring, not yet handed out
+  bool timing = false;                         // HIP-event timing of the tick kernels
+  std::vector<hipEvent_t> ev_pool;             // 3 events per tick: before probe, between, after merge
+  double probe_ms = 0, merge_ms = 0; uint64_t timed_ticks = 0;
+  bool poisoned = false;
+  std::string err;
+};
+
+namespace {
+
+int set_err(swimsim* h, int code, const std::string& msg) {
+  if (h) { h->err = msg; if (code == SWIMSIM_ERR_CAPACITY) h->poisoned = true; }
+  else g_create_err = msg;
+  return code;
+}
+
+#define HIPCHK(h, expr)                                                                         \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return set_err((h), e_ == hipErrorOutOfMemory ? SWIMSIM_ERR_NOMEM : SWIMSIM_ERR_DEVICE,   \
+                     std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+  } while (0)
+
+template <typename T>
+int dev_alloc(swimsim* h, T** p, size_t count, int fill_byte) {
+  void* q = nullptr;
+  size_t bytes = count * sizeof(T);
+  if (bytes == 0) bytes = sizeof(T);
+  HIPCHK(h, hipMalloc(&q, bytes));
+  h->allocs.push_back(q);
+  HIPCHK(h, hipMemsetAsync(q, fill_byte, bytes, h->stream));
+  *p = static_cast<T*>(q);
+  return SWIMSIM_OK;
+}
+
+int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, std::string* err) {
+  if (!in) { *err = "config is NULL"; return SWIMSIM_ERR_INVALID; }
+  if (in->struct_size != sizeof *in || in->abi_version != SWIMSIM_ABI_VERSION) {
+    *err = "config struct_size/abi_version mismatch"; return SWIMSIM_ERR_INVALID; }
+  *c = *in;
+  if (c->n_members < 2 || c->n_members > 0x7FFFFFFFu) { *err = "n_members must be in [2, 2^31)"; return SWIMSIM_ERR_INVALID; }
+  if (c->num_to_gossip < 0) { *err = "num_to_gossip must be >= 0"; return SWIMSIM_ERR_INVALID; }
+  if (c->probes_per_tick == 0) c->probes_per_tick = c->num_to_gossip;
+  if (c->indirect_k == 0) c->indirect_k = c->num_to_gossip;
+  if (c->probes_per_tick < 0 || c->probes_per_tick > 16 || c->indirect_k < 0 || c->indirect_k > 16) {
+    *err = "probes_per_tick / indirect_k must be in [0,16]"; return SWIMSIM_ERR_INVALID; }
+  if (c->loss_ppm > 1000000u) { *err = "loss_ppm must be <= 1000000"; return SWIMSIM_ERR_INVALID; }
+  if (c->suspicion_ticks == 0) c->suspicion_ticks = 3 * ceil_log2(c->n_members);
+  if (c->suspicion_ticks == 0) c->suspicion_ticks = 1;
+  if (c->retransmit_mult == 0) c->retransmit_mult = 3;
+  if ((uint64_t)c->retransmit_mult * ceil_log2((uint64_t)c->n_members + 1) > 255) {
+    *err = "retransmit budget exceeds 255"; return SWIMSIM_ERR_INVALID; }
+  if (c->max_subjects == 0) c->max_subjects = c->n_members < 1024 ? c->n_members : 1024;
+  if (c->max_subjects > 65534u) { *err = "max_subjects must be <= 65534"; return SWIMSIM_ERR_INVALID; }
+  if (c->timer_cap == 0) c->timer_cap = 64;
+  if (c->timer_cap > 32768u) { *err = "timer_cap must be <= 32768"; return SWIMSIM_ERR_INVALID; }
+  if (c->event_cap == 0) c->event_cap = 1u << 20;
+  if (c->event_mask == 0) c->event_mask = SWIMSIM_EVMASK_DEFAULT;
+  if (c->inbox_cap == 0) {
+    // expected deliveries per member-tick if every message carried a payload:
+    // P pings in + P acks in + 4 hops per proxied probe
+    const double l = c->loss_ppm / 1e6, pf = 1.0 - (1.0 - l) * (1.0 - l);
+    const double lam = 2.0 * c->probes_per_tick + 4.0 * c->probes_per_tick * c->indirect_k * pf;
+    uint32_t cap = lam <= 8.0 ? 16u : (uint32_t)(lam + 6.0 * std::sqrt(lam) + 8.0);
+    c->inbox_cap = std::min<uint32_t>(1024u, (cap + 15u) & ~15u);
+  }
+  if (c->inbox_cap > 4096u) { *err = "inbox_cap must be <= 4096"; return SWIMSIM_ERR_INVALID; }
+  if (c->n_shards == 0) c->n_shards = 1;
+  if (c->n_shards != 1 || c->shard_index != 0) { *err = "sharded handles are created through swimsim_shard_* (n_shards must be 1 here)"; return SWIMSIM_ERR_INVALID; }
+  return SWIMSIM_OK;
+}
+
+int check_device_errors(swimsim* h) {
+  uint32_t g[G_WORDS];
+  HIPCHK(h, hipMemcpy(g, h->d.g, sizeof g, hipMemcpyDeviceToHost));
+  if (g[G_ERR]) {
+    std::string m = "capacity exceeded:";
+    if (g[G_ERR] & ERRF_SUBJECTS) m += " max_subjects";
+    if (g[G_ERR] & ERRF_TIMERS) m += " timer_cap";
+    if (g[G_ERR] & ERRF_OVF) m += " inbox-overflow-list";
+    if (g[G_ERR] & ERRF_INC) m += " incarnation-bits";
+    return set_err(h, SWIMSIM_ERR_CAPACITY, m);
+  }
+  return SWIMSIM_OK;
+}
+
+int pull_events(swimsim* h) {
+  uint32_t g[G_WORDS];
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(g, h->d.g, sizeof g, hipMemcpyDeviceToHost));
+  uint32_t n = std::min(g[G_EVCUR], h->d.event_cap);
+  if (n) {
+    std::vector<uint4> raw(n);
+    HIPCHK(h, hipMemcpy(raw.data(), h->d.events, (size_t)n * sizeof(uint4), hipMemcpyDeviceToHost));
+    h->host_events.reserve(h->host_events.size() + n);
+    for (const uint4& r : raw) {
+      swimsim_event_t e{};
+      e.tick = r.x; e.observer = r.y; e.subject = r.z;
+      e.cause = (uint8_t)(r.w & 0xFFu);
+      const uint32_t key = r.w >> 8;
+      e.state = (uint8_t)(key & 3u); e.incarnation = key >> 2;
+      h->host_events.push_back(e);
+    }
+  }
+  if (g[G_EVCUR]) HIPCHK(h, hipMemset(h->d.g + G_EVCUR, 0, sizeof(uint32_t)));
+  auto key_of = [](const swimsim_event_t& e) { return (e.incarnation << 2) | e.state; };
+  std::sort(h->host_events.begin(), h->host_events.end(), [&](const swimsim_event_t& a, const swimsim_event_t& b) {
+    if (a.tick != b.tick) return a.tick < b.tick;
+    if (a.observer != b.observer) return a.observer < b.observer;
+    if (a.subject != b.subject) return a.subject < b.subject;
+    return key_of(a) < key_of(b);
+  });
+  // collapse (tick, observer, subject) to the final (largest) key
+  size_t w = 0;
+  for (size_t x = 0; x < h->host_events.size(); ++x) {
+    if (x + 1 < h->host_events.size() && h->host_events[x + 1].tick == h->host_events[x].tick &&
+        h->host_events[x + 1].observer == h->host_events[x].observer &&
+        h->host_events[x + 1].subject == h->host_events[x].subject) continue;
+    h->host_events[w++] = h->host_events[x];
+  }
+  h->host_events.resize(w);
+  return SWIMSIM_OK;
+}
+
+template <int PMAX>
+void launch_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev) {
+  if (ev) (void)hipEventRecord(ev[0], h->stream);
+  hipLaunchKernelGGL((probe_kernel<PMAX>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk);
+  if (ev) (void)hipEventRecord(ev[1], h->stream);
+  hipLaunchKernelGGL(merge_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
+  if (ev) (void)hipEventRecord(ev[2], h->stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int swimsim_default_config(swimsim_config_t* cfg) {
+  if (!cfg) return SWIMSIM_ERR_INVALID;
+  std::memset(cfg, 0, sizeof *cfg);
+  cfg->struct_size = (uint32_t)sizeof *cfg;
+  cfg->abi_version = SWIMSIM_ABI_VERSION;
+  cfg->num_to_gossip = 10;           // src/Util.hs:48
+  cfg->gossip_interval_us = 200000;  // src/Util.hs:49
+  return SWIMSIM_OK;
+}
+
+const char* swimsim_last_error(const swimsim_t* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+void swimsim_destroy(swimsim_t* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void* p : h->allocs) (void)hipFree(p);
+  if (h->d_faults) (void)hipFree(h->d_faults);
+  if (h->d_sel) (void)hipFree(h->d_sel);
+  for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
+  if (!out) return SWIMSIM_ERR_INVALID;
+  *out = nullptr;
+  swimsim_config_t c;
+  std::string e;
+  int rc = resolve_config(cfg, &c, &e);
+  if (rc) return set_err(nullptr, rc, e);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return set_err(nullptr, SWIMSIM_ERR_DEVICE, "no HIP device visible (libswimsim has no CPU fallback)");
+  if (c.device < 0 || c.device >= ndev) return set_err(nullptr, SWIMSIM_ERR_INVALID, "device ordinal out of range");
+  swimsim* h = new (std::nothrow) swimsim();
+  if (!h) return set_err(nullptr, SWIMSIM_ERR_NOMEM, "out of host memory");
+  h->cfg = c; h->device = c.device;
+  auto bail = [&](int code) { g_create_err = h->err; swimsim_destroy(h); return code; };
+#define CK(expr) do { int rc_ = (expr); if (rc_) return bail(rc_); } while (0)
+#define HK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { h->err = std::string(#expr) + ": " + hipGetErrorString(e_); return bail(e_ == hipErrorOutOfMemory ? SWIMSIM_ERR_NOMEM : SWIMSIM_ERR_DEVICE); } } while (0)
+  HK(hipSetDevice(h->device));
+  HK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  DevState& d = h->d;
+  const uint32_t N = c.n_members;
+  d.N = N; d.P = (uint32_t)c.probes_per_tick; d.K = (uint32_t)c.indirect_k; d.S = c.suspicion_ticks;
+  d.L = c.retransmit_mult * ceil_log2((uint64_t)N + 1);
+  {
+    uint64_t thr = ((uint64_t)c.loss_ppm << 32) / 1000000ull;
+    d.loss_thr = thr > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)thr;
+  }
+  d.R_max = c.max_subjects; d.timer_cap = c.timer_cap; d.event_cap = c.event_cap; d.event_mask = c.event_mask;
+  d.nblocks = (N + BLOCK - 1) / BLOCK;
+  d.inbox_cap = c.inbox_cap;
+  d.ovf_cap = std::max<uint32_t>(1u << 16, N / 8);
+  CK(dev_alloc(h, &d.minfo, N, 0));
+  CK(dev_alloc(h, &d.probe_out, N, 0));
+  CK(dev_alloc(h, &d.ackfrom, (size_t)N * (d.P ? d.P : 1), 0));
+  CK(dev_alloc(h, &d.inbox_cnt, N, 0));
+  CK(dev_alloc(h, &d.inbox, (size_t)N * d.inbox_cap, 0));
+  CK(dev_alloc(h, &d.hot, N, 0));
+  CK(dev_alloc(h, &d.subject_of, (size_t)d.R_max, 0));
+  CK(dev_alloc(h, &d.fail, (size_t)N * (d.P ? d.P : 1), 0));
+  CK(dev_alloc(h, &d.ring, (size_t)N * d.timer_cap, 0));
+  CK(dev_alloc(h, &d.V, (size_t)N * d.R_max, 0));
+  CK(dev_alloc(h, &d.pb, (size_t)2 * N * PB_SLOTS, 0));
+  CK(dev_alloc(h, &d.first_suspect, N, 0xFF));
+  CK(dev_alloc(h, &d.crash_tick, N, 0xFF));
+  CK(dev_alloc(h, &d.g, (size_t)G_WORDS, 0));
+  CK(dev_alloc(h, &d.ovf, (size_t)2 * d.ovf_cap, 0));
+  CK(dev_alloc(h, &d.events, (size_t)d.event_cap, 0));
+  CK(dev_alloc(h, &d.blk, ((size_t)d.nblocks + 1) * C_COUNT, 0));
+  CK(dev_alloc(h, &h->d_scratch64, (size_t)1, 0));
+  hipLaunchKernelGGL(init_members_kernel, dim3(d.nblocks), dim3(BLOCK), 0, h->stream, d.hot, d.minfo, N);
+  HK(hipGetLastError());
+  HK(hipStreamSynchronize(h->stream));
+#undef CK
+#undef HK
+  *out = h;
+  return SWIMSIM_OK;
+}
+
+int swimsim_get_config(const swimsim_t* h, swimsim_config_t* out) {
+  if (!h || !out) return SWIMSIM_ERR_INVALID;
+  *out = h->cfg;
+  return SWIMSIM_OK;
+}
+
+int swimsim_schedule_fault(swimsim_t* h, uint64_t tick, uint32_t member, uint8_t up) {
+  if (!h) return SWIMSIM_ERR_INVALID;
+  if (member >= h->d.N || up > 1) return set_err(h, SWIMSIM_ERR_INVALID, "schedule_fault: bad member/up");
+  if (tick < h->tick || tick >= 0xFFFFFFFEull) return set_err(h, SWIMSIM_ERR_INVALID, "schedule_fault: tick in the past");
+  Fault f{(uint32_t)tick, member, up, h->fault_order++};
+  auto pos = std::upper_bound(h->faults.begin(), h->faults.end(), f, [](const Fault& a, const Fault& b) {
+    return a.tick != b.tick ? a.tick < b.tick : a.order < b.order; });
+  h->faults.insert(pos, f);
+  return SWIMSIM_OK;
+}
+
+int swimsim_step(swimsim_t* h, uint32_t nticks) {
+  if (!h) return SWIMSIM_ERR_INVALID;
+  if (h->poisoned) return set_err(h, SWIMSIM_ERR_STATE, "handle is poisoned by an earlier capacity error");
+  HIPCHK(h, hipSetDevice(h->device));
+  // upload the fault records of this whole call once; each tick's fault kernel gets its slice
+  size_t fend = 0;
+  while (fend < h->faults.size() && (uint64_t)h->faults[fend].tick < h->tick + nticks) ++fend;
+  if (fend) {
+    std::vector<FaultRec> recs(fend);
+    for (size_t x = 0; x < fend; ++x) recs[x] = FaultRec{h->faults[x].member, h->faults[x].up};
+    if (fend > h->d_faults_cap) {
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      if (h->d_faults) HIPCHK(h, hipFree(h->d_faults));
+      h->d_faults = nullptr; h->d_faults_cap = 0;
+      const size_t cap = std::max<size_t>(1024, fend * 2);
+      HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->d_faults), cap * sizeof(FaultRec)));
+      h->d_faults_cap = cap;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // previous call's fault kernels are done with the buffer
+    HIPCHK(h, hipMemcpy(h->d_faults, recs.data(), fend * sizeof(FaultRec), hipMemcpyHostToDevice));
+  }
+  if (h->timing) {
+    while (h->ev_pool.size() < (size_t)nticks * 3) {
+      hipEvent_t e;
+      HIPCHK(h, hipEventCreate(&e));
+      h->ev_pool.push_back(e);
+    }
+  }
+  size_t fpos = 0;
+  for (uint32_t k = 0; k < nticks; ++k) {
+    const uint32_t t = (uint32_t)h->tick;
+    hipEvent_t* ev = h->timing ? &h->ev_pool[(size_t)k * 3] : nullptr;
+    const size_t f0 = fpos;
+    while (fpos < fend && h->faults[fpos].tick <= t) ++fpos;
+    if (fpos > f0)
+      hipLaunchKernelGGL(fault_kernel, dim3(1), dim3(64), 0, h->stream, h->d, t, h->d_faults + f0, (uint32_t)(fpos - f0));
+    const uint32_t tk = tick_key(h->cfg.seed, t);
+    if (h->d.P <= 4 && h->d.K <= 4) launch_tick<4>(h, t, tk, ev);
+    else launch_tick<16>(h, t, tk, ev);
+    h->tick++;
+  }
+  h->faults.erase(h->faults.begin(), h->faults.begin() + (long)fpos);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->timing) {
+    for (uint32_t k = 0; k < nticks; ++k) {
+      float a = 0, b = 0;
+      HIPCHK(h, hipEventElapsedTime(&a, h->ev_pool[(size_t)k * 3], h->ev_pool[(size_t)k * 3 + 1]));
+      HIPCHK(h, hipEventElapsedTime(&b, h->ev_pool[(size_t)k * 3 + 1], h->ev_pool[(size_t)k * 3 + 2]));
+      h->probe_ms += a; h->merge_ms += b;
+    }
+    h->timed_ticks += nticks;
+  }
+  return check_device_errors(h);
+}
+
+int swimsim_tick(const swimsim_t* h, uint64_t* tick) {
+  if (!h || !tick) return SWIMSIM_ERR_INVALID;
+  *tick = h->tick;
+  return SWIMSIM_OK;
+}
+
+int swimsim_drain_events(swimsim_t* h, swimsim_event_t* buf, size_t cap, size_t* n_out) {
+  if (!h || !n_out) return SWIMSIM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = pull_events(h);
+  if (rc) return rc;
+  const size_t n = h->host_events.size();
+  *n_out = n;
+  if (n > cap || (n && !buf)) return SWIMSIM_ERR_BUFFER;
+  if (n) std::memcpy(buf, h->host_events.data(), n * sizeof *buf);
+  h->host_events.clear();
+  return SWIMSIM_OK;
+}
+
+static int read_column(swimsim_t* h, uint32_t observer, std::vector<uint2>* col, std::vector<uint32_t>* subj) {
+  uint32_t g[G_WORDS];
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(g, h->d.g, sizeof g, hipMemcpyDeviceToHost));
+  const uint32_t ns = std::min(g[G_NSLOTS], h->d.R_max);
+  col->resize(ns); subj->resize(ns);
+  if (!ns) return SWIMSIM_OK;
+  const uint2* src = h->d.V + (size_t)observer * h->d.R_max;
+  HIPCHK(h, hipMemcpy(col->data(), src, (size_t)ns * sizeof(uint2), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(subj->data(), h->d.subject_of, (size_t)ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return SWIMSIM_OK;
+}
+
+int swimsim_read_view(swimsim_t* h, uint32_t observer, swimsim_view_entry_t* buf, size_t cap, size_t* n_out) {
+  if (!h || !n_out || observer >= h->d.N) return SWIMSIM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<uint2> col; std::vector<uint32_t> subj;
+  int rc = read_column(h, observer, &col, &subj);
+  if (rc) return rc;
+  std::vector<swimsim_view_entry_t> ents;
+  for (size_t r = 0; r < col.size(); ++r) {
+    if (col[r].x == 0 || subj[r] == observer) continue;
+    swimsim_view_entry_t e{};
+    e.subject = subj[r]; e.incarnation = col[r].x >> 2; e.state = (uint8_t)(col[r].x & 3u); e.since_tick = col[r].y - 1;
+    ents.push_back(e);
+  }
+  std::sort(ents.begin(), ents.end(), [](const swimsim_view_entry_t& a, const swimsim_view_entry_t& b) { return a.subject < b.subject; });
+  *n_out = ents.size();
+  if (ents.size() > cap || (!ents.empty() && !buf)) return SWIMSIM_ERR_BUFFER;
+  if (!ents.empty()) std::memcpy(buf, ents.data(), ents.size() * sizeof *buf);
+  return SWIMSIM_OK;
+}
+
+int swimsim_read_member(swimsim_t* h, uint32_t m, swimsim_member_t* out) {
+  if (!h || !out || m >= h->d.N) return SWIMSIM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<uint2> col; std::vector<uint32_t> subj;
+  int rc = read_column(h, m, &col, &subj);
+  if (rc) return rc;
+  uint4 hot; uint32_t mi;
+  HIPCHK(h, hipMemcpy(&hot, h->d.hot + m, sizeof hot, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(&mi, h->d.minfo + m, sizeof mi, hipMemcpyDeviceToHost));
+  std::memset(out, 0, sizeof *out);
+  out->id = m; out->incarnation = hot.x; out->up = (mi >> 21) & 1u;
+  if ((mi >> 16) & 15u) {
+    uint64_t line[PB_SLOTS];
+    HIPCHK(h, hipMemcpy(line, h->d.pb + ((size_t)((mi >> 20) & 1u) * h->d.N + m) * PB_SLOTS, sizeof line, hipMemcpyDeviceToHost));
+    for (int q = 0; q < PB_SLOTS; ++q) {
+      const uint32_t lo = (uint32_t)line[q], hi = (uint32_t)(line[q] >> 32);
+      if (!((lo >> 16) & 0xFFu)) continue;
+      swimsim_rumor_t& r = out->rumors[out->n_rumors++];
+      const uint32_t sl = lo & 0xFFFFu;
+      r.subject = sl < subj.size() ? subj[sl] : NONE32;
+      r.incarnation = hi >> 2; r.state = (uint8_t)(hi & 3u); r.tx_left = (uint8_t)((lo >> 16) & 0xFFu);
+    }
+  }
+  uint32_t nt = 0;
+  for (size_t r = 0; r < col.size(); ++r) if (subj[r] != m && (col[r].x & 3u) == ST_SUSPECT) nt++;
+  out->n_timers = (uint16_t)nt;
+  return SWIMSIM_OK;
+}
+
+int swimsim_first_detect(swimsim_t* h, uint64_t* out, size_t n) {
+  if (!h || !out || n != h->d.N) return SWIMSIM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  std::vector<uint32_t> tmp(n);
+  HIPCHK(h, hipMemcpy(tmp.data(), h->d.first_suspect, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  for (size_t j = 0; j < n; ++j) out[j] = tmp[j] == NONE32 ? SWIMSIM_TICK_NONE : tmp[j];
+  return SWIMSIM_OK;
+}
+
+int swimsim_digest(swimsim_t* h, uint64_t* out) {
+  if (!h || !out) return SWIMSIM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemsetAsync(h->d_scratch64, 0, sizeof(unsigned long long), h->stream));
+  hipLaunchKernelGGL(digest_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, h->d_scratch64);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  unsigned long long acc = 0;
+  HIPCHK(h, hipMemcpy(&acc, h->d_scratch64, sizeof acc, hipMemcpyDeviceToHost));
+  *out = mix64((uint64_t)TAG_TICK + h->tick) + acc;
+  return SWIMSIM_OK;
+}
+
+int swimsim_counters(swimsim_t* h, uint64_t* out, size_t n) {
+  if (!h || !out || n < SWIMSIM_CTR_COUNT) return SWIMSIM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const size_t rows = (size_t)h->d.nblocks + 1;
+  std::vector<uint64_t> blk(rows * C_COUNT);
+  HIPCHK(h, hipMemcpy(blk.data(), h->d.blk, blk.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  for (int c = 0; c < C_COUNT; ++c) out[c] = 0;
+  for (size_t r = 0; r < rows; ++r)
+    for (int c = 0; c < C_COUNT; ++c) out[c] += blk[r * C_COUNT + c];
+  return SWIMSIM_OK;
+}
+
+int swimsim_k_random_members(swimsim_t* h, uint32_t observer, uint32_t n, const uint32_t* excludes,
+                             size_t n_excludes, uint32_t* out, size_t cap, size_t* n_out) {
+  if (!h || !n_out || observer >= h->d.N || n > 255 || (n_excludes && !excludes)) return SWIMSIM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t need = 257 + n_excludes;
+  if (need > h->d_sel_cap) {
+    if (h->d_sel) HIPCHK(h, hipFree(h->d_sel));
+    h->d_sel = nullptr; h->d_sel_cap = 0;
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->d_sel), need * sizeof(uint32_t)));
+    h->d_sel_cap = need;
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (n_excludes) HIPCHK(h, hipMemcpy(h->d_sel + 257, excludes, n_excludes * sizeof(uint32_t), hipMemcpyHostToDevice));
+  const uint32_t tk = tick_key(h->cfg.seed, (uint32_t)h->tick);
+  hipLaunchKernelGGL(select_debug_kernel, dim3(1), dim3(64), 0, h->stream, h->d, tk, observer, n,
+                     h->d_sel + 257, (uint32_t)n_excludes, h->d_sel, h->d_sel + 256);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  uint32_t res[257];
+  HIPCHK(h, hipMemcpy(res, h->d_sel, sizeof res, hipMemcpyDeviceToHost));
+  *n_out = res[256];
+  if (res[256] > cap || (res[256] && !out)) return SWIMSIM_ERR_BUFFER;
+  std::memcpy(out, res, res[256] * sizeof(uint32_t));
+  return SWIMSIM_OK;
+}
+
+int swimsim_kernel_timing_enable(swimsim_t* h, int enable) {
+  if (!h) return SWIMSIM_ERR_INVALID;
+  h->timing = enable != 0;
+  h->probe_ms = h->merge_ms = 0; h->timed_ticks = 0;
+  return SWIMSIM_OK;
+}
+
+int swimsim_kernel_timing(swimsim_t* h, double* out, size_t n) {
+  if (!h || !out || n < 3) return SWIMSIM_ERR_INVALID;
+  out[0] = h->probe_ms; out[1] = h->merge_ms; out[2] = (double)h->timed_ticks;
+  return SWIMSIM_OK;
+}
+
+int swimsim_set_view(swimsim_t* h, uint32_t observer, uint32_t subject, uint8_t state, uint32_t incarnation) {
+  if (!h || observer >= h->d.N || subject >= h->d.N || state > 2 || incarnation > INC_MAX || observer == subject)
+    return SWIMSIM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(set_view_kernel, dim3(1), dim3(64), 0, h->stream, h->d, (uint32_t)h->tick, observer, subject,
+                     (incarnation << 2) | state);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return check_device_errors(h);
+}
+
+}  // extern "C"

@@ -37,6 +37,7 @@ def _to_c_config(sc: SimConfig) -> _abi.Config:
     c.timer_cap = sc.timerCap
     c.event_cap = sc.eventCap
     c.event_mask = sc.eventMask
+    c.inbox_cap = sc.inboxCap
     c.device = sc.device
     c.shard_index = 0
     c.n_shards = 1
@@ -174,6 +175,16 @@ class Sim:
         buf = (C.c_uint64 * _abi.CTR_COUNT)()
         self._check(self._abi.counters(self._h, buf, _abi.CTR_COUNT))
         return {name: buf[k] for k, name in enumerate(_abi.CTR_NAMES) if not name.startswith("_")}
+
+    # -- measurement (product library only) -----------------------------------------
+    def kernelTimingEnable(self, enable=True):
+        self._check(self._abi.kernel_timing_enable(self._h, 1 if enable else 0))
+
+    def kernelTiming(self):
+        """{probe_ms, merge_ms, ticks}: HIP-event time spent in each tick kernel since enabling."""
+        buf = (C.c_double * 3)()
+        self._check(self._abi.kernel_timing(self._h, buf, 3))
+        return {"probe_ms": buf[0], "merge_ms": buf[1], "ticks": int(buf[2])}
 
     # -- unit-level hooks (test/Spec.hs) -------------------------------------------
     def kRandomMembers(self, observer: int, n: int, excludes: Sequence[int] = ()) -> List[int]:

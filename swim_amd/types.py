@@ -57,6 +57,7 @@ class SimConfig:
     timerCap: int = 0
     eventCap: int = 0
     eventMask: int = 0
+    inboxCap: int = 0
     device: int = 0
 
 

@@ -1,0 +1,31 @@
+"""Generates tests/golden/*.json from the CPU oracle (the reference itself cannot be run: no GHC
+in the image).  These fixtures are a regression pin for the oracle and the common
+target the GPU tests compare against.  Usage: python tests/golden/make_golden.py"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from tests import oracle_binding  # noqa: E402
+from tests.test_oracle_semantics import run_fixture  # noqa: E402
+
+SPECS = {
+    # BASELINE config 1: 128 members, k=3 indirect probes, 1 injected failure
+    "config1_n128_k3": {"n": 128, "k": 3, "seed": 1, "loss_ppm": 0, "suspicion": 21, "ticks": 200, "every": 10,
+                        "faults": [[10, 64, 0]]},
+    "lossy_n96_k3": {"n": 96, "k": 3, "seed": 7, "loss_ppm": 200000, "suspicion": 8, "ticks": 120, "every": 10,
+                     "faults": [[4, 10, 0], [9, 50, 0]]},
+    "churn_n64_k2": {"n": 64, "k": 2, "seed": 9, "loss_ppm": 50000, "suspicion": 6, "ticks": 150, "every": 10,
+                     "faults": [[3, 5, 0], [30, 5, 1], [60, 5, 0], [90, 5, 1], [20, 33, 0]]},
+}
+
+if __name__ == "__main__":
+    abi = oracle_binding.load()
+    for name, spec in SPECS.items():
+        out = {"generator": "tests/golden/make_golden.py (oracle/swim_oracle.c)", "spec": spec,
+               "expect": run_fixture(abi, spec)}
+        with open(os.path.join(HERE, name + ".json"), "w") as f:
+            json.dump(out, f, indent=1, sort_keys=True)
+        print(name, out["expect"]["digests"][-1], out["expect"]["n_events"])

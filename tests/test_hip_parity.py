@@ -1,0 +1,125 @@
+"""GPU parity: the HIP tick (through the C ABI of libswimsim.so) against the CPU oracle on the
+same seeded inputs.  Integer path => bit-exact: state digest, event stream, counters, views,
+piggyback buffers and first-detection ticks must be identical."""
+import pytest
+
+from swim_amd import Config, Sim, SimConfig
+from swim_amd import workloads
+from tests.helpers import compare_state, make_pair, run_lockstep
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config1_every_tick(oracle_abi, hip_abi):
+    """BASELINE config 1: 128 members, k=3, member 64 crashes at tick 10; compared every tick."""
+    sc, crashes, ticks = workloads.config1()
+    a, b = make_pair(oracle_abi, hip_abi, sc, crashes)
+    run_lockstep(a, b, ticks, 1, observers=(0, 1, 63, 64, 65, 127), members=(0, 5, 64, 100))
+    fd = b.firstDetection()
+    assert fd[64] is not None and fd[64] >= 10
+    # every live member ends with m64 Dead and nothing else
+    for o in (0, 17, 127):
+        ms = b.members(o)
+        assert [(m.memberName, int(m.memberAlive)) for m in ms] == [("m64", 2)]
+
+
+@pytest.mark.parametrize("n,p,loss,seed", [
+    (2, 1, 0, 1), (3, 3, 0, 2), (65, 3, 0, 3), (64, 1, 100000, 4), (200, 3, 300000, 5),
+    (1000, 3, 50000, 6), (1000, 10, 200000, 7), (777, 5, 0, 8),
+])
+def test_small_populations_with_loss(oracle_abi, hip_abi, n, p, loss, seed):
+    """Ragged sizes (not multiples of 64/256), heavy loss => refutations, false suspicions,
+    indirect probes; P up to the reference default numToGossip=10."""
+    sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, eventMask=0x1F,
+                   suspicionTicks=6, maxSubjects=min(n, 1024), timerCap=256)
+    crashes = [(5, n // 2)] if n > 2 else []
+    faults = [(40, n // 2, True)] if n > 2 else []
+    a, b = make_pair(oracle_abi, hip_abi, sc, crashes, faults)
+    run_lockstep(a, b, 80, 1 if n <= 200 else 8, observers=(0, n - 1, n // 2), members=(0, n - 1, n // 2))
+    if loss:
+        assert b.counters()["direct_failed"] > 0
+
+
+def test_config2_full(oracle_abi, hip_abi):
+    """BASELINE config 2: 65 536 members, k=3, 1 % hashed crashes, 400 ticks."""
+    sc, crashes, ticks = workloads.config2()
+    a, b = make_pair(oracle_abi, hip_abi, sc, crashes)
+    run_lockstep(a, b, ticks, 50, observers=(0, 4242, 65535), members=(1, 4242, 65535))
+    c = b.counters()
+    assert c["suspects"] >= len(crashes)
+    assert c["false_suspects"] == 0
+
+
+def test_kat_k_random_members_device(hip_abi, oracle_abi):
+    """test/Spec.hs:108-139 on the device selection routine."""
+    for abi in (hip_abi, oracle_abi):
+        sc = SimConfig(cfg=Config(numToGossip=3), nMembers=4, seed=1)
+        s = Sim.create(abi, sc)   # 0="alive" 1="suspect" 2="dead" 3="myself"
+        s.setView(3, 1, 1, 0)
+        s.setView(3, 2, 2, 0)
+        assert s.kRandomMembers(3, 0, [0, 1, 2]) == []
+        assert s.kRandomMembers(3, 3, []) == [0]
+        assert s.kRandomMembers(3, 3, [0]) == []
+        s.close()
+    picks = []
+    for abi in (hip_abi, oracle_abi):
+        s = Sim.create(abi, SimConfig(cfg=Config(numToGossip=3), nMembers=201, seed=9))
+        r = s.kRandomMembers(200, 50, [])
+        assert len(r) == 50 and len(set(r)) == 50 and 200 not in r
+        assert r != list(range(50))
+        picks.append(r)
+        s.close()
+    assert picks[0] == picks[1]
+
+
+def test_million_members_digest(oracle_abi, hip_abi):
+    """BASELINE config 3 size (1 048 576 members): digest parity over a short seeded run."""
+    sc, _, _ = workloads.config3(max_subjects=64)
+    crashes = workloads.hashed_crashes(1 << 20, 1, 1, 100000, 2, 6)   # ~10 crashes, ticks 2..5
+    a, b = make_pair(oracle_abi, hip_abi, sc, crashes)
+    run_lockstep(a, b, 12, 4, observers=(0, 1 << 19), members=(7,), check_events=True)
+
+
+@pytest.mark.parametrize("name", ["config1_n128_k3", "lossy_n96_k3", "churn_n64_k2"])
+def test_hip_matches_committed_golden_fixtures(hip_abi, name):
+    """The HIP path against the committed golden vectors (tests/golden/*.json)."""
+    import json, os
+    from tests.test_oracle_semantics import GOLDEN, run_fixture
+    fx = json.load(open(os.path.join(GOLDEN, name + ".json")))
+    assert run_fixture(hip_abi, fx["spec"]) == fx["expect"]
+
+
+def test_million_members_properties(hip_abi):
+    """Full BASELINE size without the oracle: size-independent properties.  (a) determinism:
+    two runs give the same digest; (b) completeness/accuracy at zero loss: every crashed member
+    is Dead in sampled live views, no false suspicion; (c) detection latency >= 1 and its mean
+    near 1/(1-e^-3); (d) conservation: changes == 2 * crashes * (live observers) once settled."""
+    import math
+    n = 1 << 20
+    crashes = workloads.hashed_crashes(n, 3, 1, 20000, 2, 12)        # ~50 crashes in ticks 2..11
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=3, maxSubjects=128, timerCap=128, suspicionTicks=20)
+    digests = []
+    for rep in range(2):
+        s = Sim.create(hip_abi, sc)
+        workloads.apply_crashes(s, crashes)
+        s.step(80)
+        digests.append(s.digest())
+        if rep == 0:
+            c = s.counters()
+            fd = s.firstDetection()
+            lat = [fd[m] - t + 1 for (t, m) in crashes]
+            assert all(l >= 1 for l in lat)
+            assert abs(sum(lat) / len(lat) - 1 / (1 - math.exp(-3))) < 0.25
+            assert c["false_suspects"] == 0 and c["refutes"] == 0
+            live = n - len(crashes)
+            # every live observer saw Suspect then Dead for every crashed subject; crashed members
+            # stop observing when they go down
+            assert 2 * len(crashes) * live <= c["changes"] <= 2 * len(crashes) * n
+            dead = {"m%d" % m for (_, m) in crashes}
+            for o in (0, 12345, n - 1):
+                if "m%d" % o in dead:
+                    continue
+                v = s.members(o)
+                assert {m.memberName for m in v} == dead and all(int(m.memberAlive) == 2 for m in v)
+        s.close()
+    assert digests[0] == digests[1]

@@ -1,0 +1,155 @@
+"""Properties of the tick semantics, checked on the CPU oracle (no GPU):
+golden fixtures, analytic first-detection latency, completeness/accuracy, order independence."""
+import json
+import math
+import os
+
+import pytest
+
+from swim_amd import Config, Sim, SimConfig, workloads
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def run_fixture(abi, spec):
+    sc = SimConfig(cfg=Config(numToGossip=spec["k"]), nMembers=spec["n"], seed=spec["seed"], lossPpm=spec["loss_ppm"],
+                   eventMask=0x1F, suspicionTicks=spec["suspicion"], timerCap=256)
+    s = Sim.create(abi, sc)
+    for (tick, member, up) in spec["faults"]:
+        s.scheduleFault(tick, member, bool(up))
+    digests = []
+    for _ in range(spec["ticks"] // spec["every"]):
+        s.step(spec["every"])
+        digests.append("%016x" % s.digest())
+    ev = s.drainEventsRaw()
+    fd = s.firstDetection()
+    return {"digests": digests, "n_events": len(ev), "events_head": [list(e) for e in ev[:40]],
+            "first_detect": {str(m): fd[m] for (_, m, up) in spec["faults"] if not up},
+            "counters": {k: v for k, v in s.counters().items()}}
+
+
+@pytest.mark.parametrize("name", ["config1_n128_k3", "lossy_n96_k3", "churn_n64_k2"])
+def test_golden_fixture(oracle_abi, name):
+    """Regression pin: the committed fixtures were produced by the oracle itself
+    (tests/golden/make_golden.py); the GPU tests check the HIP path against the same files."""
+    fx = json.load(open(os.path.join(GOLDEN, name + ".json")))
+    got = run_fixture(oracle_abi, fx["spec"])
+    assert got == fx["expect"]
+
+
+def test_first_detection_latency_matches_analytic_mean(oracle_abi):
+    """SWIM: with uniform random probing and no loss the expected first-detection time is
+    1/(1-e^-P) periods for P probes per member per period."""
+    for P, n_crash in ((1, 400), (3, 400)):
+        n = 4096
+        sc = SimConfig(cfg=Config(numToGossip=P), nMembers=n, seed=11 + P, suspicionTicks=50, maxSubjects=1024, timerCap=1024)
+        s = Sim.create(oracle_abi, sc)
+        crashes = [(5 + (k % 40), (k * 10 + 3) % n) for k in range(n_crash)]
+        crashes = sorted(set(crashes))
+        seen = set()
+        crashes = [(t, m) for (t, m) in crashes if not (m in seen or seen.add(m))]
+        workloads.apply_crashes(s, crashes)
+        s.step(70)
+        fd = s.firstDetection()
+        lat = [fd[m] - t + 1 for (t, m) in crashes]
+        assert all(l >= 1 for l in lat)
+        mean = sum(lat) / len(lat)
+        # uniform draws over the n-1 others, ~10% of members crashed by the end: tolerance 6%
+        expect = 1.0 / (1.0 - math.exp(-P))
+        assert abs(mean - expect) / expect < 0.06, (P, mean, expect)
+
+
+def test_completeness_and_accuracy_without_loss(oracle_abi):
+    """Every crashed member ends up Dead in every live view; no live member is ever suspected."""
+    sc, crashes, ticks = workloads.config1()
+    s = Sim.create(oracle_abi, sc)
+    workloads.apply_crashes(s, crashes)
+    s.step(ticks)
+    c = s.counters()
+    assert c["false_suspects"] == 0 and c["refutes"] == 0
+    for o in range(128):
+        if o == 64:
+            continue
+        v = s.members(o)
+        assert [(m.memberName, int(m.memberAlive)) for m in v] == [("m64", 2)], o
+    assert s.firstDetection()[64] >= 10
+
+
+def test_refutation_keeps_live_members_alive_under_loss(oracle_abi):
+    """With 5% loss live members get suspected, refute with a higher incarnation, and nobody
+    who is up ends up Dead in a live member's view.  (At 10% loss and k=3 the 8-slot piggyback
+    queue is overloaded -- ~12 new rumours per tick cluster-wide -- and refutations lose the race:
+    protocol behaviour under overload, documented in DESIGN.md.)"""
+    n = 256
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=5, lossPpm=50000, eventMask=0x1F, suspicionTicks=24, timerCap=512)
+    s = Sim.create(oracle_abi, sc)
+    s.step(300)
+    c = s.counters()
+    assert c["false_suspects"] > 0 and c["refutes"] > 0
+    dead_views = 0
+    for o in range(n):
+        dead_views += sum(1 for m in s.members(o) if int(m.memberAlive) == 2)
+    assert dead_views == 0
+
+
+def test_dissemination_is_logarithmic(oracle_abi):
+    """One crash in 16 384 members: the Suspect rumour reaches every live member within a few
+    multiples of log2 N ticks."""
+    n = 16384
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=2, suspicionTicks=200, eventMask=0x1F, eventCap=1 << 16)
+    s = Sim.create(oracle_abi, sc)
+    s.crash(777, 3)
+    reached = None
+    for t in range(40):
+        s.step(1)
+        if s.counters()["changes"] >= n - 1:
+            reached = s.tick
+            break
+    assert reached is not None and reached <= 3 + 2 * 14
+
+
+def test_processing_order_does_not_matter(oracle_abi):
+    """The merge is commutative: shuffling the order in which members apply received rumours
+    leaves every observable unchanged."""
+    def run(shuffle):
+        sc = SimConfig(cfg=Config(numToGossip=3), nMembers=300, seed=8, lossPpm=150000, eventMask=0x1F, suspicionTicks=10, timerCap=512)
+        s = Sim.create(oracle_abi, sc)
+        oracle_abi.lib.swimoracle_set_shuffle(s._h, shuffle)
+        s.crash(5, 2); s.crash(100, 4); s.scheduleFault(30, 5, True)
+        out = []
+        for _ in range(12):
+            s.step(5)
+            out.append(s.digest())
+        return out, s.drainEventsRaw(), s.counters(), s.firstDetection()
+    base = run(0)
+    for sh in (1, 12345, 987654321):
+        assert run(sh) == base
+
+
+def test_rejoin_bumps_incarnation_and_overrides_dead(oracle_abi):
+    n = 64
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=3, eventMask=0x1F, suspicionTicks=6)
+    s = Sim.create(oracle_abi, sc)
+    s.crash(7, 2)
+    s.scheduleFault(40, 7, True)
+    s.step(39)
+    assert all([(m.memberName, int(m.memberAlive)) for m in s.members(o)] == [("m7", 2)] for o in range(n) if o != 7)
+    s.step(30)
+    assert s.readMember(7)["incarnation"] == 1
+    for o in range(n):
+        if o != 7:
+            v = s.members(o)
+            assert [(m.memberName, int(m.memberAlive), m.memberIncarnation) for m in v] == [("m7", 0, 1)], (o, v)
+
+
+def test_capacity_errors_are_loud(oracle_abi):
+    from swim_amd import SwimError
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=64, seed=1, maxSubjects=2, suspicionTicks=4)
+    s = Sim.create(oracle_abi, sc)
+    for m in (1, 2, 3, 4):
+        s.crash(m, 1)
+    with pytest.raises(SwimError) as ei:
+        s.step(20)
+    assert ei.value.status == -4
+    with pytest.raises(SwimError):
+        s.step(1)                      # poisoned
