@@ -96,13 +96,13 @@ def test_million_members_properties(hip_abi):
     near 1/(1-e^-3); (d) conservation: changes == 2 * crashes * (live observers) once settled."""
     import math
     n = 1 << 20
-    crashes = workloads.hashed_crashes(n, 3, 1, 20000, 2, 12)        # ~50 crashes in ticks 2..11
+    crashes = workloads.hashed_crashes(n, 3, 1, 20000, 2, 52)        # ~50 crashes, about one per tick
     sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=3, maxSubjects=128, timerCap=128, suspicionTicks=20)
     digests = []
     for rep in range(2):
         s = Sim.create(hip_abi, sc)
         workloads.apply_crashes(s, crashes)
-        s.step(80)
+        s.step(130)
         digests.append(s.digest())
         if rep == 0:
             c = s.counters()
