@@ -1,0 +1,222 @@
+// TEST INFRASTRUCTURE, NOT PRODUCT.
+//
+// A minimal stand-in for <hip/hip_runtime.h> that lets g++ compile the product's kernel sources
+// (swim_amd/csrc/*.hip, *.h) UNCHANGED into a host library, tests/hostemu/_build/libswimsim_hostemu.so,
+// so that the kernels' LOGIC can be parity-checked against the CPU oracle on machines without a GPU
+// (this container has none; GPU minutes are rationed).  Only tests/ loads that library; the product
+// loader (swim_amd/_lib.py) knows nothing about it and libswimsim.so has no CPU path.
+//
+// Execution model: blocks run one after another; the threads of a block are ucontext fibres run
+// round-robin, switching at __syncthreads() / wave intrinsics.  That reproduces barrier semantics and
+// LDS sharing exactly, and makes every run deterministic; it does NOT reproduce the GPU's memory
+// model, scheduling or performance -- the `-m gpu` tests remain the parity tests proper.
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+
+#include <algorithm>
+#include <chrono>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#define __host__
+#define __device__
+#define __global__
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __forceinline__ inline
+#define __restrict__
+
+struct uint2 { uint32_t x, y; };
+struct uint3 { uint32_t x, y, z; };
+struct alignas(16) uint4 { uint32_t x, y, z, w; };
+struct alignas(16) ulonglong2 { unsigned long long x, y; };
+static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+static inline ulonglong2 make_ulonglong2(unsigned long long x, unsigned long long y) { return ulonglong2{x, y}; }
+struct dim3 {
+  uint32_t x, y, z;
+  dim3(uint32_t x_ = 1, uint32_t y_ = 1, uint32_t z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+using std::max;
+using std::min;
+
+// ---- error / runtime API (single "device", synchronous) ----------------------------------------
+typedef enum hipError_t { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 } hipError_t;
+typedef struct hostemu_stream* hipStream_t;
+typedef struct hostemu_event { std::chrono::steady_clock::time_point t; }* hipEvent_t;
+enum { hipStreamNonBlocking = 1 };
+typedef enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 } hipMemcpyKind;
+
+static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "ok" : "hostemu error"; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipMalloc(void** p, size_t bytes) {
+  *p = aligned_alloc(256, (bytes + 255) & ~(size_t)255);
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)(uintptr_t)1; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hostemu_event(); return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+  *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+  return hipSuccess;
+}
+
+// ---- the fibre scheduler -------------------------------------------------------------------------
+namespace hostemu {
+constexpr size_t STACK_BYTES = 512 * 1024;
+struct Fibre { ucontext_t ctx; void* stack; int state; };   // 0 runnable, 1 at barrier, 2 done
+struct Sched {
+  ucontext_t main_ctx;
+  std::vector<Fibre> f;
+  uint32_t nthreads = 0, cur = 0;
+  void (*entry)(void*) = nullptr; void* arg = nullptr;
+  uint64_t exch[1024];                                      // cross-lane exchange (shfl / ballot)
+};
+inline Sched& sched() { static Sched s; return s; }
+inline dim3& tidx() { static dim3 v; return v; }
+inline dim3& bidx() { static dim3 v; return v; }
+inline dim3& bdim() { static dim3 v; return v; }
+inline dim3& gdim() { static dim3 v; return v; }
+
+inline void barrier() {
+  Sched& s = sched();
+  Fibre& me = s.f[s.cur];
+  me.state = 1;
+  swapcontext(&me.ctx, &s.main_ctx);
+}
+inline void trampoline() {
+  Sched& s = sched();
+  s.entry(s.arg);
+  s.f[s.cur].state = 2;
+  swapcontext(&s.f[s.cur].ctx, &s.main_ctx);
+}
+// run one block of nthreads fibres to completion
+inline void run_block(uint32_t nthreads, void (*entry)(void*), void* arg) {
+  Sched& s = sched();
+  if (s.f.size() < nthreads) {
+    size_t old = s.f.size();
+    s.f.resize(nthreads);
+    for (size_t k = old; k < nthreads; ++k) s.f[k].stack = malloc(STACK_BYTES);
+  }
+  s.nthreads = nthreads; s.entry = entry; s.arg = arg;
+  for (uint32_t k = 0; k < nthreads; ++k) {
+    getcontext(&s.f[k].ctx);
+    s.f[k].ctx.uc_stack.ss_sp = s.f[k].stack;
+    s.f[k].ctx.uc_stack.ss_size = STACK_BYTES;
+    s.f[k].ctx.uc_link = nullptr;
+    makecontext(&s.f[k].ctx, (void (*)())trampoline, 0);
+    s.f[k].state = 0;
+  }
+  for (;;) {
+    uint32_t live = 0;
+    for (uint32_t k = 0; k < nthreads; ++k) {
+      if (s.f[k].state != 0) continue;
+      s.cur = k;
+      tidx() = dim3(k, 0, 0);
+      swapcontext(&s.main_ctx, &s.f[k].ctx);
+    }
+    for (uint32_t k = 0; k < nthreads; ++k) if (s.f[k].state == 1) { s.f[k].state = 0; live++; }
+    if (!live) break;                                        // all done (exited threads leave barriers)
+  }
+}
+
+template <typename F, typename Tuple, size_t... I>
+void call_with(F f, Tuple& t, std::index_sequence<I...>) { f(std::get<I>(t)...); }
+
+template <typename... KArgs, typename... Args>
+void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, Args... args) {
+  std::tuple<KArgs...> pack(static_cast<KArgs>(args)...);
+  struct Ctx { void (*k)(KArgs...); std::tuple<KArgs...>* p; } ctx{kernel, &pack};
+  bdim() = block; gdim() = grid;
+  for (uint32_t b = 0; b < grid.x; ++b) {
+    bidx() = dim3(b, 0, 0);
+    run_block(block.x, [](void* a) {
+      Ctx* c = static_cast<Ctx*>(a);
+      call_with(c->k, *c->p, std::index_sequence_for<KArgs...>{});
+    }, &ctx);
+  }
+}
+}  // namespace hostemu
+
+#define threadIdx (hostemu::tidx())
+#define blockIdx (hostemu::bidx())
+#define blockDim (hostemu::bdim())
+#define gridDim (hostemu::gdim())
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hostemu::launch(kernel, grid, block, __VA_ARGS__)
+
+static inline void __syncthreads() { hostemu::barrier(); }
+static inline void __threadfence() {}
+static inline void __threadfence_block() {}
+static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+static inline int __popc(uint32_t x) { return __builtin_popcount(x); }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __ffs(uint32_t x) { return __builtin_ffs((int)x); }
+static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+static inline int __clz(uint32_t x) { return x ? __builtin_clz(x) : 32; }
+
+// cross-lane operations: every thread of the block must call them convergently (as on the GPU, where
+// the product code only uses them at wave-uniform points)
+template <typename T>
+static inline T __shfl_down(T x, int delta, int width = 64) {
+  auto& s = hostemu::sched();
+  const uint32_t tid = hostemu::tidx().x;
+  uint64_t v = 0; memcpy(&v, &x, sizeof(T) < 8 ? sizeof(T) : 8);
+  s.exch[tid] = v;
+  hostemu::barrier();
+  const uint32_t lane = tid % (uint32_t)width, src = lane + (uint32_t)delta < (uint32_t)width ? tid + (uint32_t)delta : tid;
+  uint64_t r = src < s.nthreads ? s.exch[src] : v;
+  hostemu::barrier();
+  T out; memcpy(&out, &r, sizeof(T) < 8 ? sizeof(T) : 8);
+  return out;
+}
+template <typename T>
+static inline T __shfl(T x, int srcLane, int width = 64) {
+  auto& s = hostemu::sched();
+  const uint32_t tid = hostemu::tidx().x;
+  uint64_t v = 0; memcpy(&v, &x, sizeof(T) < 8 ? sizeof(T) : 8);
+  s.exch[tid] = v;
+  hostemu::barrier();
+  const uint32_t base = tid - tid % (uint32_t)width, src = base + ((uint32_t)srcLane % (uint32_t)width);
+  uint64_t r = src < s.nthreads ? s.exch[src] : v;
+  hostemu::barrier();
+  T out; memcpy(&out, &r, sizeof(T) < 8 ? sizeof(T) : 8);
+  return out;
+}
+static inline unsigned long long __ballot(int pred) {
+  auto& s = hostemu::sched();
+  const uint32_t tid = hostemu::tidx().x;
+  s.exch[tid] = pred ? 1u : 0u;
+  hostemu::barrier();
+  const uint32_t base = tid - tid % 64u;
+  unsigned long long m = 0;
+  for (uint32_t l = 0; l < 64u && base + l < s.nthreads; ++l) if (s.exch[base + l]) m |= 1ull << l;
+  hostemu::barrier();
+  return m;
+}
+
+// ---- atomics (fibres never run concurrently: plain read-modify-write is atomic) ----------------------
+template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+static inline unsigned atomicAdd(unsigned* p, int v) { unsigned o = *p; *p = o + (unsigned)v; return o; }
+template <typename T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <typename T> static inline T atomicAnd(T* p, T v) { T o = *p; *p = o & v; return o; }
+template <typename T> static inline T atomicXor(T* p, T v) { T o = *p; *p = o ^ v; return o; }
+template <typename T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <typename T> static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
+template <typename T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }

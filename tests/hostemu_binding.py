@@ -1,0 +1,34 @@
+"""Builds and loads tests/hostemu/_build/libswimsim_hostemu.so: the PRODUCT's kernel sources
+(swim_amd/csrc) compiled by g++ against a stand-in <hip/hip_runtime.h> (tests/hostemu/hip/).
+TEST-ONLY: lets the kernels' logic be parity-checked against the oracle on a machine with no GPU.
+The product package never imports this; libswimsim.so itself has no CPU path."""
+import ctypes as C
+import os
+import subprocess
+
+from swim_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "hostemu")
+CSRC = os.path.join(ROOT, "swim_amd", "csrc")
+LIB = os.path.join(EMU, "_build", "libswimsim_hostemu.so")
+
+_cached = None
+
+
+def build():
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs += [os.path.join(EMU, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "swimsim.h")]
+    if os.path.exists(LIB) and all(os.path.getmtime(s) <= os.path.getmtime(LIB) for s in srcs):
+        return
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-I", EMU,
+                           "-Wno-unused-function", "-o", LIB, os.path.join(CSRC, "swimsim.hip")])
+
+
+def load():
+    global _cached
+    if _cached is None:
+        build()
+        _cached = _abi.bind(C.CDLL(LIB), "swimsim_")
+    return _cached

@@ -1,0 +1,52 @@
+"""The product's kernel sources, compiled for the host through tests/hostemu (no GPU needed),
+against the CPU oracle: same observables as tests/test_hip_parity.py at sizes a fibre emulation
+finishes in seconds.  This checks kernel LOGIC on CPU-only machines; the `-m gpu` tests are the
+parity tests proper (they run the gfx950 build through the same C ABI)."""
+import pytest
+
+from swim_amd import Config, Sim, SimConfig
+from swim_amd import workloads
+from tests.helpers import make_pair, run_lockstep
+
+
+@pytest.fixture(scope="module")
+def emu_abi():
+    from tests import hostemu_binding
+    return hostemu_binding.load()
+
+
+def test_config1_every_tick(oracle_abi, emu_abi):
+    sc, crashes, ticks = workloads.config1()
+    a, b = make_pair(oracle_abi, emu_abi, sc, crashes)
+    run_lockstep(a, b, ticks, 1, observers=(0, 1, 63, 64, 65, 127), members=(0, 5, 64, 100))
+
+
+@pytest.mark.parametrize("n,p,loss,seed", [
+    (2, 1, 0, 1), (3, 3, 0, 2), (65, 3, 0, 3), (64, 1, 100000, 4), (200, 3, 300000, 5),
+    (600, 3, 50000, 6), (300, 10, 200000, 7), (777, 5, 0, 8),
+])
+def test_small_populations_with_loss(oracle_abi, emu_abi, n, p, loss, seed):
+    sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, eventMask=0x1F,
+                   suspicionTicks=6, maxSubjects=min(n, 1024), timerCap=256)
+    crashes = [(5, n // 2)] if n > 2 else []
+    faults = [(40, n // 2, True)] if n > 2 else []
+    a, b = make_pair(oracle_abi, emu_abi, sc, crashes, faults)
+    run_lockstep(a, b, 80, 1 if n <= 200 else 8, observers=(0, n - 1, n // 2), members=(0, n - 1, n // 2))
+
+
+def test_many_crashes_saturated_queue(oracle_abi, emu_abi):
+    """Several crashes per tick: queues overflow their 8 slots, many rumours in flight at once."""
+    n = 2048
+    crashes = workloads.hashed_crashes(n, 5, 1, 8, 3, 43)       # ~256 crashes over 40 ticks
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=5, eventMask=0x1F, suspicionTicks=7,
+                   maxSubjects=1024, timerCap=512)
+    a, b = make_pair(oracle_abi, emu_abi, sc, crashes)
+    run_lockstep(a, b, 70, 5, observers=(0, 1, n - 1), members=(0, 1, n - 1))
+
+
+@pytest.mark.parametrize("name", ["config1_n128_k3", "lossy_n96_k3", "churn_n64_k2"])
+def test_matches_committed_golden_fixtures(emu_abi, name):
+    import json, os
+    from tests.test_oracle_semantics import GOLDEN, run_fixture
+    fx = json.load(open(os.path.join(GOLDEN, name + ".json")))
+    assert run_fixture(emu_abi, fx["spec"]) == fx["expect"]
