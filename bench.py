@@ -8,7 +8,8 @@ every Ping/Ack carries a full 8-rumour piggyback payload and each member accepts
 changes per tick.  State is resident in HBM before the timed region; faults are pre-scheduled.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     : dominant kernel (merge_kernel) algorithmic bytes / HIP-event duration vs 8 TB/s
+  roofline     : dominant kernel (scan_kernel: the scattered 64-B payload gathers) algorithmic bytes /
+                 HIP-event duration vs 8 TB/s, plus the per-kernel and whole-tick figures
   cpu_baseline : the CPU oracle (a "port": the Haskell reference cannot be built here, no GHC)
                  timed on a bounded sample of the same workload on this box's host cores.
 """
@@ -28,16 +29,16 @@ N_MEMBERS = 1 << 20
 def algorithmic_bytes(c0, c1, n_members, ticks, P, K):
     """A = 16 + P + 64 d + 16 r + 128 c + f k  bytes per member-tick, from the
     semantic event counters kept by the kernels (d payloads delivered, r view entries changed,
-    c piggyback lines rewritten, f failed direct probes).  Returns (A_total, A_merge, A_probe):
-    the probe kernel owns the P + f k liveness gathers, the merge kernel everything else."""
+    c piggyback lines rewritten, f failed direct probes), split by the kernel that moves them."""
     mt = float(n_members) * ticks
     d = (c1["payloads"] - c0["payloads"]) / mt
     r = (c1["changes"] - c0["changes"]) / mt
     c = (c1["pb_writes"] - c0["pb_writes"]) / mt
     f = (c1["direct_failed"] - c0["direct_failed"]) / mt
-    a_probe = P + f * K
-    a_merge = 16.0 + 64.0 * d + 16.0 * r + 128.0 * c
-    return a_probe + a_merge, a_merge, a_probe, {"d": d, "r": r, "c": c, "f": f}
+    a = {"probe_kernel": P + f * K,                    # target / proxy liveness gathers
+         "scan_kernel": 64.0 * d,                      # delivered piggyback payload lines
+         "apply_kernel": 16.0 + 16.0 * r + 128.0 * c}  # hot record, accepted rumours, own line read+write
+    return a, {"d": d, "r": r, "c": c, "f": f}
 
 
 def first_detection_latency(sim, crashes, lo_tick, hi_tick):
@@ -121,16 +122,21 @@ def main():
     if rank == 0:
         P = sim.resolved.probes_per_tick
         K = sim.resolved.indirect_k
-        a_tot, a_merge, a_probe, rates = algorithmic_bytes(c0, c1, n, args.steps, P, K)
-        merge_s = kt["merge_ms"] / 1e3 / max(1, kt["ticks"])
-        probe_s = kt["probe_ms"] / 1e3 / max(1, kt["ticks"])
-        achieved = a_merge * n / merge_s / 1e9 if merge_s > 0 else 0.0
+        a_by, rates = algorithmic_bytes(c0, c1, n, args.steps, P, K)
+        nt = max(1, kt["ticks"])
+        secs = {"probe_kernel": kt["probe_ms"] / 1e3 / nt, "scan_kernel": kt["scan_ms"] / 1e3 / nt,
+                "apply_kernel": kt["apply_ms"] / 1e3 / nt}
+        per_kernel = {k: {"algorithmic_bytes_per_member_tick": a_by[k], "avg_launch_us": secs[k] * 1e6,
+                          "achieved_GBs": (a_by[k] * n / secs[k] / 1e9) if secs[k] > 0 else 0.0} for k in secs}
+        dom = "scan_kernel"
+        achieved = per_kernel[dom]["achieved_GBs"]
+        a_tot, t_tot = sum(a_by.values()), sum(secs.values())
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj.get("regime") == args.regime and tj.get("members") == n:
-                traffic = tj.get("merge_kernel_hbm_bytes_per_launch")
+                traffic = tj.get(dom + "_hbm_bytes_per_launch")
         lat, nlat = first_detection_latency(sim, crashes, args.warmup, total - 2)
         out = {
             "metric": "member-ticks/sec at N=1M simulated members; mean first-detection latency (ticks)",
@@ -148,13 +154,15 @@ def main():
             "ticks_per_s": args.steps / dt,
             "mean_first_detection_latency_ticks": lat, "crashes_measured": nlat,
             "per_member_tick": rates,
-            "roofline": {"bound": "hbm", "kernel": "merge_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_member_tick": a_merge,
-                         "avg_launch_us": merge_s * 1e6,
+                         "algorithmic_bytes_per_member_tick": a_by[dom],
+                         "avg_launch_us": secs[dom] * 1e6,
+                         "kernels": per_kernel,
                          "whole_tick": {"algorithmic_bytes_per_member_tick": a_tot,
-                                        "probe_kernel_us": probe_s * 1e6,
-                                        "achieved_GBs": a_tot * n / (merge_s + probe_s) / 1e9 if merge_s + probe_s > 0 else 0.0}},
+                                        "kernel_us": t_tot * 1e6,
+                                        "achieved_GBs": a_tot * n / t_tot / 1e9 if t_tot > 0 else 0.0,
+                                        "frac": (a_tot * n / t_tot / 1e9 / HBM_PEAK_GBS) if t_tot > 0 else 0.0}},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

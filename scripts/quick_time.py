@@ -1,21 +1,29 @@
-"""Quick wall-clock probe of the HIP tick at 1M members (not the bench contract).
-usage: quick_time.py [per_mille ...]   (0 = one crash, n = n/1000 of members crash over 1000 ticks)"""
-import json, os, sys, time
+"""Quick per-kernel timing of the HIP tick at 1M members, saturated regime (not the bench contract).
+usage: quick_time.py [lib.so ...]   -- each library variant is timed with the library's own HIP events.
+env: WARM, TICKS, MEMBERS, REGIME (saturated|quiescent)"""
+import json, os, sys, time, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from swim_amd import Sim, workloads, _lib
-abi = _lib.load()
-regimes = [int(x) for x in sys.argv[1:]] or [0, 1]
-WARM = int(os.environ.get('WARM', 150)); TICKS = int(os.environ.get('TICKS', 400))
-for per_mille in regimes:
-    sc, crashes, _ = workloads.config3(crash_per_mille=per_mille, t0=10, t1=1010)
-    t0 = time.time(); s = Sim.create(abi, sc); workloads.apply_crashes(s, crashes); t_create = time.time() - t0
+from swim_amd import Sim, workloads, _lib, _abi
+WARM = int(os.environ.get('WARM', 150)); TICKS = int(os.environ.get('TICKS', 200))
+N = int(os.environ.get('MEMBERS', 1 << 20)); REGIME = os.environ.get('REGIME', 'saturated')
+libs = sys.argv[1:] or [_lib.LIB_PATH]
+for path in libs:
+    abi = _abi.bind(C.CDLL(os.path.abspath(path)), "swimsim_")
+    mk = workloads.saturated if REGIME == 'saturated' else workloads.quiescent
+    sc, crashes, _ = mk(N, WARM + TICKS)
+    s = Sim.create(abi, sc); workloads.apply_crashes(s, crashes)
     s.step(WARM)
-    c0 = s.counters()
+    s.kernelTimingEnable(True)
+    raw0 = (C.c_uint64 * 16)(); abi.counters(s._h, raw0, 16)
     t0 = time.time(); s.step(TICKS); dt = time.time() - t0
-    c = s.counters()
-    print(json.dumps({"per_mille": per_mille, "crashes": len(crashes), "create_s": round(t_create, 2),
-                      "ticks_per_s": round(TICKS / dt, 1), "Gmember_ticks_per_s": round(TICKS * sc.nMembers / dt / 1e9, 3),
-                      "us_per_tick": round(dt / TICKS * 1e6, 1),
-                      "changes_per_mt": round((c["changes"] - c0["changes"]) / TICKS / sc.nMembers, 3),
-                      "payloads_per_mt": round((c["payloads"] - c0["payloads"]) / TICKS / sc.nMembers, 3)}))
+    raw1 = (C.c_uint64 * 16)(); abi.counters(s._h, raw1, 16)
+    kt = s.kernelTiming()
+    print(json.dumps({"lib": os.path.basename(path), "regime": REGIME, "us_per_tick": round(dt / TICKS * 1e6, 1),
+                      "probe_us": round(kt["probe_ms"] * 1e3 / kt["ticks"], 1),
+                      "scan_us": round(kt["scan_ms"] * 1e3 / kt["ticks"], 1),
+                      "apply_us": round(kt["apply_ms"] * 1e3 / kt["ticks"], 1),
+                      "Gmt_per_s": round(TICKS * N / dt / 1e9, 3),
+                      "examined_per_mt": round((raw1[14] - raw0[14]) / TICKS / N, 3),
+                      "changes_per_mt": round((raw1[7] - raw0[7]) / TICKS / N, 3),
+                      "digest": "%016x" % s.digest()}), flush=True)
     s.close()

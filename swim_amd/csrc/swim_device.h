@@ -24,13 +24,13 @@ enum : uint64_t { TAG_SELF = 0x53454c46u, TAG_VIEW = 0x56494557u, TAG_PB = 0x504
                   TAG_INC = 0x494e4352u, TAG_TICK = 0x5449434bu, TAG_MEMBER = 0x4d454d42u };
 
 // globals word indices (DevState::g)
-enum { G_NSLOTS = 0, G_ERR = 1, G_EVCUR = 2, G_OVF0 = 3, G_OVF1 = 4, G_WORDS = 8 };
+enum { G_NSLOTS = 0, G_ERR = 1, G_EVCUR = 2, G_OVF0 = 3, G_OVF1 = 4, G_NRUM = 5, G_HEAD = 6, G_WORDS = 8 };
 enum { ERRF_SUBJECTS = 1, ERRF_TIMERS = 2, ERRF_OVF = 4, ERRF_INC = 8 };
 
 // counter slots (same order as SWIMSIM_CTR_* in include/swimsim.h)
 enum { C_PINGS = 0, C_DIRECT_FAILED, C_PING_REQS, C_SUSPECTS, C_FALSE_SUSPECTS, C_PAYLOADS,
        C_RUMORS_SEEN, C_CHANGES, C_PB_WRITES, C_TIMERS_FIRED, C_REFUTES, C_EVENTS_DROPPED,
-       C_ACTIVE, C_EVDIGEST, C_COUNT = 16 };
+       C_ACTIVE, C_EVDIGEST, C_EXAMINED /* view lookups by apply_kernel (internal) */, C_COUNT = 16 };
 
 // ---- hashes (replace the global StdGen of src/Util.hs:40, F7) -----------
 __host__ __device__ inline uint32_t mix32(uint32_t x) {
@@ -54,9 +54,12 @@ __host__ __device__ inline uint64_t h4(uint64_t tag, uint64_t a, uint64_t b, uin
 
 // ---- device state (struct of arrays) -----------------------------------------------------
 // Per-member arrays are indexed by member id so that a wave of 64 consecutive members
-// issues coalesced loads.  View entries are member-major [member][slot]: slots are handed out
-// in time order, so the rumours circulating in one tick occupy ADJACENT slots and all of a
-// member's lookups in that tick fall into 2-3 64-B sectors of its own row.
+// issues coalesced loads.  The tick is bound by the NUMBER of L2<->fabric requests (measured:
+// ~45 G requests/s for scattered 64-B accesses, profiles/), so the two big owner-private tables
+// are position-major: view entries V[slot][member] and timer rings ring[position][member].  The
+// members of a wave look at the same few rumour slots (the ones in circulation) and their FIFO
+// positions advance in step, so their accesses share 64-B sectors instead of costing one
+// request per member.
 struct DevState {
   uint32_t N, P, K, S, L, loss_thr, R_max, timer_cap, event_cap, event_mask, nblocks;
   uint32_t inbox_cap, ovf_cap;  // per-member delivery slots; exact overflow list capacity
@@ -68,12 +71,18 @@ struct DevState {
   uint32_t* ackfrom;       // [N][P] sources whose Ack reached this member with a payload
   uint32_t* inbox_cnt;     // deliveries to this member this tick
   uint32_t* inbox;         // [N][inbox_cap] source ids (bit31 = source's pb buffer)
-  uint4* hot;              // {storeIncarnation, timer ring head, timer ring count, next deadline}
+  uint4* hot;              // {storeIncarnation, timer ring head | count<<16, -, next deadline}
+  uint4* kn;               // [N][2] 256-bit ring over rumour ids: bit (rid & 255) set => this member's view
+                           //   already dominates rumour rid (pure negative filter, see KN_* below)
+  uint32_t* kn_head;       // rumour-id counter value up to which this member's ring has been cleared
+  uint2* xl;               // [XL_CAP][N] scan -> apply: rumours that need a view lookup {slot | rid<<16, key}
+  uint32_t* xinfo;         // scan -> apply: list length | overflow | refutation (XI_* in swim_kernels.h)
+  unsigned long long* rtab;// [R_max][RT_WAYS] (slot, key) -> rumour id: {key+1 : 32 | ready : 1 | rid : 16}
   uint32_t* subject_of;    // slot -> subject
   uint32_t* fail;          // [N][P] targets whose probe ended without ack
-  uint2* ring;             // [N][timer_cap] {slot, deadline}: FIFO of suspicion timers
-  uint2* V;                // [N][R_max] {key = inc<<2|state, lastChange+1}
-  uint64_t* pb;            // [2][N][PB_SLOTS] {lo: slot | tx<<16, hi: key}
+  uint2* ring;             // [timer_cap][N] {slot, deadline}: FIFO of suspicion timers
+  uint2* V;                // [R_max][N] {key = inc<<2|state, lastChange+1}
+  uint64_t* pb;            // [2][N][PB_SLOTS] {lo: slot | rid<<16, hi: key | tx<<24}, sorted by priority
   uint32_t* first_suspect;
   uint32_t* crash_tick;
   uint32_t* g;             // globals (G_*)
@@ -83,7 +92,10 @@ struct DevState {
 };
 
 __device__ inline size_t vidx(const DevState& s, uint32_t i, uint32_t slot) {
-  return (size_t)i * s.R_max + slot;
+  return (size_t)slot * s.N + i;
+}
+__device__ inline size_t ridx(const DevState& s, uint32_t i, uint32_t pos) {
+  return (size_t)pos * s.N + i;
 }
 
 __device__ inline bool lost(const DevState& s, uint32_t tk, uint32_t purpose, uint32_t src, uint32_t dst,
@@ -91,6 +103,33 @@ __device__ inline bool lost(const DevState& s, uint32_t tk, uint32_t purpose, ui
   if (!s.loss_thr) return false;
   return hash_mk(mix32(tk ^ src), (purpose << 24) | idx, dst) < s.loss_thr;
 }
+
+// ---- piggyback line entries -------------------------------------------------------------------
+// lo = rumour slot (16) | rumour id (16);  hi = key = inc<<2|state (24) | tx_left (8).  A line holds its
+// valid entries first, SORTED by priority (tx desc, subject asc): ageing subtracts the same amount from
+// every entry, so the order survives and the owner never needs the subjects of old entries.
+__host__ __device__ inline uint32_t pe_slot(uint32_t lo) { return lo & 0xFFFFu; }
+__host__ __device__ inline uint32_t pe_rid(uint32_t lo) { return lo >> 16; }
+__host__ __device__ inline uint32_t pe_key(uint32_t hi) { return hi & 0xFFFFFFu; }
+__host__ __device__ inline uint32_t pe_tx(uint32_t hi) { return hi >> 24; }
+__host__ __device__ inline uint32_t pe_lo(uint32_t slot, uint32_t rid) { return slot | (rid << 16); }
+__host__ __device__ inline uint32_t pe_hi(uint32_t key, uint32_t tx) { return key | (tx << 24); }
+
+// ---- rumour ids and the known-ring ----------------------------------------------------------------
+// Every distinct rumour (slot, key) gets a 16-bit id from a global bump counter (G_NRUM) the first time
+// any member creates it, so ids are handed out in time order and the rumours in flight at one moment
+// occupy a short id range.  G_HEAD = the counter at the start of the tick (H).  A member keeps a
+// 256-bit ring indexed by rid & 255; only ids in [H-256, H) may be tested or set, and a member clears
+// the positions of the ids allocated since it last looked ([its head, H)) before using the ring.  A set
+// bit means "my view entry already dominates this rumour", so the delivery is skipped with one bit test;
+// a clear bit (or an id outside the window) only means "look it up".  Ids are internal: never observable.
+constexpr uint32_t KN_BITS = 256, KN_WORDS = 8, RID_MASK = 0xFFFFu, RID_FAR = 0x8000u;
+constexpr int RT_WAYS = 8;
+#ifndef SWIM_XL_CAP
+#define SWIM_XL_CAP 16
+#endif
+constexpr int XL_CAP = SWIM_XL_CAP;    // examination list entries per member per tick (more: exact slow path; <= 31)
+constexpr unsigned long long RT_READY = 1ull << 16;
 
 // minfo fields
 constexpr uint32_t MI_SLOT = 0xFFFFu, MI_PBN_SHIFT = 16, MI_PBN = 0xFu << 16, MI_BUF = 1u << 20,

@@ -1,12 +1,15 @@
 // swim_kernels.h -- the per-tick HIP kernels (gfx950).  Integer / indexing work; no MFMA on
-// this path.  The binding resource is the number of scattered L2 requests per member-tick
-// (measured: profiles/), so the layout keeps ONE gathered word per probe target (minfo), the
-// receiver filters incoming rumours against its own piggyback buffer in registers before it
-// touches its view row, and only cross-member deliveries go through atomics.
-// Two launches per tick:
+// this path.  The binding resource is the number of scattered L2<->fabric requests per member-tick
+// (measured ~45 G requests/s whatever the ALU load: profiles/), so the layout keeps ONE gathered
+// word per probe target (minfo), a delivered rumour costs the receiver one bit test on its
+// known-ring (swim_device.h) instead of a view lookup, the big owner-private tables are
+// position-major so that a wave's accesses share sectors, and only cross-member deliveries go
+// through atomics.
+// Three launches per tick:
 //   probe_kernel : one period of failureDetector / probeNode' per member (src/Core.hs:233-269),
 //                  closed form of the message exchange; emits (dst <- src) payload deliveries.
-//   merge_kernel : owner-computes end of tick: timers, state rule, piggyback queue
+//   scan_kernel  : receivers gather the delivered payload lines and list the unknown rumours.
+//   apply_kernel : owner-computes end of tick: timers, state rule, piggyback queue
 //                  (src/Core.hs:89-117, 127-138, 142-218).
 #pragma once
 #include "swim_device.h"
@@ -82,6 +85,9 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
   __shared__ BlockCounters sh;
   ctr_init(&sh);
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  // rumour ids are only allocated by fault_kernel (before) and apply_kernel (after): this is the quiet
+  // point at which the tick's window head H is fixed (swim_device.h, "rumour ids and the known-ring")
+  if (blockIdx.x == 0 && threadIdx.x == 0) s.g[G_HEAD] = s.g[G_NRUM];
   const uint32_t mi = i < s.N ? s.minfo[i] : 0u;
   const bool act = mi_up(mi);
   unsigned n_pings = 0;
@@ -187,246 +193,400 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
 // merge kernel
 // ================================================================================================
 
-// candidate set for the new piggyback buffer: PB_SLOTS best by (tx desc, subject asc) (H3, D5)
-struct Cand {
-  uint32_t slot[PB_SLOTS], key[PB_SLOTS], tx[PB_SLOTS], subj[PB_SLOTS];
-  uint32_t n;
-};
-
 __device__ inline bool rumor_better(uint32_t txa, uint32_t sa, uint32_t txb, uint32_t sb) {
   return txa != txb ? txa > txb : sa < sb;
 }
 
-__device__ inline void cand_insert(Cand& c, uint32_t slot, uint32_t subj, uint32_t key, uint32_t tx) {
-  bool done = false;
-#pragma unroll
-  for (int k = 0; k < PB_SLOTS; ++k)
-    if (!done && (uint32_t)k < c.n && c.slot[k] == slot) { c.key[k] = key; c.tx[k] = tx; done = true; }
-  if (done) return;
-  if (c.n < (uint32_t)PB_SLOTS) {
-#pragma unroll
-    for (int k = 0; k < PB_SLOTS; ++k)
-      if ((uint32_t)k == c.n) { c.slot[k] = slot; c.key[k] = key; c.tx[k] = tx; c.subj[k] = subj; }
-    c.n++;
-    return;
+// (slot, key) -> rumour id, created by whoever states the rumour first (own probe, own timer,
+// refutation, join); everyone else learns the id from the piggyback entry that carries the rumour.
+// One way per (incarnation, state) combination, newer combinations evict older ones.  Duplicate ids
+// for one rumour are harmless (an id is only a filter key), so every failure path just takes a fresh id.
+__device__ inline uint32_t find_rid(const DevState& s, uint32_t slot, uint32_t key) {
+  const uint32_t way = ((key >> 2) * 3u + (key & 3u)) & (uint32_t)(RT_WAYS - 1);
+  unsigned long long* p = s.rtab + (size_t)slot * RT_WAYS + way;
+  const unsigned long long claim = (unsigned long long)(key + 1u) << 32;
+  unsigned long long e = *p;                        // cached load: a published entry never reverts
+  for (int spin = 0; spin < 1024; ++spin) {
+    const uint32_t ek = (uint32_t)(e >> 32);
+    if (ek == key + 1u) {
+      if (e & RT_READY) return (uint32_t)e & RID_MASK;
+      e = atomicCAS(p, 0ull, 0ull);                 // being published by another lane: re-read at device scope
+      continue;
+    }
+    if (ek > key + 1u) break;                       // the way belongs to a newer rumour about this subject
+    const unsigned long long seen = atomicCAS(p, e, claim);
+    if (seen == e) {
+      const uint32_t rid = atomicAdd(&s.g[G_NRUM], 1u) & RID_MASK;
+      atomicExch(p, claim | RT_READY | rid);
+      return rid;
+    }
+    e = seen;
   }
-  uint32_t wtx = c.tx[0], ws = c.subj[0]; int worst = 0;
-#pragma unroll
-  for (int k = 1; k < PB_SLOTS; ++k)
-    if (rumor_better(wtx, ws, c.tx[k], c.subj[k])) { worst = k; wtx = c.tx[k]; ws = c.subj[k]; }
-  if (rumor_better(tx, subj, wtx, ws)) {
-#pragma unroll
-    for (int k = 0; k < PB_SLOTS; ++k)
-      if (k == worst) { c.slot[k] = slot; c.key[k] = key; c.tx[k] = tx; c.subj[k] = subj; }
-  }
+  return atomicAdd(&s.g[G_NRUM], 1u) & RID_MASK;
 }
 
-constexpr int SEEN = 4;      // rumours looked up this tick (register cache of (slot, view key))
-constexpr int ACC_CAP = 8;   // per-thread list of accepted changes awaiting the apply phase (LDS)
+// rumour ids that fell out of the known-ring window are parked half the id space away so that a
+// long-lived entry can never alias back into a later window (re-parked at every rewrite)
+__device__ inline uint32_t park_rid(uint32_t lo, uint32_t H) {
+  const uint32_t above = (pe_rid(lo) - (H - KN_BITS)) & RID_MASK;     // distance above the window bottom
+  return above < KN_BITS + 0x4000u ? lo : pe_lo(pe_slot(lo), (H + RID_FAR) & RID_MASK);
+}
 
-struct MergeCtx {
-  uint32_t i, t;
-  uint4 hot;
-  Cand c;
-  uint32_t seen_slot[SEEN], seen_key[SEEN], seen_pos;
-  uint32_t nacc;
-  unsigned changes, timers_fired, evdropped;
-  unsigned long long evd, ha;
+// the tx == L group of the next piggyback line (this tick's changes), kept sorted by subject so
+// that the line's priority order (tx desc, subject asc) holds by construction (H3, D5)
+struct NewGroup {
+  uint32_t w[PB_SLOTS], key[PB_SLOTS], subj[PB_SLOTS];   // w = slot | rid<<16
+  uint32_t n;
 };
 
-__device__ inline void emit_event(const DevState& s, MergeCtx& m, uint32_t observer, uint32_t subject,
-                                  uint32_t key, uint32_t cause) {
-  if (!(s.event_mask & (1u << cause))) return;
-  uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
-  if (pos < s.event_cap) s.events[pos] = make_uint4(m.t, observer, subject, (key << 8) | cause);
-  else m.evdropped++;
+__device__ inline void group_put(NewGroup& c, uint32_t slot, uint32_t rid, uint32_t key, uint32_t subj) {
+  bool hit = false;
+#pragma unroll
+  for (int k = 0; k < PB_SLOTS; ++k)
+    if ((uint32_t)k < c.n && pe_slot(c.w[k]) == slot) { c.w[k] = pe_lo(slot, rid); c.key[k] = key; hit = true; }
+  if (hit) return;
+  uint32_t pos = 0;
+#pragma unroll
+  for (int k = 0; k < PB_SLOTS; ++k) pos += ((uint32_t)k < c.n && c.subj[k] < subj) ? 1u : 0u;
+  if (pos >= (uint32_t)PB_SLOTS) return;                  // worse than the 8 kept (largest subjects drop)
+#pragma unroll
+  for (int k = PB_SLOTS - 1; k >= 1; --k)
+    if ((uint32_t)k > pos) { c.w[k] = c.w[k - 1]; c.key[k] = c.key[k - 1]; c.subj[k] = c.subj[k - 1]; }
+#pragma unroll
+  for (int k = 0; k < PB_SLOTS; ++k)
+    if ((uint32_t)k == pos) { c.w[k] = pe_lo(slot, rid); c.key[k] = key; c.subj[k] = subj; }
+  if (c.n < (uint32_t)PB_SLOTS) c.n++;
 }
 
-// Apply phase for one accepted change (heavy, runs convergently over the short per-thread list):
-// bookkeeping that follows `saveMember m'` in suspectOrDeadNode' (src/Core.hs:169-179): timer
-// start (D4), enqueue for piggybacking (D5), membership event, digest.
-__device__ inline void apply_change(const DevState& s, MergeCtx& m, uint32_t w0, uint32_t key, uint32_t oldkey) {
-  const uint32_t slot = w0 & 0xFFFFu, cause = (w0 >> 16) & 3u, first = (w0 >> 18) & 1u;
-  const uint32_t subject = s.subject_of[slot];
-  const unsigned long long x = mix64(m.ha + subject);          // h4(TAG_EV, a, subject, .) prefix
-  m.evd += mix64(x + key) - mix64(x + oldkey);
-  m.changes += first;
-  if (cause == 1u) m.timers_fired++;
-  if ((key & 3u) == ST_SUSPECT) {                              // start the suspicion timer (D4)
-    if (m.hot.z >= s.timer_cap) atomicOr(&s.g[G_ERR], (uint32_t)ERRF_TIMERS);
-    else {
-      uint32_t pos = m.hot.y + m.hot.z; if (pos >= s.timer_cap) pos -= s.timer_cap;
-      s.ring[(size_t)m.i * s.timer_cap + pos] = make_uint2(slot, m.t + s.S);
-      if (m.hot.z == 0) m.hot.w = m.t + s.S;
-      m.hot.z++;
-    }
-  }
-  cand_insert(m.c, slot, subject, key, s.L);                   // `Just msg` -> Broadcast -> enqueue (D5)
-  emit_event(s, m, m.i, subject, key, cause);
+// The end of a tick is two launches, one thread per member each:
+//   scan_kernel  : every delivered piggyback entry (src/Core.hs:110-117) is tested against the
+//                  member's known-ring with ONE bit test; the few unknown ones are appended to the
+//                  member's examination list in global memory ([position][member], coalesced).  Owns
+//                  the scattered 64-B payload gathers, so it is kept lean for occupancy.
+//   apply_kernel : suspicion timers (the FIXME at src/Core.hs:141; D4), own probes that ended without
+//                  an ack (src/Core.hs:253) and the listed rumours go through the state rule
+//                  suspectOrDeadNode' (src/Core.hs:142-187) + the unwritten aliveNode (:197-218, D6)
+//                  as the commutative merge entry := max(entry, (incarnation,state)) (H3, D13), with
+//                  what follows `saveMember m'` (:169-179): lastChange, timer start, enqueue for
+//                  piggybacking, membership event, digest; then the piggyback queue `disseminate`
+//                  leaves as a FIXME (src/Core.hs:136-138; D5) is rebuilt.
+
+// xinfo word (scan -> apply): list length (5) | overflow (1) | refute seen (1) | max refuting incarnation (22)
+constexpr uint32_t XI_OVF = 1u << 5, XI_REF = 1u << 6;
+
+__device__ inline void refute_note(uint32_t& refute, uint32_t key) {
+  // about self -> refute (src/Core.hs:155-166): remember the largest non-Alive incarnation
+  if ((key & 3u) != ST_ALIVE) refute = (refute == NONE32 || (key >> 2) > refute) ? (key >> 2) : refute;
 }
 
-__global__ __launch_bounds__(BLOCK) void merge_kernel(DevState s, uint32_t t) {
-  __shared__ BlockCounters sh;
-  __shared__ uint32_t acc[ACC_CAP][3][BLOCK];                  // [entry][word][thread]: conflict-free
-  ctr_init(&sh);
+#ifndef SWIM_SCAN_WAVES
+#define SWIM_SCAN_WAVES 5
+#endif
+__global__ __launch_bounds__(BLOCK, SWIM_SCAN_WAVES) void scan_kernel(DevState s, uint32_t t) {
+  __shared__ uint32_t knl[KN_WORDS][BLOCK];       // [word][thread]: conflict-free for any word index
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   const uint32_t tid = threadIdx.x;
   if (blockIdx.x == 0 && threadIdx.x == 0) s.g[G_OVF0 + ((t + 1) & 1u)] = 0;  // next tick's overflow list
+  if (i >= s.N) return;
+  const uint32_t mi = s.minfo[i];
+  uint32_t xi = 0;
+  if (mi_up(mi)) {
+    const uint32_t nack = s.probe_out[i] >> 10;
+    const uint32_t cnt = s.inbox_cnt[i];
+    if (cnt | nack) {
+      const uint32_t H = s.g[G_HEAD];
+      // ---- known-ring: load, forget the positions of ids allocated since this member last looked
+      {
+        const uint4 k0 = s.kn[2 * (size_t)i], k1 = s.kn[2 * (size_t)i + 1];
+        const uint32_t head = s.kn_head[i];
+        const bool wipe = H - head >= 64u;          // clearing more than needed is always safe
+        knl[0][tid] = wipe ? 0u : k0.x; knl[1][tid] = wipe ? 0u : k0.y; knl[2][tid] = wipe ? 0u : k0.z;
+        knl[3][tid] = wipe ? 0u : k0.w; knl[4][tid] = wipe ? 0u : k1.x; knl[5][tid] = wipe ? 0u : k1.y;
+        knl[6][tid] = wipe ? 0u : k1.z; knl[7][tid] = wipe ? 0u : k1.w;
+        if (!wipe)
+          for (uint32_t id = head; id != H; ++id) knl[(id >> 5) & (KN_WORDS - 1)][tid] &= ~(1u << (id & 31u));
+      }
+      const uint32_t my_slot1 = mi & MI_SLOT;       // slot+1 of rumours about me
+      const uint32_t my_slot0 = my_slot1 ? my_slot1 - 1u : NONE32;
+      uint32_t refute = NONE32, nex = 0, ovf = 0;
+      // ---- delivered payload sources: own-ack sources, inbox, exact overflow list
+      const uint32_t nin = cnt < s.inbox_cap ? cnt : s.inbox_cap;
+      const uint32_t nsrc = nack + nin;
+      uint32_t ox = 0, novf = 0;
+      if (cnt > s.inbox_cap) novf = min(s.g[G_OVF0 + (t & 1u)], s.ovf_cap);
+      auto fetch_src = [&](uint32_t k) -> uint32_t {
+        if (k < nack) return s.ackfrom[(size_t)i * s.P + k];
+        if (k < nsrc) return s.inbox[(size_t)i * s.inbox_cap + (k - nack)];
+        return NONE32;
+      };
+      uint32_t x = 0, nxt = fetch_src(0);
+      for (;;) {
+        uint32_t srcw = NONE32;
+        if (x < nsrc) { srcw = nxt; x++; nxt = fetch_src(x); }         // the next source word loads under this line
+        else
+          while (ox < novf) {
+            const uint2 o = s.ovf[(size_t)(t & 1u) * s.ovf_cap + ox];
+            ox++;
+            if (o.x == i) { srcw = o.y; break; }
+          }
+        if (srcw == NONE32) break;
+        const uint32_t src = srcw & 0x7FFFFFFFu, buf = srcw >> 31;
+        const uint4* line = reinterpret_cast<const uint4*>(s.pb + ((size_t)buf * s.N + src) * PB_SLOTS);
+        uint32_t lw[2 * PB_SLOTS];
+#pragma unroll
+        for (int h = 0; h < PB_SLOTS / 2; ++h) {
+          const uint4 v = line[h];
+          lw[4 * h] = v.x; lw[4 * h + 1] = v.y; lw[4 * h + 2] = v.z; lw[4 * h + 3] = v.w;
+        }
+        // classify the 8 entries branch-free: one ring-bit test each (the hot loop of the tick)
+        uint32_t unk = 0, inw = 0, selfm = 0;       // to be listed / inside the window / about myself
+        uint32_t kw[PB_SLOTS];
+#pragma unroll
+        for (int k = 0; k < PB_SLOTS; ++k) kw[k] = knl[(lw[2 * k] >> 21) & (KN_WORDS - 1)][tid];
+#pragma unroll
+        for (int k = 0; k < PB_SLOTS; ++k) {
+          const uint32_t lo = lw[2 * k], hi = lw[2 * k + 1], rid = pe_rid(lo);
+          const uint32_t valid = pe_tx(hi) ? 1u : 0u;
+          const uint32_t self = (pe_slot(lo) == my_slot0) ? 1u : 0u;
+          const uint32_t in = (((H - 1u - rid) & RID_MASK) < KN_BITS) ? 1u : 0u;
+          const uint32_t known = in & (kw[k] >> (rid & 31u));            // view already dominates it
+          unk |= (valid & ~self & ~known & 1u) << k;
+          inw |= in << k;
+          selfm |= (valid & self) << k;
+        }
+        if (selfm) {
+#pragma unroll
+          for (int k = 0; k < PB_SLOTS; ++k) if ((selfm >> k) & 1u) refute_note(refute, pe_key(lw[2 * k + 1]));
+        }
+        if (unk) {
+#pragma unroll
+          for (int k = 0; k < PB_SLOTS; ++k)
+            if ((unk >> k) & 1u) {
+              if (nex < (uint32_t)XL_CAP) {
+                const uint32_t lo = lw[2 * k], rid = pe_rid(lo);
+                // listed at most once per tick: mark it now (the examination settles it either way)
+                if ((inw >> k) & 1u) knl[(rid >> 5) & (KN_WORDS - 1)][tid] |= 1u << (rid & 31u);
+                s.xl[ridx(s, i, nex)] = make_uint2(lo, pe_key(lw[2 * k + 1]));
+                nex++;
+              } else ovf = XI_OVF;                   // apply_kernel walks this member's sources itself
+            }
+        }
+      }
+      s.kn[2 * (size_t)i] = make_uint4(knl[0][tid], knl[1][tid], knl[2][tid], knl[3][tid]);
+      s.kn[2 * (size_t)i + 1] = make_uint4(knl[4][tid], knl[5][tid], knl[6][tid], knl[7][tid]);
+      s.kn_head[i] = H;
+      xi = nex | ovf | (refute != NONE32 ? (XI_REF | (refute << 7)) : 0u);
+      if (cnt && !ovf) s.inbox_cnt[i] = 0;
+    }
+  }
+  s.xinfo[i] = xi;
+}
+
+// the tx == L group of the next piggyback line is appended after it is complete; old survivors
+// keep their order behind it
+#ifndef SWIM_APPLY_WAVES
+#define SWIM_APPLY_WAVES 4
+#endif
+__global__ __launch_bounds__(BLOCK, SWIM_APPLY_WAVES) void apply_kernel(DevState s, uint32_t t) {
+  __shared__ BlockCounters sh;
+  __shared__ uint32_t asm_[PB_SLOTS][2][BLOCK];   // the outgoing line is assembled here: [entry][word][thread]
+  ctr_init(&sh);
+  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  const uint32_t tid = threadIdx.x;
   const uint32_t mi = i < s.N ? s.minfo[i] : 0u;
   if (mi_up(mi)) {
     const uint32_t po = s.probe_out[i];
-    const uint32_t nsent = po & 31u, nfail = (po >> 5) & 31u, nack = po >> 10;
-    const uint32_t cnt = s.inbox_cnt[i];
-    MergeCtx m;
-    m.i = i; m.t = t; m.hot = s.hot[i];
+    const uint32_t nsent = po & 31u, nfail = (po >> 5) & 31u;
+    const uint32_t xi = s.xinfo[i];
+    const uint4 hot0 = s.hot[i];
+    uint32_t self_inc = hot0.x, thead = hot0.y & 0xFFFFu, tcount = hot0.y >> 16, tnext = hot0.w;
     const uint32_t pcount = mi_pbn(mi), cur = mi_buf(mi);
-    const bool timer_due = m.hot.z && m.hot.w <= t;
-    if (cnt | nfail | nack | pcount | (uint32_t)timer_due) {
-      m.c.n = 0; m.changes = 0; m.timers_fired = 0; m.evdropped = 0; m.evd = 0; m.seen_pos = 0; m.nacc = 0;
-      m.ha = 0;
+    const bool timer_due = tcount && tnext <= t;
+    if (xi | nfail | pcount | (uint32_t)timer_due) {
+      const uint32_t H = s.g[G_HEAD];
+      // ---- own queue (sorted by priority; see swim_device.h): only the slot ids stay live (two per
+      // register) for the "superseded" test; the line itself is read again when the queue is rebuilt
+      NewGroup c; c.n = 0;
 #pragma unroll
-      for (int k = 0; k < SEEN; ++k) { m.seen_slot[k] = NONE32; m.seen_key[k] = 0; }
-      const uint4 hot0 = m.hot;
-      // age the queue: every ping sent this tick carried every slot (D5)
+      for (int k = 0; k < PB_SLOTS; ++k) { c.w[k] = 0; c.key[k] = 0; c.subj[k] = 0; }
+      uint32_t killmask = 0;                        // own entries superseded by (or moved into) the new group
+      uint32_t oslot[PB_SLOTS / 2];
+#pragma unroll
+      for (int h = 0; h < PB_SLOTS / 2; ++h) oslot[h] = 0xFFFFFFFFu;   // no entry: matches no slot (< 0xFFFF)
+      const uint4* own_line = reinterpret_cast<const uint4*>(s.pb + ((size_t)cur * s.N + i) * PB_SLOTS);
       if (pcount) {
-        const uint4* line = reinterpret_cast<const uint4*>(s.pb + ((size_t)cur * s.N + i) * PB_SLOTS);
-        uint4 v[PB_SLOTS / 2];
-#pragma unroll
-        for (int h = 0; h < PB_SLOTS / 2; ++h) v[h] = line[h];
 #pragma unroll
         for (int h = 0; h < PB_SLOTS / 2; ++h) {
-          const uint32_t tx0 = (v[h].x >> 16) & 0xFFu, tx1 = (v[h].z >> 16) & 0xFFu;
-          if (tx0 > nsent) cand_insert(m.c, v[h].x & 0xFFFFu, s.subject_of[v[h].x & 0xFFFFu], v[h].y, tx0 - nsent);
-          if (tx1 > nsent) cand_insert(m.c, v[h].z & 0xFFFFu, s.subject_of[v[h].z & 0xFFFFu], v[h].w, tx1 - nsent);
+          const uint4 v = own_line[h];
+          oslot[h] = (pe_tx(v.y) ? pe_slot(v.x) : 0xFFFFu) | ((pe_tx(v.w) ? pe_slot(v.z) : 0xFFFFu) << 16);
         }
       }
-      const uint32_t my_slot1 = mi & MI_SLOT;                   // slot+1 of rumours about me
-      const uint32_t self_inc0 = m.hot.x;
-      uint32_t refute = NONE32;
-
-      auto apply_all = [&]() {
-        if (m.nacc && !m.ha) m.ha = mix64(mix64((uint64_t)TAG_EV) + (((uint64_t)t << 32) | i));
-        for (uint32_t k = 0; k < m.nacc; ++k) apply_change(s, m, acc[k][0][tid], acc[k][1][tid], acc[k][2][tid]);
-        m.nacc = 0;
-      };
-      // The state rule: suspectOrDeadNode' (src/Core.hs:142-187) + the unwritten aliveNode
-      // (:197-218, D6) as the commutative merge entry := max(entry, (incarnation,state)) (H3,
-      // D13).  Scan phase: the entry is updated at once (memberLastChange = now, :176) and the
-      // change is queued; everything else happens in apply_change.  Caller checked key > e.x.
-      auto note = [&](uint32_t slot, uint32_t key, uint32_t cause, uint2 e) {
-        s.V[vidx(s, i, slot)] = make_uint2(key, t + 1);
-        if (m.nacc == (uint32_t)ACC_CAP) apply_all();
-        acc[m.nacc][0][tid] = slot | (cause << 16) | ((e.y != t + 1 ? 1u : 0u) << 18);
-        acc[m.nacc][1][tid] = key;
-        acc[m.nacc][2][tid] = e.x;
-        m.nacc++;
-#pragma unroll
-        for (int k = 0; k < SEEN; ++k) if ((uint32_t)k == m.seen_pos) { m.seen_slot[k] = slot; m.seen_key[k] = key; }
-        m.seen_pos = (m.seen_pos + 1) & (SEEN - 1);
-      };
-
-      // phase 1: suspicion timers (the FIXME at src/Core.hs:141; D4)
-      while (m.hot.z) {
-        const uint2 tm = s.ring[(size_t)i * s.timer_cap + m.hot.y];
-        if (tm.y > t) break;
-        m.hot.y = (m.hot.y + 1 == s.timer_cap) ? 0 : m.hot.y + 1;
-        m.hot.z--;
-        const uint2 e = s.V[vidx(s, i, tm.x)];
-        if ((e.x & 3u) == ST_SUSPECT && e.y - 1 + s.S == tm.y) note(tm.x, (e.x & ~3u) | ST_DEAD, 1u /*TIMER*/, e);
+      if (pcount && nsent == 0) {
+        // nothing was sent, nothing ages: entries still at tx == L tie with this tick's changes and
+        // are ordered with them by subject (the only case that needs the subjects of old entries)
+        const uint2* own = reinterpret_cast<const uint2*>(own_line);
+        for (uint32_t k = 0; k < pcount; ++k) {
+          const uint2 v = own[k];
+          if (pe_tx(v.y) != s.L) break;             // sorted: the tx == L entries come first
+          group_put(c, pe_slot(v.x), pe_rid(v.x), pe_key(v.y), s.subject_of[pe_slot(v.x)]);
+          killmask |= 1u << k;
+        }
       }
+      const uint32_t my_slot1 = mi & MI_SLOT;       // slot+1 of rumours about me
+      uint32_t refute = (xi & XI_REF) ? (xi >> 7) : NONE32;
+      unsigned changes = 0, timers_fired = 0, evdropped = 0, examined = 0;
+      unsigned long long evd = 0, ha = 0;
+
+      auto kill_slot = [&](uint32_t slot) {
+#pragma unroll
+        for (int h = 0; h < PB_SLOTS / 2; ++h) {
+          if ((oslot[h] & 0xFFFFu) == slot) killmask |= 1u << (2 * h);
+          if ((oslot[h] >> 16) == slot) killmask |= 1u << (2 * h + 1);
+        }
+      };
+      // The state rule on one proposal (slot, key): e is the member's current entry.
+      auto examine = [&](uint32_t slot, uint32_t key, uint32_t cause, bool hasrid, uint32_t rid_in) {
+        examined++;
+        const uint2 e = s.V[vidx(s, i, slot)];
+        if (key <= e.x) return;                      // old incarnation / weaker state: ignore (:151)
+        s.V[vidx(s, i, slot)] = make_uint2(key, t + 1);                    // memberLastChange = now (:176)
+        const uint32_t subject = s.subject_of[slot];
+        if (!ha) ha = mix64(mix64((uint64_t)TAG_EV) + (((uint64_t)t << 32) | i));
+        const unsigned long long hx = mix64(ha + subject);                // h4(TAG_EV, a, subject, .) prefix
+        evd += mix64(hx + key) - mix64(hx + e.x);
+        changes += (e.y != t + 1) ? 1u : 0u;
+        if (cause == 1u) timers_fired++;
+        if ((key & 3u) == ST_SUSPECT) {              // start the suspicion timer (D4)
+          if (tcount >= s.timer_cap) atomicOr(&s.g[G_ERR], (uint32_t)ERRF_TIMERS);
+          else {
+            uint32_t pos = thead + tcount; if (pos >= s.timer_cap) pos -= s.timer_cap;
+            s.ring[ridx(s, i, pos)] = make_uint2(slot, t + s.S);
+            if (tcount == 0) tnext = t + s.S;
+            tcount++;
+          }
+        }
+        const uint32_t rid = hasrid ? rid_in : find_rid(s, slot, key);
+        kill_slot(slot);
+        group_put(c, slot, rid, key, subject);       // `Just msg` -> Broadcast -> enqueue (D5)
+        if (s.event_mask & (1u << cause)) {
+          const uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
+          if (pos < s.event_cap) s.events[pos] = make_uint4(t, i, subject, (key << 8) | cause);
+          else evdropped++;
+        }
+      };
+
+      // phase 1: suspicion timers, evaluated on the start-of-tick view
+      if (timer_due)
+        while (tcount) {
+          const uint2 tm = s.ring[ridx(s, i, thead)];
+          if (tm.y > t) break;
+          thead = (thead + 1 == s.timer_cap) ? 0 : thead + 1;
+          tcount--;
+          const uint2 e = s.V[vidx(s, i, tm.x)];
+          if ((e.x & 3u) == ST_SUSPECT && e.y - 1 + s.S == tm.y) examine(tm.x, (e.x & ~3u) | ST_DEAD, 1u, false, 0u);
+        }
       // phase 2: own probes that ended without any ack: Suspect at the viewed incarnation
       for (uint32_t f = 0; f < nfail; ++f) {
         const uint32_t j = s.fail[(size_t)i * s.P + f];
         const uint32_t sl = (s.minfo[j] & MI_SLOT) - 1;
         const uint2 e = s.V[vidx(s, i, sl)];
         const uint32_t key = (e.x & ~3u) | ST_SUSPECT;
-        if (key > e.x) note(sl, key, 0u /*PROBE*/, e);
+        if (key > e.x) examine(sl, key, 0u, false, 0u);
       }
       // phase 3: rumours received this tick (any order: the merge is commutative)
-      auto take = [&](uint32_t srcw) {
-        const uint32_t src = srcw & 0x7FFFFFFFu, buf = srcw >> 31;
-        const uint4* line = reinterpret_cast<const uint4*>(s.pb + ((size_t)buf * s.N + src) * PB_SLOTS);
-        uint4 v[PB_SLOTS / 2];
+      if (!(xi & XI_OVF)) {
+        const uint32_t nex = xi & 31u;
+        for (uint32_t k = 0; k < nex; ++k) {
+          const uint2 r = s.xl[ridx(s, i, k)];
+          examine(pe_slot(r.x), r.y, 2u, true, pe_rid(r.x));
+        }
+      } else {
+        // the scan found more unknown rumours than the list holds: take every delivered entry
+        // straight through the rule (rare; idempotent, so entries the list did hold do no harm)
+        const uint32_t nack = po >> 10, cnt = s.inbox_cnt[i];
+        const uint32_t nin = cnt < s.inbox_cap ? cnt : s.inbox_cap;
+        const uint32_t novf = cnt > s.inbox_cap ? min(s.g[G_OVF0 + (t & 1u)], s.ovf_cap) : 0u;
+        for (uint32_t x = 0; x < nack + nin + novf; ++x) {
+          uint32_t srcw = NONE32;
+          if (x < nack) srcw = s.ackfrom[(size_t)i * s.P + x];
+          else if (x < nack + nin) srcw = s.inbox[(size_t)i * s.inbox_cap + (x - nack)];
+          else {
+            const uint2 o = s.ovf[(size_t)(t & 1u) * s.ovf_cap + (x - nack - nin)];
+            if (o.x == i) srcw = o.y;
+          }
+          if (srcw == NONE32) continue;
+          const uint2* line = reinterpret_cast<const uint2*>(s.pb + ((size_t)(srcw >> 31) * s.N + (srcw & 0x7FFFFFFFu)) * PB_SLOTS);
+          for (int k = 0; k < PB_SLOTS; ++k) {
+            const uint2 r = line[k];
+            if (!pe_tx(r.y)) break;
+            if (pe_slot(r.x) + 1 == my_slot1) continue;          // the scan took care of rumours about me
+            examine(pe_slot(r.x), pe_key(r.y), 2u, true, pe_rid(r.x));
+          }
+        }
+        s.inbox_cnt[i] = 0;
+      }
+      // ---- refutation: bump own incarnation past the rumour's (src/Core.hs:155-166; D10); rumours at
+      // an incarnation below my own are stale and ignored (:151)
+      unsigned refutes = 0;
+      if (refute != NONE32 && refute >= self_inc) {
+        uint32_t ni = refute + 1;
+        if (ni > INC_MAX) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_INC); ni = INC_MAX; }
+        self_inc = ni;
+        evd += h4(TAG_INC, ((uint64_t)t << 32) | i, ni, 0);
+        refutes = 1;
+        const uint32_t akey = (ni << 2) | ST_ALIVE;
+        kill_slot(my_slot1 - 1);
+        group_put(c, my_slot1 - 1, find_rid(s, my_slot1 - 1, akey), akey, i);   // Just Alive{..} (:163)
+        if (s.event_mask & (1u << 3)) {
+          const uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
+          if (pos < s.event_cap) s.events[pos] = make_uint4(t, i, i, (akey << 8) | 3u /*REFUTE*/);
+          else evdropped++;
+        }
+      }
+      // ---- rebuild the queue: [this tick's group, by subject][aged survivors, order kept], best 8 (D5),
+      // assembled in LDS columns, then written as one 64-B line.
+      uint32_t nout = c.n;
 #pragma unroll
-        for (int h = 0; h < PB_SLOTS / 2; ++h) v[h] = line[h];
+      for (int k = 0; k < PB_SLOTS; ++k) {
+        const bool have = (uint32_t)k < c.n;
+        asm_[k][0][tid] = have ? park_rid(c.w[k], H) : 0u;
+        asm_[k][1][tid] = have ? pe_hi(c.key[k], s.L) : 0u;
+      }
+      if (pcount) {
 #pragma unroll
         for (int h = 0; h < PB_SLOTS / 2; ++h) {
+          const uint4 v = own_line[h];
 #pragma unroll
           for (int w = 0; w < 2; ++w) {
-            const uint32_t lo = w ? v[h].z : v[h].x, key = w ? v[h].w : v[h].y;
-            if (!((lo >> 16) & 0xFFu)) continue;
-            const uint32_t sl = lo & 0xFFFFu;
-            if (sl + 1 == my_slot1) {
-              // about self -> refute (src/Core.hs:155-166); old incarnations ignored (:151)
-              if ((key & 3u) != ST_ALIVE && (key >> 2) >= self_inc0)
-                refute = (refute == NONE32 || (key >> 2) > refute) ? (key >> 2) : refute;
-              continue;
-            }
-            // already known?  my own queue and this tick's lookups are in registers: no memory touch
-            bool known = false;
-#pragma unroll
-            for (int k = 0; k < PB_SLOTS; ++k) known |= ((uint32_t)k < m.c.n) && m.c.slot[k] == sl && m.c.key[k] >= key;
-#pragma unroll
-            for (int k = 0; k < SEEN; ++k) known |= m.seen_slot[k] == sl && m.seen_key[k] >= key;
-            if (known) continue;
-            const uint2 e = s.V[vidx(s, i, sl)];
-            if (key > e.x) note(sl, key, 2u /*GOSSIP*/, e);
-            else {
-#pragma unroll
-              for (int k = 0; k < SEEN; ++k) if ((uint32_t)k == m.seen_pos) { m.seen_slot[k] = sl; m.seen_key[k] = e.x; }
-              m.seen_pos = (m.seen_pos + 1) & (SEEN - 1);
+            const uint32_t lo = w ? v.z : v.x, hi = w ? v.w : v.y, tx = pe_tx(hi);
+            if (tx > nsent && !((killmask >> (2 * h + w)) & 1u) && nout < (uint32_t)PB_SLOTS) {
+              asm_[nout][0][tid] = park_rid(lo, H);
+              asm_[nout][1][tid] = pe_hi(pe_key(hi), tx - nsent);
+              nout++;
             }
           }
         }
-      };
-      for (uint32_t x = 0; x < nack; ++x) take(s.ackfrom[(size_t)i * s.P + x]);
-      const uint32_t nin = cnt < s.inbox_cap ? cnt : s.inbox_cap;
-      for (uint32_t x = 0; x < nin; ++x) take(s.inbox[(size_t)i * s.inbox_cap + x]);
-      if (cnt > s.inbox_cap) {
-        const uint32_t no = min(s.g[G_OVF0 + (t & 1u)], s.ovf_cap);
-        for (uint32_t x = 0; x < no; ++x) {
-          const uint2 o = s.ovf[(size_t)(t & 1u) * s.ovf_cap + x];
-          if (o.x == i) take(o.y);
-        }
       }
-      apply_all();
-      // refutation: bump own incarnation past the rumour's (src/Core.hs:155-166; D10)
-      unsigned refutes = 0;
-      if (refute != NONE32) {
-        uint32_t ni = refute + 1;
-        if (ni > INC_MAX) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_INC); ni = INC_MAX; }
-        m.hot.x = ni;
-        m.evd += h4(TAG_INC, ((uint64_t)t << 32) | i, ni, 0);
-        refutes = 1;
-        cand_insert(m.c, my_slot1 - 1, i, (ni << 2) | ST_ALIVE, s.L);   // Just Alive{..} (:163)
-        emit_event(s, m, i, i, (ni << 2) | ST_ALIVE, 3u /*REFUTE*/);
-      }
-      // write back
-      if (m.c.n) {
+      if (nout) {
         uint4* line = reinterpret_cast<uint4*>(s.pb + ((size_t)(cur ^ 1u) * s.N + i) * PB_SLOTS);
 #pragma unroll
-        for (int h = 0; h < PB_SLOTS / 2; ++h) {
-          uint4 v;
-          v.x = (uint32_t)(2 * h) < m.c.n ? (m.c.slot[2 * h] | (m.c.tx[2 * h] << 16)) : 0u;
-          v.y = (uint32_t)(2 * h) < m.c.n ? m.c.key[2 * h] : 0u;
-          v.z = (uint32_t)(2 * h + 1) < m.c.n ? (m.c.slot[2 * h + 1] | (m.c.tx[2 * h + 1] << 16)) : 0u;
-          v.w = (uint32_t)(2 * h + 1) < m.c.n ? m.c.key[2 * h + 1] : 0u;
-          line[h] = v;
-        }
-        s.minfo[i] = (mi & ~MI_PB) | (m.c.n << MI_PBN_SHIFT) | ((cur ^ 1u) << 20);
+        for (int h = 0; h < PB_SLOTS / 2; ++h)
+          line[h] = make_uint4(asm_[2 * h][0][tid], asm_[2 * h][1][tid], asm_[2 * h + 1][0][tid], asm_[2 * h + 1][1][tid]);
+        s.minfo[i] = (mi & ~MI_PB) | (nout << MI_PBN_SHIFT) | ((cur ^ 1u) << 20);
       } else if (pcount) {
         s.minfo[i] = mi & ~MI_PB;
       }
-      if (m.hot.z == 0) m.hot.w = NONE32;
-      else if (m.hot.y != hot0.y) m.hot.w = s.ring[(size_t)i * s.timer_cap + m.hot.y].y;
-      if (m.hot.x != hot0.x || m.hot.y != hot0.y || m.hot.z != hot0.z || m.hot.w != hot0.w) s.hot[i] = m.hot;
-      if (cnt) s.inbox_cnt[i] = 0;
-      ctr_add(&sh, C_CHANGES, m.changes);
-      ctr_add(&sh, C_PB_WRITES, (pcount || m.c.n) ? 1u : 0u);
-      ctr_add(&sh, C_TIMERS_FIRED, m.timers_fired);
+      if (tcount == 0) tnext = NONE32;
+      else if (thead != (hot0.y & 0xFFFFu)) tnext = s.ring[ridx(s, i, thead)].y;
+      const uint4 hot1 = make_uint4(self_inc, thead | (tcount << 16), 0u, tnext);
+      if (hot1.x != hot0.x || hot1.y != hot0.y || hot1.w != hot0.w) s.hot[i] = hot1;
+      ctr_add(&sh, C_CHANGES, changes);
+      ctr_add(&sh, C_PB_WRITES, (pcount || nout) ? 1u : 0u);
+      ctr_add(&sh, C_TIMERS_FIRED, timers_fired);
       ctr_add(&sh, C_REFUTES, refutes);
-      ctr_add(&sh, C_EVENTS_DROPPED, m.evdropped);
-      if (m.evd) atomicAdd(&sh.evd, m.evd);
+      ctr_add(&sh, C_EVENTS_DROPPED, evdropped);
+      ctr_add(&sh, C_EXAMINED, examined);
+      if (evd) atomicAdd(&sh.evd, evd);
     }
   }
   ctr_flush(s, &sh, blockIdx.x);
@@ -451,30 +611,44 @@ __global__ void fault_kernel(DevState s, uint32_t t, const FaultRec* faults, uin
     uint4 hot = s.hot[mbr];
     uint32_t ni = hot.x + 1;
     if (ni > INC_MAX) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_INC); ni = INC_MAX; }
-    hot.x = ni; s.hot[mbr] = hot;
     evd += h4(TAG_INC, ((uint64_t)t << 32) | mbr, ni, 0);
     ensure_slot(s, mbr);
     mi = s.minfo[mbr];
     const uint32_t sl = (mi & MI_SLOT) - 1;
     const uint32_t pcount = mi_pbn(mi), cur = mi_buf(mi);
-    Cand c; c.n = 0;
+    const uint32_t akey = (ni << 2) | ST_ALIVE;
+    // queue := best 8 of (old entries not about self) + (self, Alive@ni, tx = L), priority order.
+    // The member slept through an unknown number of rumour ids: its old entries' ids are parked and
+    // its known-ring starts empty.
+    uint32_t lo[PB_SLOTS + 1], hi[PB_SLOTS + 1], sj[PB_SLOTS + 1], n = 0;
     uint64_t* line = s.pb + ((size_t)cur * s.N + mbr) * PB_SLOTS;
+    const uint32_t far = (s.g[G_NRUM] + RID_FAR) & RID_MASK;
     if (pcount)
       for (int q = 0; q < PB_SLOTS; ++q) {
-        const uint32_t lo = (uint32_t)line[q], hi = (uint32_t)(line[q] >> 32);
-        if ((lo >> 16) & 0xFFu) cand_insert(c, lo & 0xFFFFu, s.subject_of[lo & 0xFFFFu], hi, (lo >> 16) & 0xFFu);
+        const uint32_t l = (uint32_t)line[q], h = (uint32_t)(line[q] >> 32);
+        if (!pe_tx(h) || pe_slot(l) == sl) continue;
+        lo[n] = pe_lo(pe_slot(l), far); hi[n] = h; sj[n] = s.subject_of[pe_slot(l)]; n++;
       }
-    cand_insert(c, sl, mbr, (ni << 2) | ST_ALIVE, s.L);
-    for (int q = 0; q < PB_SLOTS; ++q) {
-      uint64_t v = 0;
-      for (int k2 = 0; k2 < PB_SLOTS; ++k2)
-        if (k2 == q && (uint32_t)q < c.n) v = ((uint64_t)c.key[k2] << 32) | (c.slot[k2] | (c.tx[k2] << 16));
-      line[q] = v;
-    }
-    s.minfo[mbr] = (mi & ~MI_PBN) | (c.n << MI_PBN_SHIFT) | MI_UP;
+    lo[n] = pe_lo(sl, find_rid(s, sl, akey)); hi[n] = pe_hi(akey, s.L); sj[n] = mbr; n++;
+    for (uint32_t a = 1; a < n; ++a)                      // insertion sort by (tx desc, subject asc)
+      for (uint32_t b = a; b > 0 && rumor_better(pe_tx(hi[b]), sj[b], pe_tx(hi[b - 1]), sj[b - 1]); --b) {
+        uint32_t x;
+        x = lo[b]; lo[b] = lo[b - 1]; lo[b - 1] = x;
+        x = hi[b]; hi[b] = hi[b - 1]; hi[b - 1] = x;
+        x = sj[b]; sj[b] = sj[b - 1]; sj[b - 1] = x;
+      }
+    if (n > (uint32_t)PB_SLOTS) n = PB_SLOTS;
+    for (uint32_t q = 0; q < (uint32_t)PB_SLOTS; ++q)
+      line[q] = q < n ? (((uint64_t)hi[q] << 32) | lo[q]) : 0ull;
+    s.minfo[mbr] = (mi & ~MI_PBN) | (n << MI_PBN_SHIFT) | MI_UP;
+    s.kn[2 * (size_t)mbr] = make_uint4(0u, 0u, 0u, 0u);
+    s.kn[2 * (size_t)mbr + 1] = make_uint4(0u, 0u, 0u, 0u);
+    hot.x = ni;
+    s.hot[mbr] = hot;
+    s.kn_head[mbr] = s.g[G_NRUM];
     if (s.event_mask & (1u << 4)) {
       uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
-      if (pos < s.event_cap) s.events[pos] = make_uint4(t, mbr, mbr, (((ni << 2) | ST_ALIVE) << 8) | 4u);
+      if (pos < s.event_cap) s.events[pos] = make_uint4(t, mbr, mbr, (akey << 8) | 4u);
       else dropped++;
     }
   }
@@ -505,7 +679,7 @@ __global__ __launch_bounds__(BLOCK) void digest_kernel(DevState s, unsigned long
       const uint64_t* line = s.pb + ((size_t)mi_buf(mi) * s.N + i) * PB_SLOTS;
       for (int q = 0; q < PB_SLOTS; ++q) {
         const uint32_t lo = (uint32_t)line[q], hi = (uint32_t)(line[q] >> 32);
-        if ((lo >> 16) & 0xFFu) mh += h4(TAG_PB, s.subject_of[lo & 0xFFFFu], hi, (lo >> 16) & 0xFFu);
+        if (pe_tx(hi)) mh += h4(TAG_PB, s.subject_of[pe_slot(lo)], pe_key(hi), pe_tx(hi));
       }
     }
     unsigned long long d = mix64(mh + mix64((uint64_t)TAG_MEMBER + i));
@@ -535,11 +709,12 @@ __global__ void set_view_kernel(DevState s, uint32_t t, uint32_t observer, uint3
   s.V[vidx(s, observer, sl)] = make_uint2(key, t + 1);
   if ((key & 3u) == ST_SUSPECT) {
     uint4 hot = s.hot[observer];
-    if (hot.z >= s.timer_cap) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_TIMERS); return; }
-    uint32_t pos = hot.y + hot.z; if (pos >= s.timer_cap) pos -= s.timer_cap;
-    s.ring[(size_t)observer * s.timer_cap + pos] = make_uint2(sl, t + s.S);
-    if (hot.z == 0) hot.w = t + s.S;
-    hot.z++;
+    const uint32_t thead = hot.y & 0xFFFFu, tcount = hot.y >> 16;
+    if (tcount >= s.timer_cap) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_TIMERS); return; }
+    uint32_t pos = thead + tcount; if (pos >= s.timer_cap) pos -= s.timer_cap;
+    s.ring[ridx(s, observer, pos)] = make_uint2(sl, t + s.S);
+    if (tcount == 0) hot.w = t + s.S;
+    hot.y = thead | ((tcount + 1) << 16);
     s.hot[observer] = hot;
   }
 }

@@ -1,7 +1,7 @@
 // swimsim.hip -- C ABI (include/swimsim.h) over the gfx950 tick kernels.
 //
 // Host side of libswimsim.so: owns device memory, the fault schedule and the launch
-// sequence (per tick: [fault_kernel] -> probe_kernel -> merge_kernel on one HIP stream).
+// sequence (per tick: [fault_kernel] -> probe_kernel -> scan_kernel -> apply_kernel on one HIP stream).
 // There is no CPU implementation behind this ABI: without a HIP device swimsim_create fails.
 #include "../../include/swimsim.h"
 
@@ -44,8 +44,8 @@ struct swimsim {
   std::vector<void*> allocs;
   std::vector<swimsim_event_t> host_events;    // drained from the device ring, not yet handed out
   bool timing = false;                         // HIP-event timing of the tick kernels
-  std::vector<hipEvent_t> ev_pool;             // 3 events per tick: before probe, between, after merge
-  double probe_ms = 0, merge_ms = 0; uint64_t timed_ticks = 0;
+  std::vector<hipEvent_t> ev_pool;             // 4 events per tick: before probe, after probe, after scan, after apply
+  double probe_ms = 0, scan_ms = 0, apply_ms = 0; uint64_t timed_ticks = 0;
   bool poisoned = false;
   std::string err;
 };
@@ -172,8 +172,10 @@ void launch_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev) {
   if (ev) (void)hipEventRecord(ev[0], h->stream);
   hipLaunchKernelGGL((probe_kernel<PMAX>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk);
   if (ev) (void)hipEventRecord(ev[1], h->stream);
-  hipLaunchKernelGGL(merge_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
+  hipLaunchKernelGGL(scan_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
   if (ev) (void)hipEventRecord(ev[2], h->stream);
+  hipLaunchKernelGGL(apply_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
+  if (ev) (void)hipEventRecord(ev[3], h->stream);
 }
 
 }  // namespace
@@ -241,6 +243,11 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   CK(dev_alloc(h, &d.inbox_cnt, N, 0));
   CK(dev_alloc(h, &d.inbox, (size_t)N * d.inbox_cap, 0));
   CK(dev_alloc(h, &d.hot, N, 0));
+  CK(dev_alloc(h, &d.kn, (size_t)2 * N, 0));
+  CK(dev_alloc(h, &d.kn_head, N, 0));
+  CK(dev_alloc(h, &d.xl, (size_t)XL_CAP * N, 0));
+  CK(dev_alloc(h, &d.xinfo, N, 0));
+  CK(dev_alloc(h, &d.rtab, (size_t)d.R_max * RT_WAYS, 0));
   CK(dev_alloc(h, &d.subject_of, (size_t)d.R_max, 0));
   CK(dev_alloc(h, &d.fail, (size_t)N * (d.P ? d.P : 1), 0));
   CK(dev_alloc(h, &d.ring, (size_t)N * d.timer_cap, 0));
@@ -301,7 +308,7 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
     HIPCHK(h, hipMemcpy(h->d_faults, recs.data(), fend * sizeof(FaultRec), hipMemcpyHostToDevice));
   }
   if (h->timing) {
-    while (h->ev_pool.size() < (size_t)nticks * 3) {
+    while (h->ev_pool.size() < (size_t)nticks * 4) {
       hipEvent_t e;
       HIPCHK(h, hipEventCreate(&e));
       h->ev_pool.push_back(e);
@@ -310,7 +317,7 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
   size_t fpos = 0;
   for (uint32_t k = 0; k < nticks; ++k) {
     const uint32_t t = (uint32_t)h->tick;
-    hipEvent_t* ev = h->timing ? &h->ev_pool[(size_t)k * 3] : nullptr;
+    hipEvent_t* ev = h->timing ? &h->ev_pool[(size_t)k * 4] : nullptr;
     const size_t f0 = fpos;
     while (fpos < fend && h->faults[fpos].tick <= t) ++fpos;
     if (fpos > f0)
@@ -325,10 +332,11 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (h->timing) {
     for (uint32_t k = 0; k < nticks; ++k) {
-      float a = 0, b = 0;
-      HIPCHK(h, hipEventElapsedTime(&a, h->ev_pool[(size_t)k * 3], h->ev_pool[(size_t)k * 3 + 1]));
-      HIPCHK(h, hipEventElapsedTime(&b, h->ev_pool[(size_t)k * 3 + 1], h->ev_pool[(size_t)k * 3 + 2]));
-      h->probe_ms += a; h->merge_ms += b;
+      float a = 0, b = 0, c = 0;
+      HIPCHK(h, hipEventElapsedTime(&a, h->ev_pool[(size_t)k * 4], h->ev_pool[(size_t)k * 4 + 1]));
+      HIPCHK(h, hipEventElapsedTime(&b, h->ev_pool[(size_t)k * 4 + 1], h->ev_pool[(size_t)k * 4 + 2]));
+      HIPCHK(h, hipEventElapsedTime(&c, h->ev_pool[(size_t)k * 4 + 2], h->ev_pool[(size_t)k * 4 + 3]));
+      h->probe_ms += a; h->scan_ms += b; h->apply_ms += c;
     }
     h->timed_ticks += nticks;
   }
@@ -361,8 +369,9 @@ static int read_column(swimsim_t* h, uint32_t observer, std::vector<uint2>* col,
   const uint32_t ns = std::min(g[G_NSLOTS], h->d.R_max);
   col->resize(ns); subj->resize(ns);
   if (!ns) return SWIMSIM_OK;
-  const uint2* src = h->d.V + (size_t)observer * h->d.R_max;
-  HIPCHK(h, hipMemcpy(col->data(), src, (size_t)ns * sizeof(uint2), hipMemcpyDeviceToHost));
+  // V is slot-major [slot][member]: one observer's entries are a strided column
+  HIPCHK(h, hipMemcpy2D(col->data(), sizeof(uint2), h->d.V + observer, (size_t)h->d.N * sizeof(uint2),
+                        sizeof(uint2), ns, hipMemcpyDeviceToHost));
   HIPCHK(h, hipMemcpy(subj->data(), h->d.subject_of, (size_t)ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return SWIMSIM_OK;
 }
@@ -403,11 +412,11 @@ int swimsim_read_member(swimsim_t* h, uint32_t m, swimsim_member_t* out) {
     HIPCHK(h, hipMemcpy(line, h->d.pb + ((size_t)((mi >> 20) & 1u) * h->d.N + m) * PB_SLOTS, sizeof line, hipMemcpyDeviceToHost));
     for (int q = 0; q < PB_SLOTS; ++q) {
       const uint32_t lo = (uint32_t)line[q], hi = (uint32_t)(line[q] >> 32);
-      if (!((lo >> 16) & 0xFFu)) continue;
+      if (!pe_tx(hi)) continue;
       swimsim_rumor_t& r = out->rumors[out->n_rumors++];
-      const uint32_t sl = lo & 0xFFFFu;
+      const uint32_t sl = pe_slot(lo);
       r.subject = sl < subj.size() ? subj[sl] : NONE32;
-      r.incarnation = hi >> 2; r.state = (uint8_t)(hi & 3u); r.tx_left = (uint8_t)((lo >> 16) & 0xFFu);
+      r.incarnation = pe_key(hi) >> 2; r.state = (uint8_t)(pe_key(hi) & 3u); r.tx_left = (uint8_t)pe_tx(hi);
     }
   }
   uint32_t nt = 0;
@@ -481,13 +490,13 @@ int swimsim_k_random_members(swimsim_t* h, uint32_t observer, uint32_t n, const 
 int swimsim_kernel_timing_enable(swimsim_t* h, int enable) {
   if (!h) return SWIMSIM_ERR_INVALID;
   h->timing = enable != 0;
-  h->probe_ms = h->merge_ms = 0; h->timed_ticks = 0;
+  h->probe_ms = h->scan_ms = h->apply_ms = 0; h->timed_ticks = 0;
   return SWIMSIM_OK;
 }
 
 int swimsim_kernel_timing(swimsim_t* h, double* out, size_t n) {
-  if (!h || !out || n < 3) return SWIMSIM_ERR_INVALID;
-  out[0] = h->probe_ms; out[1] = h->merge_ms; out[2] = (double)h->timed_ticks;
+  if (!h || !out || n < 4) return SWIMSIM_ERR_INVALID;
+  out[0] = h->probe_ms; out[1] = h->scan_ms; out[2] = h->apply_ms; out[3] = (double)h->timed_ticks;
   return SWIMSIM_OK;
 }
 

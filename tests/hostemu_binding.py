@@ -16,14 +16,15 @@ LIB = os.path.join(EMU, "_build", "libswimsim_hostemu.so")
 _cached = None
 
 
-def build():
+def build(lib=None, defines=()):
+    lib = lib or LIB
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
     srcs += [os.path.join(EMU, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "swimsim.h")]
-    if os.path.exists(LIB) and all(os.path.getmtime(s) <= os.path.getmtime(LIB) for s in srcs):
+    if os.path.exists(lib) and all(os.path.getmtime(s) <= os.path.getmtime(lib) for s in srcs):
         return
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-I", EMU,
-                           "-Wno-unused-function", "-o", LIB, os.path.join(CSRC, "swimsim.hip")])
+                           "-Wno-unused-function", "-Wl,-Bsymbolic", *["-D" + d for d in defines], "-o", lib, os.path.join(CSRC, "swimsim.hip")])
 
 
 def load():
@@ -32,3 +33,11 @@ def load():
         build()
         _cached = _abi.bind(C.CDLL(LIB), "swimsim_")
     return _cached
+
+
+def load_variant(tag, defines):
+    """A second build of the same sources with compile-time knobs changed (e.g. a tiny examination
+    list so that the overflow path runs), for stress tests."""
+    lib = os.path.join(EMU, "_build", "libswimsim_hostemu_%s.so" % tag)
+    build(lib, defines)
+    return _abi.bind(C.CDLL(lib), "swimsim_")

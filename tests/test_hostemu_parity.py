@@ -50,3 +50,17 @@ def test_matches_committed_golden_fixtures(emu_abi, name):
     from tests.test_oracle_semantics import GOLDEN, run_fixture
     fx = json.load(open(os.path.join(GOLDEN, name + ".json")))
     assert run_fixture(emu_abi, fx["spec"]) == fx["expect"]
+
+
+def test_overflow_paths(oracle_abi):
+    """Tiny examination list (2 entries) and a 1-slot inbox: the exact slow paths of scan/apply and the
+    inbox overflow list carry most of the traffic and must still be bit-exact."""
+    from tests import hostemu_binding
+    emu = hostemu_binding.load_variant("xl2", ["SWIM_XL_CAP=2"])
+    n = 700
+    crashes = workloads.hashed_crashes(n, 9, 1, 6, 3, 33)
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=9, lossPpm=30000, eventMask=0x1F, suspicionTicks=6,
+                   maxSubjects=700, timerCap=512, inboxCap=1)
+    faults = [(45, m, True) for (_, m) in crashes[:20]]
+    a, b = make_pair(oracle_abi, emu, sc, crashes, faults)
+    run_lockstep(a, b, 70, 5, observers=(0, 1, n - 1), members=(0, 1, n - 1))
