@@ -8,8 +8,8 @@ every Ping/Ack carries a full 8-rumour piggyback payload and each member accepts
 changes per tick.  State is resident in HBM before the timed region; faults are pre-scheduled.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     : dominant kernel (scan_kernel: the scattered 64-B payload gathers) algorithmic bytes /
-                 HIP-event duration vs 8 TB/s, plus the per-kernel and whole-tick figures
+  roofline     : dominant kernel (probe_kernel: it performs the 2P payload deliveries per member) algorithmic
+                 bytes / HIP-event duration vs 8 TB/s, plus the per-kernel and whole-tick figures
   cpu_baseline : the CPU oracle (a "port": the Haskell reference cannot be built here, no GHC)
                  timed on a bounded sample of the same workload on this box's host cores.
 """
@@ -35,9 +35,8 @@ def algorithmic_bytes(c0, c1, n_members, ticks, P, K):
     r = (c1["changes"] - c0["changes"]) / mt
     c = (c1["pb_writes"] - c0["pb_writes"]) / mt
     f = (c1["direct_failed"] - c0["direct_failed"]) / mt
-    a = {"probe_kernel": P + f * K,                    # target / proxy liveness gathers
-         "scan_kernel": 64.0 * d,                      # delivered piggyback payload lines
-         "apply_kernel": 16.0 + 16.0 * r + 128.0 * c}  # hot record, accepted rumours, own line read+write
+    a = {"probe_kernel": P + f * K + 64.0 * d,         # liveness gathers + delivered piggyback payloads
+         "merge_kernel": 16.0 + 16.0 * r + 128.0 * c}  # hot record, accepted rumours, own line read+write
     return a, {"d": d, "r": r, "c": c, "f": f}
 
 
@@ -124,11 +123,10 @@ def main():
         K = sim.resolved.indirect_k
         a_by, rates = algorithmic_bytes(c0, c1, n, args.steps, P, K)
         nt = max(1, kt["ticks"])
-        secs = {"probe_kernel": kt["probe_ms"] / 1e3 / nt, "scan_kernel": kt["scan_ms"] / 1e3 / nt,
-                "apply_kernel": kt["apply_ms"] / 1e3 / nt}
+        secs = {"probe_kernel": kt["probe_ms"] / 1e3 / nt, "merge_kernel": kt["merge_ms"] / 1e3 / nt}
         per_kernel = {k: {"algorithmic_bytes_per_member_tick": a_by[k], "avg_launch_us": secs[k] * 1e6,
                           "achieved_GBs": (a_by[k] * n / secs[k] / 1e9) if secs[k] > 0 else 0.0} for k in secs}
-        dom = "scan_kernel"
+        dom = "probe_kernel"
         achieved = per_kernel[dom]["achieved_GBs"]
         a_tot, t_tot = sum(a_by.values()), sum(secs.values())
         traffic = None

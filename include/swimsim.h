@@ -241,8 +241,8 @@ int swimsim_get_config(const swimsim_t* h, swimsim_config_t* out);
 
 /* When enabled, swimsim_step brackets every tick-kernel launch with HIP events on the
  * library's own stream (torch.cuda.Event would not see it) and accumulates the elapsed
- * times.  out[0..2] = total ms in probe_kernel, scan_kernel, apply_kernel; out[3] = number
- * of ticks measured (n >= 4); reading resets nothing, enabling resets. */
+ * times.  out[0] = total ms in probe_kernel, out[1] = total ms in merge_kernel,
+ * out[2] = number of ticks measured; reading resets nothing, enabling resets. */
 int swimsim_kernel_timing_enable(swimsim_t* h, int enable);
 int swimsim_kernel_timing(swimsim_t* h, double* out, size_t n);
 

@@ -20,8 +20,7 @@ for path in libs:
     kt = s.kernelTiming()
     print(json.dumps({"lib": os.path.basename(path), "regime": REGIME, "us_per_tick": round(dt / TICKS * 1e6, 1),
                       "probe_us": round(kt["probe_ms"] * 1e3 / kt["ticks"], 1),
-                      "scan_us": round(kt["scan_ms"] * 1e3 / kt["ticks"], 1),
-                      "apply_us": round(kt["apply_ms"] * 1e3 / kt["ticks"], 1),
+                      "merge_us": round(kt["merge_ms"] * 1e3 / kt["ticks"], 1),
                       "Gmt_per_s": round(TICKS * N / dt / 1e9, 3),
                       "examined_per_mt": round((raw1[14] - raw0[14]) / TICKS / N, 3),
                       "changes_per_mt": round((raw1[7] - raw0[7]) / TICKS / N, 3),

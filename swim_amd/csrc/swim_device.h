@@ -24,7 +24,7 @@ enum : uint64_t { TAG_SELF = 0x53454c46u, TAG_VIEW = 0x56494557u, TAG_PB = 0x504
                   TAG_INC = 0x494e4352u, TAG_TICK = 0x5449434bu, TAG_MEMBER = 0x4d454d42u };
 
 // globals word indices (DevState::g)
-enum { G_NSLOTS = 0, G_ERR = 1, G_EVCUR = 2, G_OVF0 = 3, G_OVF1 = 4, G_NRUM = 5, G_HEAD = 6, G_WORDS = 8 };
+enum { G_NSLOTS = 0, G_ERR = 1, G_EVCUR = 2, G_OVF0 = 3, G_OVF1 = 4, G_NRUM = 5, G_HEAD = 6, G_PREV = 7, G_WORDS = 16 };
 enum { ERRF_SUBJECTS = 1, ERRF_TIMERS = 2, ERRF_OVF = 4, ERRF_INC = 8 };
 
 // counter slots (same order as SWIMSIM_CTR_* in include/swimsim.h)
@@ -66,18 +66,23 @@ struct DevState {
   uint32_t* minfo;         // per member, ONE gather per probe target:
                            //   bits 0-15 rumour slot+1 of this member as a subject (0 none,
                            //   0xFFFF being allocated), 16-19 valid piggyback slots,
-                           //   20 which pb buffer is current, 21 up (ground truth)
-  uint16_t* probe_out;     // nsent | nfail<<5 | n own-ack sources<<10, probe -> merge kernel
-  uint32_t* ackfrom;       // [N][P] sources whose Ack reached this member with a payload
-  uint32_t* inbox_cnt;     // deliveries to this member this tick
+                           //   20 which pb buffer is current, 21 up (ground truth),
+                           //   22 the queue holds an entry its mask cannot express (MI_OOW)
+  uint16_t* probe_out;     // nsent | nfail<<5 | n explicit own-ack sources<<10, probe -> merge kernel
+  unsigned long long* qm;  // [2][N] the member's queue as a 64-bit mask over rumour-id positions (rid & 63)
+  unsigned long long* inmask;   // OR of the masks pushed to this member this tick (atomicOr by the pingers)
+  unsigned long long* ackmask;  // OR of the masks this member pulled with its Acks (plain store by the prober)
+  unsigned long long* kn;  // 64-bit ring over rumour ids: bit (rid & 63) set => this member's view already
+                           //   dominates rumour rid (pure negative filter, see below)
+  uint32_t* kn_head;       // rumour-id counter value up to which this member's ring has been cleared
+  uint2* rum;              // [65536] rumour id -> {slot, key}
+  unsigned long long* rtab;// [R_max][RT_WAYS] (slot, key) -> rumour id: {key+1 : 32 | ready : 1 | rid : 16}
+  // explicit delivery records "dst merges src's 64-B line": the exact fallback for queues with
+  // entries outside the mask window, and for ticks that follow a burst of new rumour ids
+  uint32_t* ackfrom;       // [N][P] sources whose Ack reached this member with such a payload
+  uint32_t* inbox_cnt;     // explicit deliveries to this member this tick
   uint32_t* inbox;         // [N][inbox_cap] source ids (bit31 = source's pb buffer)
   uint4* hot;              // {storeIncarnation, timer ring head | count<<16, -, next deadline}
-  uint4* kn;               // [N][2] 256-bit ring over rumour ids: bit (rid & 255) set => this member's view
-                           //   already dominates rumour rid (pure negative filter, see KN_* below)
-  uint32_t* kn_head;       // rumour-id counter value up to which this member's ring has been cleared
-  uint2* xl;               // [XL_CAP][N] scan -> apply: rumours that need a view lookup {slot | rid<<16, key}
-  uint32_t* xinfo;         // scan -> apply: list length | overflow | refutation (XI_* in swim_kernels.h)
-  unsigned long long* rtab;// [R_max][RT_WAYS] (slot, key) -> rumour id: {key+1 : 32 | ready : 1 | rid : 16}
   uint32_t* subject_of;    // slot -> subject
   uint32_t* fail;          // [N][P] targets whose probe ended without ack
   uint2* ring;             // [timer_cap][N] {slot, deadline}: FIFO of suspicion timers
@@ -115,25 +120,48 @@ __host__ __device__ inline uint32_t pe_tx(uint32_t hi) { return hi >> 24; }
 __host__ __device__ inline uint32_t pe_lo(uint32_t slot, uint32_t rid) { return slot | (rid << 16); }
 __host__ __device__ inline uint32_t pe_hi(uint32_t key, uint32_t tx) { return key | (tx << 24); }
 
-// ---- rumour ids and the known-ring ----------------------------------------------------------------
+// ---- rumour ids, queue masks and the known-ring --------------------------------------------------
 // Every distinct rumour (slot, key) gets a 16-bit id from a global bump counter (G_NRUM) the first time
-// any member creates it, so ids are handed out in time order and the rumours in flight at one moment
-// occupy a short id range.  G_HEAD = the counter at the start of the tick (H).  A member keeps a
-// 256-bit ring indexed by rid & 255; only ids in [H-256, H) may be tested or set, and a member clears
-// the positions of the ids allocated since it last looked ([its head, H)) before using the ring.  A set
-// bit means "my view entry already dominates this rumour", so the delivery is skipped with one bit test;
-// a clear bit (or an id outside the window) only means "look it up".  Ids are internal: never observable.
-constexpr uint32_t KN_BITS = 256, KN_WORDS = 8, RID_MASK = 0xFFFFu, RID_FAR = 0x8000u;
-constexpr int RT_WAYS = 8;
-#ifndef SWIM_XL_CAP
-#define SWIM_XL_CAP 16
+// any member creates it (rum[id] = {slot, key}), so ids are handed out in time order and the rumours in
+// flight at one moment occupy a short id range (measured at 1 M members, one crash per tick: none older
+// than 48 ids, profiles/).  H = the counter at the start of the tick (G_HEAD; G_PREV = the tick before).
+//
+// Transport.  A member's queue is published twice: as the 64-B line and as a 64-bit MASK, bit (rid & 63)
+// for every entry with rid in [H-48, H+16) at build time.  "dst merges src's queue" is then ONE
+// atomicOr of 8 bytes into inmask[dst] (Pings) or an 8-byte gather from the 8-MB mask table (Acks)
+// instead of a 64-B gather from a 64-MB one: the fabric request rate, not bytes, bounds the tick.  A
+// receiver decodes bit p as the only id in [H-64, H) with that position, which is exact as long as at
+// most 16 ids were allocated since the masks were built (G_HEAD - G_PREV <= MASK_SLACK); otherwise,
+// and for queues holding an entry the mask cannot express (MI_OOW), the delivery also travels as an
+// explicit record and the receiver reads the source's 64-B line.
+//
+// Known-ring.  A member keeps a 64-bit ring indexed the same way; only ids in [H-64, H) may be tested
+// or set, and the member first clears the positions of the ids allocated since it last looked
+// ([its head, H)).  A set bit means "my view entry already dominates this rumour": new = incoming &
+// ~known is the whole per-delivery filter.  A clear bit (or an id outside the window) only means "look
+// it up".  Ids, masks and the ring are internal: never observable.
+#ifndef SWIM_MASK_WIN        // compile-time knobs so that tests can force the fallback paths
+#define SWIM_MASK_WIN 48
+#define SWIM_MASK_SLACK 16
 #endif
-constexpr int XL_CAP = SWIM_XL_CAP;    // examination list entries per member per tick (more: exact slow path; <= 31)
+constexpr uint32_t KN_BITS = 64, MASK_WIN = SWIM_MASK_WIN, MASK_SLACK = SWIM_MASK_SLACK, RID_MASK = 0xFFFFu, RID_FAR = 0x8000u;
+static_assert(MASK_WIN + MASK_SLACK <= KN_BITS, "mask positions must be unambiguous");
+constexpr int RT_WAYS = 8;
 constexpr unsigned long long RT_READY = 1ull << 16;
+
+// ring / mask position arithmetic (H = head of the tick)
+__device__ inline bool rid_in_ring(uint32_t rid, uint32_t H) { return ((H - 1u - rid) & RID_MASK) < KN_BITS; }
+__device__ inline unsigned long long rid_bit(uint32_t rid) { return 1ull << (rid & 63u); }
+// the id in [H-64, H) that owns position p
+__device__ inline uint32_t rid_at(uint32_t p, uint32_t H) { return (H - 1u) - ((H - 1u - p) & 63u); }
+// can an entry with this id be expressed in a mask built at head H?
+__device__ inline bool rid_maskable(uint32_t rid, uint32_t H) {
+  return ((rid - (H - MASK_WIN)) & RID_MASK) < MASK_WIN + MASK_SLACK;
+}
 
 // minfo fields
 constexpr uint32_t MI_SLOT = 0xFFFFu, MI_PBN_SHIFT = 16, MI_PBN = 0xFu << 16, MI_BUF = 1u << 20,
-                   MI_UP = 1u << 21, MI_PB = MI_PBN | MI_BUF;
+                   MI_UP = 1u << 21, MI_OOW = 1u << 22, MI_PB = MI_PBN | MI_BUF | MI_OOW;
 __device__ inline uint32_t mi_pbn(uint32_t mi) { return (mi >> MI_PBN_SHIFT) & 0xFu; }
 __device__ inline uint32_t mi_buf(uint32_t mi) { return (mi >> 20) & 1u; }
 __device__ inline bool mi_up(uint32_t mi) { return (mi & MI_UP) != 0; }

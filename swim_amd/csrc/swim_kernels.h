@@ -7,9 +7,9 @@
 // through atomics.
 // Three launches per tick:
 //   probe_kernel : one period of failureDetector / probeNode' per member (src/Core.hs:233-269),
-//                  closed form of the message exchange; emits (dst <- src) payload deliveries.
-//   scan_kernel  : receivers gather the delivered payload lines and list the unknown rumours.
-//   apply_kernel : owner-computes end of tick: timers, state rule, piggyback queue
+//                  closed form of the message exchange; delivers the piggyback payloads as masks.
+//   begin_kernel : one thread: scheduled faults, rumour-id window head.
+//   merge_kernel : owner-computes end of tick: delivered rumours, timers, state rule, piggyback queue
 //                  (src/Core.hs:89-117, 127-138, 142-218).
 #pragma once
 #include "swim_device.h"
@@ -85,22 +85,29 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
   __shared__ BlockCounters sh;
   ctr_init(&sh);
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-  // rumour ids are only allocated by fault_kernel (before) and apply_kernel (after): this is the quiet
-  // point at which the tick's window head H is fixed (swim_device.h, "rumour ids and the known-ring")
-  if (blockIdx.x == 0 && threadIdx.x == 0) s.g[G_HEAD] = s.g[G_NRUM];
   const uint32_t mi = i < s.N ? s.minfo[i] : 0u;
   const bool act = mi_up(mi);
+  // masks are exact only if few rumour ids appeared since they were built (swim_device.h)
+  const bool use_mask = s.g[G_HEAD] - s.g[G_PREV] <= MASK_SLACK;
   unsigned n_pings = 0;
+  unsigned long long ackacc = 0;                  // masks this member pulls in with its Acks
   if (act) {
     const uint32_t mk = mix32(tk ^ i);
     const uint32_t mycnt = mi_pbn(mi);
     const uint32_t mysrc = mi_src(i, mi);
+    const unsigned long long mymask = (mycnt && use_mask) ? s.qm[(size_t)mi_buf(mi) * s.N + i] : 0ull;
     uint32_t picks[PMAX], pinfo[PMAX];
     // ms <- kRandomMembers store (numToGossip cfg) []        (src/Core.hs:239)
     const uint32_t np = select_members<PMAX>(s, mk, i, s.P, P_SELECT, 0, nullptr, 0, picks, pinfo);
     n_pings = np;
     uint32_t nfail = 0, nack = 0;
     unsigned payloads = 0, rumors = 0, dfail = 0, preqs = 0, susp = 0, fsusp = 0;
+    // "dst merges src's start-of-tick queue": the mask by atomicOr (or into ackacc when dst is me),
+    // plus an explicit record when the mask cannot carry all of it
+    auto explicit_needed = [&](uint32_t msrc) { return !use_mask || (msrc & MI_OOW); };
+    auto src_mask = [&](uint32_t src, uint32_t msrc) -> unsigned long long {
+      return use_mask ? s.qm[(size_t)mi_buf(msrc) * s.N + src] : 0ull;
+    };
     // pass 1: outcome of every direct probe -- pure arithmetic on the gathered info words.
     //   Direct (Ping seq j) is delivered iff not lost and j is up (src/Core.hs:246);
     //   j answers Ack (src/Core.hs:97-99), which may be lost too.
@@ -113,26 +120,46 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
         ack_ok[p] = ping_ok[p] && !lost(s, tk, P_L_ACK, picks[p], i, p);
       }
     }
-    // pass 2: the Pings' piggyback payloads: one delivery record per target.  The reservation
-    // atomics are independent, so they are issued back to back and overlap in the fabric.
-    if (mycnt) {
-      uint32_t pos[PMAX];
+    // pass 2: the Acks' payloads are pulled by the prober itself: 8-byte gathers, issued together
+    unsigned long long am[PMAX];
 #pragma unroll
-      for (int p = 0; p < PMAX; ++p) { pos[p] = 0; if (ping_ok[p]) pos[p] = atomicAdd(&s.inbox_cnt[picks[p]], 1u); }
+    for (int p = 0; p < PMAX; ++p) {
+      am[p] = 0;
+      if (ack_ok[p] && mi_pbn(pinfo[p])) am[p] = src_mask(picks[p], pinfo[p]);
+    }
+    // pass 3: the Pings' piggyback payloads: one atomicOr per target
+    if (mycnt) {
 #pragma unroll
       for (int p = 0; p < PMAX; ++p)
-        if (ping_ok[p]) { push_commit(s, t, picks[p], mysrc, pos[p]); payloads++; rumors += mycnt; }
+        if (ping_ok[p]) {
+          if (mymask) atomicOr(&s.inmask[picks[p]], mymask);
+          payloads++; rumors += mycnt;
+        }
+      if (explicit_needed(mi)) {
+        uint32_t pos[PMAX];
+#pragma unroll
+        for (int p = 0; p < PMAX; ++p) { pos[p] = 0; if (ping_ok[p]) pos[p] = atomicAdd(&s.inbox_cnt[picks[p]], 1u); }
+#pragma unroll
+        for (int p = 0; p < PMAX; ++p) if (ping_ok[p]) push_commit(s, t, picks[p], mysrc, pos[p]);
+      }
     }
-    // pass 3: the Acks' payloads are pulled by the prober itself: private list, no atomics
 #pragma unroll
     for (int p = 0; p < PMAX; ++p) {
       const uint32_t pj = mi_pbn(pinfo[p]);
       if (ack_ok[p] && pj) {
-        s.ackfrom[(size_t)i * s.P + nack] = mi_src(picks[p], pinfo[p]);
-        nack++; payloads++; rumors += pj;
+        ackacc |= am[p];
+        if (explicit_needed(pinfo[p])) { s.ackfrom[(size_t)i * s.P + nack] = mi_src(picks[p], pinfo[p]); nack++; }
+        payloads++; rumors += pj;
       }
     }
     // pass 4 (rare): probes without an ack -> k indirect probes -> maybe Suspect
+    auto deliver = [&](uint32_t dst, uint32_t src, uint32_t msrc) {
+      const unsigned long long m = src == i ? mymask : src_mask(src, msrc);
+      if (dst == i) ackacc |= m;
+      else if (m) atomicOr(&s.inmask[dst], m);
+      if (explicit_needed(msrc)) push(s, t, dst, mi_src(src, msrc));
+      payloads++; rumors += mi_pbn(msrc);
+    };
     for (int p = 0; p < PMAX; ++p) {
       if ((uint32_t)p >= np) break;
       if (ack_ok[p]) continue;                               // unlessAck (D2, D3)
@@ -153,16 +180,16 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
         const uint32_t idx = ((uint32_t)p << 8) | (uint32_t)k;
         // i -> q : IndirectPing (src/Core.hs:250, 262-269)
         if (lost(s, tk, P_L_REQ, i, q, idx) || !mi_up(mq)) continue;
-        if (mycnt) { push(s, t, q, mysrc); payloads++; rumors += mycnt; }
+        if (mycnt) deliver(q, i, mi);
         // q -> j : Ping on behalf of i (src/Core.hs:105-108; D8, D12)
         if (!upj || lost(s, tk, P_L_FWD, q, j, idx)) continue;
-        if (pq) { push(s, t, j, mi_src(q, mq)); payloads++; rumors += pq; }
+        if (pq) deliver(j, q, mq);
         // j -> q : Ack
         if (lost(s, tk, P_L_BACK, j, q, idx)) continue;
-        if (pj) { push(s, t, q, mi_src(j, mj)); payloads++; rumors += pj; }
+        if (pj) deliver(q, j, mj);
         // q -> i : relayed Ack (D9)
         if (lost(s, tk, P_L_RELAY, q, i, idx)) continue;
-        if (pq) { push(s, t, i, mi_src(q, mq)); payloads++; rumors += pq; }
+        if (pq) deliver(i, q, mq);
         acked = true;
       }
       if (acked) continue;                                   // second unlessAck (src/Core.hs:251)
@@ -182,6 +209,7 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
     ctr_add(&sh, C_SUSPECTS, susp);
     ctr_add(&sh, C_FALSE_SUSPECTS, fsusp);
   }
+  if (i < s.N) s.ackmask[i] = ackacc;
   // the two always-nonzero counters: wave-reduce first
   unsigned wp = wave_sum(n_pings);
   unsigned wa = wave_sum(act ? 1u : 0u);
@@ -217,12 +245,15 @@ __device__ inline uint32_t find_rid(const DevState& s, uint32_t slot, uint32_t k
     const unsigned long long seen = atomicCAS(p, e, claim);
     if (seen == e) {
       const uint32_t rid = atomicAdd(&s.g[G_NRUM], 1u) & RID_MASK;
+      s.rum[rid] = make_uint2(slot, key);           // read by other members from the next launch on
       atomicExch(p, claim | RT_READY | rid);
       return rid;
     }
     e = seen;
   }
-  return atomicAdd(&s.g[G_NRUM], 1u) & RID_MASK;
+  const uint32_t rid = atomicAdd(&s.g[G_NRUM], 1u) & RID_MASK;
+  s.rum[rid] = make_uint2(slot, key);
+  return rid;
 }
 
 // rumour ids that fell out of the known-ring window are parked half the id space away so that a
@@ -258,152 +289,48 @@ __device__ inline void group_put(NewGroup& c, uint32_t slot, uint32_t rid, uint3
   if (c.n < (uint32_t)PB_SLOTS) c.n++;
 }
 
-// The end of a tick is two launches, one thread per member each:
-//   scan_kernel  : every delivered piggyback entry (src/Core.hs:110-117) is tested against the
-//                  member's known-ring with ONE bit test; the few unknown ones are appended to the
-//                  member's examination list in global memory ([position][member], coalesced).  Owns
-//                  the scattered 64-B payload gathers, so it is kept lean for occupancy.
-//   apply_kernel : suspicion timers (the FIXME at src/Core.hs:141; D4), own probes that ended without
-//                  an ack (src/Core.hs:253) and the listed rumours go through the state rule
-//                  suspectOrDeadNode' (src/Core.hs:142-187) + the unwritten aliveNode (:197-218, D6)
-//                  as the commutative merge entry := max(entry, (incarnation,state)) (H3, D13), with
-//                  what follows `saveMember m'` (:169-179): lastChange, timer start, enqueue for
-//                  piggybacking, membership event, digest; then the piggyback queue `disseminate`
-//                  leaves as a FIXME (src/Core.hs:136-138; D5) is rebuilt.
-
-// xinfo word (scan -> apply): list length (5) | overflow (1) | refute seen (1) | max refuting incarnation (22)
-constexpr uint32_t XI_OVF = 1u << 5, XI_REF = 1u << 6;
-
-__device__ inline void refute_note(uint32_t& refute, uint32_t key) {
-  // about self -> refute (src/Core.hs:155-166): remember the largest non-Alive incarnation
-  if ((key & 3u) != ST_ALIVE) refute = (refute == NONE32 || (key >> 2) > refute) ? (key >> 2) : refute;
-}
-
-#ifndef SWIM_SCAN_WAVES
-#define SWIM_SCAN_WAVES 5
+// One thread = one member's end of tick:
+//   suspicion timers (the FIXME at src/Core.hs:141; D4), own probes that ended without an ack
+//   (src/Core.hs:253) and the rumours delivered this tick (src/Core.hs:110-117) go through the state
+//   rule suspectOrDeadNode' (src/Core.hs:142-187) + the unwritten aliveNode (:197-218, D6) as the
+//   commutative merge entry := max(entry, (incarnation,state)) (H3, D13), with what follows
+//   `saveMember m'` (:169-179): lastChange, timer start, enqueue for piggybacking, membership event,
+//   digest; then the piggyback queue `disseminate` leaves as a FIXME (src/Core.hs:136-138; D5) is rebuilt.
+// Delivered rumours arrive as masks: new = (pushed | pulled) & ~known is the whole filter, and the
+// lanes of a wave walk their new bits in the same order, so their view / timer accesses coalesce.
+#ifndef SWIM_MERGE_WAVES
+#define SWIM_MERGE_WAVES 4
 #endif
-__global__ __launch_bounds__(BLOCK, SWIM_SCAN_WAVES) void scan_kernel(DevState s, uint32_t t) {
-  __shared__ uint32_t knl[KN_WORDS][BLOCK];       // [word][thread]: conflict-free for any word index
-  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-  const uint32_t tid = threadIdx.x;
-  if (blockIdx.x == 0 && threadIdx.x == 0) s.g[G_OVF0 + ((t + 1) & 1u)] = 0;  // next tick's overflow list
-  if (i >= s.N) return;
-  const uint32_t mi = s.minfo[i];
-  uint32_t xi = 0;
-  if (mi_up(mi)) {
-    const uint32_t nack = s.probe_out[i] >> 10;
-    const uint32_t cnt = s.inbox_cnt[i];
-    if (cnt | nack) {
-      const uint32_t H = s.g[G_HEAD];
-      // ---- known-ring: load, forget the positions of ids allocated since this member last looked
-      {
-        const uint4 k0 = s.kn[2 * (size_t)i], k1 = s.kn[2 * (size_t)i + 1];
-        const uint32_t head = s.kn_head[i];
-        const bool wipe = H - head >= 64u;          // clearing more than needed is always safe
-        knl[0][tid] = wipe ? 0u : k0.x; knl[1][tid] = wipe ? 0u : k0.y; knl[2][tid] = wipe ? 0u : k0.z;
-        knl[3][tid] = wipe ? 0u : k0.w; knl[4][tid] = wipe ? 0u : k1.x; knl[5][tid] = wipe ? 0u : k1.y;
-        knl[6][tid] = wipe ? 0u : k1.z; knl[7][tid] = wipe ? 0u : k1.w;
-        if (!wipe)
-          for (uint32_t id = head; id != H; ++id) knl[(id >> 5) & (KN_WORDS - 1)][tid] &= ~(1u << (id & 31u));
-      }
-      const uint32_t my_slot1 = mi & MI_SLOT;       // slot+1 of rumours about me
-      const uint32_t my_slot0 = my_slot1 ? my_slot1 - 1u : NONE32;
-      uint32_t refute = NONE32, nex = 0, ovf = 0;
-      // ---- delivered payload sources: own-ack sources, inbox, exact overflow list
-      const uint32_t nin = cnt < s.inbox_cap ? cnt : s.inbox_cap;
-      const uint32_t nsrc = nack + nin;
-      uint32_t ox = 0, novf = 0;
-      if (cnt > s.inbox_cap) novf = min(s.g[G_OVF0 + (t & 1u)], s.ovf_cap);
-      auto fetch_src = [&](uint32_t k) -> uint32_t {
-        if (k < nack) return s.ackfrom[(size_t)i * s.P + k];
-        if (k < nsrc) return s.inbox[(size_t)i * s.inbox_cap + (k - nack)];
-        return NONE32;
-      };
-      uint32_t x = 0, nxt = fetch_src(0);
-      for (;;) {
-        uint32_t srcw = NONE32;
-        if (x < nsrc) { srcw = nxt; x++; nxt = fetch_src(x); }         // the next source word loads under this line
-        else
-          while (ox < novf) {
-            const uint2 o = s.ovf[(size_t)(t & 1u) * s.ovf_cap + ox];
-            ox++;
-            if (o.x == i) { srcw = o.y; break; }
-          }
-        if (srcw == NONE32) break;
-        const uint32_t src = srcw & 0x7FFFFFFFu, buf = srcw >> 31;
-        const uint4* line = reinterpret_cast<const uint4*>(s.pb + ((size_t)buf * s.N + src) * PB_SLOTS);
-        uint32_t lw[2 * PB_SLOTS];
-#pragma unroll
-        for (int h = 0; h < PB_SLOTS / 2; ++h) {
-          const uint4 v = line[h];
-          lw[4 * h] = v.x; lw[4 * h + 1] = v.y; lw[4 * h + 2] = v.z; lw[4 * h + 3] = v.w;
-        }
-        // classify the 8 entries branch-free: one ring-bit test each (the hot loop of the tick)
-        uint32_t unk = 0, inw = 0, selfm = 0;       // to be listed / inside the window / about myself
-        uint32_t kw[PB_SLOTS];
-#pragma unroll
-        for (int k = 0; k < PB_SLOTS; ++k) kw[k] = knl[(lw[2 * k] >> 21) & (KN_WORDS - 1)][tid];
-#pragma unroll
-        for (int k = 0; k < PB_SLOTS; ++k) {
-          const uint32_t lo = lw[2 * k], hi = lw[2 * k + 1], rid = pe_rid(lo);
-          const uint32_t valid = pe_tx(hi) ? 1u : 0u;
-          const uint32_t self = (pe_slot(lo) == my_slot0) ? 1u : 0u;
-          const uint32_t in = (((H - 1u - rid) & RID_MASK) < KN_BITS) ? 1u : 0u;
-          const uint32_t known = in & (kw[k] >> (rid & 31u));            // view already dominates it
-          unk |= (valid & ~self & ~known & 1u) << k;
-          inw |= in << k;
-          selfm |= (valid & self) << k;
-        }
-        if (selfm) {
-#pragma unroll
-          for (int k = 0; k < PB_SLOTS; ++k) if ((selfm >> k) & 1u) refute_note(refute, pe_key(lw[2 * k + 1]));
-        }
-        if (unk) {
-#pragma unroll
-          for (int k = 0; k < PB_SLOTS; ++k)
-            if ((unk >> k) & 1u) {
-              if (nex < (uint32_t)XL_CAP) {
-                const uint32_t lo = lw[2 * k], rid = pe_rid(lo);
-                // listed at most once per tick: mark it now (the examination settles it either way)
-                if ((inw >> k) & 1u) knl[(rid >> 5) & (KN_WORDS - 1)][tid] |= 1u << (rid & 31u);
-                s.xl[ridx(s, i, nex)] = make_uint2(lo, pe_key(lw[2 * k + 1]));
-                nex++;
-              } else ovf = XI_OVF;                   // apply_kernel walks this member's sources itself
-            }
-        }
-      }
-      s.kn[2 * (size_t)i] = make_uint4(knl[0][tid], knl[1][tid], knl[2][tid], knl[3][tid]);
-      s.kn[2 * (size_t)i + 1] = make_uint4(knl[4][tid], knl[5][tid], knl[6][tid], knl[7][tid]);
-      s.kn_head[i] = H;
-      xi = nex | ovf | (refute != NONE32 ? (XI_REF | (refute << 7)) : 0u);
-      if (cnt && !ovf) s.inbox_cnt[i] = 0;
-    }
-  }
-  s.xinfo[i] = xi;
-}
-
-// the tx == L group of the next piggyback line is appended after it is complete; old survivors
-// keep their order behind it
-#ifndef SWIM_APPLY_WAVES
-#define SWIM_APPLY_WAVES 4
-#endif
-__global__ __launch_bounds__(BLOCK, SWIM_APPLY_WAVES) void apply_kernel(DevState s, uint32_t t) {
+__global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState s, uint32_t t) {
   __shared__ BlockCounters sh;
   __shared__ uint32_t asm_[PB_SLOTS][2][BLOCK];   // the outgoing line is assembled here: [entry][word][thread]
   ctr_init(&sh);
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   const uint32_t tid = threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x == 0) s.g[G_OVF0 + ((t + 1) & 1u)] = 0;  // next tick's overflow list
   const uint32_t mi = i < s.N ? s.minfo[i] : 0u;
   if (mi_up(mi)) {
     const uint32_t po = s.probe_out[i];
-    const uint32_t nsent = po & 31u, nfail = (po >> 5) & 31u;
-    const uint32_t xi = s.xinfo[i];
+    const uint32_t nsent = po & 31u, nfail = (po >> 5) & 31u, nack = po >> 10;
+    const uint32_t cnt = s.inbox_cnt[i];
+    const unsigned long long pushed = s.inmask[i], pulled = s.ackmask[i];
     const uint4 hot0 = s.hot[i];
     uint32_t self_inc = hot0.x, thead = hot0.y & 0xFFFFu, tcount = hot0.y >> 16, tnext = hot0.w;
     const uint32_t pcount = mi_pbn(mi), cur = mi_buf(mi);
     const bool timer_due = tcount && tnext <= t;
-    if (xi | nfail | pcount | (uint32_t)timer_due) {
+    if ((pushed | pulled) != 0ull || (cnt | nack | nfail | pcount | (uint32_t)timer_due)) {
       const uint32_t H = s.g[G_HEAD];
+      // ---- known-ring: forget the positions of the ids allocated since this member last looked
+      unsigned long long kn = s.kn[i];
+      {
+        const uint32_t head = s.kn_head[i], lag = H - head;
+        if (lag >= KN_BITS) kn = 0;
+        else if (lag) {
+          const unsigned long long run = (1ull << lag) - 1ull;      // lag consecutive positions from head
+          const uint32_t sh0 = head & 63u;
+          kn &= ~((run << sh0) | (sh0 ? (run >> (64u - sh0)) : 0ull));
+        }
+      }
       // ---- own queue (sorted by priority; see swim_device.h): only the slot ids stay live (two per
       // register) for the "superseded" test; the line itself is read again when the queue is rebuilt
       NewGroup c; c.n = 0;
@@ -433,7 +360,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_APPLY_WAVES) void apply_kernel(DevState
         }
       }
       const uint32_t my_slot1 = mi & MI_SLOT;       // slot+1 of rumours about me
-      uint32_t refute = (xi & XI_REF) ? (xi >> 7) : NONE32;
+      uint32_t refute = NONE32;
       unsigned changes = 0, timers_fired = 0, evdropped = 0, examined = 0;
       unsigned long long evd = 0, ha = 0;
 
@@ -444,8 +371,13 @@ __global__ __launch_bounds__(BLOCK, SWIM_APPLY_WAVES) void apply_kernel(DevState
           if ((oslot[h] >> 16) == slot) killmask |= 1u << (2 * h + 1);
         }
       };
-      // The state rule on one proposal (slot, key): e is the member's current entry.
+      // The state rule on one proposal (slot, key).
       auto examine = [&](uint32_t slot, uint32_t key, uint32_t cause, bool hasrid, uint32_t rid_in) {
+        if (slot + 1 == my_slot1) {
+          // about self -> refute (src/Core.hs:155-166): remember the largest non-Alive incarnation
+          if ((key & 3u) != ST_ALIVE) refute = (refute == NONE32 || (key >> 2) > refute) ? (key >> 2) : refute;
+          return;
+        }
         examined++;
         const uint2 e = s.V[vidx(s, i, slot)];
         if (key <= e.x) return;                      // old incarnation / weaker state: ignore (:151)
@@ -494,16 +426,19 @@ __global__ __launch_bounds__(BLOCK, SWIM_APPLY_WAVES) void apply_kernel(DevState
         if (key > e.x) examine(sl, key, 0u, false, 0u);
       }
       // phase 3: rumours received this tick (any order: the merge is commutative)
-      if (!(xi & XI_OVF)) {
-        const uint32_t nex = xi & 31u;
-        for (uint32_t k = 0; k < nex; ++k) {
-          const uint2 r = s.xl[ridx(s, i, k)];
-          examine(pe_slot(r.x), r.y, 2u, true, pe_rid(r.x));
+      {
+        unsigned long long fresh = (pushed | pulled) & ~kn;
+        kn |= fresh;
+        while (fresh) {
+          const uint32_t p = (uint32_t)__ffsll((unsigned long long)fresh) - 1u;
+          fresh &= fresh - 1ull;
+          const uint32_t rid = rid_at(p, H) & RID_MASK;
+          const uint2 r = s.rum[rid];
+          examine(r.x, r.y, 2u, true, rid);
         }
-      } else {
-        // the scan found more unknown rumours than the list holds: take every delivered entry
-        // straight through the rule (rare; idempotent, so entries the list did hold do no harm)
-        const uint32_t nack = po >> 10, cnt = s.inbox_cnt[i];
+      }
+      if (cnt | nack) {
+        // explicit records: the sources' 64-B lines (queues the masks could not carry in full)
         const uint32_t nin = cnt < s.inbox_cap ? cnt : s.inbox_cap;
         const uint32_t novf = cnt > s.inbox_cap ? min(s.g[G_OVF0 + (t & 1u)], s.ovf_cap) : 0u;
         for (uint32_t x = 0; x < nack + nin + novf; ++x) {
@@ -515,15 +450,22 @@ __global__ __launch_bounds__(BLOCK, SWIM_APPLY_WAVES) void apply_kernel(DevState
             if (o.x == i) srcw = o.y;
           }
           if (srcw == NONE32) continue;
-          const uint2* line = reinterpret_cast<const uint2*>(s.pb + ((size_t)(srcw >> 31) * s.N + (srcw & 0x7FFFFFFFu)) * PB_SLOTS);
-          for (int k = 0; k < PB_SLOTS; ++k) {
-            const uint2 r = line[k];
-            if (!pe_tx(r.y)) break;
-            if (pe_slot(r.x) + 1 == my_slot1) continue;          // the scan took care of rumours about me
-            examine(pe_slot(r.x), pe_key(r.y), 2u, true, pe_rid(r.x));
+          const uint4* line = reinterpret_cast<const uint4*>(s.pb + ((size_t)(srcw >> 31) * s.N + (srcw & 0x7FFFFFFFu)) * PB_SLOTS);
+          for (int h = 0; h < PB_SLOTS / 2; ++h) {
+            const uint4 v = line[h];
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+              const uint32_t lo = w ? v.z : v.x, hi = w ? v.w : v.y;
+              if (!pe_tx(hi)) continue;
+              const uint32_t rid = pe_rid(lo);
+              if (rid_in_ring(rid, H)) {
+                if (kn & rid_bit(rid)) continue;     // view already dominates it
+                kn |= rid_bit(rid);
+              }
+              examine(pe_slot(lo), pe_key(hi), 2u, true, rid);
+            }
           }
         }
-        s.inbox_cnt[i] = 0;
       }
       // ---- refutation: bump own incarnation past the rumour's (src/Core.hs:155-166; D10); rumours at
       // an incarnation below my own are stale and ignored (:151)
@@ -544,12 +486,20 @@ __global__ __launch_bounds__(BLOCK, SWIM_APPLY_WAVES) void apply_kernel(DevState
         }
       }
       // ---- rebuild the queue: [this tick's group, by subject][aged survivors, order kept], best 8 (D5),
-      // assembled in LDS columns, then written as one 64-B line.
+      // assembled in LDS columns, then written as one 64-B line together with its mask.
       uint32_t nout = c.n;
+      unsigned long long qmask = 0;
+      uint32_t oow = 0;
+      auto publish = [&](uint32_t lo) -> uint32_t {  // mask bit or "cannot express", id parked if too old
+        const uint32_t rid = pe_rid(lo);
+        if (rid_maskable(rid, H)) qmask |= rid_bit(rid);
+        else oow = MI_OOW;
+        return park_rid(lo, H);
+      };
 #pragma unroll
       for (int k = 0; k < PB_SLOTS; ++k) {
         const bool have = (uint32_t)k < c.n;
-        asm_[k][0][tid] = have ? park_rid(c.w[k], H) : 0u;
+        asm_[k][0][tid] = have ? publish(c.w[k]) : 0u;
         asm_[k][1][tid] = have ? pe_hi(c.key[k], s.L) : 0u;
       }
       if (pcount) {
@@ -560,7 +510,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_APPLY_WAVES) void apply_kernel(DevState
           for (int w = 0; w < 2; ++w) {
             const uint32_t lo = w ? v.z : v.x, hi = w ? v.w : v.y, tx = pe_tx(hi);
             if (tx > nsent && !((killmask >> (2 * h + w)) & 1u) && nout < (uint32_t)PB_SLOTS) {
-              asm_[nout][0][tid] = park_rid(lo, H);
+              asm_[nout][0][tid] = publish(lo);
               asm_[nout][1][tid] = pe_hi(pe_key(hi), tx - nsent);
               nout++;
             }
@@ -572,14 +522,19 @@ __global__ __launch_bounds__(BLOCK, SWIM_APPLY_WAVES) void apply_kernel(DevState
 #pragma unroll
         for (int h = 0; h < PB_SLOTS / 2; ++h)
           line[h] = make_uint4(asm_[2 * h][0][tid], asm_[2 * h][1][tid], asm_[2 * h + 1][0][tid], asm_[2 * h + 1][1][tid]);
-        s.minfo[i] = (mi & ~MI_PB) | (nout << MI_PBN_SHIFT) | ((cur ^ 1u) << 20);
+        s.qm[(size_t)(cur ^ 1u) * s.N + i] = qmask;
+        s.minfo[i] = (mi & ~MI_PB) | (nout << MI_PBN_SHIFT) | ((cur ^ 1u) << 20) | oow;
       } else if (pcount) {
         s.minfo[i] = mi & ~MI_PB;
       }
+      s.kn[i] = kn;
+      s.kn_head[i] = H;
+      if (pushed) s.inmask[i] = 0;
       if (tcount == 0) tnext = NONE32;
       else if (thead != (hot0.y & 0xFFFFu)) tnext = s.ring[ridx(s, i, thead)].y;
       const uint4 hot1 = make_uint4(self_inc, thead | (tcount << 16), 0u, tnext);
       if (hot1.x != hot0.x || hot1.y != hot0.y || hot1.w != hot0.w) s.hot[i] = hot1;
+      if (cnt) s.inbox_cnt[i] = 0;
       ctr_add(&sh, C_CHANGES, changes);
       ctr_add(&sh, C_PB_WRITES, (pcount || nout) ? 1u : 0u);
       ctr_add(&sh, C_TIMERS_FIRED, timers_fired);
@@ -597,8 +552,10 @@ __global__ __launch_bounds__(BLOCK, SWIM_APPLY_WAVES) void apply_kernel(DevState
 // ================================================================================================
 struct FaultRec { uint32_t member, up; };
 
-// ground-truth changes for tick t, applied in order by one thread (few per tick)
-__global__ void fault_kernel(DevState s, uint32_t t, const FaultRec* faults, uint32_t nfaults) {
+// Start of tick t, one thread: the ground-truth changes scheduled for t, in order (few per tick), then
+// the snapshot of the rumour-id counter that fixes the tick's window head H (no ids are allocated
+// between here and merge_kernel).
+__global__ void begin_kernel(DevState s, uint32_t t, const FaultRec* faults, uint32_t nfaults) {
   if (blockIdx.x || threadIdx.x) return;
   unsigned long long evd = 0; unsigned dropped = 0;
   for (uint32_t k = 0; k < nfaults; ++k) {
@@ -629,7 +586,8 @@ __global__ void fault_kernel(DevState s, uint32_t t, const FaultRec* faults, uin
         if (!pe_tx(h) || pe_slot(l) == sl) continue;
         lo[n] = pe_lo(pe_slot(l), far); hi[n] = h; sj[n] = s.subject_of[pe_slot(l)]; n++;
       }
-    lo[n] = pe_lo(sl, find_rid(s, sl, akey)); hi[n] = pe_hi(akey, s.L); sj[n] = mbr; n++;
+    const uint32_t arid = find_rid(s, sl, akey);
+    lo[n] = pe_lo(sl, arid); hi[n] = pe_hi(akey, s.L); sj[n] = mbr; n++;
     for (uint32_t a = 1; a < n; ++a)                      // insertion sort by (tx desc, subject asc)
       for (uint32_t b = a; b > 0 && rumor_better(pe_tx(hi[b]), sj[b], pe_tx(hi[b - 1]), sj[b - 1]); --b) {
         uint32_t x;
@@ -640,9 +598,16 @@ __global__ void fault_kernel(DevState s, uint32_t t, const FaultRec* faults, uin
     if (n > (uint32_t)PB_SLOTS) n = PB_SLOTS;
     for (uint32_t q = 0; q < (uint32_t)PB_SLOTS; ++q)
       line[q] = q < n ? (((uint64_t)hi[q] << 32) | lo[q]) : 0ull;
-    s.minfo[mbr] = (mi & ~MI_PBN) | (n << MI_PBN_SHIFT) | MI_UP;
-    s.kn[2 * (size_t)mbr] = make_uint4(0u, 0u, 0u, 0u);
-    s.kn[2 * (size_t)mbr + 1] = make_uint4(0u, 0u, 0u, 0u);
+    // mask: only the fresh announcement can be expressed (its id is the newest) -- if it made the cut;
+    // the rest is parked
+    unsigned long long jm = 0; uint32_t joow = 0;
+    for (uint32_t q = 0; q < n; ++q) {
+      if (pe_slot(lo[q]) == sl) jm = rid_bit(arid); else joow = MI_OOW;
+    }
+    s.qm[(size_t)cur * s.N + mbr] = jm;
+    s.minfo[mbr] = (mi & ~(MI_PBN | MI_OOW)) | (n << MI_PBN_SHIFT) | MI_UP | joow;
+    s.kn[mbr] = 0;
+    s.inmask[mbr] = 0;
     hot.x = ni;
     s.hot[mbr] = hot;
     s.kn_head[mbr] = s.g[G_NRUM];
@@ -652,8 +617,10 @@ __global__ void fault_kernel(DevState s, uint32_t t, const FaultRec* faults, uin
       else dropped++;
     }
   }
-  s.blk[(size_t)s.nblocks * C_COUNT + C_EVDIGEST] += evd;
-  s.blk[(size_t)s.nblocks * C_COUNT + C_EVENTS_DROPPED] += dropped;
+  if (evd) s.blk[(size_t)s.nblocks * C_COUNT + C_EVDIGEST] += evd;
+  if (dropped) s.blk[(size_t)s.nblocks * C_COUNT + C_EVENTS_DROPPED] += dropped;
+  s.g[G_PREV] = s.g[G_HEAD];
+  s.g[G_HEAD] = s.g[G_NRUM];
 }
 
 // full-state digest: Sum_i mix64(member_hash(i) + mix64(TAG_MEMBER + i)) + first-detection terms

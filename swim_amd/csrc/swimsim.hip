@@ -1,7 +1,7 @@
 // swimsim.hip -- C ABI (include/swimsim.h) over the gfx950 tick kernels.
 //
 // Host side of libswimsim.so: owns device memory, the fault schedule and the launch
-// sequence (per tick: [fault_kernel] -> probe_kernel -> scan_kernel -> apply_kernel on one HIP stream).
+// sequence (per tick: begin_kernel -> probe_kernel -> merge_kernel on one HIP stream).
 // There is no CPU implementation behind this ABI: without a HIP device swimsim_create fails.
 #include "../../include/swimsim.h"
 
@@ -44,8 +44,8 @@ struct swimsim {
   std::vector<void*> allocs;
   std::vector<swimsim_event_t> host_events;    // drained from the device ring, not yet handed out
   bool timing = false;                         // HIP-event timing of the tick kernels
-  std::vector<hipEvent_t> ev_pool;             // 4 events per tick: before probe, after probe, after scan, after apply
-  double probe_ms = 0, scan_ms = 0, apply_ms = 0; uint64_t timed_ticks = 0;
+  std::vector<hipEvent_t> ev_pool;             // 3 events per tick: before probe, between, after merge
+  double probe_ms = 0, merge_ms = 0; uint64_t timed_ticks = 0;
   bool poisoned = false;
   std::string err;
 };
@@ -172,10 +172,8 @@ void launch_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev) {
   if (ev) (void)hipEventRecord(ev[0], h->stream);
   hipLaunchKernelGGL((probe_kernel<PMAX>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk);
   if (ev) (void)hipEventRecord(ev[1], h->stream);
-  hipLaunchKernelGGL(scan_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
+  hipLaunchKernelGGL(merge_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
   if (ev) (void)hipEventRecord(ev[2], h->stream);
-  hipLaunchKernelGGL(apply_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
-  if (ev) (void)hipEventRecord(ev[3], h->stream);
 }
 
 }  // namespace
@@ -243,10 +241,12 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   CK(dev_alloc(h, &d.inbox_cnt, N, 0));
   CK(dev_alloc(h, &d.inbox, (size_t)N * d.inbox_cap, 0));
   CK(dev_alloc(h, &d.hot, N, 0));
-  CK(dev_alloc(h, &d.kn, (size_t)2 * N, 0));
+  CK(dev_alloc(h, &d.kn, (size_t)N, 0));
   CK(dev_alloc(h, &d.kn_head, N, 0));
-  CK(dev_alloc(h, &d.xl, (size_t)XL_CAP * N, 0));
-  CK(dev_alloc(h, &d.xinfo, N, 0));
+  CK(dev_alloc(h, &d.qm, (size_t)2 * N, 0));
+  CK(dev_alloc(h, &d.inmask, (size_t)N, 0));
+  CK(dev_alloc(h, &d.ackmask, (size_t)N, 0));
+  CK(dev_alloc(h, &d.rum, (size_t)65536, 0));
   CK(dev_alloc(h, &d.rtab, (size_t)d.R_max * RT_WAYS, 0));
   CK(dev_alloc(h, &d.subject_of, (size_t)d.R_max, 0));
   CK(dev_alloc(h, &d.fail, (size_t)N * (d.P ? d.P : 1), 0));
@@ -308,7 +308,7 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
     HIPCHK(h, hipMemcpy(h->d_faults, recs.data(), fend * sizeof(FaultRec), hipMemcpyHostToDevice));
   }
   if (h->timing) {
-    while (h->ev_pool.size() < (size_t)nticks * 4) {
+    while (h->ev_pool.size() < (size_t)nticks * 3) {
       hipEvent_t e;
       HIPCHK(h, hipEventCreate(&e));
       h->ev_pool.push_back(e);
@@ -317,11 +317,10 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
   size_t fpos = 0;
   for (uint32_t k = 0; k < nticks; ++k) {
     const uint32_t t = (uint32_t)h->tick;
-    hipEvent_t* ev = h->timing ? &h->ev_pool[(size_t)k * 4] : nullptr;
+    hipEvent_t* ev = h->timing ? &h->ev_pool[(size_t)k * 3] : nullptr;
     const size_t f0 = fpos;
     while (fpos < fend && h->faults[fpos].tick <= t) ++fpos;
-    if (fpos > f0)
-      hipLaunchKernelGGL(fault_kernel, dim3(1), dim3(64), 0, h->stream, h->d, t, h->d_faults + f0, (uint32_t)(fpos - f0));
+    hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(64), 0, h->stream, h->d, t, h->d_faults + f0, (uint32_t)(fpos - f0));
     const uint32_t tk = tick_key(h->cfg.seed, t);
     if (h->d.P <= 4 && h->d.K <= 4) launch_tick<4>(h, t, tk, ev);
     else launch_tick<16>(h, t, tk, ev);
@@ -332,11 +331,10 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (h->timing) {
     for (uint32_t k = 0; k < nticks; ++k) {
-      float a = 0, b = 0, c = 0;
-      HIPCHK(h, hipEventElapsedTime(&a, h->ev_pool[(size_t)k * 4], h->ev_pool[(size_t)k * 4 + 1]));
-      HIPCHK(h, hipEventElapsedTime(&b, h->ev_pool[(size_t)k * 4 + 1], h->ev_pool[(size_t)k * 4 + 2]));
-      HIPCHK(h, hipEventElapsedTime(&c, h->ev_pool[(size_t)k * 4 + 2], h->ev_pool[(size_t)k * 4 + 3]));
-      h->probe_ms += a; h->scan_ms += b; h->apply_ms += c;
+      float a = 0, b = 0;
+      HIPCHK(h, hipEventElapsedTime(&a, h->ev_pool[(size_t)k * 3], h->ev_pool[(size_t)k * 3 + 1]));
+      HIPCHK(h, hipEventElapsedTime(&b, h->ev_pool[(size_t)k * 3 + 1], h->ev_pool[(size_t)k * 3 + 2]));
+      h->probe_ms += a; h->merge_ms += b;
     }
     h->timed_ticks += nticks;
   }
@@ -487,16 +485,22 @@ int swimsim_k_random_members(swimsim_t* h, uint32_t observer, uint32_t n, const 
   return SWIMSIM_OK;
 }
 
+#ifdef SWIM_STATS
+extern "C" int swimsim_debug_globals(swimsim_t* h, uint32_t* out) {
+  return hipMemcpy(out, h->d.g, G_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif
+
 int swimsim_kernel_timing_enable(swimsim_t* h, int enable) {
   if (!h) return SWIMSIM_ERR_INVALID;
   h->timing = enable != 0;
-  h->probe_ms = h->scan_ms = h->apply_ms = 0; h->timed_ticks = 0;
+  h->probe_ms = h->merge_ms = 0; h->timed_ticks = 0;
   return SWIMSIM_OK;
 }
 
 int swimsim_kernel_timing(swimsim_t* h, double* out, size_t n) {
-  if (!h || !out || n < 4) return SWIMSIM_ERR_INVALID;
-  out[0] = h->probe_ms; out[1] = h->scan_ms; out[2] = h->apply_ms; out[3] = (double)h->timed_ticks;
+  if (!h || !out || n < 3) return SWIMSIM_ERR_INVALID;
+  out[0] = h->probe_ms; out[1] = h->merge_ms; out[2] = (double)h->timed_ticks;
   return SWIMSIM_OK;
 }
 

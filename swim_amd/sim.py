@@ -181,10 +181,10 @@ class Sim:
         self._check(self._abi.kernel_timing_enable(self._h, 1 if enable else 0))
 
     def kernelTiming(self):
-        """{probe_ms, scan_ms, apply_ms, ticks}: HIP-event time spent in each tick kernel since enabling."""
-        buf = (C.c_double * 4)()
-        self._check(self._abi.kernel_timing(self._h, buf, 4))
-        return {"probe_ms": buf[0], "scan_ms": buf[1], "apply_ms": buf[2], "ticks": int(buf[3])}
+        """{probe_ms, merge_ms, ticks}: HIP-event time spent in each tick kernel since enabling."""
+        buf = (C.c_double * 3)()
+        self._check(self._abi.kernel_timing(self._h, buf, 3))
+        return {"probe_ms": buf[0], "merge_ms": buf[1], "ticks": int(buf[2])}
 
     # -- unit-level hooks (test/Spec.hs) -------------------------------------------
     def kRandomMembers(self, observer: int, n: int, excludes: Sequence[int] = ()) -> List[int]:

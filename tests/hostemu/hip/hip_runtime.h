@@ -17,6 +17,7 @@
 #include <ucontext.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <chrono>
 #include <tuple>
 #include <utility>

@@ -52,11 +52,12 @@ def test_matches_committed_golden_fixtures(emu_abi, name):
     assert run_fixture(emu_abi, fx["spec"]) == fx["expect"]
 
 
-def test_overflow_paths(oracle_abi):
-    """Tiny examination list (2 entries) and a 1-slot inbox: the exact slow paths of scan/apply and the
-    inbox overflow list carry most of the traffic and must still be bit-exact."""
+def test_explicit_record_paths(oracle_abi):
+    """A tiny mask window (4 ids + 2 slack) and a 1-slot inbox: nearly every delivery needs the explicit
+    64-B-line records, the inbox overflow list and the "burst of new ids" fallback, and must still be
+    bit-exact."""
     from tests import hostemu_binding
-    emu = hostemu_binding.load_variant("xl2", ["SWIM_XL_CAP=2"])
+    emu = hostemu_binding.load_variant("win4", ["SWIM_MASK_WIN=4", "SWIM_MASK_SLACK=2"])
     n = 700
     crashes = workloads.hashed_crashes(n, 9, 1, 6, 3, 33)
     sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=9, lossPpm=30000, eventMask=0x1F, suspicionTicks=6,
