@@ -69,12 +69,12 @@ struct DevState {
                            //   20 which pb buffer is current, 21 up (ground truth),
                            //   22 the queue holds an entry its mask cannot express (MI_OOW)
   uint16_t* probe_out;     // nsent | nfail<<5 | n explicit own-ack sources<<10, probe -> merge kernel
-  unsigned long long* qm;  // [2][N] the member's queue as a 64-bit mask over rumour-id positions (rid & 63)
+  ulonglong2* pk;          // per member {x: the queue as a 64-bit mask over rumour-id positions (rid & 63),
+                           //   y: known-ring, bit (rid & 63) set => this member's view already dominates
+                           //   rumour rid}: ONE 16-byte gather per probe target serves the Ack's payload
+                           //   (x) and the "anything new for you?" test before a push (y)
   unsigned long long* inmask;   // OR of the masks pushed to this member this tick (atomicOr by the pingers)
   unsigned long long* ackmask;  // OR of the masks this member pulled with its Acks (plain store by the prober)
-  unsigned long long* kn;  // 64-bit ring over rumour ids: bit (rid & 63) set => this member's view already
-                           //   dominates rumour rid (pure negative filter, see below)
-  uint32_t* kn_head;       // rumour-id counter value up to which this member's ring has been cleared
   uint2* rum;              // [65536] rumour id -> {slot, key}
   unsigned long long* rtab;// [R_max][RT_WAYS] (slot, key) -> rumour id: {key+1 : 32 | ready : 1 | rid : 16}
   // explicit delivery records "dst merges src's 64-B line": the exact fallback for queues with
@@ -136,10 +136,13 @@ __host__ __device__ inline uint32_t pe_hi(uint32_t key, uint32_t tx) { return ke
 // explicit record and the receiver reads the source's 64-B line.
 //
 // Known-ring.  A member keeps a 64-bit ring indexed the same way; only ids in [H-64, H) may be tested
-// or set, and the member first clears the positions of the ids allocated since it last looked
-// ([its head, H)).  A set bit means "my view entry already dominates this rumour": new = incoming &
-// ~known is the whole per-delivery filter.  A clear bit (or an id outside the window) only means "look
-// it up".  Ids, masks and the ring are internal: never observable.
+// or set.  Every up member drops, at every tick, the positions of the ids allocated during the
+// previous tick ([G_PREV, G_HEAD): the same positions for everybody), so a ring read at tick t is valid
+// once those positions are masked off -- by its owner AND by a pinger, which pushes only the bits its
+// target does not know yet (atomics run at a fixed ~20-27 G/s on this chip whatever the table size, so
+// a skipped push is the cheapest one).  A set bit means "my view entry already dominates this rumour":
+// new = incoming & ~known is the whole per-delivery filter.  A clear bit (or an id outside the window)
+// only means "look it up".  Ids, masks and the ring are internal: never observable.
 #ifndef SWIM_MASK_WIN        // compile-time knobs so that tests can force the fallback paths
 #define SWIM_MASK_WIN 48
 #define SWIM_MASK_SLACK 16
@@ -154,6 +157,15 @@ __device__ inline bool rid_in_ring(uint32_t rid, uint32_t H) { return ((H - 1u -
 __device__ inline unsigned long long rid_bit(uint32_t rid) { return 1ull << (rid & 63u); }
 // the id in [H-64, H) that owns position p
 __device__ inline uint32_t rid_at(uint32_t p, uint32_t H) { return (H - 1u) - ((H - 1u - p) & 63u); }
+// ring positions of the ids in [prev, head): what every reader of a ring must disregard this tick
+__device__ inline unsigned long long stale_positions(uint32_t prev, uint32_t head) {
+  const uint32_t lag = head - prev;
+  if (lag >= KN_BITS) return ~0ull;
+  if (!lag) return 0ull;
+  const unsigned long long run = (1ull << lag) - 1ull;
+  const uint32_t sh = prev & 63u;
+  return (run << sh) | (sh ? (run >> (64u - sh)) : 0ull);
+}
 // can an entry with this id be expressed in a mask built at head H?
 __device__ inline bool rid_maskable(uint32_t rid, uint32_t H) {
   return ((rid - (H - MASK_WIN)) & RID_MASK) < MASK_WIN + MASK_SLACK;

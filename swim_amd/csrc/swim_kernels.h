@@ -88,14 +88,16 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
   const uint32_t mi = i < s.N ? s.minfo[i] : 0u;
   const bool act = mi_up(mi);
   // masks are exact only if few rumour ids appeared since they were built (swim_device.h)
-  const bool use_mask = s.g[G_HEAD] - s.g[G_PREV] <= MASK_SLACK;
+  const uint32_t Hprev = s.g[G_PREV], H = s.g[G_HEAD];
+  const bool use_mask = H - Hprev <= MASK_SLACK;
+  const unsigned long long stale = stale_positions(Hprev, H);   // ring positions nobody may trust this tick
   unsigned n_pings = 0;
   unsigned long long ackacc = 0;                  // masks this member pulls in with its Acks
   if (act) {
     const uint32_t mk = mix32(tk ^ i);
     const uint32_t mycnt = mi_pbn(mi);
     const uint32_t mysrc = mi_src(i, mi);
-    const unsigned long long mymask = (mycnt && use_mask) ? s.qm[(size_t)mi_buf(mi) * s.N + i] : 0ull;
+    const unsigned long long mymask = (mycnt && use_mask) ? s.pk[i].x : 0ull;
     uint32_t picks[PMAX], pinfo[PMAX];
     // ms <- kRandomMembers store (numToGossip cfg) []        (src/Core.hs:239)
     const uint32_t np = select_members<PMAX>(s, mk, i, s.P, P_SELECT, 0, nullptr, 0, picks, pinfo);
@@ -105,8 +107,11 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
     // "dst merges src's start-of-tick queue": the mask by atomicOr (or into ackacc when dst is me),
     // plus an explicit record when the mask cannot carry all of it
     auto explicit_needed = [&](uint32_t msrc) { return !use_mask || (msrc & MI_OOW); };
-    auto src_mask = [&](uint32_t src, uint32_t msrc) -> unsigned long long {
-      return use_mask ? s.qm[(size_t)mi_buf(msrc) * s.N + src] : 0ull;
+    auto src_mask = [&](uint32_t src) -> unsigned long long { return use_mask ? s.pk[src].x : 0ull; };
+    // push only what the receiver does not know yet
+    auto push_mask = [&](uint32_t dst, unsigned long long m, unsigned long long dst_known) {
+      m &= ~(dst_known & ~stale);
+      if (m) atomicOr(&s.inmask[dst], m);
     };
     // pass 1: outcome of every direct probe -- pure arithmetic on the gathered info words.
     //   Direct (Ping seq j) is delivered iff not lost and j is up (src/Core.hs:246);
@@ -120,19 +125,20 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
         ack_ok[p] = ping_ok[p] && !lost(s, tk, P_L_ACK, picks[p], i, p);
       }
     }
-    // pass 2: the Acks' payloads are pulled by the prober itself: 8-byte gathers, issued together
-    unsigned long long am[PMAX];
+    // pass 2: one 16-byte gather per reached target, issued together: its queue mask (the Ack's
+    // payload, pulled by the prober itself) and its known-ring (what my Ping's payload can still tell it)
+    ulonglong2 tk2[PMAX];
 #pragma unroll
     for (int p = 0; p < PMAX; ++p) {
-      am[p] = 0;
-      if (ack_ok[p] && mi_pbn(pinfo[p])) am[p] = src_mask(picks[p], pinfo[p]);
+      tk2[p] = make_ulonglong2(0ull, 0ull);
+      if (use_mask && ping_ok[p] && (mymask || (ack_ok[p] && mi_pbn(pinfo[p])))) tk2[p] = s.pk[picks[p]];
     }
-    // pass 3: the Pings' piggyback payloads: one atomicOr per target
+    // pass 3: the Pings' piggyback payloads: at most one atomicOr per target
     if (mycnt) {
 #pragma unroll
       for (int p = 0; p < PMAX; ++p)
         if (ping_ok[p]) {
-          if (mymask) atomicOr(&s.inmask[picks[p]], mymask);
+          if (mymask) push_mask(picks[p], mymask, tk2[p].y);
           payloads++; rumors += mycnt;
         }
       if (explicit_needed(mi)) {
@@ -147,16 +153,16 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
     for (int p = 0; p < PMAX; ++p) {
       const uint32_t pj = mi_pbn(pinfo[p]);
       if (ack_ok[p] && pj) {
-        ackacc |= am[p];
+        ackacc |= tk2[p].x;
         if (explicit_needed(pinfo[p])) { s.ackfrom[(size_t)i * s.P + nack] = mi_src(picks[p], pinfo[p]); nack++; }
         payloads++; rumors += pj;
       }
     }
     // pass 4 (rare): probes without an ack -> k indirect probes -> maybe Suspect
     auto deliver = [&](uint32_t dst, uint32_t src, uint32_t msrc) {
-      const unsigned long long m = src == i ? mymask : src_mask(src, msrc);
+      const unsigned long long m = src == i ? mymask : src_mask(src);
       if (dst == i) ackacc |= m;
-      else if (m) atomicOr(&s.inmask[dst], m);
+      else if (m) push_mask(dst, m, s.pk[dst].y);
       if (explicit_needed(msrc)) push(s, t, dst, mi_src(src, msrc));
       payloads++; rumors += mi_pbn(msrc);
     };
@@ -304,11 +310,15 @@ __device__ inline void group_put(NewGroup& c, uint32_t slot, uint32_t rid, uint3
 __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState s, uint32_t t) {
   __shared__ BlockCounters sh;
   __shared__ uint32_t asm_[PB_SLOTS][2][BLOCK];   // the outgoing line is assembled here: [entry][word][thread]
+  __shared__ uint32_t wfl[BLOCK];
   ctr_init(&sh);
   const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   const uint32_t tid = threadIdx.x;
   if (blockIdx.x == 0 && threadIdx.x == 0) s.g[G_OVF0 + ((t + 1) & 1u)] = 0;  // next tick's overflow list
   const uint32_t mi = i < s.N ? s.minfo[i] : 0u;
+  const uint32_t H = s.g[G_HEAD];
+  const unsigned long long stale = stale_positions(s.g[G_PREV], H);
+  uint32_t wflag = 0;                              // bit 0: my line was rebuilt in asm_, bit 1: into which buffer
   if (mi_up(mi)) {
     const uint32_t po = s.probe_out[i];
     const uint32_t nsent = po & 31u, nfail = (po >> 5) & 31u, nack = po >> 10;
@@ -318,19 +328,12 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     uint32_t self_inc = hot0.x, thead = hot0.y & 0xFFFFu, tcount = hot0.y >> 16, tnext = hot0.w;
     const uint32_t pcount = mi_pbn(mi), cur = mi_buf(mi);
     const bool timer_due = tcount && tnext <= t;
-    if ((pushed | pulled) != 0ull || (cnt | nack | nfail | pcount | (uint32_t)timer_due)) {
-      const uint32_t H = s.g[G_HEAD];
-      // ---- known-ring: forget the positions of the ids allocated since this member last looked
-      unsigned long long kn = s.kn[i];
-      {
-        const uint32_t head = s.kn_head[i], lag = H - head;
-        if (lag >= KN_BITS) kn = 0;
-        else if (lag) {
-          const unsigned long long run = (1ull << lag) - 1ull;      // lag consecutive positions from head
-          const uint32_t sh0 = head & 63u;
-          kn &= ~((run << sh0) | (sh0 ? (run >> (64u - sh0)) : 0ull));
-        }
-      }
+    if (!((pushed | pulled) != 0ull || (cnt | nack | nfail | pcount | (uint32_t)timer_due))) {
+      // idle this tick: only keep the ring valid (swim_device.h); nothing to write when no id was allocated
+      if (stale) { const ulonglong2 v = s.pk[i]; if (v.y & stale) s.pk[i] = make_ulonglong2(v.x, v.y & ~stale); }
+    } else {
+      // ---- known-ring: forget the positions of the ids allocated during the previous tick
+      unsigned long long kn = s.pk[i].y & ~stale;
       // ---- own queue (sorted by priority; see swim_device.h): only the slot ids stay live (two per
       // register) for the "superseded" test; the line itself is read again when the queue is rebuilt
       NewGroup c; c.n = 0;
@@ -518,17 +521,12 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
         }
       }
       if (nout) {
-        uint4* line = reinterpret_cast<uint4*>(s.pb + ((size_t)(cur ^ 1u) * s.N + i) * PB_SLOTS);
-#pragma unroll
-        for (int h = 0; h < PB_SLOTS / 2; ++h)
-          line[h] = make_uint4(asm_[2 * h][0][tid], asm_[2 * h][1][tid], asm_[2 * h + 1][0][tid], asm_[2 * h + 1][1][tid]);
-        s.qm[(size_t)(cur ^ 1u) * s.N + i] = qmask;
+        wflag = 1u | ((cur ^ 1u) << 1);              // the line itself is stored below, a whole wave at a time
         s.minfo[i] = (mi & ~MI_PB) | (nout << MI_PBN_SHIFT) | ((cur ^ 1u) << 20) | oow;
       } else if (pcount) {
         s.minfo[i] = mi & ~MI_PB;
       }
-      s.kn[i] = kn;
-      s.kn_head[i] = H;
+      s.pk[i] = make_ulonglong2(nout ? qmask : 0ull, kn);
       if (pushed) s.inmask[i] = 0;
       if (tcount == 0) tnext = NONE32;
       else if (thead != (hot0.y & 0xFFFFu)) tnext = s.ring[ridx(s, i, thead)].y;
@@ -542,6 +540,24 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
       ctr_add(&sh, C_EVENTS_DROPPED, evdropped);
       ctr_add(&sh, C_EXAMINED, examined);
       if (evd) atomicAdd(&sh.evd, evd);
+    }
+  }
+  // ---- store the rebuilt lines.  L2 does not merge a lane's four 16-B pieces into one fabric write, so
+  // the wave stores its 64 lines transposed: instruction k, lane l writes piece (l & 3) of the line of
+  // member 16 k + (l >> 2): every instruction covers 1 KB of contiguous memory in full 128-B lines.
+  wfl[tid] = wflag;
+  __syncthreads();
+  {
+    const uint32_t wbase = tid & ~63u, lane = tid & 63u, q = lane & 3u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t m = wbase + 16u * k + (lane >> 2);          // thread whose line this lane helps to store
+      const uint32_t fl = wfl[m];
+      if (fl & 1u) {
+        const uint32_t gm = blockIdx.x * BLOCK + m;
+        uint4* line = reinterpret_cast<uint4*>(s.pb + ((size_t)(fl >> 1) * s.N + gm) * PB_SLOTS);
+        line[q] = make_uint4(asm_[2 * q][0][m], asm_[2 * q][1][m], asm_[2 * q + 1][0][m], asm_[2 * q + 1][1][m]);
+      }
     }
   }
   ctr_flush(s, &sh, blockIdx.x);
@@ -604,13 +620,11 @@ __global__ void begin_kernel(DevState s, uint32_t t, const FaultRec* faults, uin
     for (uint32_t q = 0; q < n; ++q) {
       if (pe_slot(lo[q]) == sl) jm = rid_bit(arid); else joow = MI_OOW;
     }
-    s.qm[(size_t)cur * s.N + mbr] = jm;
+    s.pk[mbr] = make_ulonglong2(jm, 0ull);         // and an empty known-ring
     s.minfo[mbr] = (mi & ~(MI_PBN | MI_OOW)) | (n << MI_PBN_SHIFT) | MI_UP | joow;
-    s.kn[mbr] = 0;
     s.inmask[mbr] = 0;
     hot.x = ni;
     s.hot[mbr] = hot;
-    s.kn_head[mbr] = s.g[G_NRUM];
     if (s.event_mask & (1u << 4)) {
       uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
       if (pos < s.event_cap) s.events[pos] = make_uint4(t, mbr, mbr, (akey << 8) | 4u);

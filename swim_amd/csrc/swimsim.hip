@@ -241,9 +241,7 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   CK(dev_alloc(h, &d.inbox_cnt, N, 0));
   CK(dev_alloc(h, &d.inbox, (size_t)N * d.inbox_cap, 0));
   CK(dev_alloc(h, &d.hot, N, 0));
-  CK(dev_alloc(h, &d.kn, (size_t)N, 0));
-  CK(dev_alloc(h, &d.kn_head, N, 0));
-  CK(dev_alloc(h, &d.qm, (size_t)2 * N, 0));
+  CK(dev_alloc(h, &d.pk, (size_t)N, 0));
   CK(dev_alloc(h, &d.inmask, (size_t)N, 0));
   CK(dev_alloc(h, &d.ackmask, (size_t)N, 0));
   CK(dev_alloc(h, &d.rum, (size_t)65536, 0));
