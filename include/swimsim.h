@@ -95,8 +95,9 @@ typedef struct swimsim_config {
                                   expected fan-in (2P + 4PK*P[direct probe fails]); rarer
                                   excess goes through an exact overflow list             */
   int32_t  device;             /* HIP device ordinal                                  */
-  uint32_t shard_index;        /* this handle owns members [lo,hi) of the population  */
-  uint32_t n_shards;           /* 0/1 -> unsharded                                    */
+  uint32_t shard_index;        /* this handle owns members [shard_index*n_members/n_shards,
+                                  ...) of the population; n_members is the WHOLE population */
+  uint32_t n_shards;           /* 0/1 -> unsharded; <= 16, must divide n_members      */
 } swimsim_config_t;
 
 typedef struct swimsim swimsim_t; /* opaque; owned by the library */
@@ -236,6 +237,30 @@ int swimsim_set_view(swimsim_t* h, uint32_t observer, uint32_t subject, uint8_t 
 
 /* Resolved configuration (defaults filled in). */
 int swimsim_get_config(const swimsim_t* h, swimsim_config_t* out);
+
+/* ---- sharded clusters (one handle per GPU / process) -------------------------------
+ * The population is split into n_shards contiguous id ranges.  Every shard gets the SAME
+ * configuration (n_members = whole population) and the SAME fault schedule; ground truth and
+ * probe outcomes need no communication, only piggyback payloads cross shards.  One tick is
+ *   phase1  -> the caller delivers r_send[p][0..r_counts[p]) to shard p's r_recv[me][..]
+ *   phase2  -> the caller delivers x_send[p][0..x_counts[p]) to shard p's x_recv[me][..]
+ *   phase3
+ * on every shard in lock step (swim_amd/shard.py does the exchange with torch.distributed:
+ * RCCL over xGMI on GPUs).  Buffers are [n_shards][cap] records owned by the library:
+ * requests are 8 bytes {dst, src}, payload records SWIMSIM_XREC_BYTES {dst, n, n x {subject,
+ * incarnation<<2|state}}.  swimsim_step is refused on sharded handles; digest / counters /
+ * events return this shard's part (the parts add up / concatenate); view and member reads are
+ * answered by the owner only; first-detection ticks must be combined (element-wise minimum)
+ * and set back before digest or first_detect are read. */
+#define SWIMSIM_XREC_BYTES 72u
+int swimsim_shard_info(const swimsim_t* h, uint32_t* lo, uint32_t* n_local, uint32_t* r_cap, uint32_t* x_cap);
+int swimsim_shard_buffers(swimsim_t* h, void** r_send, void** r_recv, void** x_send, void** x_recv,
+                          void** first_suspect);
+int swimsim_shard_phase1(swimsim_t* h, uint32_t* r_counts, uint32_t* x_counts);
+int swimsim_shard_phase2(swimsim_t* h, const uint32_t* r_counts_in, uint32_t* x_counts);
+int swimsim_shard_phase3(swimsim_t* h, const uint32_t* x_counts_in);
+int swimsim_shard_get_first_suspect(swimsim_t* h, uint32_t* out, size_t n);
+int swimsim_shard_set_first_suspect(swimsim_t* h, const uint32_t* combined, size_t n);
 
 /* ---- measurement ------------------------------------------------------------ */
 

@@ -61,7 +61,12 @@ __host__ __device__ inline uint64_t h4(uint64_t tag, uint64_t a, uint64_t b, uin
 // positions advance in step, so their accesses share 64-B sectors instead of costing one
 // request per member.
 struct DevState {
-  uint32_t N, P, K, S, L, loss_thr, R_max, timer_cap, event_cap, event_mask, nblocks;
+  // N = members owned by this handle (local index li in [0,N)), NT = whole population, lo = global id of
+  // local member 0 (unsharded: lo = 0, NT = N).  minfo / first_suspect / crash_tick are indexed by GLOBAL
+  // id (ground truth and the subject -> slot table are replicated on every shard); every other
+  // per-member array by LOCAL index.  Hashes, events and digests always use global ids.
+  uint32_t N, NT, lo, n_shards, shard;
+  uint32_t P, K, S, L, loss_thr, R_max, timer_cap, event_cap, event_mask, nblocks;
   uint32_t inbox_cap, ovf_cap;  // per-member delivery slots; exact overflow list capacity
   uint32_t* minfo;         // per member, ONE gather per probe target:
                            //   bits 0-15 rumour slot+1 of this member as a subject (0 none,
@@ -94,13 +99,33 @@ struct DevState {
   uint2* ovf;              // [2][ovf_cap] inbox overflow (dst, src)
   uint4* events;           // {tick, observer, subject, key<<8|cause}
   uint64_t* blk;           // [nblocks+1][C_COUNT] per-block counter rows (no atomics)
+  // ---- cross-shard exchange (n_shards > 1) --------------------------------------
+  uint2* ord;              // [nblocks][ord_cap] deliveries {dst, src} (global ids) the probe could not do locally
+  uint32_t* ord_cnt;       // [nblocks]
+  uint32_t ord_cap;
+  uint2* r_send; uint2* r_recv;         // [n_shards][r_cap] pull requests {dst, src}, routed to the owner of src
+  uint32_t* x_send; uint32_t* x_recv;   // [n_shards][x_cap][XREC_WORDS] payload records, routed to the owner of dst
+  uint32_t r_cap, x_cap;
+  uint32_t* send_cnt;      // [2][n_shards] records appended per peer: requests, payloads
+  uint4* fl;               // [n_shards * x_cap][4] "foreign lines": received entries the masks cannot carry
 };
 
-__device__ inline size_t vidx(const DevState& s, uint32_t i, uint32_t slot) {
-  return (size_t)slot * s.N + i;
+// payload record on the wire: {dst (global id), n, n x {subject, key}} -- ids, not slots: every shard
+// has its own slot and rumour-id numbering
+constexpr int XREC_WORDS = 2 + 2 * PB_SLOTS;
+constexpr uint32_t SRC_FOREIGN = 1u << 30;      // explicit-record source word: index into fl, not a member
+
+__device__ inline bool is_local(const DevState& s, uint32_t g) { return g - s.lo < s.N; }
+__device__ inline uint32_t owner_of(const DevState& s, uint32_t g) { return g / s.N; }   // equal-sized shards
+
+__device__ inline size_t vidx(const DevState& s, uint32_t li, uint32_t slot) {
+  return (size_t)slot * s.N + li;
 }
-__device__ inline size_t ridx(const DevState& s, uint32_t i, uint32_t pos) {
-  return (size_t)pos * s.N + i;
+__device__ inline size_t ridx(const DevState& s, uint32_t li, uint32_t pos) {
+  return (size_t)pos * s.N + li;
+}
+__device__ inline const uint4* line_ptr(const DevState& s, uint32_t buf, uint32_t li) {
+  return reinterpret_cast<const uint4*>(s.pb + ((size_t)buf * s.N + li) * PB_SLOTS);
 }
 
 __device__ inline bool lost(const DevState& s, uint32_t tk, uint32_t purpose, uint32_t src, uint32_t dst,
@@ -180,11 +205,11 @@ __device__ inline bool mi_up(uint32_t mi) { return (mi & MI_UP) != 0; }
 // source word for "merge this member's current piggyback line": id | buffer<<31
 __device__ inline uint32_t mi_src(uint32_t id, uint32_t mi) { return id | (mi_buf(mi) << 31); }
 
-// `isAlive` on member i's view of c (src/Core.hs:33-34, 72-74); mc = minfo[c]
-__device__ inline bool view_alive(const DevState& s, uint32_t i, uint32_t mc) {
+// `isAlive` on local member li's view of c (src/Core.hs:33-34, 72-74); mc = minfo[c]
+__device__ inline bool view_alive(const DevState& s, uint32_t li, uint32_t mc) {
   const uint32_t sl = mc & MI_SLOT;
   if (sl == 0 || sl == MI_SLOT) return true;       // nobody ever gossiped about c: Alive@0
-  return (s.V[vidx(s, i, sl - 1)].x & 3u) == ST_ALIVE;
+  return (s.V[vidx(s, li, sl - 1)].x & 3u) == ST_ALIVE;
 }
 
 // kRandomMembers (src/Core.hs:69-74) + shuffle (src/Util.hs:37-42) as n draws without
@@ -196,7 +221,7 @@ __device__ inline uint32_t select_members(const DevState& s, uint32_t mk, uint32
                                           uint32_t nexcl, uint32_t (&out)[MAXN],
                                           uint32_t (&info)[MAXN]) {
   uint32_t np = 0;
-  const uint32_t N = s.N;
+  const uint32_t N = s.NT;
   // Issue the first-attempt gathers of all picks together (independent loads); eligibility is
   // then decided pick by pick in order, exactly as the sequential definition does.
   uint32_t c0[MAXN <= 16 ? MAXN : 1], m0[MAXN <= 16 ? MAXN : 1];
@@ -223,7 +248,7 @@ __device__ inline uint32_t select_members(const DevState& s, uint32_t mk, uint32
       for (int e = 0; e < MAXN; ++e) dup |= ((uint32_t)e < np) && (out[e] == cand);
       if (dup) return false;
       mc = have ? mhave : s.minfo[cand];
-      return view_alive(s, i, mc);
+      return view_alive(s, i - s.lo, mc);
     };
     for (uint32_t a = 0; a < SEL_ATTEMPTS; ++a) {
       bool have = false; uint32_t mh = 0;

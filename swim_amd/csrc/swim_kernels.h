@@ -59,8 +59,8 @@ __device__ inline void push(const DevState& s, uint32_t t, uint32_t dst, uint32_
   push_commit(s, t, dst, srcw, atomicAdd(&s.inbox_cnt[dst], 1u));
 }
 
-// make sure subject j has a rumour slot (first Suspect about j); returns nothing: the slot is
-// only needed by the NEXT kernel
+// make sure subject j (global id) has a rumour slot (first rumour about j); returns nothing: the slot
+// is usually only needed by the NEXT kernel (get_slot waits for it)
 __device__ inline void ensure_slot(const DevState& s, uint32_t j) {
   uint32_t cur = s.minfo[j];
   while ((cur & MI_SLOT) == 0u) {
@@ -77,15 +77,39 @@ __device__ inline void ensure_slot(const DevState& s, uint32_t j) {
   }
 }
 
+// slot of subject j, allocated if need be, for callers that need it at once (payload ingest)
+__device__ inline uint32_t get_slot(const DevState& s, uint32_t j) {
+  ensure_slot(s, j);
+  uint32_t v = s.minfo[j] & MI_SLOT;
+  for (int spin = 0; spin < 4096 && (v == 0u || v == MI_SLOT); ++spin) v = atomicOr(&s.minfo[j], 0u) & MI_SLOT;
+  if (v == 0u || v == MI_SLOT) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_SUBJECTS); return 0u; }
+  return v - 1u;
+}
+
 // ================================================================================================
 // probe kernel
 // ================================================================================================
+// "dst merges src's start-of-tick queue" for a LOCAL source and a LOCAL destination: the mask by
+// atomicOr, filtered by what dst already knows, plus an explicit record when the mask cannot carry all
+// of it (swim_device.h).  dst_known = pk[dst].y if the caller has it, else it is fetched.
+__device__ inline void deliver_local(const DevState& s, uint32_t t, bool use_mask, unsigned long long stale,
+                                     uint32_t dst_li, uint32_t src_li, uint32_t msrc, unsigned long long srcmask) {
+  if (use_mask) {
+    const unsigned long long m = srcmask & ~(s.pk[dst_li].y & ~stale);
+    if (m) atomicOr(&s.inmask[dst_li], m);
+  }
+  if (!use_mask || (msrc & MI_OOW)) push(s, t, dst_li, mi_src(src_li, msrc));
+}
+
 template <int PMAX>
 __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, uint32_t tk) {
   __shared__ BlockCounters sh;
+  __shared__ uint32_t ordn;                        // deliveries left to the exchange (sharded runs)
+  if (threadIdx.x == 0) ordn = 0;
   ctr_init(&sh);
-  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-  const uint32_t mi = i < s.N ? s.minfo[i] : 0u;
+  const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
+  const uint32_t i = s.lo + li;                    // global id
+  const uint32_t mi = li < s.N ? s.minfo[i] : 0u;
   const bool act = mi_up(mi);
   // masks are exact only if few rumour ids appeared since they were built (swim_device.h)
   const uint32_t Hprev = s.g[G_PREV], H = s.g[G_HEAD];
@@ -96,22 +120,34 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
   if (act) {
     const uint32_t mk = mix32(tk ^ i);
     const uint32_t mycnt = mi_pbn(mi);
-    const uint32_t mysrc = mi_src(i, mi);
-    const unsigned long long mymask = (mycnt && use_mask) ? s.pk[i].x : 0ull;
+    const unsigned long long mymask = (mycnt && use_mask) ? s.pk[li].x : 0ull;
     uint32_t picks[PMAX], pinfo[PMAX];
     // ms <- kRandomMembers store (numToGossip cfg) []        (src/Core.hs:239)
     const uint32_t np = select_members<PMAX>(s, mk, i, s.P, P_SELECT, 0, nullptr, 0, picks, pinfo);
     n_pings = np;
     uint32_t nfail = 0, nack = 0;
     unsigned payloads = 0, rumors = 0, dfail = 0, preqs = 0, susp = 0, fsusp = 0;
-    // "dst merges src's start-of-tick queue": the mask by atomicOr (or into ackacc when dst is me),
-    // plus an explicit record when the mask cannot carry all of it
-    auto explicit_needed = [&](uint32_t msrc) { return !use_mask || (msrc & MI_OOW); };
-    auto src_mask = [&](uint32_t src) -> unsigned long long { return use_mask ? s.pk[src].x : 0ull; };
-    // push only what the receiver does not know yet
-    auto push_mask = [&](uint32_t dst, unsigned long long m, unsigned long long dst_known) {
-      m &= ~(dst_known & ~stale);
-      if (m) atomicOr(&s.inmask[dst], m);
+    // a delivery this shard cannot complete alone: the exchange routes it
+    auto emit_order = [&](uint32_t dst, uint32_t src) {
+      const uint32_t pos = atomicAdd(&ordn, 1u);
+      if (pos < s.ord_cap) s.ord[(size_t)blockIdx.x * s.ord_cap + pos] = make_uint2(dst, src);
+      else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_OVF);
+    };
+    // "dst merges src's start-of-tick queue", any dst / src (global ids); msrc = minfo[src]
+    auto deliver = [&](uint32_t dst, uint32_t src, uint32_t msrc) {
+      if (!is_local(s, src)) { emit_order(dst, src); return; }       // the owner of src knows its queue
+      const uint32_t cnt = mi_pbn(msrc);
+      if (!cnt) return;                                             // empty payload
+      payloads++; rumors += cnt;
+      if (dst == i) {
+        // pulled by myself: no atomics, a private word and (rarely) a private explicit list
+        if (use_mask) ackacc |= src == i ? mymask : s.pk[src - s.lo].x;
+        if (!use_mask || (msrc & MI_OOW)) push(s, t, li, mi_src(src - s.lo, msrc));
+      } else if (is_local(s, dst)) {
+        deliver_local(s, t, use_mask, stale, dst - s.lo, src - s.lo, msrc, src == i ? mymask : (use_mask ? s.pk[src - s.lo].x : 0ull));
+      } else {
+        emit_order(dst, src);
+      }
     };
     // pass 1: outcome of every direct probe -- pure arithmetic on the gathered info words.
     //   Direct (Ping seq j) is delivered iff not lost and j is up (src/Core.hs:246);
@@ -125,53 +161,58 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
         ack_ok[p] = ping_ok[p] && !lost(s, tk, P_L_ACK, picks[p], i, p);
       }
     }
-    // pass 2: one 16-byte gather per reached target, issued together: its queue mask (the Ack's
+    // pass 2: one 16-byte gather per reached LOCAL target, issued together: its queue mask (the Ack's
     // payload, pulled by the prober itself) and its known-ring (what my Ping's payload can still tell it)
     ulonglong2 tk2[PMAX];
 #pragma unroll
     for (int p = 0; p < PMAX; ++p) {
       tk2[p] = make_ulonglong2(0ull, 0ull);
-      if (use_mask && ping_ok[p] && (mymask || (ack_ok[p] && mi_pbn(pinfo[p])))) tk2[p] = s.pk[picks[p]];
+      if (use_mask && ping_ok[p] && is_local(s, picks[p]) && (mymask || (ack_ok[p] && mi_pbn(pinfo[p]))))
+        tk2[p] = s.pk[picks[p] - s.lo];
     }
     // pass 3: the Pings' piggyback payloads: at most one atomicOr per target
     if (mycnt) {
+      uint32_t pos[PMAX];
+      const bool expl = !use_mask || (mi & MI_OOW);
 #pragma unroll
-      for (int p = 0; p < PMAX; ++p)
+      for (int p = 0; p < PMAX; ++p) {
+        pos[p] = 0;
         if (ping_ok[p]) {
-          if (mymask) push_mask(picks[p], mymask, tk2[p].y);
           payloads++; rumors += mycnt;
+          if (is_local(s, picks[p])) {
+            const uint32_t dl = picks[p] - s.lo;
+            const unsigned long long m = mymask & ~(tk2[p].y & ~stale);   // only what the target does not know
+            if (m) atomicOr(&s.inmask[dl], m);
+            if (expl) pos[p] = atomicAdd(&s.inbox_cnt[dl], 1u);
+          } else {
+            emit_order(picks[p], i);
+          }
         }
-      if (explicit_needed(mi)) {
-        uint32_t pos[PMAX];
+      }
+      if (expl) {
 #pragma unroll
-        for (int p = 0; p < PMAX; ++p) { pos[p] = 0; if (ping_ok[p]) pos[p] = atomicAdd(&s.inbox_cnt[picks[p]], 1u); }
-#pragma unroll
-        for (int p = 0; p < PMAX; ++p) if (ping_ok[p]) push_commit(s, t, picks[p], mysrc, pos[p]);
+        for (int p = 0; p < PMAX; ++p)
+          if (ping_ok[p] && is_local(s, picks[p])) push_commit(s, t, picks[p] - s.lo, mi_src(li, mi), pos[p]);
       }
     }
+    // pass 4: the Acks' payloads, pulled by the prober itself
 #pragma unroll
     for (int p = 0; p < PMAX; ++p) {
+      if (!ack_ok[p]) continue;
+      if (!is_local(s, picks[p])) { emit_order(i, picks[p]); continue; }   // its owner serves the pull
       const uint32_t pj = mi_pbn(pinfo[p]);
-      if (ack_ok[p] && pj) {
+      if (pj) {
         ackacc |= tk2[p].x;
-        if (explicit_needed(pinfo[p])) { s.ackfrom[(size_t)i * s.P + nack] = mi_src(picks[p], pinfo[p]); nack++; }
+        if (!use_mask || (pinfo[p] & MI_OOW)) { s.ackfrom[(size_t)li * s.P + nack] = mi_src(picks[p] - s.lo, pinfo[p]); nack++; }
         payloads++; rumors += pj;
       }
     }
-    // pass 4 (rare): probes without an ack -> k indirect probes -> maybe Suspect
-    auto deliver = [&](uint32_t dst, uint32_t src, uint32_t msrc) {
-      const unsigned long long m = src == i ? mymask : src_mask(src);
-      if (dst == i) ackacc |= m;
-      else if (m) push_mask(dst, m, s.pk[dst].y);
-      if (explicit_needed(msrc)) push(s, t, dst, mi_src(src, msrc));
-      payloads++; rumors += mi_pbn(msrc);
-    };
+    // pass 5 (rare): probes without an ack -> k indirect probes -> maybe Suspect
     for (int p = 0; p < PMAX; ++p) {
       if ((uint32_t)p >= np) break;
       if (ack_ok[p]) continue;                               // unlessAck (D2, D3)
       const uint32_t j = picks[p], mj = pinfo[p];
       const bool upj = mi_up(mj);
-      const uint32_t pj = mi_pbn(mj);
       dfail++;
       // kRandomMembers store (numToGossip cfg) [] for proxies (src/Core.hs:249), D7: not the target
       uint32_t qs[PMAX], qinfo[PMAX];
@@ -182,32 +223,31 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
       for (int k = 0; k < PMAX; ++k) {
         if ((uint32_t)k >= nq) break;
         const uint32_t q = qs[k], mq = qinfo[k];
-        const uint32_t pq = mi_pbn(mq);
         const uint32_t idx = ((uint32_t)p << 8) | (uint32_t)k;
         // i -> q : IndirectPing (src/Core.hs:250, 262-269)
         if (lost(s, tk, P_L_REQ, i, q, idx) || !mi_up(mq)) continue;
-        if (mycnt) deliver(q, i, mi);
+        deliver(q, i, mi);
         // q -> j : Ping on behalf of i (src/Core.hs:105-108; D8, D12)
         if (!upj || lost(s, tk, P_L_FWD, q, j, idx)) continue;
-        if (pq) deliver(j, q, mq);
+        deliver(j, q, mq);
         // j -> q : Ack
         if (lost(s, tk, P_L_BACK, j, q, idx)) continue;
-        if (pj) deliver(q, j, mj);
+        deliver(q, j, mj);
         // q -> i : relayed Ack (D9)
         if (lost(s, tk, P_L_RELAY, q, i, idx)) continue;
-        if (pq) deliver(i, q, mq);
+        deliver(i, q, mq);
         acked = true;
       }
       if (acked) continue;                                   // second unlessAck (src/Core.hs:251)
       // suspectNode store (Suspect (memberIncarnation m) name)  (src/Core.hs:253): lands in merge
       ensure_slot(s, j);
-      s.fail[(size_t)i * s.P + nfail] = j;
+      s.fail[(size_t)li * s.P + nfail] = j;
       nfail++;
       susp++;
       if (upj) fsusp++;
       else atomicMin(&s.first_suspect[j], t);
     }
-    s.probe_out[i] = (uint16_t)(np | (nfail << 5) | (nack << 10));
+    s.probe_out[li] = (uint16_t)(np | (nfail << 5) | (nack << 10));
     ctr_add(&sh, C_PAYLOADS, payloads);
     ctr_add(&sh, C_RUMORS_SEEN, rumors);
     ctr_add(&sh, C_DIRECT_FAILED, dfail);
@@ -215,12 +255,13 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
     ctr_add(&sh, C_SUSPECTS, susp);
     ctr_add(&sh, C_FALSE_SUSPECTS, fsusp);
   }
-  if (i < s.N) s.ackmask[i] = ackacc;
+  if (li < s.N) s.ackmask[li] = ackacc;
   // the two always-nonzero counters: wave-reduce first
   unsigned wp = wave_sum(n_pings);
   unsigned wa = wave_sum(act ? 1u : 0u);
   if ((threadIdx.x & 63) == 0) { ctr_add(&sh, C_PINGS, wp); ctr_add(&sh, C_ACTIVE, wa); }
   ctr_flush(s, &sh, blockIdx.x);
+  if (s.n_shards > 1 && threadIdx.x == 0) s.ord_cnt[blockIdx.x] = ordn < s.ord_cap ? ordn : s.ord_cap;
 }
 
 // ================================================================================================
@@ -312,28 +353,29 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
   __shared__ uint32_t asm_[PB_SLOTS][2][BLOCK];   // the outgoing line is assembled here: [entry][word][thread]
   __shared__ uint32_t wfl[BLOCK];
   ctr_init(&sh);
-  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
+  const uint32_t i = s.lo + li;                    // global id
   const uint32_t tid = threadIdx.x;
   if (blockIdx.x == 0 && threadIdx.x == 0) s.g[G_OVF0 + ((t + 1) & 1u)] = 0;  // next tick's overflow list
-  const uint32_t mi = i < s.N ? s.minfo[i] : 0u;
+  const uint32_t mi = li < s.N ? s.minfo[i] : 0u;
   const uint32_t H = s.g[G_HEAD];
   const unsigned long long stale = stale_positions(s.g[G_PREV], H);
   uint32_t wflag = 0;                              // bit 0: my line was rebuilt in asm_, bit 1: into which buffer
   if (mi_up(mi)) {
-    const uint32_t po = s.probe_out[i];
+    const uint32_t po = s.probe_out[li];
     const uint32_t nsent = po & 31u, nfail = (po >> 5) & 31u, nack = po >> 10;
-    const uint32_t cnt = s.inbox_cnt[i];
-    const unsigned long long pushed = s.inmask[i], pulled = s.ackmask[i];
-    const uint4 hot0 = s.hot[i];
+    const uint32_t cnt = s.inbox_cnt[li];
+    const unsigned long long pushed = s.inmask[li], pulled = s.ackmask[li];
+    const uint4 hot0 = s.hot[li];
     uint32_t self_inc = hot0.x, thead = hot0.y & 0xFFFFu, tcount = hot0.y >> 16, tnext = hot0.w;
     const uint32_t pcount = mi_pbn(mi), cur = mi_buf(mi);
     const bool timer_due = tcount && tnext <= t;
     if (!((pushed | pulled) != 0ull || (cnt | nack | nfail | pcount | (uint32_t)timer_due))) {
       // idle this tick: only keep the ring valid (swim_device.h); nothing to write when no id was allocated
-      if (stale) { const ulonglong2 v = s.pk[i]; if (v.y & stale) s.pk[i] = make_ulonglong2(v.x, v.y & ~stale); }
+      if (stale) { const ulonglong2 v = s.pk[li]; if (v.y & stale) s.pk[li] = make_ulonglong2(v.x, v.y & ~stale); }
     } else {
       // ---- known-ring: forget the positions of the ids allocated during the previous tick
-      unsigned long long kn = s.pk[i].y & ~stale;
+      unsigned long long kn = s.pk[li].y & ~stale;
       // ---- own queue (sorted by priority; see swim_device.h): only the slot ids stay live (two per
       // register) for the "superseded" test; the line itself is read again when the queue is rebuilt
       NewGroup c; c.n = 0;
@@ -343,7 +385,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
       uint32_t oslot[PB_SLOTS / 2];
 #pragma unroll
       for (int h = 0; h < PB_SLOTS / 2; ++h) oslot[h] = 0xFFFFFFFFu;   // no entry: matches no slot (< 0xFFFF)
-      const uint4* own_line = reinterpret_cast<const uint4*>(s.pb + ((size_t)cur * s.N + i) * PB_SLOTS);
+      const uint4* own_line = reinterpret_cast<const uint4*>(s.pb + ((size_t)cur * s.N + li) * PB_SLOTS);
       if (pcount) {
 #pragma unroll
         for (int h = 0; h < PB_SLOTS / 2; ++h) {
@@ -382,9 +424,9 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
           return;
         }
         examined++;
-        const uint2 e = s.V[vidx(s, i, slot)];
+        const uint2 e = s.V[vidx(s, li, slot)];
         if (key <= e.x) return;                      // old incarnation / weaker state: ignore (:151)
-        s.V[vidx(s, i, slot)] = make_uint2(key, t + 1);                    // memberLastChange = now (:176)
+        s.V[vidx(s, li, slot)] = make_uint2(key, t + 1);                    // memberLastChange = now (:176)
         const uint32_t subject = s.subject_of[slot];
         if (!ha) ha = mix64(mix64((uint64_t)TAG_EV) + (((uint64_t)t << 32) | i));
         const unsigned long long hx = mix64(ha + subject);                // h4(TAG_EV, a, subject, .) prefix
@@ -395,7 +437,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
           if (tcount >= s.timer_cap) atomicOr(&s.g[G_ERR], (uint32_t)ERRF_TIMERS);
           else {
             uint32_t pos = thead + tcount; if (pos >= s.timer_cap) pos -= s.timer_cap;
-            s.ring[ridx(s, i, pos)] = make_uint2(slot, t + s.S);
+            s.ring[ridx(s, li, pos)] = make_uint2(slot, t + s.S);
             if (tcount == 0) tnext = t + s.S;
             tcount++;
           }
@@ -413,18 +455,18 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
       // phase 1: suspicion timers, evaluated on the start-of-tick view
       if (timer_due)
         while (tcount) {
-          const uint2 tm = s.ring[ridx(s, i, thead)];
+          const uint2 tm = s.ring[ridx(s, li, thead)];
           if (tm.y > t) break;
           thead = (thead + 1 == s.timer_cap) ? 0 : thead + 1;
           tcount--;
-          const uint2 e = s.V[vidx(s, i, tm.x)];
+          const uint2 e = s.V[vidx(s, li, tm.x)];
           if ((e.x & 3u) == ST_SUSPECT && e.y - 1 + s.S == tm.y) examine(tm.x, (e.x & ~3u) | ST_DEAD, 1u, false, 0u);
         }
       // phase 2: own probes that ended without any ack: Suspect at the viewed incarnation
       for (uint32_t f = 0; f < nfail; ++f) {
-        const uint32_t j = s.fail[(size_t)i * s.P + f];
+        const uint32_t j = s.fail[(size_t)li * s.P + f];
         const uint32_t sl = (s.minfo[j] & MI_SLOT) - 1;
-        const uint2 e = s.V[vidx(s, i, sl)];
+        const uint2 e = s.V[vidx(s, li, sl)];
         const uint32_t key = (e.x & ~3u) | ST_SUSPECT;
         if (key > e.x) examine(sl, key, 0u, false, 0u);
       }
@@ -446,14 +488,15 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
         const uint32_t novf = cnt > s.inbox_cap ? min(s.g[G_OVF0 + (t & 1u)], s.ovf_cap) : 0u;
         for (uint32_t x = 0; x < nack + nin + novf; ++x) {
           uint32_t srcw = NONE32;
-          if (x < nack) srcw = s.ackfrom[(size_t)i * s.P + x];
-          else if (x < nack + nin) srcw = s.inbox[(size_t)i * s.inbox_cap + (x - nack)];
+          if (x < nack) srcw = s.ackfrom[(size_t)li * s.P + x];
+          else if (x < nack + nin) srcw = s.inbox[(size_t)li * s.inbox_cap + (x - nack)];
           else {
             const uint2 o = s.ovf[(size_t)(t & 1u) * s.ovf_cap + (x - nack - nin)];
-            if (o.x == i) srcw = o.y;
+            if (o.x == li) srcw = o.y;
           }
           if (srcw == NONE32) continue;
-          const uint4* line = reinterpret_cast<const uint4*>(s.pb + ((size_t)(srcw >> 31) * s.N + (srcw & 0x7FFFFFFFu)) * PB_SLOTS);
+          const uint4* line = (srcw & SRC_FOREIGN) ? s.fl + (size_t)(srcw & (SRC_FOREIGN - 1u)) * 4
+                                                   : line_ptr(s, srcw >> 31, srcw & 0x7FFFFFFFu);
           for (int h = 0; h < PB_SLOTS / 2; ++h) {
             const uint4 v = line[h];
 #pragma unroll
@@ -526,13 +569,13 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
       } else if (pcount) {
         s.minfo[i] = mi & ~MI_PB;
       }
-      s.pk[i] = make_ulonglong2(nout ? qmask : 0ull, kn);
-      if (pushed) s.inmask[i] = 0;
+      s.pk[li] = make_ulonglong2(nout ? qmask : 0ull, kn);
+      if (pushed) s.inmask[li] = 0;
       if (tcount == 0) tnext = NONE32;
-      else if (thead != (hot0.y & 0xFFFFu)) tnext = s.ring[ridx(s, i, thead)].y;
+      else if (thead != (hot0.y & 0xFFFFu)) tnext = s.ring[ridx(s, li, thead)].y;
       const uint4 hot1 = make_uint4(self_inc, thead | (tcount << 16), 0u, tnext);
-      if (hot1.x != hot0.x || hot1.y != hot0.y || hot1.w != hot0.w) s.hot[i] = hot1;
-      if (cnt) s.inbox_cnt[i] = 0;
+      if (hot1.x != hot0.x || hot1.y != hot0.y || hot1.w != hot0.w) s.hot[li] = hot1;
+      if (cnt) s.inbox_cnt[li] = 0;
       ctr_add(&sh, C_CHANGES, changes);
       ctr_add(&sh, C_PB_WRITES, (pcount || nout) ? 1u : 0u);
       ctr_add(&sh, C_TIMERS_FIRED, timers_fired);
@@ -564,6 +607,141 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
 }
 
 // ================================================================================================
+// cross-shard exchange kernels (n_shards > 1)
+// ================================================================================================
+// Records are appended to per-peer send buffers with ONE global atomic per (block, peer): ranks within
+// the block come from LDS counters.  Every thread of the block calls this together (peer < 0: nothing).
+struct AppendCtx { uint32_t cnt[16]; uint32_t base[16]; };   // n_shards <= 16
+__device__ inline uint32_t block_append(AppendCtx* a, uint32_t* gcnt, uint32_t n_peers, int peer) {
+  if (threadIdx.x < 16) a->cnt[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t rank = 0;
+  if (peer >= 0) rank = atomicAdd(&a->cnt[peer], 1u);
+  __syncthreads();
+  if (threadIdx.x < n_peers && a->cnt[threadIdx.x]) a->base[threadIdx.x] = atomicAdd(&gcnt[threadIdx.x], a->cnt[threadIdx.x]);
+  __syncthreads();
+  return peer >= 0 ? a->base[peer] + rank : 0u;
+}
+
+// the payload record of local member src_li for destination dst: ids instead of slots
+__device__ inline void write_xrec(const DevState& s, uint32_t* rec, uint32_t dst, uint32_t src_li, uint32_t msrc) {
+  const uint2* line = reinterpret_cast<const uint2*>(line_ptr(s, mi_buf(msrc), src_li));
+  uint32_t n = 0;
+  for (int k = 0; k < PB_SLOTS; ++k) {
+    const uint2 e = line[k];
+    if (!pe_tx(e.y)) break;
+    rec[2 + 2 * n] = s.subject_of[pe_slot(e.x)];
+    rec[3 + 2 * n] = pe_key(e.y);
+    n++;
+  }
+  rec[0] = dst; rec[1] = n;
+}
+
+// One delivery order {dst, src} whose source is LOCAL: dst local -> done here; else a payload record for
+// the owner of dst.  count = this shard accounts for the payload (it was not counted by the prober).
+__device__ inline void route_order(const DevState& s, uint32_t t, AppendCtx* a, BlockCounters* sh, bool have,
+                                   uint32_t dst, uint32_t src, bool count) {
+  const uint32_t Hprev = s.g[G_PREV], H = s.g[G_HEAD];
+  const bool use_mask = H - Hprev <= MASK_SLACK;
+  int peer = -1;
+  uint32_t msrc = 0, src_li = 0;
+  if (have) {
+    src_li = src - s.lo;
+    msrc = s.minfo[src];
+    const uint32_t cnt = mi_pbn(msrc);
+    if (!cnt) have = false;                         // empty payload: nothing travels
+    else {
+      if (count) { ctr_add(sh, C_PAYLOADS, 1u); ctr_add(sh, C_RUMORS_SEEN, cnt); }
+      if (is_local(s, dst))
+        deliver_local(s, t, use_mask, stale_positions(Hprev, H), dst - s.lo, src_li, msrc, use_mask ? s.pk[src_li].x : 0ull);
+      else peer = (int)owner_of(s, dst);
+    }
+  }
+  const uint32_t pos = block_append(a, s.send_cnt + s.n_shards, s.n_shards, peer);
+  if (peer >= 0) {
+    if (pos < s.x_cap) write_xrec(s, s.x_send + ((size_t)peer * s.x_cap + pos) * XREC_WORDS, dst, src_li, msrc);
+    else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_OVF);
+  }
+}
+
+// after probe_kernel: the orders it left.  Source remote -> pull request to its owner; source local ->
+// payload record to the owner of dst.  One block per probe block (its own order region).
+__global__ __launch_bounds__(BLOCK) void split_kernel(DevState s, uint32_t t) {
+  __shared__ BlockCounters sh;
+  __shared__ AppendCtx ar, ax;
+  ctr_init(&sh);
+  const uint32_t n = s.ord_cnt[blockIdx.x];
+  for (uint32_t base = 0; base < n; base += BLOCK) {
+    const uint32_t k = base + threadIdx.x;
+    const bool have = k < n;
+    const uint2 o = have ? s.ord[(size_t)blockIdx.x * s.ord_cap + k] : make_uint2(0u, 0u);
+    const bool src_local = have && is_local(s, o.y);
+    // requests
+    const int rpeer = (have && !src_local) ? (int)owner_of(s, o.y) : -1;
+    const uint32_t rpos = block_append(&ar, s.send_cnt, s.n_shards, rpeer);
+    if (rpeer >= 0) {
+      if (rpos < s.r_cap) s.r_send[(size_t)rpeer * s.r_cap + rpos] = o;
+      else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_OVF);
+    }
+    // payloads of local sources (already counted by the prober)
+    route_order(s, t, &ax, &sh, src_local, o.x, o.y, false);
+  }
+  ctr_flush(s, &sh, blockIdx.x);
+}
+
+// after round 1: the pull requests other shards sent me (their source is mine).  Fixed grid (= nblocks)
+// so that every block owns a counter row.
+__global__ __launch_bounds__(BLOCK) void serve_kernel(DevState s, uint32_t t, const uint32_t* r_counts) {
+  __shared__ BlockCounters sh;
+  __shared__ AppendCtx ax;
+  ctr_init(&sh);
+  for (uint32_t peer = 0; peer < s.n_shards; ++peer) {
+    const uint32_t n = min(r_counts[peer], s.r_cap);
+    for (uint32_t base = blockIdx.x * BLOCK; base < n; base += gridDim.x * BLOCK) {
+      const uint32_t k = base + threadIdx.x;
+      const bool have = k < n;
+      const uint2 o = have ? s.r_recv[(size_t)peer * s.r_cap + k] : make_uint2(0u, 0u);
+      route_order(s, t, &ax, &sh, have, o.x, o.y, true);
+    }
+  }
+  ctr_flush(s, &sh, blockIdx.x);
+}
+
+// after round 2: payload records for my members: ids -> my slots and rumour ids; what my masks can carry
+// is pushed as a mask, the rest becomes a "foreign line" read through an explicit record.
+__global__ __launch_bounds__(BLOCK) void ingest_kernel(DevState s, uint32_t t, const uint32_t* x_counts) {
+  const uint32_t Hprev = s.g[G_PREV], H = s.g[G_HEAD];
+  const bool use_mask = H - Hprev <= MASK_SLACK;
+  const unsigned long long stale = stale_positions(Hprev, H);
+  for (uint32_t peer = 0; peer < s.n_shards; ++peer) {
+    const uint32_t n = min(x_counts[peer], s.x_cap);
+    for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < n; k += gridDim.x * BLOCK) {
+      const size_t ridx_ = (size_t)peer * s.x_cap + k;
+      const uint32_t* rec = s.x_recv + ridx_ * XREC_WORDS;
+      const uint32_t dst_li = rec[0] - s.lo, ne = min(rec[1], (uint32_t)PB_SLOTS);
+      unsigned long long bits = 0;
+      uint32_t nf = 0;
+      uint32_t* fl = reinterpret_cast<uint32_t*>(s.fl + ridx_ * 4);
+      for (uint32_t e = 0; e < ne; ++e) {
+        const uint32_t subject = rec[2 + 2 * e], key = rec[3 + 2 * e];
+        const uint32_t slot = get_slot(s, subject);
+        const uint32_t rid = find_rid(s, slot, key);
+        if (use_mask && rid_in_ring(rid, H)) bits |= rid_bit(rid);     // an id of an earlier tick
+        else { fl[2 * nf] = pe_lo(slot, rid); fl[2 * nf + 1] = pe_hi(key, 1u); nf++; }
+      }
+      if (bits) {
+        const unsigned long long m = bits & ~(s.pk[dst_li].y & ~stale);
+        if (m) atomicOr(&s.inmask[dst_li], m);
+      }
+      if (nf) {
+        for (uint32_t e = nf; e < (uint32_t)PB_SLOTS; ++e) { fl[2 * e] = 0; fl[2 * e + 1] = 0; }
+        push(s, t, dst_li, SRC_FOREIGN | (uint32_t)ridx_);
+      }
+    }
+  }
+}
+
+// ================================================================================================
 // auxiliary kernels
 // ================================================================================================
 struct FaultRec { uint32_t member, up; };
@@ -580,8 +758,10 @@ __global__ void begin_kernel(DevState s, uint32_t t, const FaultRec* faults, uin
     if ((uint32_t)mi_up(mi) == up) continue;
     s.first_suspect[mbr] = NONE32;
     if (!up) { s.minfo[mbr] = mi & ~MI_UP; s.crash_tick[mbr] = t; continue; }
+    if (!is_local(s, mbr)) { s.minfo[mbr] = mi | MI_UP; continue; }   // its owner does the rest
     // (re)join: new incarnation, announce Alive
-    uint4 hot = s.hot[mbr];
+    const uint32_t ml = mbr - s.lo;
+    uint4 hot = s.hot[ml];
     uint32_t ni = hot.x + 1;
     if (ni > INC_MAX) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_INC); ni = INC_MAX; }
     evd += h4(TAG_INC, ((uint64_t)t << 32) | mbr, ni, 0);
@@ -594,7 +774,7 @@ __global__ void begin_kernel(DevState s, uint32_t t, const FaultRec* faults, uin
     // The member slept through an unknown number of rumour ids: its old entries' ids are parked and
     // its known-ring starts empty.
     uint32_t lo[PB_SLOTS + 1], hi[PB_SLOTS + 1], sj[PB_SLOTS + 1], n = 0;
-    uint64_t* line = s.pb + ((size_t)cur * s.N + mbr) * PB_SLOTS;
+    uint64_t* line = s.pb + ((size_t)cur * s.N + ml) * PB_SLOTS;
     const uint32_t far = (s.g[G_NRUM] + RID_FAR) & RID_MASK;
     if (pcount)
       for (int q = 0; q < PB_SLOTS; ++q) {
@@ -620,11 +800,11 @@ __global__ void begin_kernel(DevState s, uint32_t t, const FaultRec* faults, uin
     for (uint32_t q = 0; q < n; ++q) {
       if (pe_slot(lo[q]) == sl) jm = rid_bit(arid); else joow = MI_OOW;
     }
-    s.pk[mbr] = make_ulonglong2(jm, 0ull);         // and an empty known-ring
+    s.pk[ml] = make_ulonglong2(jm, 0ull);         // and an empty known-ring
     s.minfo[mbr] = (mi & ~(MI_PBN | MI_OOW)) | (n << MI_PBN_SHIFT) | MI_UP | joow;
-    s.inmask[mbr] = 0;
+    s.inmask[ml] = 0;
     hot.x = ni;
-    s.hot[mbr] = hot;
+    s.hot[ml] = hot;
     if (s.event_mask & (1u << 4)) {
       uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
       if (pos < s.event_cap) s.events[pos] = make_uint4(t, mbr, mbr, (akey << 8) | 4u);
@@ -642,14 +822,15 @@ __global__ __launch_bounds__(BLOCK) void digest_kernel(DevState s, unsigned long
   __shared__ unsigned long long acc;
   if (threadIdx.x == 0) acc = 0;
   __syncthreads();
-  const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i < s.N) {
-    const uint4 hot = s.hot[i];
+  const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
+  const uint32_t i = s.lo + li;
+  if (li < s.N) {
+    const uint4 hot = s.hot[li];
     const uint32_t mi = s.minfo[i];
     unsigned long long mh = h4(TAG_SELF, i, hot.x, mi_up(mi) ? 1u : 0u);
     const uint32_t ns = min(s.g[G_NSLOTS], s.R_max);
     for (uint32_t r = 0; r < ns; ++r) {
-      const uint2 e = s.V[vidx(s, i, r)];
+      const uint2 e = s.V[vidx(s, li, r)];
       if (e.x == 0) continue;
       const uint32_t subject = s.subject_of[r];
       if (subject == i) continue;
@@ -657,7 +838,7 @@ __global__ __launch_bounds__(BLOCK) void digest_kernel(DevState s, unsigned long
       if ((e.x & 3u) == ST_SUSPECT) mh += h4(TAG_TIMER, subject, (uint64_t)e.y - 1 + s.S, 0);
     }
     if (mi_pbn(mi)) {
-      const uint64_t* line = s.pb + ((size_t)mi_buf(mi) * s.N + i) * PB_SLOTS;
+      const uint64_t* line = s.pb + ((size_t)mi_buf(mi) * s.N + li) * PB_SLOTS;
       for (int q = 0; q < PB_SLOTS; ++q) {
         const uint32_t lo = (uint32_t)line[q], hi = (uint32_t)(line[q] >> 32);
         if (pe_tx(hi)) mh += h4(TAG_PB, s.subject_of[pe_slot(lo)], pe_key(hi), pe_tx(hi));
@@ -687,22 +868,24 @@ __global__ void set_view_kernel(DevState s, uint32_t t, uint32_t observer, uint3
   if (blockIdx.x || threadIdx.x) return;
   ensure_slot(s, subject);
   const uint32_t sl = (s.minfo[subject] & MI_SLOT) - 1;
-  s.V[vidx(s, observer, sl)] = make_uint2(key, t + 1);
+  const uint32_t ol = observer - s.lo;
+  s.V[vidx(s, ol, sl)] = make_uint2(key, t + 1);
   if ((key & 3u) == ST_SUSPECT) {
-    uint4 hot = s.hot[observer];
+    uint4 hot = s.hot[ol];
     const uint32_t thead = hot.y & 0xFFFFu, tcount = hot.y >> 16;
     if (tcount >= s.timer_cap) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_TIMERS); return; }
     uint32_t pos = thead + tcount; if (pos >= s.timer_cap) pos -= s.timer_cap;
-    s.ring[ridx(s, observer, pos)] = make_uint2(sl, t + s.S);
+    s.ring[ridx(s, ol, pos)] = make_uint2(sl, t + s.S);
     if (tcount == 0) hot.w = t + s.S;
     hot.y = thead | ((tcount + 1) << 16);
-    s.hot[observer] = hot;
+    s.hot[ol] = hot;
   }
 }
 
-__global__ void init_members_kernel(uint4* hot, uint32_t* minfo, uint32_t n) {
+__global__ void init_members_kernel(uint4* hot, uint32_t* minfo, uint32_t n_local, uint32_t n_total) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { hot[i] = make_uint4(0u, 0u, 0u, NONE32); minfo[i] = MI_UP; }
+  if (i < n_local) hot[i] = make_uint4(0u, 0u, 0u, NONE32);
+  if (i < n_total) minfo[i] = MI_UP;
 }
 
 }  // namespace swim

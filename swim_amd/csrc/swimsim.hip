@@ -48,6 +48,10 @@ struct swimsim {
   double probe_ms = 0, merge_ms = 0; uint64_t timed_ticks = 0;
   bool poisoned = false;
   std::string err;
+  // sharded stepping (swimsim_shard_*): which phase of the current tick comes next, the tick's fault slice
+  int shard_phase = 0;
+  uint32_t* d_counts = nullptr;                // [2][n_shards] received record counts, device copy
+  hipEvent_t tick_ev[3] = {nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -111,7 +115,8 @@ int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, std::string*
   }
   if (c->inbox_cap > 4096u) { *err = "inbox_cap must be <= 4096"; return SWIMSIM_ERR_INVALID; }
   if (c->n_shards == 0) c->n_shards = 1;
-  if (c->n_shards != 1 || c->shard_index != 0) { *err = "sharded handles are created through swimsim_shard_* (n_shards must be 1 here)"; return SWIMSIM_ERR_INVALID; }
+  if (c->n_shards > 16 || c->shard_index >= c->n_shards) { *err = "n_shards must be <= 16 and shard_index < n_shards"; return SWIMSIM_ERR_INVALID; }
+  if (c->n_members % c->n_shards) { *err = "n_members must be a multiple of n_shards"; return SWIMSIM_ERR_INVALID; }
   return SWIMSIM_OK;
 }
 
@@ -200,6 +205,7 @@ void swimsim_destroy(swimsim_t* h) {
   if (h->d_faults) (void)hipFree(h->d_faults);
   if (h->d_sel) (void)hipFree(h->d_sel);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->tick_ev) if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -224,9 +230,10 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   HK(hipSetDevice(h->device));
   HK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   DevState& d = h->d;
-  const uint32_t N = c.n_members;
-  d.N = N; d.P = (uint32_t)c.probes_per_tick; d.K = (uint32_t)c.indirect_k; d.S = c.suspicion_ticks;
-  d.L = c.retransmit_mult * ceil_log2((uint64_t)N + 1);
+  const uint32_t NT = c.n_members, N = NT / c.n_shards;   // N = members owned by this handle
+  d.N = N; d.NT = NT; d.lo = c.shard_index * N; d.n_shards = c.n_shards; d.shard = c.shard_index;
+  d.P = (uint32_t)c.probes_per_tick; d.K = (uint32_t)c.indirect_k; d.S = c.suspicion_ticks;
+  d.L = c.retransmit_mult * ceil_log2((uint64_t)NT + 1);
   {
     uint64_t thr = ((uint64_t)c.loss_ppm << 32) / 1000000ull;
     d.loss_thr = thr > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)thr;
@@ -235,7 +242,8 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   d.nblocks = (N + BLOCK - 1) / BLOCK;
   d.inbox_cap = c.inbox_cap;
   d.ovf_cap = std::max<uint32_t>(1u << 16, N / 8);
-  CK(dev_alloc(h, &d.minfo, N, 0));
+  d.ord_cap = 0; d.r_cap = d.x_cap = 0;
+  CK(dev_alloc(h, &d.minfo, NT, 0));
   CK(dev_alloc(h, &d.probe_out, N, 0));
   CK(dev_alloc(h, &d.ackfrom, (size_t)N * (d.P ? d.P : 1), 0));
   CK(dev_alloc(h, &d.inbox_cnt, N, 0));
@@ -251,14 +259,32 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   CK(dev_alloc(h, &d.ring, (size_t)N * d.timer_cap, 0));
   CK(dev_alloc(h, &d.V, (size_t)N * d.R_max, 0));
   CK(dev_alloc(h, &d.pb, (size_t)2 * N * PB_SLOTS, 0));
-  CK(dev_alloc(h, &d.first_suspect, N, 0xFF));
-  CK(dev_alloc(h, &d.crash_tick, N, 0xFF));
+  CK(dev_alloc(h, &d.first_suspect, NT, 0xFF));
+  CK(dev_alloc(h, &d.crash_tick, NT, 0xFF));
   CK(dev_alloc(h, &d.g, (size_t)G_WORDS, 0));
   CK(dev_alloc(h, &d.ovf, (size_t)2 * d.ovf_cap, 0));
   CK(dev_alloc(h, &d.events, (size_t)d.event_cap, 0));
   CK(dev_alloc(h, &d.blk, ((size_t)d.nblocks + 1) * C_COUNT, 0));
   CK(dev_alloc(h, &h->d_scratch64, (size_t)1, 0));
-  hipLaunchKernelGGL(init_members_kernel, dim3(d.nblocks), dim3(BLOCK), 0, h->stream, d.hot, d.minfo, N);
+  if (d.n_shards > 1) {
+    // exchange buffers, sized from the expected traffic (2P deliveries per member, spread over the shards)
+    // with headroom; overruns are loud (SWIMSIM_ERR_CAPACITY), never silent drops
+    const double per_peer = (double)N * std::max(1u, d.P) / d.n_shards;
+    const double lossf = 1.0 + 8.0 * c.loss_ppm / 1e6 * std::max(1u, d.K);
+    d.ord_cap = (uint32_t)std::min<double>(BLOCK * 64.0, BLOCK * (2.0 * std::max(1u, d.P) * lossf + 4.0));
+    d.r_cap = (uint32_t)(per_peer * 1.5 * lossf) + 4096;
+    d.x_cap = (uint32_t)(per_peer * 3.0 * lossf) + 4096;
+    CK(dev_alloc(h, &d.ord, (size_t)d.nblocks * d.ord_cap, 0));
+    CK(dev_alloc(h, &d.ord_cnt, (size_t)d.nblocks, 0));
+    CK(dev_alloc(h, &d.r_send, (size_t)d.n_shards * d.r_cap, 0));
+    CK(dev_alloc(h, &d.r_recv, (size_t)d.n_shards * d.r_cap, 0));
+    CK(dev_alloc(h, &d.x_send, (size_t)d.n_shards * d.x_cap * XREC_WORDS, 0));
+    CK(dev_alloc(h, &d.x_recv, (size_t)d.n_shards * d.x_cap * XREC_WORDS, 0));
+    CK(dev_alloc(h, &d.send_cnt, (size_t)2 * d.n_shards, 0));
+    CK(dev_alloc(h, &d.fl, (size_t)d.n_shards * d.x_cap * 4, 0));
+    CK(dev_alloc(h, &h->d_counts, (size_t)2 * d.n_shards, 0));
+  }
+  hipLaunchKernelGGL(init_members_kernel, dim3((std::max(N, NT) + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, d.hot, d.minfo, N, NT);
   HK(hipGetLastError());
   HK(hipStreamSynchronize(h->stream));
 #undef CK
@@ -275,7 +301,7 @@ int swimsim_get_config(const swimsim_t* h, swimsim_config_t* out) {
 
 int swimsim_schedule_fault(swimsim_t* h, uint64_t tick, uint32_t member, uint8_t up) {
   if (!h) return SWIMSIM_ERR_INVALID;
-  if (member >= h->d.N || up > 1) return set_err(h, SWIMSIM_ERR_INVALID, "schedule_fault: bad member/up");
+  if (member >= h->d.NT || up > 1) return set_err(h, SWIMSIM_ERR_INVALID, "schedule_fault: bad member/up");
   if (tick < h->tick || tick >= 0xFFFFFFFEull) return set_err(h, SWIMSIM_ERR_INVALID, "schedule_fault: tick in the past");
   Fault f{(uint32_t)tick, member, up, h->fault_order++};
   auto pos = std::upper_bound(h->faults.begin(), h->faults.end(), f, [](const Fault& a, const Fault& b) {
@@ -284,11 +310,8 @@ int swimsim_schedule_fault(swimsim_t* h, uint64_t tick, uint32_t member, uint8_t
   return SWIMSIM_OK;
 }
 
-int swimsim_step(swimsim_t* h, uint32_t nticks) {
-  if (!h) return SWIMSIM_ERR_INVALID;
-  if (h->poisoned) return set_err(h, SWIMSIM_ERR_STATE, "handle is poisoned by an earlier capacity error");
-  HIPCHK(h, hipSetDevice(h->device));
-  // upload the fault records of this whole call once; each tick's fault kernel gets its slice
+// upload the fault records of the next nticks ticks; *fend = how many of h->faults they are
+static int upload_faults(swimsim* h, uint32_t nticks, size_t* fend_out) {
   size_t fend = 0;
   while (fend < h->faults.size() && (uint64_t)h->faults[fend].tick < h->tick + nticks) ++fend;
   if (fend) {
@@ -302,9 +325,20 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
       HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->d_faults), cap * sizeof(FaultRec)));
       h->d_faults_cap = cap;
     }
-    HIPCHK(h, hipStreamSynchronize(h->stream));   // previous call's fault kernels are done with the buffer
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // previous call's begin kernels are done with the buffer
     HIPCHK(h, hipMemcpy(h->d_faults, recs.data(), fend * sizeof(FaultRec), hipMemcpyHostToDevice));
   }
+  *fend_out = fend;
+  return SWIMSIM_OK;
+}
+
+int swimsim_step(swimsim_t* h, uint32_t nticks) {
+  if (!h) return SWIMSIM_ERR_INVALID;
+  if (h->poisoned) return set_err(h, SWIMSIM_ERR_STATE, "handle is poisoned by an earlier capacity error");
+  if (h->d.n_shards > 1) return set_err(h, SWIMSIM_ERR_STATE, "a shard is stepped with swimsim_shard_phase1/2/3 (its peers must take part)");
+  HIPCHK(h, hipSetDevice(h->device));
+  size_t fend = 0;
+  { int rc_ = upload_faults(h, nticks, &fend); if (rc_) return rc_; }
   if (h->timing) {
     while (h->ev_pool.size() < (size_t)nticks * 3) {
       hipEvent_t e;
@@ -373,10 +407,10 @@ static int read_column(swimsim_t* h, uint32_t observer, std::vector<uint2>* col,
 }
 
 int swimsim_read_view(swimsim_t* h, uint32_t observer, swimsim_view_entry_t* buf, size_t cap, size_t* n_out) {
-  if (!h || !n_out || observer >= h->d.N) return SWIMSIM_ERR_INVALID;
+  if (!h || !n_out || observer - h->d.lo >= h->d.N) return SWIMSIM_ERR_INVALID;   // not a member this handle owns
   HIPCHK(h, hipSetDevice(h->device));
   std::vector<uint2> col; std::vector<uint32_t> subj;
-  int rc = read_column(h, observer, &col, &subj);
+  int rc = read_column(h, observer - h->d.lo, &col, &subj);
   if (rc) return rc;
   std::vector<swimsim_view_entry_t> ents;
   for (size_t r = 0; r < col.size(); ++r) {
@@ -393,19 +427,20 @@ int swimsim_read_view(swimsim_t* h, uint32_t observer, swimsim_view_entry_t* buf
 }
 
 int swimsim_read_member(swimsim_t* h, uint32_t m, swimsim_member_t* out) {
-  if (!h || !out || m >= h->d.N) return SWIMSIM_ERR_INVALID;
+  if (!h || !out || m - h->d.lo >= h->d.N) return SWIMSIM_ERR_INVALID;           // not a member this handle owns
   HIPCHK(h, hipSetDevice(h->device));
+  const uint32_t ml = m - h->d.lo;
   std::vector<uint2> col; std::vector<uint32_t> subj;
-  int rc = read_column(h, m, &col, &subj);
+  int rc = read_column(h, ml, &col, &subj);
   if (rc) return rc;
   uint4 hot; uint32_t mi;
-  HIPCHK(h, hipMemcpy(&hot, h->d.hot + m, sizeof hot, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(&hot, h->d.hot + ml, sizeof hot, hipMemcpyDeviceToHost));
   HIPCHK(h, hipMemcpy(&mi, h->d.minfo + m, sizeof mi, hipMemcpyDeviceToHost));
   std::memset(out, 0, sizeof *out);
   out->id = m; out->incarnation = hot.x; out->up = (mi >> 21) & 1u;
   if ((mi >> 16) & 15u) {
     uint64_t line[PB_SLOTS];
-    HIPCHK(h, hipMemcpy(line, h->d.pb + ((size_t)((mi >> 20) & 1u) * h->d.N + m) * PB_SLOTS, sizeof line, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(line, h->d.pb + ((size_t)((mi >> 20) & 1u) * h->d.N + ml) * PB_SLOTS, sizeof line, hipMemcpyDeviceToHost));
     for (int q = 0; q < PB_SLOTS; ++q) {
       const uint32_t lo = (uint32_t)line[q], hi = (uint32_t)(line[q] >> 32);
       if (!pe_tx(hi)) continue;
@@ -422,7 +457,7 @@ int swimsim_read_member(swimsim_t* h, uint32_t m, swimsim_member_t* out) {
 }
 
 int swimsim_first_detect(swimsim_t* h, uint64_t* out, size_t n) {
-  if (!h || !out || n != h->d.N) return SWIMSIM_ERR_INVALID;
+  if (!h || !out || n != h->d.NT) return SWIMSIM_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   std::vector<uint32_t> tmp(n);
@@ -440,7 +475,8 @@ int swimsim_digest(swimsim_t* h, uint64_t* out) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   unsigned long long acc = 0;
   HIPCHK(h, hipMemcpy(&acc, h->d_scratch64, sizeof acc, hipMemcpyDeviceToHost));
-  *out = mix64((uint64_t)TAG_TICK + h->tick) + acc;
+  // a shard returns its members' part; shard 0 adds the tick term, so the parts simply add up
+  *out = (h->d.shard == 0 ? mix64((uint64_t)TAG_TICK + h->tick) : 0ull) + acc;
   return SWIMSIM_OK;
 }
 
@@ -459,7 +495,7 @@ int swimsim_counters(swimsim_t* h, uint64_t* out, size_t n) {
 
 int swimsim_k_random_members(swimsim_t* h, uint32_t observer, uint32_t n, const uint32_t* excludes,
                              size_t n_excludes, uint32_t* out, size_t cap, size_t* n_out) {
-  if (!h || !n_out || observer >= h->d.N || n > 255 || (n_excludes && !excludes)) return SWIMSIM_ERR_INVALID;
+  if (!h || !n_out || observer - h->d.lo >= h->d.N || n > 255 || (n_excludes && !excludes)) return SWIMSIM_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
   const size_t need = 257 + n_excludes;
   if (need > h->d_sel_cap) {
@@ -489,6 +525,133 @@ extern "C" int swimsim_debug_globals(swimsim_t* h, uint32_t* out) {
 }
 #endif
 
+
+/* ---- sharded stepping: one tick = phase1 -> [exchange requests] -> phase2 -> [exchange payloads] -> phase3 ---- */
+
+int swimsim_shard_info(const swimsim_t* h, uint32_t* lo, uint32_t* n_local, uint32_t* r_cap, uint32_t* x_cap) {
+  if (!h) return SWIMSIM_ERR_INVALID;
+  if (lo) *lo = h->d.lo;
+  if (n_local) *n_local = h->d.N;
+  if (r_cap) *r_cap = h->d.r_cap;
+  if (x_cap) *x_cap = h->d.x_cap;
+  return SWIMSIM_OK;
+}
+
+int swimsim_shard_buffers(swimsim_t* h, void** r_send, void** r_recv, void** x_send, void** x_recv, void** first_suspect) {
+  if (!h) return SWIMSIM_ERR_INVALID;
+  if (r_send) *r_send = h->d.r_send;
+  if (r_recv) *r_recv = h->d.r_recv;
+  if (x_send) *x_send = h->d.x_send;
+  if (x_recv) *x_recv = h->d.x_recv;
+  if (first_suspect) *first_suspect = h->d.first_suspect;
+  return SWIMSIM_OK;
+}
+
+static int shard_check(swimsim* h, int phase) {
+  if (!h) return SWIMSIM_ERR_INVALID;
+  if (h->poisoned) return set_err(h, SWIMSIM_ERR_STATE, "handle is poisoned by an earlier capacity error");
+  if (h->d.n_shards < 2) return set_err(h, SWIMSIM_ERR_STATE, "not a sharded handle (use swimsim_step)");
+  if (h->shard_phase != phase) return set_err(h, SWIMSIM_ERR_STATE, "shard phases must run in the order 1, 2, 3");
+  return SWIMSIM_OK;
+}
+
+static int read_send_counts(swimsim* h, uint32_t* r_counts, uint32_t* x_counts) {
+  const uint32_t G = h->d.n_shards;
+  std::vector<uint32_t> c(2 * G);
+  HIPCHK(h, hipMemcpy(c.data(), h->d.send_cnt, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  for (uint32_t g = 0; g < G; ++g) {
+    if (r_counts) r_counts[g] = std::min(c[g], h->d.r_cap);
+    if (x_counts) x_counts[g] = std::min(c[G + g], h->d.x_cap);
+  }
+  return SWIMSIM_OK;
+}
+
+int swimsim_shard_phase1(swimsim_t* h, uint32_t* r_counts, uint32_t* x_counts) {
+  int rc = shard_check(h, 0);
+  if (rc) return rc;
+  if (!r_counts || !x_counts) return SWIMSIM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  size_t fend = 0;
+  rc = upload_faults(h, 1, &fend);
+  if (rc) return rc;
+  if (h->timing && !h->tick_ev[0]) for (int k = 0; k < 3; ++k) HIPCHK(h, hipEventCreate(&h->tick_ev[k]));
+  const uint32_t t = (uint32_t)h->tick;
+  HIPCHK(h, hipMemsetAsync(h->d.send_cnt, 0, (size_t)2 * h->d.n_shards * sizeof(uint32_t), h->stream));
+  hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(64), 0, h->stream, h->d, t, h->d_faults, (uint32_t)fend);
+  h->faults.erase(h->faults.begin(), h->faults.begin() + (long)fend);
+  const uint32_t tk = tick_key(h->cfg.seed, t);
+  if (h->timing) (void)hipEventRecord(h->tick_ev[0], h->stream);
+  if (h->d.P <= 4 && h->d.K <= 4)
+    hipLaunchKernelGGL((probe_kernel<4>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk);
+  else
+    hipLaunchKernelGGL((probe_kernel<16>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk);
+  if (h->timing) (void)hipEventRecord(h->tick_ev[1], h->stream);
+  hipLaunchKernelGGL(split_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->timing) { float a = 0; HIPCHK(h, hipEventElapsedTime(&a, h->tick_ev[0], h->tick_ev[1])); h->probe_ms += a; }
+  rc = read_send_counts(h, r_counts, x_counts);
+  if (rc) return rc;
+  rc = check_device_errors(h);
+  if (rc) return rc;
+  h->shard_phase = 1;
+  return SWIMSIM_OK;
+}
+
+int swimsim_shard_phase2(swimsim_t* h, const uint32_t* r_counts_in, uint32_t* x_counts) {
+  int rc = shard_check(h, 1);
+  if (rc) return rc;
+  if (!r_counts_in || !x_counts) return SWIMSIM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpy(h->d_counts, r_counts_in, h->d.n_shards * sizeof(uint32_t), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(serve_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, (uint32_t)h->tick, h->d_counts);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  rc = read_send_counts(h, nullptr, x_counts);
+  if (rc) return rc;
+  rc = check_device_errors(h);
+  if (rc) return rc;
+  h->shard_phase = 2;
+  return SWIMSIM_OK;
+}
+
+int swimsim_shard_phase3(swimsim_t* h, const uint32_t* x_counts_in) {
+  int rc = shard_check(h, 2);
+  if (rc) return rc;
+  if (!x_counts_in) return SWIMSIM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  const uint32_t G = h->d.n_shards, t = (uint32_t)h->tick;
+  HIPCHK(h, hipMemcpy(h->d_counts + G, x_counts_in, G * sizeof(uint32_t), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(ingest_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, h->d_counts + G);
+  if (h->timing) (void)hipEventRecord(h->tick_ev[1], h->stream);
+  hipLaunchKernelGGL(merge_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
+  if (h->timing) (void)hipEventRecord(h->tick_ev[2], h->stream);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->timing) { float b = 0; HIPCHK(h, hipEventElapsedTime(&b, h->tick_ev[1], h->tick_ev[2])); h->merge_ms += b; h->timed_ticks++; }
+  h->tick++;
+  h->shard_phase = 0;
+  return check_device_errors(h);
+}
+
+/* First-detection ticks are recorded by the prober's shard: set the combined (element-wise minimum over
+ * all shards) array back before digest / first_detect are read on a sharded cluster. */
+int swimsim_shard_set_first_suspect(swimsim_t* h, const uint32_t* combined, size_t n) {
+  if (!h || !combined || n != h->d.NT) return SWIMSIM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(h->d.first_suspect, combined, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+  return SWIMSIM_OK;
+}
+
+int swimsim_shard_get_first_suspect(swimsim_t* h, uint32_t* out, size_t n) {
+  if (!h || !out || n != h->d.NT) return SWIMSIM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(out, h->d.first_suspect, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return SWIMSIM_OK;
+}
+
 int swimsim_kernel_timing_enable(swimsim_t* h, int enable) {
   if (!h) return SWIMSIM_ERR_INVALID;
   h->timing = enable != 0;
@@ -503,7 +666,7 @@ int swimsim_kernel_timing(swimsim_t* h, double* out, size_t n) {
 }
 
 int swimsim_set_view(swimsim_t* h, uint32_t observer, uint32_t subject, uint8_t state, uint32_t incarnation) {
-  if (!h || observer >= h->d.N || subject >= h->d.N || state > 2 || incarnation > INC_MAX || observer == subject)
+  if (!h || observer - h->d.lo >= h->d.N || subject >= h->d.NT || state > 2 || incarnation > INC_MAX || observer == subject)
     return SWIMSIM_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
   hipLaunchKernelGGL(set_view_kernel, dim3(1), dim3(64), 0, h->stream, h->d, (uint32_t)h->tick, observer, subject,

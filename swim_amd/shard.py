@@ -1,0 +1,255 @@
+"""ShardedSim: one simulated population split over several handles (one per GPU).
+
+Members shard by contiguous id range; every shard holds the same configuration and the same
+fault schedule.  Probe outcomes need no communication (ground truth and the loss hashes are
+known everywhere); only piggyback payloads cross shards, in two rounds per tick
+(include/swimsim.h, "sharded clusters"):
+
+    phase1  begin + probe + split      -> pull requests  {dst, src}            to the owner of src
+    phase2  serve                      -> payload records {dst, n x (subject,key)} to the owner of dst
+    phase3  ingest + merge
+
+Two fabrics move the records:
+  * LocalFabric  -- all shards live in this process (several handles on one device): plain copies.
+                    This is how the sharded path is checked against the unsharded one on a single GPU.
+  * DistFabric   -- one shard per process, `torch.distributed` point-to-point sends
+                    (backend "nccl" = RCCL over xGMI on GPUs, "gloo" for the CPU tests).
+PyTorch is only plumbing here (device buffers are wrapped zero-copy); all compute is in libswimsim.so.
+"""
+import ctypes as C
+from typing import List, Sequence
+
+from . import _abi
+from .sim import Sim, SwimError
+from .types import SimConfig
+
+_M64 = (1 << 64) - 1
+XREC_BYTES = 72
+RREC_BYTES = 8
+
+
+def _wrap(ptr: int, nbytes: int, device):
+    """Zero-copy uint8 torch view of library-owned memory (device or host)."""
+    import torch
+    if nbytes == 0:
+        return torch.empty(0, dtype=torch.uint8, device=device)
+    if str(device).startswith("cuda"):
+        class _Iface:
+            __cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+        return torch.as_tensor(_Iface(), device=device)
+    import numpy as np
+    buf = (C.c_uint8 * nbytes).from_address(ptr)
+    return torch.from_numpy(np.ctypeslib.as_array(buf))
+
+
+class _Shard:
+    """One handle + views of its exchange buffers."""
+
+    def __init__(self, abi, sim_config: SimConfig, index: int, n_shards: int, device):
+        self.index, self.n_shards = index, n_shards
+        self.sim = Sim.create(abi, sim_config, shard_index=index, n_shards=n_shards)
+        a, h = abi, self.sim._h
+        lo, nl, rc, xc = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self.sim._check(a.shard_info(h, C.byref(lo), C.byref(nl), C.byref(rc), C.byref(xc)))
+        self.lo, self.n_local, self.r_cap, self.x_cap = lo.value, nl.value, rc.value, xc.value
+        ptrs = [C.c_void_p() for _ in range(5)]
+        self.sim._check(a.shard_buffers(h, *[C.byref(p) for p in ptrs]))
+        G = n_shards
+        self.r_send = _wrap(ptrs[0].value, G * self.r_cap * RREC_BYTES, device).view(G, self.r_cap * RREC_BYTES)
+        self.r_recv = _wrap(ptrs[1].value, G * self.r_cap * RREC_BYTES, device).view(G, self.r_cap * RREC_BYTES)
+        self.x_send = _wrap(ptrs[2].value, G * self.x_cap * XREC_BYTES, device).view(G, self.x_cap * XREC_BYTES)
+        self.x_recv = _wrap(ptrs[3].value, G * self.x_cap * XREC_BYTES, device).view(G, self.x_cap * XREC_BYTES)
+
+    def phase1(self):
+        G = self.n_shards
+        r, x = (C.c_uint32 * G)(), (C.c_uint32 * G)()
+        self.sim._check(self.sim._abi.shard_phase1(self.sim._h, r, x))
+        return list(r), list(x)
+
+    def phase2(self, r_in: Sequence[int]):
+        G = self.n_shards
+        x = (C.c_uint32 * G)()
+        self.sim._check(self.sim._abi.shard_phase2(self.sim._h, (C.c_uint32 * G)(*r_in), x))
+        return list(x)
+
+    def phase3(self, x_in: Sequence[int]):
+        G = self.n_shards
+        self.sim._check(self.sim._abi.shard_phase3(self.sim._h, (C.c_uint32 * G)(*x_in)))
+
+
+class LocalFabric:
+    """All shards in this process: record exchange = copies between their buffers."""
+
+    def __init__(self, n_shards):
+        self.n_shards = n_shards
+        self.local = list(range(n_shards))
+        self.rank0 = True
+
+    def exchange(self, shards: List[_Shard], counts, send_attr, recv_attr, rec_bytes):
+        """counts[k][p] = records local shard k sends to shard p.  Returns recv counts per local shard."""
+        G = self.n_shards
+        recv = [[0] * G for _ in shards]
+        for k, src in enumerate(shards):
+            for p in range(G):
+                n = counts[k][p]
+                if n == 0:
+                    continue
+                assert p != src.index, "a shard never sends to itself"
+                getattr(shards[p], recv_attr)[src.index, : n * rec_bytes].copy_(getattr(src, send_attr)[p, : n * rec_bytes])
+                recv[p][src.index] = n
+        return recv
+
+    def gather(self, obj):
+        return [obj]
+
+    def reduce_min_u32(self, arrays):
+        import numpy as np
+        out = arrays[0]
+        for a in arrays[1:]:
+            out = np.minimum(out, a)
+        return out
+
+
+class DistFabric:
+    """One shard per process; torch.distributed moves the records (RCCL over xGMI on GPUs)."""
+
+    def __init__(self, device):
+        import torch.distributed as dist
+        self.dist = dist
+        self.n_shards = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.local = [self.rank]
+        self.rank0 = self.rank == 0
+        self.device = device
+
+    def exchange(self, shards, counts, send_attr, recv_attr, rec_bytes):
+        import torch
+        dist, G, me = self.dist, self.n_shards, self.rank
+        sh = shards[0]
+        cs = torch.tensor(counts[0], dtype=torch.int64, device=self.device)
+        cr = torch.empty_like(cs)
+        dist.all_to_all_single(cr, cs)
+        recv = [int(v) for v in cr.tolist()]
+        ops = []
+        for p in range(G):
+            if p == me:
+                continue
+            if counts[0][p]:
+                ops.append(dist.P2POp(dist.isend, getattr(sh, send_attr)[p, : counts[0][p] * rec_bytes], p))
+            if recv[p]:
+                ops.append(dist.P2POp(dist.irecv, getattr(sh, recv_attr)[p, : recv[p] * rec_bytes], p))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return [recv]
+
+    def gather(self, obj):
+        out = [None] * self.n_shards
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def reduce_min_u32(self, arrays):
+        import numpy as np
+        import torch
+        t = torch.from_numpy(arrays[0].astype(np.int64)).to(self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return t.cpu().numpy().astype(np.uint32)
+
+
+class ShardedSim:
+    """The whole population behind one object, whatever the number of shards / processes."""
+
+    def __init__(self, abi, sim_config: SimConfig, fabric, device="cpu"):
+        self.fabric = fabric
+        self.n_shards = fabric.n_shards
+        self.simConfig = sim_config
+        self.shards = [_Shard(abi, sim_config, k, self.n_shards, device) for k in fabric.local]
+        self.nMembers = sim_config.nMembers
+        self.n_local = self.shards[0].n_local
+        self.resolved = self.shards[0].sim.resolved
+        self._fd_synced_at = -1
+
+    def close(self):
+        for s in self.shards:
+            s.sim.close()
+
+    # -- fault injection: every shard gets the whole schedule (ground truth is replicated) ------------
+    def scheduleFault(self, tick: int, member: int, up: bool):
+        for s in self.shards:
+            s.sim.scheduleFault(tick, member, up)
+
+    def crash(self, member: int, tick: int):
+        self.scheduleFault(tick, member, False)
+
+    # -- the hot path ------------------------------------------------------------------------------------
+    def step(self, nticks: int = 1):
+        f, sh = self.fabric, self.shards
+        for _ in range(nticks):
+            p1 = [s.phase1() for s in sh]
+            r_in = f.exchange(sh, [p[0] for p in p1], "r_send", "r_recv", RREC_BYTES)
+            x_out = [s.phase2(r_in[k]) for k, s in enumerate(sh)]
+            x_in = f.exchange(sh, x_out, "x_send", "x_recv", XREC_BYTES)
+            for k, s in enumerate(sh):
+                s.phase3(x_in[k])
+
+    @property
+    def tick(self) -> int:
+        return self.shards[0].sim.tick
+
+    # -- results --------------------------------------------------------------------------------------------
+    def _sync_first_suspect(self):
+        """First-detection ticks are recorded by the prober's shard: combine (min) and set back."""
+        import numpy as np
+        if self._fd_synced_at == self.tick:
+            return
+        n = self.nMembers
+        arrays = []
+        for s in self.shards:
+            buf = np.empty(n, dtype=np.uint32)
+            s.sim._check(s.sim._abi.shard_get_first_suspect(s.sim._h, buf.ctypes.data_as(C.POINTER(C.c_uint32)), n))
+            arrays.append(buf)
+        comb = np.ascontiguousarray(self.fabric.reduce_min_u32(arrays))
+        for s in self.shards:
+            s.sim._check(s.sim._abi.shard_set_first_suspect(s.sim._h, comb.ctypes.data_as(C.POINTER(C.c_uint32)), n))
+        self._fd_synced_at = self.tick
+
+    def counters(self) -> dict:
+        local = [s.sim.counters() for s in self.shards]
+        parts = [c for group in self.fabric.gather(local) for c in group]
+        return {k: sum(p[k] for p in parts) & _M64 for k in parts[0]}
+
+    def digest(self) -> int:
+        self._sync_first_suspect()
+        local = sum(s.sim.digest() for s in self.shards) & _M64
+        return sum(self.fabric.gather(local)) & _M64
+
+    def drainEventsRaw(self):
+        local = [e for s in self.shards for e in s.sim.drainEventsRaw()]
+        return sorted(e for group in self.fabric.gather(local) for e in group)
+
+    def firstDetection(self):
+        self._sync_first_suspect()
+        return self.shards[0].sim.firstDetection()
+
+    def _owner(self, member: int):
+        for s in self.shards:
+            if s.lo <= member < s.lo + s.n_local:
+                return s
+        return None
+
+    def members(self, observer: int):
+        s = self._owner(observer)
+        local = s.sim.members(observer) if s is not None else None
+        return next(v for v in self.fabric.gather(local) if v is not None)
+
+    def readMember(self, member: int):
+        s = self._owner(member)
+        local = s.sim.readMember(member) if s is not None else None
+        return next(v for v in self.fabric.gather(local) if v is not None)
+
+    def kernelTimingEnable(self, enable=True):
+        for s in self.shards:
+            s.sim.kernelTimingEnable(enable)
+
+    def kernelTiming(self):
+        return self.shards[0].sim.kernelTiming()

@@ -20,7 +20,7 @@ class SwimError(RuntimeError):
         self.message = message
 
 
-def _to_c_config(sc: SimConfig) -> _abi.Config:
+def _to_c_config(sc: SimConfig, shard_index: int = 0, n_shards: int = 1) -> _abi.Config:
     c = _abi.Config()
     c.struct_size = C.sizeof(_abi.Config)
     c.abi_version = _abi.ABI_VERSION
@@ -39,8 +39,8 @@ def _to_c_config(sc: SimConfig) -> _abi.Config:
     c.event_mask = sc.eventMask
     c.inbox_cap = sc.inboxCap
     c.device = sc.device
-    c.shard_index = 0
-    c.n_shards = 1
+    c.shard_index = shard_index
+    c.n_shards = n_shards
     return c
 
 
@@ -58,15 +58,16 @@ class Sim:
 
     # -- lifecycle -------------------------------------------------------------
     @classmethod
-    def create(cls, abi, sim_config: SimConfig) -> "Sim":
-        err, sim = cls.configure(abi, sim_config)
+    def create(cls, abi, sim_config: SimConfig, shard_index: int = 0, n_shards: int = 1) -> "Sim":
+        err, sim = cls.configure(abi, sim_config, shard_index, n_shards)
         if err is not None:
             raise SwimError(-1, err)
         return sim
 
     @classmethod
-    def configure(cls, abi, sim_config: SimConfig) -> Tuple[Optional[str], Optional["Sim"]]:
-        c = _to_c_config(sim_config)
+    def configure(cls, abi, sim_config: SimConfig, shard_index: int = 0,
+                  n_shards: int = 1) -> Tuple[Optional[str], Optional["Sim"]]:
+        c = _to_c_config(sim_config, shard_index, n_shards)
         h = C.c_void_p()
         rc = abi.create(C.byref(c), C.byref(h))
         if rc != _abi.OK:

@@ -1,0 +1,48 @@
+"""Worker for tests/test_shard_dist.py: one process = one shard (torch.distributed, gloo on CPU).
+Every rank drives its shard through the host emulation of the product kernels; rank 0 also runs the
+oracle and compares every observable.  usage: dist_worker.py <n_members> <p> <loss_ppm> <seed> <ticks>"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    n, p, loss, seed, ticks = (int(x) for x in sys.argv[1:6])
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    rank = dist.get_rank()
+    from swim_amd import Config, Sim, SimConfig
+    from swim_amd.shard import DistFabric, ShardedSim
+    from tests import hostemu_binding, oracle_binding
+    sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, eventMask=0x1F,
+                   suspicionTicks=6, maxSubjects=min(n, 1024), timerCap=256)
+    sh = ShardedSim(hostemu_binding.load(), sc, DistFabric("cpu"))
+    ref = Sim.create(oracle_binding.load(), sc) if rank == 0 else None
+    for s in (sh, ref):
+        if s is None:
+            continue
+        s.crash(n // 2, 5)
+        s.crash(3, 7)
+        s.scheduleFault(30, n // 2, True)
+    done = 0
+    while done < ticks:
+        k = min(5, ticks - done)
+        sh.step(k)
+        done += k
+        got = (sh.counters(), sh.digest(), sh.drainEventsRaw(), sh.members(0), sh.members(n - 1), sh.readMember(n // 2))
+        if rank == 0:
+            ref.step(k)
+            want = (ref.counters(), ref.digest(), ref.drainEventsRaw(), ref.members(0), ref.members(n - 1), ref.readMember(n // 2))
+            assert got == want, "sharded run (world %d) differs from the oracle after %d ticks" % (dist.get_world_size(), done)
+    fd = sh.firstDetection()
+    if rank == 0:
+        assert fd == ref.firstDetection()
+        print("DIST-OK world=%d digest=%016x" % (dist.get_world_size(), got[1]))
+    sh.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

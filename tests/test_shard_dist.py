@@ -1,0 +1,27 @@
+"""The N > 1 path with one PROCESS per shard over torch.distributed (gloo, world_size 2 and 4, CPU):
+the same host code (swim_amd/shard.py DistFabric) that runs RCCL on GPUs.  Kernels run through the
+host emulation; rank 0 compares every observable with the oracle."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_world(world, args, port):
+    from tests import hostemu_binding, oracle_binding
+    hostemu_binding.build()
+    oracle_binding.build()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py")] + [str(a) for a in args]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "DIST-OK world=%d" % world in out.stdout, out.stdout[-2000:]
+
+
+@pytest.mark.parametrize("world,n,p,loss,seed,port", [(2, 128, 3, 0, 1, 29611), (2, 256, 3, 100000, 2, 29612), (4, 256, 2, 50000, 3, 29613)])
+def test_one_process_per_shard_gloo(world, n, p, loss, seed, port):
+    run_world(world, (n, p, loss, seed, 45), port)

@@ -1,0 +1,61 @@
+"""The sharded path (row e): the population split over several handles must be bit-identical to the
+unsharded run and to the oracle.  Runs the product's kernel sources through the host emulation, with
+all shards in one process (LocalFabric); tests/test_shard_dist.py repeats it with one process per shard
+over torch.distributed (gloo)."""
+import pytest
+
+from swim_amd import Config, SimConfig, workloads
+from swim_amd.shard import LocalFabric, ShardedSim
+from swim_amd import Sim
+
+
+@pytest.fixture(scope="module")
+def emu_abi():
+    from tests import hostemu_binding
+    return hostemu_binding.load()
+
+
+def lockstep(oracle, sharded, ticks, chunk, observers, members):
+    done = 0
+    while done < ticks:
+        n = min(chunk, ticks - done)
+        oracle.step(n); sharded.step(n)
+        done += n
+        assert oracle.counters() == sharded.counters(), "counters differ after %d ticks" % done
+        assert oracle.digest() == sharded.digest(), "digest differs after %d ticks" % done
+        assert oracle.drainEventsRaw() == sharded.drainEventsRaw(), "events differ after %d ticks" % done
+        for o in observers:
+            assert oracle.members(o) == sharded.members(o)
+        for m in members:
+            assert oracle.readMember(m) == sharded.readMember(m)
+    assert oracle.firstDetection() == sharded.firstDetection()
+
+
+@pytest.mark.parametrize("n,shards,p,loss,seed", [
+    (128, 2, 3, 0, 1), (256, 4, 3, 0, 2), (192, 3, 2, 50000, 3), (512, 8, 3, 200000, 4), (64, 2, 10, 300000, 5),
+])
+def test_sharded_matches_oracle(oracle_abi, emu_abi, n, shards, p, loss, seed):
+    sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, eventMask=0x1F,
+                   suspicionTicks=6, maxSubjects=min(n, 1024), timerCap=256)
+    a = Sim.create(oracle_abi, sc)
+    b = ShardedSim(emu_abi, sc, LocalFabric(shards))
+    for s in (a, b):
+        s.crash(n // 2, 5)
+        s.crash(3, 7)
+        s.scheduleFault(40, n // 2, True)
+    lockstep(a, b, 70, 1 if n <= 200 else 5, observers=(0, n - 1, n // 2), members=(0, n - 1, n // 2))
+    b.close()
+
+
+def test_sharded_saturated_queues(oracle_abi, emu_abi):
+    """Many crashes: full queues, many rumours in flight, cross-shard payloads dominate."""
+    n = 1024
+    crashes = workloads.hashed_crashes(n, 5, 1, 8, 3, 33)
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=5, eventMask=0x1F, suspicionTicks=7,
+                   maxSubjects=512, timerCap=512)
+    a = Sim.create(oracle_abi, sc)
+    b = ShardedSim(emu_abi, sc, LocalFabric(4))
+    for s in (a, b):
+        workloads.apply_crashes(s, crashes)
+    lockstep(a, b, 50, 5, observers=(0, 1, n - 1), members=(0, 1, n - 1))
+    b.close()
