@@ -41,8 +41,8 @@ def algorithmic_bytes(c0, c1, n_members, ticks, P, K):
 
 
 def first_detection_latency(sim, crashes, lo_tick, hi_tick):
-    fd = sim.firstDetectionArray()
-    lat = [int(fd[m]) - t + 1 for (t, m) in crashes if lo_tick <= t < hi_tick and int(fd[m]) != 0xFFFFFFFFFFFFFFFF]
+    fd = sim.firstDetection()
+    lat = [fd[m] - t + 1 for (t, m) in crashes if lo_tick <= t < hi_tick and fd[m] is not None]
     return (sum(lat) / len(lat), len(lat)) if lat else (None, 0)
 
 
@@ -85,17 +85,27 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("cpu:gloo,cuda:nccl", device_id=torch.device("cuda", local_rank))
 
     from swim_amd import Sim, _lib, workloads
     total = args.warmup + args.steps
-    n = args.members
+    n = args.members                          # per GPU: weak scaling, ONE cluster of world * n members
+    nt = n * world
+    # the same global failure rate at every size (~1 crash per tick): per-member rumour load, and so the
+    # per-GPU work, stays what it is on one GPU
     if args.regime == "saturated":
-        sc, crashes, _ = workloads.saturated(n, total, seed=1 + rank)
+        sc, crashes, _ = workloads.saturated(nt, total, seed=1)
     else:
-        sc, crashes, _ = workloads.quiescent(n, total, seed=1 + rank)
+        sc, crashes, _ = workloads.quiescent(nt, total, seed=1)
     sc.device = local_rank
-    sim = Sim.create(_lib.load(), sc)
+    exchange = "none (one shard)"
+    if world == 1:
+        sim = Sim.create(_lib.load(), sc)
+    else:
+        from swim_amd.shard import DistFabric, ShardedSim
+        fabric = DistFabric("cuda:%d" % local_rank)
+        sim = ShardedSim(_lib.load(), sc, fabric, device="cuda:%d" % local_rank)
+        exchange = "torch.distributed p2p, transport=%s%s" % (fabric.transport, (" [" + fabric.note + "]") if fabric.note else "")
     workloads.apply_crashes(sim, crashes)
 
     def barrier():
@@ -118,10 +128,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    lat_all = first_detection_latency(sim, crashes, args.warmup, total - 2)   # collective on a sharded cluster
     if rank == 0:
         P = sim.resolved.probes_per_tick
         K = sim.resolved.indirect_k
-        a_by, rates = algorithmic_bytes(c0, c1, n, args.steps, P, K)
+        a_by, rates = algorithmic_bytes(c0, c1, nt, args.steps, P, K)
         nt = max(1, kt["ticks"])
         secs = {"probe_kernel": kt["probe_ms"] / 1e3 / nt, "merge_kernel": kt["merge_ms"] / 1e3 / nt}
         per_kernel = {k: {"algorithmic_bytes_per_member_tick": a_by[k], "avg_launch_us": secs[k] * 1e6,
@@ -135,7 +146,7 @@ def main():
             tj = json.load(open(tpath))
             if tj.get("regime") == args.regime and tj.get("members") == n:
                 traffic = tj.get(dom + "_hbm_bytes_per_launch")
-        lat, nlat = first_detection_latency(sim, crashes, args.warmup, total - 2)
+        lat, nlat = lat_all
         out = {
             "metric": "member-ticks/sec at N=1M simulated members; mean first-detection latency (ticks)",
             "value": n * world * args.steps / dt,
@@ -148,7 +159,7 @@ def main():
                                    "suspicion %d ticks, retransmit %dx log2 N" % (
                                        args.regime, n, sim.resolved.suspicion_ticks, sim.resolved.retransmit_mult),
                        "members_per_gpu": n, "num_to_gossip": sim.resolved.num_to_gossip,
-                       "parallelism": "1 GPU" if world == 1 else "%d independent replica clusters (cross-shard exchange: see DESIGN.md)" % world},
+                       "parallelism": "1 GPU" if world == 1 else "ONE cluster of %d members in %d shards (contiguous id ranges, one per GPU); piggyback payloads cross shards in two rounds per tick (%s)" % (nt, world, exchange)},
             "ticks_per_s": args.steps / dt,
             "mean_first_detection_latency_ticks": lat, "crashes_measured": nlat,
             "per_member_tick": rates,

@@ -111,49 +111,96 @@ class LocalFabric:
 
 
 class DistFabric:
-    """One shard per process; torch.distributed moves the records (RCCL over xGMI on GPUs)."""
+    """One shard per process; torch.distributed moves the records.
 
-    def __init__(self, device):
+    transport "nccl": device-to-device sends (RCCL over xGMI), records staged through torch-allocated
+    tensors so that RCCL only ever sees memory from torch's allocator.  transport "host": records are
+    copied to host memory and sent with the CPU backend (gloo) -- the CPU tests, and the fallback when a
+    point-to-point self-test over RCCL fails on the machine at hand (the choice is reported, never silent).
+    """
+
+    def __init__(self, device, transport="auto"):
+        import torch
         import torch.distributed as dist
-        self.dist = dist
+        self.dist, self.torch = dist, torch
         self.n_shards = dist.get_world_size()
         self.rank = dist.get_rank()
         self.local = [self.rank]
         self.rank0 = self.rank == 0
         self.device = device
+        self.on_gpu = str(device).startswith("cuda")
+        self.note = ""
+        if not self.on_gpu:
+            transport = "host"
+        elif transport == "auto":
+            transport, self.note = self._self_test()
+        self.transport = transport
+
+    def _self_test(self):
+        """Ring send/recv of a small device tensor over the device backend; all ranks agree on the result."""
+        torch, dist = self.torch, self.dist
+        ok, why = 1, ""
+        try:
+            if self.n_shards > 1:
+                a = torch.full((256,), self.rank, dtype=torch.uint8, device=self.device)
+                b = torch.empty_like(a)
+                nxt, prv = (self.rank + 1) % self.n_shards, (self.rank - 1) % self.n_shards
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, a, nxt), dist.P2POp(dist.irecv, b, prv)]):
+                    w.wait()
+                torch.cuda.synchronize()
+                ok = int(int(b[0].item()) == prv)
+        except Exception as e:                      # noqa: BLE001 -- reported in the bench line
+            ok, why = 0, repr(e)[:200]
+        flag = torch.tensor([ok], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self._cpu_group())
+        if int(flag.item()):
+            return "nccl", ""
+        return "host", "device p2p self-test failed (%s): records staged through host memory" % (why or "peer")
+
+    def _cpu_group(self):
+        if not hasattr(self, "_cpug"):
+            self._cpug = self.dist.new_group(backend="gloo")
+        return self._cpug
 
     def exchange(self, shards, counts, send_attr, recv_attr, rec_bytes):
-        import torch
-        dist, G, me = self.dist, self.n_shards, self.rank
+        torch, dist, G, me = self.torch, self.dist, self.n_shards, self.rank
         sh = shards[0]
-        cs = torch.tensor(counts[0], dtype=torch.int64, device=self.device)
+        host = self.transport == "host"
+        cs = torch.tensor(counts[0], dtype=torch.int64, device="cpu" if host else self.device)
         cr = torch.empty_like(cs)
-        dist.all_to_all_single(cr, cs)
+        dist.all_to_all_single(cr, cs, group=self._cpu_group() if (host and self.on_gpu) else None)
         recv = [int(v) for v in cr.tolist()]
-        ops = []
+        ops, landing = [], []
         for p in range(G):
             if p == me:
                 continue
             if counts[0][p]:
-                ops.append(dist.P2POp(dist.isend, getattr(sh, send_attr)[p, : counts[0][p] * rec_bytes], p))
+                src = getattr(sh, send_attr)[p, : counts[0][p] * rec_bytes]
+                ops.append(dist.P2POp(dist.isend, src.cpu() if host else src.clone(), p,
+                                      group=self._cpu_group() if (host and self.on_gpu) else None))
             if recv[p]:
-                ops.append(dist.P2POp(dist.irecv, getattr(sh, recv_attr)[p, : recv[p] * rec_bytes], p))
+                tmp = torch.empty(recv[p] * rec_bytes, dtype=torch.uint8, device="cpu" if host else self.device)
+                landing.append((p, tmp))
+                ops.append(dist.P2POp(dist.irecv, tmp, p, group=self._cpu_group() if (host and self.on_gpu) else None))
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+        for p, tmp in landing:
+            getattr(sh, recv_attr)[p, : tmp.numel()].copy_(tmp)
+        if self.on_gpu:
+            torch.cuda.synchronize()                # the library launches on its own stream
         return [recv]
 
     def gather(self, obj):
         out = [None] * self.n_shards
-        self.dist.all_gather_object(out, obj)
+        self.dist.all_gather_object(out, obj, group=self._cpu_group() if self.on_gpu else None)
         return out
 
     def reduce_min_u32(self, arrays):
         import numpy as np
-        import torch
-        t = torch.from_numpy(arrays[0].astype(np.int64)).to(self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
-        return t.cpu().numpy().astype(np.uint32)
+        t = self.torch.from_numpy(arrays[0].astype(np.int64))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self._cpu_group() if self.on_gpu else None)
+        return t.numpy().astype(np.uint32)
 
 
 class ShardedSim:

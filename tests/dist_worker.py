@@ -18,7 +18,15 @@ def main():
     from tests import hostemu_binding, oracle_binding
     sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, eventMask=0x1F,
                    suspicionTicks=6, maxSubjects=min(n, 1024), timerCap=256)
-    sh = ShardedSim(hostemu_binding.load(), sc, DistFabric("cpu"))
+    if os.environ.get("SWIM_DIST_DEVICE", "cpu") == "cuda":
+        # all ranks share GPU 0 (RCCL refuses two ranks on one device): the real HIP library, device
+        # buffers wrapped zero-copy, records staged through host memory over gloo
+        import torch
+        from swim_amd import _lib
+        torch.cuda.set_device(0)
+        sh = ShardedSim(_lib.load(), sc, DistFabric("cuda:0", transport="host"), device="cuda:0")
+    else:
+        sh = ShardedSim(hostemu_binding.load(), sc, DistFabric("cpu"))
     ref = Sim.create(oracle_binding.load(), sc) if rank == 0 else None
     for s in (sh, ref):
         if s is None:

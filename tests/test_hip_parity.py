@@ -123,3 +123,44 @@ def test_million_members_properties(hip_abi):
                 assert {m.memberName for m in v} == dead and all(int(m.memberAlive) == 2 for m in v)
         s.close()
     assert digests[0] == digests[1]
+
+
+@pytest.mark.parametrize("n,shards,loss,seed", [(4096, 4, 0, 1), (3072, 3, 100000, 2), (65536, 8, 20000, 3)])
+def test_sharded_cluster_on_one_gpu(oracle_abi, hip_abi, n, shards, loss, seed):
+    """Row (e): the population split over several handles on this GPU (LocalFabric copies the exchange
+    records between them) must be bit-identical to the oracle, every observable."""
+    from swim_amd.shard import LocalFabric, ShardedSim
+    # every gossip event is compared on the small clusters; on the large one only probe / refute / join
+    # events (the per-handle event rings would overflow at different points, which is not protocol state)
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=seed, lossPpm=loss, eventMask=0x1F if n <= 4096 else 0,
+                   suspicionTicks=8, maxSubjects=min(n, 4096), timerCap=1024)
+    crashes = workloads.hashed_crashes(n, seed, 1, 256, 3, 23)
+    a = Sim.create(oracle_abi, sc)
+    b = ShardedSim(hip_abi, sc, LocalFabric(shards), device="cuda:0")
+    for s in (a, b):
+        workloads.apply_crashes(s, crashes)
+        s.scheduleFault(30, crashes[0][1], True)
+    done = 0
+    while done < 60:
+        a.step(10); b.step(10); done += 10
+        assert a.counters() == b.counters(), "counters differ after %d ticks" % done
+        assert a.digest() == b.digest(), "digest differs after %d ticks" % done
+        assert a.drainEventsRaw() == b.drainEventsRaw()
+        for o in (0, n - 1, crashes[0][1]):
+            assert a.members(o) == b.members(o)
+            assert a.readMember(o) == b.readMember(o)
+    assert a.firstDetection() == b.firstDetection()
+    b.close()
+
+
+def test_one_process_per_shard_on_one_gpu():
+    """Two processes, one shard each, both on GPU 0, torch.distributed (gloo, records staged through
+    host memory because RCCL refuses two ranks on one device): the DistFabric host code with the real
+    HIP library."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", SWIM_DIST_DEVICE="cuda")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29655", os.path.join(root, "tests", "dist_worker.py"), "8192", "3", "50000", "4", "40"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "DIST-OK world=2" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
