@@ -242,23 +242,29 @@ int swimsim_get_config(const swimsim_t* h, swimsim_config_t* out);
  * The population is split into n_shards contiguous id ranges.  Every shard gets the SAME
  * configuration (n_members = whole population) and the SAME fault schedule; ground truth and
  * probe outcomes need no communication, only piggyback payloads cross shards.  One tick is
- *   phase1  -> the caller delivers r_send[p][0..r_counts[p]) to shard p's r_recv[me][..]
- *   phase2  -> the caller delivers x_send[p][0..x_counts[p]) to shard p's x_recv[me][..]
+ *   phase1  -> round 1: the caller delivers send[0][p][0 .. counts[p]) to shard p's recv[0][me][..]
+ *   phase2  -> round 2: likewise for send[1] (mask payloads) and send[2] (explicit payloads)
  *   phase3
  * on every shard in lock step (swim_amd/shard.py does the exchange with torch.distributed:
- * RCCL over xGMI on GPUs).  Buffers are [n_shards][cap] records owned by the library:
- * requests are 8 bytes {dst, src}, payload records SWIMSIM_XREC_BYTES {dst, n, n x {subject,
- * incarnation<<2|state}}.  swimsim_step is refused on sharded handles; digest / counters /
- * events return this shard's part (the parts add up / concatenate); view and member reads are
- * answered by the owner only; first-detection ticks must be combined (element-wise minimum)
- * and set back before digest or first_detect are read. */
+ * RCCL over xGMI on GPUs).  Buffers are [n_shards][cap] records owned by the library, three kinds:
+ *   0  8 bytes   this tick's id dictionary (64 x {subject, incarnation<<2|state}, one per mask
+ *                position), then pull requests {dst, src} for the owner of src
+ *   1  16 bytes  {dst, -, 64-bit mask over the SENDER's dictionary}: a queue as it travels normally
+ *   2  72 bytes  {dst, n, n x {subject, incarnation<<2|state}}: the exact fallback
+ * counts[] arrays hold n_shards entries per kind (kind-major, 3 * n_shards).  swimsim_step is refused
+ * on sharded handles; digest / counters / events return this shard's part (the parts add up /
+ * concatenate); view and member reads are answered by the owner only; first-detection ticks must be
+ * combined (element-wise minimum) and set back before digest or first_detect are read. */
+#define SWIMSIM_RREC_BYTES 8u
+#define SWIMSIM_PREC_BYTES 16u
 #define SWIMSIM_XREC_BYTES 72u
-int swimsim_shard_info(const swimsim_t* h, uint32_t* lo, uint32_t* n_local, uint32_t* r_cap, uint32_t* x_cap);
-int swimsim_shard_buffers(swimsim_t* h, void** r_send, void** r_recv, void** x_send, void** x_recv,
-                          void** first_suspect);
-int swimsim_shard_phase1(swimsim_t* h, uint32_t* r_counts, uint32_t* x_counts);
-int swimsim_shard_phase2(swimsim_t* h, const uint32_t* r_counts_in, uint32_t* x_counts);
-int swimsim_shard_phase3(swimsim_t* h, const uint32_t* x_counts_in);
+int swimsim_shard_info(const swimsim_t* h, uint32_t* lo, uint32_t* n_local, uint32_t* r_cap,
+                       uint32_t* p_cap, uint32_t* x_cap);
+int swimsim_shard_buffers(swimsim_t* h, void** send /*[3]*/, void** recv /*[3]*/);
+int swimsim_shard_phase1(swimsim_t* h, uint32_t* counts /*[3*n_shards] out*/);
+int swimsim_shard_phase2(swimsim_t* h, const uint32_t* r_counts_in /*[n_shards]*/,
+                         uint32_t* counts /*[3*n_shards] out: kinds 1 and 2 now final*/);
+int swimsim_shard_phase3(swimsim_t* h, const uint32_t* p_counts_in, const uint32_t* x_counts_in);
 int swimsim_shard_get_first_suspect(swimsim_t* h, uint32_t* out, size_t n);
 int swimsim_shard_set_first_suspect(swimsim_t* h, const uint32_t* combined, size_t n);
 

@@ -92,11 +92,11 @@ _SIGS = {
 _U32P = C.POINTER(C.c_uint32)
 _VPP = C.POINTER(C.c_void_p)
 _PRODUCT_ONLY = {
-    "shard_info": (C.c_int, [_H, _U32P, _U32P, _U32P, _U32P]),
-    "shard_buffers": (C.c_int, [_H, _VPP, _VPP, _VPP, _VPP, _VPP]),
-    "shard_phase1": (C.c_int, [_H, _U32P, _U32P]),
+    "shard_info": (C.c_int, [_H, _U32P, _U32P, _U32P, _U32P, _U32P]),
+    "shard_buffers": (C.c_int, [_H, _VPP, _VPP]),
+    "shard_phase1": (C.c_int, [_H, _U32P]),
     "shard_phase2": (C.c_int, [_H, _U32P, _U32P]),
-    "shard_phase3": (C.c_int, [_H, _U32P]),
+    "shard_phase3": (C.c_int, [_H, _U32P, _U32P]),
     "shard_get_first_suspect": (C.c_int, [_H, _U32P, C.c_size_t]),
     "shard_set_first_suspect": (C.c_int, [_H, _U32P, C.c_size_t]),
     "kernel_timing_enable": (C.c_int, [_H, C.c_int]),

@@ -103,12 +103,16 @@ struct DevState {
   uint2* ord;              // [nblocks][ord_cap] deliveries {dst, src} (global ids) the probe could not do locally
   uint32_t* ord_cnt;       // [nblocks]
   uint32_t ord_cap;
-  uint2* r_send; uint2* r_recv;         // [n_shards][r_cap] pull requests {dst, src}, routed to the owner of src
-  uint32_t* x_send; uint32_t* x_recv;   // [n_shards][x_cap][XREC_WORDS] payload records, routed to the owner of dst
-  uint32_t r_cap, x_cap;
-  uint32_t* send_cnt;      // [2][n_shards] records appended per peer: requests, payloads
-  uint4* fl;               // [n_shards * x_cap][4] "foreign lines": received entries the masks cannot carry
+  uint2* r_send; uint2* r_recv;         // [n_shards][DICT_RECS + r_cap]: this tick's id dictionary (position ->
+                                        //   {subject, key}), then pull requests {dst, src} for the owner of src
+  uint4* p_send; uint4* p_recv;         // [n_shards][p_cap] mask payloads {dst, -, mask over MY dictionary}
+  uint32_t* x_send; uint32_t* x_recv;   // [n_shards][x_cap][XREC_WORDS] explicit payload records (exact fallback)
+  uint32_t r_cap, p_cap, x_cap;
+  uint32_t* send_cnt;      // [3][n_shards] records appended per peer: requests, mask payloads, explicit payloads
+  uint2* xl;               // [n_shards][DICT_RECS] a peer's dictionary in MY numbering {slot | rid<<16, key}
+  uint4* fl;               // [n_shards * (x_cap + p_cap)][4] "foreign lines": received entries my masks cannot carry
 };
+constexpr uint32_t DICT_RECS = 64;      // one entry per ring position
 
 // payload record on the wire: {dst (global id), n, n x {subject, key}} -- ids, not slots: every shard
 // has its own slot and rumour-id numbering

@@ -638,28 +638,36 @@ __device__ inline void write_xrec(const DevState& s, uint32_t* rec, uint32_t dst
 }
 
 // One delivery order {dst, src} whose source is LOCAL: dst local -> done here; else a payload record for
-// the owner of dst.  count = this shard accounts for the payload (it was not counted by the prober).
-__device__ inline void route_order(const DevState& s, uint32_t t, AppendCtx* a, BlockCounters* sh, bool have,
-                                   uint32_t dst, uint32_t src, bool count) {
+// the owner of dst: the queue's mask (over this shard's dictionary of the tick) when it says everything,
+// the explicit ids otherwise.  count = this shard accounts for the payload (the prober could not).
+__device__ inline void route_order(const DevState& s, uint32_t t, AppendCtx* ap, AppendCtx* ax, BlockCounters* sh,
+                                   bool have, uint32_t dst, uint32_t src, bool count) {
   const uint32_t Hprev = s.g[G_PREV], H = s.g[G_HEAD];
   const bool use_mask = H - Hprev <= MASK_SLACK;
-  int peer = -1;
+  int ppeer = -1, xpeer = -1;
   uint32_t msrc = 0, src_li = 0;
   if (have) {
     src_li = src - s.lo;
     msrc = s.minfo[src];
     const uint32_t cnt = mi_pbn(msrc);
-    if (!cnt) have = false;                         // empty payload: nothing travels
-    else {
+    if (cnt) {
       if (count) { ctr_add(sh, C_PAYLOADS, 1u); ctr_add(sh, C_RUMORS_SEEN, cnt); }
       if (is_local(s, dst))
         deliver_local(s, t, use_mask, stale_positions(Hprev, H), dst - s.lo, src_li, msrc, use_mask ? s.pk[src_li].x : 0ull);
-      else peer = (int)owner_of(s, dst);
+      else if (use_mask && !(msrc & MI_OOW)) ppeer = (int)owner_of(s, dst);
+      else xpeer = (int)owner_of(s, dst);
     }
   }
-  const uint32_t pos = block_append(a, s.send_cnt + s.n_shards, s.n_shards, peer);
-  if (peer >= 0) {
-    if (pos < s.x_cap) write_xrec(s, s.x_send + ((size_t)peer * s.x_cap + pos) * XREC_WORDS, dst, src_li, msrc);
+  const uint32_t ppos = block_append(ap, s.send_cnt + s.n_shards, s.n_shards, ppeer);
+  if (ppeer >= 0) {
+    if (ppos < s.p_cap) {
+      const unsigned long long m = s.pk[src_li].x;
+      s.p_send[(size_t)ppeer * s.p_cap + ppos] = make_uint4(dst, 0u, (uint32_t)m, (uint32_t)(m >> 32));
+    } else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_OVF);
+  }
+  const uint32_t xpos = block_append(ax, s.send_cnt + 2 * s.n_shards, s.n_shards, xpeer);
+  if (xpeer >= 0) {
+    if (xpos < s.x_cap) write_xrec(s, s.x_send + ((size_t)xpeer * s.x_cap + xpos) * XREC_WORDS, dst, src_li, msrc);
     else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_OVF);
   }
 }
@@ -668,9 +676,10 @@ __device__ inline void route_order(const DevState& s, uint32_t t, AppendCtx* a, 
 // payload record to the owner of dst.  One block per probe block (its own order region).
 __global__ __launch_bounds__(BLOCK) void split_kernel(DevState s, uint32_t t) {
   __shared__ BlockCounters sh;
-  __shared__ AppendCtx ar, ax;
+  __shared__ AppendCtx ar, ap, ax;
   ctr_init(&sh);
   const uint32_t n = s.ord_cnt[blockIdx.x];
+  const size_t rstride = DICT_RECS + s.r_cap;
   for (uint32_t base = 0; base < n; base += BLOCK) {
     const uint32_t k = base + threadIdx.x;
     const bool have = k < n;
@@ -680,11 +689,11 @@ __global__ __launch_bounds__(BLOCK) void split_kernel(DevState s, uint32_t t) {
     const int rpeer = (have && !src_local) ? (int)owner_of(s, o.y) : -1;
     const uint32_t rpos = block_append(&ar, s.send_cnt, s.n_shards, rpeer);
     if (rpeer >= 0) {
-      if (rpos < s.r_cap) s.r_send[(size_t)rpeer * s.r_cap + rpos] = o;
+      if (rpos < s.r_cap) s.r_send[(size_t)rpeer * rstride + DICT_RECS + rpos] = o;
       else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_OVF);
     }
     // payloads of local sources (already counted by the prober)
-    route_order(s, t, &ax, &sh, src_local, o.x, o.y, false);
+    route_order(s, t, &ap, &ax, &sh, src_local, o.x, o.y, false);
   }
   ctr_flush(s, &sh, blockIdx.x);
 }
@@ -693,35 +702,92 @@ __global__ __launch_bounds__(BLOCK) void split_kernel(DevState s, uint32_t t) {
 // so that every block owns a counter row.
 __global__ __launch_bounds__(BLOCK) void serve_kernel(DevState s, uint32_t t, const uint32_t* r_counts) {
   __shared__ BlockCounters sh;
-  __shared__ AppendCtx ax;
+  __shared__ AppendCtx ap, ax;
   ctr_init(&sh);
+  const size_t rstride = DICT_RECS + s.r_cap;
   for (uint32_t peer = 0; peer < s.n_shards; ++peer) {
-    const uint32_t n = min(r_counts[peer], s.r_cap);
+    const uint32_t got = r_counts[peer];            // dictionary + requests
+    const uint32_t n = got > DICT_RECS ? min(got - DICT_RECS, s.r_cap) : 0u;
     for (uint32_t base = blockIdx.x * BLOCK; base < n; base += gridDim.x * BLOCK) {
       const uint32_t k = base + threadIdx.x;
       const bool have = k < n;
-      const uint2 o = have ? s.r_recv[(size_t)peer * s.r_cap + k] : make_uint2(0u, 0u);
-      route_order(s, t, &ax, &sh, have, o.x, o.y, true);
+      const uint2 o = have ? s.r_recv[(size_t)peer * rstride + DICT_RECS + k] : make_uint2(0u, 0u);
+      route_order(s, t, &ap, &ax, &sh, have, o.x, o.y, true);
     }
   }
   ctr_flush(s, &sh, blockIdx.x);
 }
 
-// after round 2: payload records for my members: ids -> my slots and rumour ids; what my masks can carry
-// is pushed as a mask, the rest becomes a "foreign line" read through an explicit record.
-__global__ __launch_bounds__(BLOCK) void ingest_kernel(DevState s, uint32_t t, const uint32_t* x_counts) {
+// after round 1: every peer's dictionary of the tick in MY numbering (slots and rumour ids are per shard).
+// Rumours this shard never heard of get their slot and id here; such ids are younger than this tick's
+// head, so ingest hands them over through foreign lines until the next tick.
+__global__ void xlat_kernel(DevState s, const uint32_t* r_counts) {
+  const uint32_t peer = blockIdx.x, p = threadIdx.x;
+  if (p >= DICT_RECS) return;
+  uint2 out = make_uint2(NONE32, 0u);
+  if (peer != s.shard && r_counts[peer] >= DICT_RECS) {
+    const uint2 e = s.r_recv[(size_t)peer * (DICT_RECS + s.r_cap) + p];       // {subject, key}
+    if (e.x != NONE32) {
+      const uint32_t slot = get_slot(s, e.x);
+      out = make_uint2(pe_lo(slot, find_rid(s, slot, e.y)), e.y);
+    }
+  }
+  s.xl[(size_t)peer * DICT_RECS + p] = out;
+}
+
+// hand a received payload to local member dst_li: what my masks can carry is pushed as a mask, the rest
+// becomes a "foreign line" read through an explicit record
+__device__ inline void ingest_finish(const DevState& s, uint32_t t, unsigned long long stale, uint32_t dst_li,
+                                     unsigned long long bits, uint32_t* fl, uint32_t nf, uint32_t fl_index) {
+  if (bits) {
+    const unsigned long long m = bits & ~(s.pk[dst_li].y & ~stale);
+    if (m) atomicOr(&s.inmask[dst_li], m);
+  }
+  if (nf) {
+    for (uint32_t e = nf; e < (uint32_t)PB_SLOTS; ++e) { fl[2 * e] = 0; fl[2 * e + 1] = 0; }
+    push(s, t, dst_li, SRC_FOREIGN | fl_index);
+  }
+}
+
+// after round 2: payload records for my members, as masks over the sender's dictionary or as explicit ids
+__global__ __launch_bounds__(BLOCK) void ingest_kernel(DevState s, uint32_t t, const uint32_t* p_counts, const uint32_t* x_counts) {
+  __shared__ uint2 xls[DICT_RECS];
   const uint32_t Hprev = s.g[G_PREV], H = s.g[G_HEAD];
   const bool use_mask = H - Hprev <= MASK_SLACK;
   const unsigned long long stale = stale_positions(Hprev, H);
+  const size_t fl_x = (size_t)s.n_shards * s.x_cap;            // foreign lines of mask records come after these
   for (uint32_t peer = 0; peer < s.n_shards; ++peer) {
-    const uint32_t n = min(x_counts[peer], s.x_cap);
-    for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < n; k += gridDim.x * BLOCK) {
-      const size_t ridx_ = (size_t)peer * s.x_cap + k;
-      const uint32_t* rec = s.x_recv + ridx_ * XREC_WORDS;
-      const uint32_t dst_li = rec[0] - s.lo, ne = min(rec[1], (uint32_t)PB_SLOTS);
+    // ---- mask records
+    const uint32_t np = min(p_counts[peer], s.p_cap);
+    __syncthreads();
+    if (threadIdx.x < DICT_RECS) xls[threadIdx.x] = s.xl[(size_t)peer * DICT_RECS + threadIdx.x];
+    __syncthreads();
+    for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < np; k += gridDim.x * BLOCK) {
+      const size_t ri = (size_t)peer * s.p_cap + k;
+      const uint4 rec = s.p_recv[ri];
+      unsigned long long m = ((unsigned long long)rec.w << 32) | rec.z, bits = 0;
+      uint32_t* fl = reinterpret_cast<uint32_t*>(s.fl + (fl_x + ri) * 4);
+      uint32_t nf = 0;
+      while (m) {
+        const uint32_t p = (uint32_t)__ffsll((unsigned long long)m) - 1u;
+        m &= m - 1ull;
+        const uint2 e = xls[p];                                // {slot | rid<<16, key} in my numbering
+        if (e.x == NONE32) continue;                           // cannot happen: the sender set the bit from an entry
+        const uint32_t rid = pe_rid(e.x);
+        if (use_mask && rid_in_ring(rid, H)) bits |= rid_bit(rid);
+        else if (nf < (uint32_t)PB_SLOTS) { fl[2 * nf] = e.x; fl[2 * nf + 1] = pe_hi(e.y, 1u); nf++; }
+      }
+      ingest_finish(s, t, stale, rec.x - s.lo, bits, fl, nf, (uint32_t)(fl_x + ri));
+    }
+    // ---- explicit records
+    const uint32_t nx = min(x_counts[peer], s.x_cap);
+    for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < nx; k += gridDim.x * BLOCK) {
+      const size_t ri = (size_t)peer * s.x_cap + k;
+      const uint32_t* rec = s.x_recv + ri * XREC_WORDS;
+      const uint32_t ne = min(rec[1], (uint32_t)PB_SLOTS);
       unsigned long long bits = 0;
       uint32_t nf = 0;
-      uint32_t* fl = reinterpret_cast<uint32_t*>(s.fl + ridx_ * 4);
+      uint32_t* fl = reinterpret_cast<uint32_t*>(s.fl + ri * 4);
       for (uint32_t e = 0; e < ne; ++e) {
         const uint32_t subject = rec[2 + 2 * e], key = rec[3 + 2 * e];
         const uint32_t slot = get_slot(s, subject);
@@ -729,14 +795,7 @@ __global__ __launch_bounds__(BLOCK) void ingest_kernel(DevState s, uint32_t t, c
         if (use_mask && rid_in_ring(rid, H)) bits |= rid_bit(rid);     // an id of an earlier tick
         else { fl[2 * nf] = pe_lo(slot, rid); fl[2 * nf + 1] = pe_hi(key, 1u); nf++; }
       }
-      if (bits) {
-        const unsigned long long m = bits & ~(s.pk[dst_li].y & ~stale);
-        if (m) atomicOr(&s.inmask[dst_li], m);
-      }
-      if (nf) {
-        for (uint32_t e = nf; e < (uint32_t)PB_SLOTS; ++e) { fl[2 * e] = 0; fl[2 * e + 1] = 0; }
-        push(s, t, dst_li, SRC_FOREIGN | (uint32_t)ridx_);
-      }
+      ingest_finish(s, t, stale, rec[0] - s.lo, bits, fl, nf, (uint32_t)ri);
     }
   }
 }
@@ -814,7 +873,18 @@ __global__ void begin_kernel(DevState s, uint32_t t, const FaultRec* faults, uin
   if (evd) s.blk[(size_t)s.nblocks * C_COUNT + C_EVDIGEST] += evd;
   if (dropped) s.blk[(size_t)s.nblocks * C_COUNT + C_EVENTS_DROPPED] += dropped;
   s.g[G_PREV] = s.g[G_HEAD];
-  s.g[G_HEAD] = s.g[G_NRUM];
+  const uint32_t H = s.g[G_NRUM];
+  s.g[G_HEAD] = H;
+  if (s.n_shards > 1) {
+    // this tick's dictionary for the peers: ring position -> {subject, key} of the id that owns it
+    const size_t rstride = DICT_RECS + s.r_cap;
+    for (uint32_t p = 0; p < DICT_RECS; ++p) {
+      const uint32_t rid = rid_at(p, H);
+      uint2 e = make_uint2(NONE32, 0u);
+      if (rid < H) { const uint2 r = s.rum[rid & RID_MASK]; e = make_uint2(s.subject_of[r.x], r.y); }   // else: no such id yet
+      for (uint32_t g = 0; g < s.n_shards; ++g) if (g != s.shard) s.r_send[(size_t)g * rstride + p] = e;
+    }
+  }
 }
 
 // full-state digest: Sum_i mix64(member_hash(i) + mix64(TAG_MEMBER + i)) + first-detection terms

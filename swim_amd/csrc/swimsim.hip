@@ -242,7 +242,7 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   d.nblocks = (N + BLOCK - 1) / BLOCK;
   d.inbox_cap = c.inbox_cap;
   d.ovf_cap = std::max<uint32_t>(1u << 16, N / 8);
-  d.ord_cap = 0; d.r_cap = d.x_cap = 0;
+  d.ord_cap = 0; d.r_cap = d.p_cap = d.x_cap = 0;
   CK(dev_alloc(h, &d.minfo, NT, 0));
   CK(dev_alloc(h, &d.probe_out, N, 0));
   CK(dev_alloc(h, &d.ackfrom, (size_t)N * (d.P ? d.P : 1), 0));
@@ -273,16 +273,20 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     const double lossf = 1.0 + 8.0 * c.loss_ppm / 1e6 * std::max(1u, d.K);
     d.ord_cap = (uint32_t)std::min<double>(BLOCK * 64.0, BLOCK * (2.0 * std::max(1u, d.P) * lossf + 4.0));
     d.r_cap = (uint32_t)(per_peer * 1.5 * lossf) + 4096;
-    d.x_cap = (uint32_t)(per_peer * 3.0 * lossf) + 4096;
+    d.p_cap = (uint32_t)(per_peer * 3.0 * lossf) + 4096;
+    d.x_cap = d.p_cap;                           // a tick after a burst of rumour ids sends everything explicitly
     CK(dev_alloc(h, &d.ord, (size_t)d.nblocks * d.ord_cap, 0));
     CK(dev_alloc(h, &d.ord_cnt, (size_t)d.nblocks, 0));
-    CK(dev_alloc(h, &d.r_send, (size_t)d.n_shards * d.r_cap, 0));
-    CK(dev_alloc(h, &d.r_recv, (size_t)d.n_shards * d.r_cap, 0));
+    CK(dev_alloc(h, &d.r_send, (size_t)d.n_shards * (DICT_RECS + d.r_cap), 0));
+    CK(dev_alloc(h, &d.r_recv, (size_t)d.n_shards * (DICT_RECS + d.r_cap), 0));
+    CK(dev_alloc(h, &d.p_send, (size_t)d.n_shards * d.p_cap, 0));
+    CK(dev_alloc(h, &d.p_recv, (size_t)d.n_shards * d.p_cap, 0));
     CK(dev_alloc(h, &d.x_send, (size_t)d.n_shards * d.x_cap * XREC_WORDS, 0));
     CK(dev_alloc(h, &d.x_recv, (size_t)d.n_shards * d.x_cap * XREC_WORDS, 0));
-    CK(dev_alloc(h, &d.send_cnt, (size_t)2 * d.n_shards, 0));
-    CK(dev_alloc(h, &d.fl, (size_t)d.n_shards * d.x_cap * 4, 0));
-    CK(dev_alloc(h, &h->d_counts, (size_t)2 * d.n_shards, 0));
+    CK(dev_alloc(h, &d.send_cnt, (size_t)3 * d.n_shards, 0));
+    CK(dev_alloc(h, &d.xl, (size_t)d.n_shards * DICT_RECS, 0xFF));
+    CK(dev_alloc(h, &d.fl, (size_t)d.n_shards * ((size_t)d.x_cap + d.p_cap) * 4, 0));
+    CK(dev_alloc(h, &h->d_counts, (size_t)3 * d.n_shards, 0));
   }
   hipLaunchKernelGGL(init_members_kernel, dim3((std::max(N, NT) + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, d.hot, d.minfo, N, NT);
   HK(hipGetLastError());
@@ -528,22 +532,20 @@ extern "C" int swimsim_debug_globals(swimsim_t* h, uint32_t* out) {
 
 /* ---- sharded stepping: one tick = phase1 -> [exchange requests] -> phase2 -> [exchange payloads] -> phase3 ---- */
 
-int swimsim_shard_info(const swimsim_t* h, uint32_t* lo, uint32_t* n_local, uint32_t* r_cap, uint32_t* x_cap) {
+int swimsim_shard_info(const swimsim_t* h, uint32_t* lo, uint32_t* n_local, uint32_t* r_cap, uint32_t* p_cap, uint32_t* x_cap) {
   if (!h) return SWIMSIM_ERR_INVALID;
   if (lo) *lo = h->d.lo;
   if (n_local) *n_local = h->d.N;
-  if (r_cap) *r_cap = h->d.r_cap;
+  if (r_cap) *r_cap = DICT_RECS + h->d.r_cap;      // a segment starts with the tick's dictionary
+  if (p_cap) *p_cap = h->d.p_cap;
   if (x_cap) *x_cap = h->d.x_cap;
   return SWIMSIM_OK;
 }
 
-int swimsim_shard_buffers(swimsim_t* h, void** r_send, void** r_recv, void** x_send, void** x_recv, void** first_suspect) {
-  if (!h) return SWIMSIM_ERR_INVALID;
-  if (r_send) *r_send = h->d.r_send;
-  if (r_recv) *r_recv = h->d.r_recv;
-  if (x_send) *x_send = h->d.x_send;
-  if (x_recv) *x_recv = h->d.x_recv;
-  if (first_suspect) *first_suspect = h->d.first_suspect;
+int swimsim_shard_buffers(swimsim_t* h, void** send /*[3]*/, void** recv /*[3]*/) {
+  if (!h || !send || !recv) return SWIMSIM_ERR_INVALID;
+  send[0] = h->d.r_send; send[1] = h->d.p_send; send[2] = h->d.x_send;
+  recv[0] = h->d.r_recv; recv[1] = h->d.p_recv; recv[2] = h->d.x_recv;
   return SWIMSIM_OK;
 }
 
@@ -555,28 +557,30 @@ static int shard_check(swimsim* h, int phase) {
   return SWIMSIM_OK;
 }
 
-static int read_send_counts(swimsim* h, uint32_t* r_counts, uint32_t* x_counts) {
+// counts[k * n_shards + g], k = 0 requests (dictionary included), 1 mask payloads, 2 explicit payloads
+static int read_send_counts(swimsim* h, uint32_t* counts) {
   const uint32_t G = h->d.n_shards;
-  std::vector<uint32_t> c(2 * G);
+  std::vector<uint32_t> c(3 * G);
   HIPCHK(h, hipMemcpy(c.data(), h->d.send_cnt, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
   for (uint32_t g = 0; g < G; ++g) {
-    if (r_counts) r_counts[g] = std::min(c[g], h->d.r_cap);
-    if (x_counts) x_counts[g] = std::min(c[G + g], h->d.x_cap);
+    counts[g] = g == h->d.shard ? 0u : DICT_RECS + std::min(c[g], h->d.r_cap);
+    counts[G + g] = std::min(c[G + g], h->d.p_cap);
+    counts[2 * G + g] = std::min(c[2 * G + g], h->d.x_cap);
   }
   return SWIMSIM_OK;
 }
 
-int swimsim_shard_phase1(swimsim_t* h, uint32_t* r_counts, uint32_t* x_counts) {
+int swimsim_shard_phase1(swimsim_t* h, uint32_t* counts) {
   int rc = shard_check(h, 0);
   if (rc) return rc;
-  if (!r_counts || !x_counts) return SWIMSIM_ERR_INVALID;
+  if (!counts) return SWIMSIM_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
   size_t fend = 0;
   rc = upload_faults(h, 1, &fend);
   if (rc) return rc;
   if (h->timing && !h->tick_ev[0]) for (int k = 0; k < 3; ++k) HIPCHK(h, hipEventCreate(&h->tick_ev[k]));
   const uint32_t t = (uint32_t)h->tick;
-  HIPCHK(h, hipMemsetAsync(h->d.send_cnt, 0, (size_t)2 * h->d.n_shards * sizeof(uint32_t), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d.send_cnt, 0, (size_t)3 * h->d.n_shards * sizeof(uint32_t), h->stream));
   hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(64), 0, h->stream, h->d, t, h->d_faults, (uint32_t)fend);
   h->faults.erase(h->faults.begin(), h->faults.begin() + (long)fend);
   const uint32_t tk = tick_key(h->cfg.seed, t);
@@ -590,7 +594,7 @@ int swimsim_shard_phase1(swimsim_t* h, uint32_t* r_counts, uint32_t* x_counts) {
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (h->timing) { float a = 0; HIPCHK(h, hipEventElapsedTime(&a, h->tick_ev[0], h->tick_ev[1])); h->probe_ms += a; }
-  rc = read_send_counts(h, r_counts, x_counts);
+  rc = read_send_counts(h, counts);
   if (rc) return rc;
   rc = check_device_errors(h);
   if (rc) return rc;
@@ -598,16 +602,17 @@ int swimsim_shard_phase1(swimsim_t* h, uint32_t* r_counts, uint32_t* x_counts) {
   return SWIMSIM_OK;
 }
 
-int swimsim_shard_phase2(swimsim_t* h, const uint32_t* r_counts_in, uint32_t* x_counts) {
+int swimsim_shard_phase2(swimsim_t* h, const uint32_t* r_counts_in, uint32_t* counts) {
   int rc = shard_check(h, 1);
   if (rc) return rc;
-  if (!r_counts_in || !x_counts) return SWIMSIM_ERR_INVALID;
+  if (!r_counts_in || !counts) return SWIMSIM_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemcpy(h->d_counts, r_counts_in, h->d.n_shards * sizeof(uint32_t), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(xlat_kernel, dim3(h->d.n_shards), dim3(DICT_RECS), 0, h->stream, h->d, h->d_counts);
   hipLaunchKernelGGL(serve_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, (uint32_t)h->tick, h->d_counts);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  rc = read_send_counts(h, nullptr, x_counts);
+  rc = read_send_counts(h, counts);
   if (rc) return rc;
   rc = check_device_errors(h);
   if (rc) return rc;
@@ -615,14 +620,15 @@ int swimsim_shard_phase2(swimsim_t* h, const uint32_t* r_counts_in, uint32_t* x_
   return SWIMSIM_OK;
 }
 
-int swimsim_shard_phase3(swimsim_t* h, const uint32_t* x_counts_in) {
+int swimsim_shard_phase3(swimsim_t* h, const uint32_t* p_counts_in, const uint32_t* x_counts_in) {
   int rc = shard_check(h, 2);
   if (rc) return rc;
-  if (!x_counts_in) return SWIMSIM_ERR_INVALID;
+  if (!p_counts_in || !x_counts_in) return SWIMSIM_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
   const uint32_t G = h->d.n_shards, t = (uint32_t)h->tick;
-  HIPCHK(h, hipMemcpy(h->d_counts + G, x_counts_in, G * sizeof(uint32_t), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(ingest_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, h->d_counts + G);
+  HIPCHK(h, hipMemcpy(h->d_counts + G, p_counts_in, G * sizeof(uint32_t), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_counts + 2 * G, x_counts_in, G * sizeof(uint32_t), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(ingest_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, h->d_counts + G, h->d_counts + 2 * G);
   if (h->timing) (void)hipEventRecord(h->tick_ev[1], h->stream);
   hipLaunchKernelGGL(merge_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
   if (h->timing) (void)hipEventRecord(h->tick_ev[2], h->stream);

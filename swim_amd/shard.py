@@ -5,8 +5,10 @@ fault schedule.  Probe outcomes need no communication (ground truth and the loss
 known everywhere); only piggyback payloads cross shards, in two rounds per tick
 (include/swimsim.h, "sharded clusters"):
 
-    phase1  begin + probe + split      -> pull requests  {dst, src}            to the owner of src
-    phase2  serve                      -> payload records {dst, n x (subject,key)} to the owner of dst
+    phase1  begin + probe + split   -> round 1: the tick's id dictionary + pull requests {dst, src}
+                                       (to the owner of src)
+    phase2  xlat + serve            -> round 2: payloads to the owner of dst, as 16-byte masks over the
+                                       sender's dictionary (normal case) or 72-byte explicit id lists
     phase3  ingest + merge
 
 Two fabrics move the records:
@@ -24,8 +26,7 @@ from .sim import Sim, SwimError
 from .types import SimConfig
 
 _M64 = (1 << 64) - 1
-XREC_BYTES = 72
-RREC_BYTES = 8
+REC_BYTES = (8, 16, 72)          # record kinds: requests (+dictionary), mask payloads, explicit payloads
 
 
 def _wrap(ptr: int, nbytes: int, device):
@@ -43,38 +44,36 @@ def _wrap(ptr: int, nbytes: int, device):
 
 
 class _Shard:
-    """One handle + views of its exchange buffers."""
+    """One handle + views of its exchange buffers (send[kind][peer, bytes], recv[kind][peer, bytes])."""
 
     def __init__(self, abi, sim_config: SimConfig, index: int, n_shards: int, device):
         self.index, self.n_shards = index, n_shards
         self.sim = Sim.create(abi, sim_config, shard_index=index, n_shards=n_shards)
-        a, h = abi, self.sim._h
-        lo, nl, rc, xc = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
-        self.sim._check(a.shard_info(h, C.byref(lo), C.byref(nl), C.byref(rc), C.byref(xc)))
-        self.lo, self.n_local, self.r_cap, self.x_cap = lo.value, nl.value, rc.value, xc.value
-        ptrs = [C.c_void_p() for _ in range(5)]
-        self.sim._check(a.shard_buffers(h, *[C.byref(p) for p in ptrs]))
-        G = n_shards
-        self.r_send = _wrap(ptrs[0].value, G * self.r_cap * RREC_BYTES, device).view(G, self.r_cap * RREC_BYTES)
-        self.r_recv = _wrap(ptrs[1].value, G * self.r_cap * RREC_BYTES, device).view(G, self.r_cap * RREC_BYTES)
-        self.x_send = _wrap(ptrs[2].value, G * self.x_cap * XREC_BYTES, device).view(G, self.x_cap * XREC_BYTES)
-        self.x_recv = _wrap(ptrs[3].value, G * self.x_cap * XREC_BYTES, device).view(G, self.x_cap * XREC_BYTES)
+        a, h, G = abi, self.sim._h, n_shards
+        vals = [C.c_uint32() for _ in range(5)]
+        self.sim._check(a.shard_info(h, *[C.byref(v) for v in vals]))
+        self.lo, self.n_local = vals[0].value, vals[1].value
+        caps = [v.value for v in vals[2:]]
+        sp, rp = (C.c_void_p * 3)(), (C.c_void_p * 3)()
+        self.sim._check(a.shard_buffers(h, sp, rp))
+        self.send = [_wrap(sp[k], G * caps[k] * REC_BYTES[k], device).view(G, caps[k] * REC_BYTES[k]) for k in range(3)]
+        self.recv = [_wrap(rp[k], G * caps[k] * REC_BYTES[k], device).view(G, caps[k] * REC_BYTES[k]) for k in range(3)]
 
     def phase1(self):
         G = self.n_shards
-        r, x = (C.c_uint32 * G)(), (C.c_uint32 * G)()
-        self.sim._check(self.sim._abi.shard_phase1(self.sim._h, r, x))
-        return list(r), list(x)
+        c = (C.c_uint32 * (3 * G))()
+        self.sim._check(self.sim._abi.shard_phase1(self.sim._h, c))
+        return [list(c[k * G:(k + 1) * G]) for k in range(3)]
 
     def phase2(self, r_in: Sequence[int]):
         G = self.n_shards
-        x = (C.c_uint32 * G)()
-        self.sim._check(self.sim._abi.shard_phase2(self.sim._h, (C.c_uint32 * G)(*r_in), x))
-        return list(x)
+        c = (C.c_uint32 * (3 * G))()
+        self.sim._check(self.sim._abi.shard_phase2(self.sim._h, (C.c_uint32 * G)(*r_in), c))
+        return [list(c[k * G:(k + 1) * G]) for k in range(3)]
 
-    def phase3(self, x_in: Sequence[int]):
+    def phase3(self, p_in: Sequence[int], x_in: Sequence[int]):
         G = self.n_shards
-        self.sim._check(self.sim._abi.shard_phase3(self.sim._h, (C.c_uint32 * G)(*x_in)))
+        self.sim._check(self.sim._abi.shard_phase3(self.sim._h, (C.c_uint32 * G)(*p_in), (C.c_uint32 * G)(*x_in)))
 
 
 class LocalFabric:
@@ -85,18 +84,21 @@ class LocalFabric:
         self.local = list(range(n_shards))
         self.rank0 = True
 
-    def exchange(self, shards: List[_Shard], counts, send_attr, recv_attr, rec_bytes):
-        """counts[k][p] = records local shard k sends to shard p.  Returns recv counts per local shard."""
+    def exchange(self, shards: List[_Shard], kinds, counts):
+        """counts[s][j][p] = records of kind kinds[j] local shard s sends to shard p.
+        Returns recv[s][j][p] = records shard s received from p."""
         G = self.n_shards
-        recv = [[0] * G for _ in shards]
-        for k, src in enumerate(shards):
-            for p in range(G):
-                n = counts[k][p]
-                if n == 0:
-                    continue
-                assert p != src.index, "a shard never sends to itself"
-                getattr(shards[p], recv_attr)[src.index, : n * rec_bytes].copy_(getattr(src, send_attr)[p, : n * rec_bytes])
-                recv[p][src.index] = n
+        recv = [[[0] * G for _ in kinds] for _ in shards]
+        for si, src in enumerate(shards):
+            for j, kind in enumerate(kinds):
+                for p in range(G):
+                    n = counts[si][j][p]
+                    if n == 0:
+                        continue
+                    assert p != src.index, "a shard never sends to itself"
+                    nb = n * REC_BYTES[kind]
+                    shards[p].recv[kind][src.index, :nb].copy_(src.send[kind][p, :nb])
+                    recv[p][j][src.index] = n
         return recv
 
     def gather(self, obj):
@@ -162,31 +164,36 @@ class DistFabric:
             self._cpug = self.dist.new_group(backend="gloo")
         return self._cpug
 
-    def exchange(self, shards, counts, send_attr, recv_attr, rec_bytes):
+    def exchange(self, shards, kinds, counts):
+        """One round: the counts of every kind in ONE all_to_all, then all records in ONE batch of p2p ops."""
         torch, dist, G, me = self.torch, self.dist, self.n_shards, self.rank
-        sh = shards[0]
+        sh, nk = shards[0], len(kinds)
         host = self.transport == "host"
-        cs = torch.tensor(counts[0], dtype=torch.int64, device="cpu" if host else self.device)
+        grp = self._cpu_group() if (host and self.on_gpu) else None
+        flat = [counts[0][j][p] for p in range(G) for j in range(nk)]          # peer-major for all_to_all
+        cs = torch.tensor(flat, dtype=torch.int64, device="cpu" if host else self.device)
         cr = torch.empty_like(cs)
-        dist.all_to_all_single(cr, cs, group=self._cpu_group() if (host and self.on_gpu) else None)
-        recv = [int(v) for v in cr.tolist()]
+        dist.all_to_all_single(cr, cs, group=grp)
+        got = [int(v) for v in cr.tolist()]
+        recv = [[got[p * nk + j] for p in range(G)] for j in range(nk)]
         ops, landing = [], []
         for p in range(G):
             if p == me:
                 continue
-            if counts[0][p]:
-                src = getattr(sh, send_attr)[p, : counts[0][p] * rec_bytes]
-                ops.append(dist.P2POp(dist.isend, src.cpu() if host else src.clone(), p,
-                                      group=self._cpu_group() if (host and self.on_gpu) else None))
-            if recv[p]:
-                tmp = torch.empty(recv[p] * rec_bytes, dtype=torch.uint8, device="cpu" if host else self.device)
-                landing.append((p, tmp))
-                ops.append(dist.P2POp(dist.irecv, tmp, p, group=self._cpu_group() if (host and self.on_gpu) else None))
+            for j, kind in enumerate(kinds):
+                n_out, n_in = counts[0][j][p], recv[j][p]
+                if n_out:
+                    src = sh.send[kind][p, : n_out * REC_BYTES[kind]]
+                    ops.append(dist.P2POp(dist.isend, src.cpu() if host else src.clone(), p, group=grp))
+                if n_in:
+                    tmp = torch.empty(n_in * REC_BYTES[kind], dtype=torch.uint8, device="cpu" if host else self.device)
+                    landing.append((kind, p, tmp))
+                    ops.append(dist.P2POp(dist.irecv, tmp, p, group=grp))
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
-        for p, tmp in landing:
-            getattr(sh, recv_attr)[p, : tmp.numel()].copy_(tmp)
+        for kind, p, tmp in landing:
+            sh.recv[kind][p, : tmp.numel()].copy_(tmp)
         if self.on_gpu:
             torch.cuda.synchronize()                # the library launches on its own stream
         return [recv]
@@ -232,12 +239,12 @@ class ShardedSim:
     def step(self, nticks: int = 1):
         f, sh = self.fabric, self.shards
         for _ in range(nticks):
-            p1 = [s.phase1() for s in sh]
-            r_in = f.exchange(sh, [p[0] for p in p1], "r_send", "r_recv", RREC_BYTES)
-            x_out = [s.phase2(r_in[k]) for k, s in enumerate(sh)]
-            x_in = f.exchange(sh, x_out, "x_send", "x_recv", XREC_BYTES)
+            c1 = [s.phase1() for s in sh]
+            r_in = f.exchange(sh, (0,), [[c[0]] for c in c1])                       # round 1
+            c2 = [s.phase2(r_in[k][0]) for k, s in enumerate(sh)]
+            px_in = f.exchange(sh, (1, 2), [[c[1], c[2]] for c in c2])              # round 2
             for k, s in enumerate(sh):
-                s.phase3(x_in[k])
+                s.phase3(px_in[k][0], px_in[k][1])
 
     @property
     def tick(self) -> int:

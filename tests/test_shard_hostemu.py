@@ -59,3 +59,21 @@ def test_sharded_saturated_queues(oracle_abi, emu_abi):
         workloads.apply_crashes(s, crashes)
     lockstep(a, b, 50, 5, observers=(0, 1, n - 1), members=(0, 1, n - 1))
     b.close()
+
+
+def test_sharded_with_tiny_mask_window(oracle_abi):
+    """4-id mask window: most cross-shard payloads take the explicit 72-byte records and foreign lines,
+    ticks after id bursts disable masks altogether."""
+    from tests import hostemu_binding
+    emu = hostemu_binding.load_variant("win4", ["SWIM_MASK_WIN=4", "SWIM_MASK_SLACK=2"])
+    n = 384
+    crashes = workloads.hashed_crashes(n, 11, 1, 8, 3, 33)
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=11, lossPpm=20000, eventMask=0x1F, suspicionTicks=6,
+                   maxSubjects=384, timerCap=512, inboxCap=2)
+    a = Sim.create(oracle_abi, sc)
+    b = ShardedSim(emu, sc, LocalFabric(3))
+    for s in (a, b):
+        workloads.apply_crashes(s, crashes)
+        s.scheduleFault(40, crashes[0][1], True)
+    lockstep(a, b, 60, 5, observers=(0, n - 1), members=(0, n - 1))
+    b.close()
