@@ -17,3 +17,27 @@ for G in [int(x) for x in sys.argv[1:]] or [1, 2, 4, 8]:
     print(json.dumps({"shards_on_one_gpu": G, "members": N, "us_per_tick": round(dt / TICKS * 1e6, 1),
                       "Gmt_per_s": round(N * TICKS / dt / 1e9, 3), "digest": "%016x" % s.digest()}), flush=True)
     s.close()
+
+# where a sharded tick spends its time (host view, G = 2)
+if os.environ.get("PHASES", "1") == "1":
+    G = 2
+    sc, crashes, _ = workloads.saturated(N, WARM + TICKS)
+    s = ShardedSim(abi, sc, LocalFabric(G), device="cuda:0")
+    workloads.apply_crashes(s, crashes)
+    s.step(WARM); torch.cuda.synchronize()
+    acc = [0.0] * 5
+    f, sh = s.fabric, s.shards
+    for _ in range(TICKS):
+        t0 = time.perf_counter(); c1 = [x.phase1() for x in sh]
+        t1 = time.perf_counter(); r_in = f.exchange(sh, (0,), [[c[0]] for c in c1])
+        t2 = time.perf_counter(); c2 = [x.phase2(r_in[k][0]) for k, x in enumerate(sh)]
+        t3 = time.perf_counter(); px = f.exchange(sh, (1, 2), [[c[1], c[2]] for c in c2])
+        t4 = time.perf_counter()
+        for k, x in enumerate(sh):
+            x.phase3(px[k][0], px[k][1])
+        t5 = time.perf_counter()
+        for j, d in enumerate((t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
+            acc[j] += d
+    print(json.dumps({"per_tick_us_both_shards": {k: round(v / TICKS * 1e6, 1) for k, v in zip(("phase1", "round1", "phase2", "round2", "phase3"), acc)},
+                      "records_per_shard": {"requests": c1[0][0][1] - 64, "mask_payloads": c2[0][1][1], "explicit_payloads": c2[0][2][1]}}), flush=True)
+    s.close()

@@ -24,7 +24,8 @@ enum : uint64_t { TAG_SELF = 0x53454c46u, TAG_VIEW = 0x56494557u, TAG_PB = 0x504
                   TAG_INC = 0x494e4352u, TAG_TICK = 0x5449434bu, TAG_MEMBER = 0x4d454d42u };
 
 // globals word indices (DevState::g)
-enum { G_NSLOTS = 0, G_ERR = 1, G_EVCUR = 2, G_OVF0 = 3, G_OVF1 = 4, G_NRUM = 5, G_HEAD = 6, G_PREV = 7, G_WORDS = 16 };
+enum { G_NSLOTS = 0, G_ERR = 1, G_EVCUR = 2, G_OVF0 = 3, G_OVF1 = 4, G_NRUM = 5, G_HEAD = 6, G_PREV = 7,
+       G_SEND = 16 /* [3][16] exchange records appended per peer (send_cnt) */, G_WORDS = 64 };
 enum { ERRF_SUBJECTS = 1, ERRF_TIMERS = 2, ERRF_OVF = 4, ERRF_INC = 8 };
 
 // counter slots (same order as SWIMSIM_CTR_* in include/swimsim.h)
@@ -108,11 +109,14 @@ struct DevState {
   uint4* p_send; uint4* p_recv;         // [n_shards][p_cap] mask payloads {dst, -, mask over MY dictionary}
   uint32_t* x_send; uint32_t* x_recv;   // [n_shards][x_cap][XREC_WORDS] explicit payload records (exact fallback)
   uint32_t r_cap, p_cap, x_cap;
-  uint32_t* send_cnt;      // [3][n_shards] records appended per peer: requests, mask payloads, explicit payloads
+  uint32_t* send_cnt;      // = g + G_SEND: [3][MAX_SHARDS] records appended per peer: requests, mask payloads,
+                           //   explicit payloads (inside g so that ONE small copy brings flags and counts to the host)
   uint2* xl;               // [n_shards][DICT_RECS] a peer's dictionary in MY numbering {slot | rid<<16, key}
   uint4* fl;               // [n_shards * (x_cap + p_cap)][4] "foreign lines": received entries my masks cannot carry
 };
 constexpr uint32_t DICT_RECS = 64;      // one entry per ring position
+constexpr int MAX_SHARDS = 16;
+struct PeerCounts { uint32_t v[MAX_SHARDS]; };   // received records per peer, passed to kernels by value
 
 // payload record on the wire: {dst (global id), n, n x {subject, key}} -- ids, not slots: every shard
 // has its own slot and rumour-id numbering

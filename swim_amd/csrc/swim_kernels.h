@@ -609,19 +609,10 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
 // ================================================================================================
 // cross-shard exchange kernels (n_shards > 1)
 // ================================================================================================
-// Records are appended to per-peer send buffers with ONE global atomic per (block, peer): ranks within
-// the block come from LDS counters.  Every thread of the block calls this together (peer < 0: nothing).
-struct AppendCtx { uint32_t cnt[16]; uint32_t base[16]; };   // n_shards <= 16
-__device__ inline uint32_t block_append(AppendCtx* a, uint32_t* gcnt, uint32_t n_peers, int peer) {
-  if (threadIdx.x < 16) a->cnt[threadIdx.x] = 0;
-  __syncthreads();
-  uint32_t rank = 0;
-  if (peer >= 0) rank = atomicAdd(&a->cnt[peer], 1u);
-  __syncthreads();
-  if (threadIdx.x < n_peers && a->cnt[threadIdx.x]) a->base[threadIdx.x] = atomicAdd(&gcnt[threadIdx.x], a->cnt[threadIdx.x]);
-  __syncthreads();
-  return peer >= 0 ? a->base[peer] + rank : 0u;
-}
+// Records are appended to per-peer send buffers with ONE global atomic per (block, kind, peer): a block
+// first counts what its orders need (LDS), reserves the ranges, then writes -- two passes over its own
+// chunk of orders, so contended same-address atomics stay in the low thousands per tick.
+struct AppendCtx { uint32_t cnt[3][MAX_SHARDS]; uint32_t base[3][MAX_SHARDS]; };
 
 // the payload record of local member src_li for destination dst: ids instead of slots
 __device__ inline void write_xrec(const DevState& s, uint32_t* rec, uint32_t dst, uint32_t src_li, uint32_t msrc) {
@@ -637,38 +628,64 @@ __device__ inline void write_xrec(const DevState& s, uint32_t* rec, uint32_t dst
   rec[0] = dst; rec[1] = n;
 }
 
-// One delivery order {dst, src} whose source is LOCAL: dst local -> done here; else a payload record for
-// the owner of dst: the queue's mask (over this shard's dictionary of the tick) when it says everything,
-// the explicit ids otherwise.  count = this shard accounts for the payload (the prober could not).
-__device__ inline void route_order(const DevState& s, uint32_t t, AppendCtx* ap, AppendCtx* ax, BlockCounters* sh,
-                                   bool have, uint32_t dst, uint32_t src, bool count) {
+// What one order {dst, src} needs.  kind 0: pull request to the owner of src (src remote); 1: mask
+// payload / 2: explicit payload to the owner of dst (src local, queue not empty); -1: nothing to send
+// (dropped, or delivered here by do_local).
+struct OrderPlan { int kind; uint32_t peer; bool local; uint32_t msrc; };
+__device__ inline OrderPlan plan_order(const DevState& s, bool use_mask, uint32_t dst, uint32_t src) {
+  OrderPlan pl{-1, 0u, false, 0u};
+  if (!is_local(s, src)) { pl.kind = 0; pl.peer = owner_of(s, src); return pl; }
+  pl.msrc = s.minfo[src];
+  if (!mi_pbn(pl.msrc)) return pl;                  // empty payload: nothing travels
+  if (is_local(s, dst)) { pl.local = true; return pl; }
+  pl.kind = (use_mask && !(pl.msrc & MI_OOW)) ? 1 : 2;
+  pl.peer = owner_of(s, dst);
+  return pl;
+}
+
+// One block routes the orders [first, first + n) of `list`: pass 1 counts, pass 2 writes.  count = this
+// shard accounts for the payloads (the prober could not: orders that came in as pull requests).
+__device__ inline void route_block(const DevState& s, uint32_t t, AppendCtx* a, BlockCounters* sh, const uint2* list,
+                                   uint32_t n, bool count) {
   const uint32_t Hprev = s.g[G_PREV], H = s.g[G_HEAD];
   const bool use_mask = H - Hprev <= MASK_SLACK;
-  int ppeer = -1, xpeer = -1;
-  uint32_t msrc = 0, src_li = 0;
-  if (have) {
-    src_li = src - s.lo;
-    msrc = s.minfo[src];
-    const uint32_t cnt = mi_pbn(msrc);
-    if (cnt) {
-      if (count) { ctr_add(sh, C_PAYLOADS, 1u); ctr_add(sh, C_RUMORS_SEEN, cnt); }
-      if (is_local(s, dst))
-        deliver_local(s, t, use_mask, stale_positions(Hprev, H), dst - s.lo, src_li, msrc, use_mask ? s.pk[src_li].x : 0ull);
-      else if (use_mask && !(msrc & MI_OOW)) ppeer = (int)owner_of(s, dst);
-      else xpeer = (int)owner_of(s, dst);
+  const unsigned long long stale = stale_positions(Hprev, H);
+  const size_t rstride = DICT_RECS + s.r_cap;
+  __syncthreads();                                  // the previous call's ranks are done with the counters
+  if (threadIdx.x < 3 * MAX_SHARDS) a->cnt[threadIdx.x / MAX_SHARDS][threadIdx.x % MAX_SHARDS] = 0;
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < n; k += BLOCK) {
+    const uint2 o = list[k];
+    const OrderPlan pl = plan_order(s, use_mask, o.x, o.y);
+    if (pl.kind >= 0) atomicAdd(&a->cnt[pl.kind][pl.peer], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 3 * MAX_SHARDS) {
+    const uint32_t kind = threadIdx.x / MAX_SHARDS, peer = threadIdx.x % MAX_SHARDS, c = a->cnt[kind][peer];
+    if (c) a->base[kind][peer] = atomicAdd(&s.send_cnt[kind * MAX_SHARDS + peer], c);
+    a->cnt[kind][peer] = 0;
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < n; k += BLOCK) {
+    const uint2 o = list[k];
+    const OrderPlan pl = plan_order(s, use_mask, o.x, o.y);
+    const uint32_t src_li = o.y - s.lo;
+    if (count && is_local(s, o.y) && mi_pbn(pl.msrc)) { ctr_add(sh, C_PAYLOADS, 1u); ctr_add(sh, C_RUMORS_SEEN, mi_pbn(pl.msrc)); }
+    if (pl.local) deliver_local(s, t, use_mask, stale, o.x - s.lo, src_li, pl.msrc, use_mask ? s.pk[src_li].x : 0ull);
+    if (pl.kind < 0) continue;
+    const uint32_t pos = a->base[pl.kind][pl.peer] + atomicAdd(&a->cnt[pl.kind][pl.peer], 1u);
+    if (pl.kind == 0) {
+      if (pos < s.r_cap) s.r_send[(size_t)pl.peer * rstride + DICT_RECS + pos] = o;
+      else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_OVF);
+    } else if (pl.kind == 1) {
+      if (pos < s.p_cap) {
+        const unsigned long long m = s.pk[src_li].x;
+        s.p_send[(size_t)pl.peer * s.p_cap + pos] = make_uint4(o.x, 0u, (uint32_t)m, (uint32_t)(m >> 32));
+      } else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_OVF);
+    } else {
+      if (pos < s.x_cap) write_xrec(s, s.x_send + ((size_t)pl.peer * s.x_cap + pos) * XREC_WORDS, o.x, src_li, pl.msrc);
+      else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_OVF);
     }
-  }
-  const uint32_t ppos = block_append(ap, s.send_cnt + s.n_shards, s.n_shards, ppeer);
-  if (ppeer >= 0) {
-    if (ppos < s.p_cap) {
-      const unsigned long long m = s.pk[src_li].x;
-      s.p_send[(size_t)ppeer * s.p_cap + ppos] = make_uint4(dst, 0u, (uint32_t)m, (uint32_t)(m >> 32));
-    } else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_OVF);
-  }
-  const uint32_t xpos = block_append(ax, s.send_cnt + 2 * s.n_shards, s.n_shards, xpeer);
-  if (xpeer >= 0) {
-    if (xpos < s.x_cap) write_xrec(s, s.x_send + ((size_t)xpeer * s.x_cap + xpos) * XREC_WORDS, dst, src_li, msrc);
-    else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_OVF);
   }
 }
 
@@ -676,44 +693,25 @@ __device__ inline void route_order(const DevState& s, uint32_t t, AppendCtx* ap,
 // payload record to the owner of dst.  One block per probe block (its own order region).
 __global__ __launch_bounds__(BLOCK) void split_kernel(DevState s, uint32_t t) {
   __shared__ BlockCounters sh;
-  __shared__ AppendCtx ar, ap, ax;
+  __shared__ AppendCtx a;
   ctr_init(&sh);
-  const uint32_t n = s.ord_cnt[blockIdx.x];
-  const size_t rstride = DICT_RECS + s.r_cap;
-  for (uint32_t base = 0; base < n; base += BLOCK) {
-    const uint32_t k = base + threadIdx.x;
-    const bool have = k < n;
-    const uint2 o = have ? s.ord[(size_t)blockIdx.x * s.ord_cap + k] : make_uint2(0u, 0u);
-    const bool src_local = have && is_local(s, o.y);
-    // requests
-    const int rpeer = (have && !src_local) ? (int)owner_of(s, o.y) : -1;
-    const uint32_t rpos = block_append(&ar, s.send_cnt, s.n_shards, rpeer);
-    if (rpeer >= 0) {
-      if (rpos < s.r_cap) s.r_send[(size_t)rpeer * rstride + DICT_RECS + rpos] = o;
-      else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_OVF);
-    }
-    // payloads of local sources (already counted by the prober)
-    route_order(s, t, &ap, &ax, &sh, src_local, o.x, o.y, false);
-  }
+  route_block(s, t, &a, &sh, s.ord + (size_t)blockIdx.x * s.ord_cap, s.ord_cnt[blockIdx.x], false);
   ctr_flush(s, &sh, blockIdx.x);
 }
 
 // after round 1: the pull requests other shards sent me (their source is mine).  Fixed grid (= nblocks)
-// so that every block owns a counter row.
-__global__ __launch_bounds__(BLOCK) void serve_kernel(DevState s, uint32_t t, const uint32_t* r_counts) {
+// so that every block owns a counter row; each block takes one contiguous chunk of each peer's list.
+__global__ __launch_bounds__(BLOCK) void serve_kernel(DevState s, uint32_t t, PeerCounts r_counts) {
   __shared__ BlockCounters sh;
-  __shared__ AppendCtx ap, ax;
+  __shared__ AppendCtx a;
   ctr_init(&sh);
   const size_t rstride = DICT_RECS + s.r_cap;
   for (uint32_t peer = 0; peer < s.n_shards; ++peer) {
-    const uint32_t got = r_counts[peer];            // dictionary + requests
+    const uint32_t got = r_counts.v[peer];          // dictionary + requests
     const uint32_t n = got > DICT_RECS ? min(got - DICT_RECS, s.r_cap) : 0u;
-    for (uint32_t base = blockIdx.x * BLOCK; base < n; base += gridDim.x * BLOCK) {
-      const uint32_t k = base + threadIdx.x;
-      const bool have = k < n;
-      const uint2 o = have ? s.r_recv[(size_t)peer * rstride + DICT_RECS + k] : make_uint2(0u, 0u);
-      route_order(s, t, &ap, &ax, &sh, have, o.x, o.y, true);
-    }
+    const uint32_t chunk = (n + gridDim.x - 1) / gridDim.x;
+    const uint32_t first = min(n, blockIdx.x * chunk), cnt = min(n - first, chunk);
+    route_block(s, t, &a, &sh, s.r_recv + (size_t)peer * rstride + DICT_RECS + first, cnt, true);
   }
   ctr_flush(s, &sh, blockIdx.x);
 }
@@ -721,11 +719,11 @@ __global__ __launch_bounds__(BLOCK) void serve_kernel(DevState s, uint32_t t, co
 // after round 1: every peer's dictionary of the tick in MY numbering (slots and rumour ids are per shard).
 // Rumours this shard never heard of get their slot and id here; such ids are younger than this tick's
 // head, so ingest hands them over through foreign lines until the next tick.
-__global__ void xlat_kernel(DevState s, const uint32_t* r_counts) {
+__global__ void xlat_kernel(DevState s, PeerCounts r_counts) {
   const uint32_t peer = blockIdx.x, p = threadIdx.x;
   if (p >= DICT_RECS) return;
   uint2 out = make_uint2(NONE32, 0u);
-  if (peer != s.shard && r_counts[peer] >= DICT_RECS) {
+  if (peer != s.shard && r_counts.v[peer] >= DICT_RECS) {
     const uint2 e = s.r_recv[(size_t)peer * (DICT_RECS + s.r_cap) + p];       // {subject, key}
     if (e.x != NONE32) {
       const uint32_t slot = get_slot(s, e.x);
@@ -750,7 +748,7 @@ __device__ inline void ingest_finish(const DevState& s, uint32_t t, unsigned lon
 }
 
 // after round 2: payload records for my members, as masks over the sender's dictionary or as explicit ids
-__global__ __launch_bounds__(BLOCK) void ingest_kernel(DevState s, uint32_t t, const uint32_t* p_counts, const uint32_t* x_counts) {
+__global__ __launch_bounds__(BLOCK) void ingest_kernel(DevState s, uint32_t t, PeerCounts p_counts, PeerCounts x_counts) {
   __shared__ uint2 xls[DICT_RECS];
   const uint32_t Hprev = s.g[G_PREV], H = s.g[G_HEAD];
   const bool use_mask = H - Hprev <= MASK_SLACK;
@@ -758,7 +756,7 @@ __global__ __launch_bounds__(BLOCK) void ingest_kernel(DevState s, uint32_t t, c
   const size_t fl_x = (size_t)s.n_shards * s.x_cap;            // foreign lines of mask records come after these
   for (uint32_t peer = 0; peer < s.n_shards; ++peer) {
     // ---- mask records
-    const uint32_t np = min(p_counts[peer], s.p_cap);
+    const uint32_t np = min(p_counts.v[peer], s.p_cap);
     __syncthreads();
     if (threadIdx.x < DICT_RECS) xls[threadIdx.x] = s.xl[(size_t)peer * DICT_RECS + threadIdx.x];
     __syncthreads();
@@ -780,7 +778,7 @@ __global__ __launch_bounds__(BLOCK) void ingest_kernel(DevState s, uint32_t t, c
       ingest_finish(s, t, stale, rec.x - s.lo, bits, fl, nf, (uint32_t)(fl_x + ri));
     }
     // ---- explicit records
-    const uint32_t nx = min(x_counts[peer], s.x_cap);
+    const uint32_t nx = min(x_counts.v[peer], s.x_cap);
     for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < nx; k += gridDim.x * BLOCK) {
       const size_t ri = (size_t)peer * s.x_cap + k;
       const uint32_t* rec = s.x_recv + ri * XREC_WORDS;
@@ -876,6 +874,7 @@ __global__ void begin_kernel(DevState s, uint32_t t, const FaultRec* faults, uin
   const uint32_t H = s.g[G_NRUM];
   s.g[G_HEAD] = H;
   if (s.n_shards > 1) {
+    for (int k = 0; k < 3 * MAX_SHARDS; ++k) s.send_cnt[k] = 0;
     // this tick's dictionary for the peers: ring position -> {subject, key} of the id that owns it
     const size_t rstride = DICT_RECS + s.r_cap;
     for (uint32_t p = 0; p < DICT_RECS; ++p) {

@@ -50,7 +50,7 @@ struct swimsim {
   std::string err;
   // sharded stepping (swimsim_shard_*): which phase of the current tick comes next, the tick's fault slice
   int shard_phase = 0;
-  uint32_t* d_counts = nullptr;                // [2][n_shards] received record counts, device copy
+  uint32_t* h_sync = nullptr;                  // pinned host copy of the globals (flags + send counts)
   hipEvent_t tick_ev[3] = {nullptr, nullptr, nullptr};
 };
 
@@ -206,6 +206,7 @@ void swimsim_destroy(swimsim_t* h) {
   if (h->d_sel) (void)hipFree(h->d_sel);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->tick_ev) if (e) (void)hipEventDestroy(e);
+  if (h->h_sync) (void)hipHostFree(h->h_sync);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -262,6 +263,8 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   CK(dev_alloc(h, &d.first_suspect, NT, 0xFF));
   CK(dev_alloc(h, &d.crash_tick, NT, 0xFF));
   CK(dev_alloc(h, &d.g, (size_t)G_WORDS, 0));
+  d.send_cnt = d.g + G_SEND;
+  HK(hipHostMalloc(reinterpret_cast<void**>(&h->h_sync), G_WORDS * sizeof(uint32_t)));
   CK(dev_alloc(h, &d.ovf, (size_t)2 * d.ovf_cap, 0));
   CK(dev_alloc(h, &d.events, (size_t)d.event_cap, 0));
   CK(dev_alloc(h, &d.blk, ((size_t)d.nblocks + 1) * C_COUNT, 0));
@@ -283,10 +286,8 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     CK(dev_alloc(h, &d.p_recv, (size_t)d.n_shards * d.p_cap, 0));
     CK(dev_alloc(h, &d.x_send, (size_t)d.n_shards * d.x_cap * XREC_WORDS, 0));
     CK(dev_alloc(h, &d.x_recv, (size_t)d.n_shards * d.x_cap * XREC_WORDS, 0));
-    CK(dev_alloc(h, &d.send_cnt, (size_t)3 * d.n_shards, 0));
     CK(dev_alloc(h, &d.xl, (size_t)d.n_shards * DICT_RECS, 0xFF));
     CK(dev_alloc(h, &d.fl, (size_t)d.n_shards * ((size_t)d.x_cap + d.p_cap) * 4, 0));
-    CK(dev_alloc(h, &h->d_counts, (size_t)3 * d.n_shards, 0));
   }
   hipLaunchKernelGGL(init_members_kernel, dim3((std::max(N, NT) + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, d.hot, d.minfo, N, NT);
   HK(hipGetLastError());
@@ -557,17 +558,31 @@ static int shard_check(swimsim* h, int phase) {
   return SWIMSIM_OK;
 }
 
-// counts[k * n_shards + g], k = 0 requests (dictionary included), 1 mask payloads, 2 explicit payloads
-static int read_send_counts(swimsim* h, uint32_t* counts) {
-  const uint32_t G = h->d.n_shards;
-  std::vector<uint32_t> c(3 * G);
-  HIPCHK(h, hipMemcpy(c.data(), h->d.send_cnt, c.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  for (uint32_t g = 0; g < G; ++g) {
-    counts[g] = g == h->d.shard ? 0u : DICT_RECS + std::min(c[g], h->d.r_cap);
-    counts[G + g] = std::min(c[G + g], h->d.p_cap);
-    counts[2 * G + g] = std::min(c[2 * G + g], h->d.x_cap);
+// End of a phase: ONE small pinned copy brings the capacity flags and the per-peer send counts to the
+// host, one stream synchronisation.  counts[k * n_shards + g], k = 0 requests (dictionary included),
+// 1 mask payloads, 2 explicit payloads.
+static int finish_phase(swimsim* h, uint32_t* counts) {
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(h->h_sync, h->d.g, G_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const uint32_t* g = h->h_sync;
+  if (g[G_ERR]) return check_device_errors(h);
+  if (counts) {
+    const uint32_t G = h->d.n_shards;
+    const uint32_t* c = g + G_SEND;
+    for (uint32_t p = 0; p < G; ++p) {
+      counts[p] = p == h->d.shard ? 0u : DICT_RECS + std::min(c[p], h->d.r_cap);
+      counts[G + p] = std::min(c[MAX_SHARDS + p], h->d.p_cap);
+      counts[2 * G + p] = std::min(c[2 * MAX_SHARDS + p], h->d.x_cap);
+    }
   }
   return SWIMSIM_OK;
+}
+
+static PeerCounts peer_counts(const swimsim* h, const uint32_t* in) {
+  PeerCounts pc{};
+  for (uint32_t p = 0; p < h->d.n_shards; ++p) pc.v[p] = in[p];
+  return pc;
 }
 
 int swimsim_shard_phase1(swimsim_t* h, uint32_t* counts) {
@@ -580,7 +595,6 @@ int swimsim_shard_phase1(swimsim_t* h, uint32_t* counts) {
   if (rc) return rc;
   if (h->timing && !h->tick_ev[0]) for (int k = 0; k < 3; ++k) HIPCHK(h, hipEventCreate(&h->tick_ev[k]));
   const uint32_t t = (uint32_t)h->tick;
-  HIPCHK(h, hipMemsetAsync(h->d.send_cnt, 0, (size_t)3 * h->d.n_shards * sizeof(uint32_t), h->stream));
   hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(64), 0, h->stream, h->d, t, h->d_faults, (uint32_t)fend);
   h->faults.erase(h->faults.begin(), h->faults.begin() + (long)fend);
   const uint32_t tk = tick_key(h->cfg.seed, t);
@@ -591,13 +605,9 @@ int swimsim_shard_phase1(swimsim_t* h, uint32_t* counts) {
     hipLaunchKernelGGL((probe_kernel<16>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk);
   if (h->timing) (void)hipEventRecord(h->tick_ev[1], h->stream);
   hipLaunchKernelGGL(split_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
-  HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  rc = finish_phase(h, counts);
+  if (rc) return rc;
   if (h->timing) { float a = 0; HIPCHK(h, hipEventElapsedTime(&a, h->tick_ev[0], h->tick_ev[1])); h->probe_ms += a; }
-  rc = read_send_counts(h, counts);
-  if (rc) return rc;
-  rc = check_device_errors(h);
-  if (rc) return rc;
   h->shard_phase = 1;
   return SWIMSIM_OK;
 }
@@ -607,14 +617,10 @@ int swimsim_shard_phase2(swimsim_t* h, const uint32_t* r_counts_in, uint32_t* co
   if (rc) return rc;
   if (!r_counts_in || !counts) return SWIMSIM_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipMemcpy(h->d_counts, r_counts_in, h->d.n_shards * sizeof(uint32_t), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(xlat_kernel, dim3(h->d.n_shards), dim3(DICT_RECS), 0, h->stream, h->d, h->d_counts);
-  hipLaunchKernelGGL(serve_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, (uint32_t)h->tick, h->d_counts);
-  HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  rc = read_send_counts(h, counts);
-  if (rc) return rc;
-  rc = check_device_errors(h);
+  const PeerCounts rc_in = peer_counts(h, r_counts_in);
+  hipLaunchKernelGGL(xlat_kernel, dim3(h->d.n_shards), dim3(DICT_RECS), 0, h->stream, h->d, rc_in);
+  hipLaunchKernelGGL(serve_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, (uint32_t)h->tick, rc_in);
+  rc = finish_phase(h, counts);
   if (rc) return rc;
   h->shard_phase = 2;
   return SWIMSIM_OK;
@@ -625,19 +631,17 @@ int swimsim_shard_phase3(swimsim_t* h, const uint32_t* p_counts_in, const uint32
   if (rc) return rc;
   if (!p_counts_in || !x_counts_in) return SWIMSIM_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
-  const uint32_t G = h->d.n_shards, t = (uint32_t)h->tick;
-  HIPCHK(h, hipMemcpy(h->d_counts + G, p_counts_in, G * sizeof(uint32_t), hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemcpy(h->d_counts + 2 * G, x_counts_in, G * sizeof(uint32_t), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(ingest_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, h->d_counts + G, h->d_counts + 2 * G);
+  const uint32_t t = (uint32_t)h->tick;
+  hipLaunchKernelGGL(ingest_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, peer_counts(h, p_counts_in), peer_counts(h, x_counts_in));
   if (h->timing) (void)hipEventRecord(h->tick_ev[1], h->stream);
   hipLaunchKernelGGL(merge_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
   if (h->timing) (void)hipEventRecord(h->tick_ev[2], h->stream);
-  HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  rc = finish_phase(h, nullptr);
+  if (rc) return rc;
   if (h->timing) { float b = 0; HIPCHK(h, hipEventElapsedTime(&b, h->tick_ev[1], h->tick_ev[2])); h->merge_ms += b; h->timed_ticks++; }
   h->tick++;
   h->shard_phase = 0;
-  return check_device_errors(h);
+  return SWIMSIM_OK;
 }
 
 /* First-detection ticks are recorded by the prober's shard: set the combined (element-wise minimum over

@@ -99,6 +99,9 @@ class LocalFabric:
                     nb = n * REC_BYTES[kind]
                     shards[p].recv[kind][src.index, :nb].copy_(src.send[kind][p, :nb])
                     recv[p][j][src.index] = n
+        if shards and shards[0].send[0].is_cuda:
+            import torch
+            torch.cuda.synchronize()                # torch copies are asynchronous; the library has its own stream
         return recv
 
     def gather(self, obj):
