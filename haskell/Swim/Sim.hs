@@ -69,6 +69,14 @@ foreign import ccall safe   "swimsim_drain_events"   c_drain :: Ptr SwimsimT -> 
 foreign import ccall safe   "swimsim_read_view"      c_view  :: Ptr SwimsimT -> Word32 -> Ptr () -> CSize -> Ptr CSize -> IO CInt
 foreign import ccall safe   "swimsim_first_detect"   c_first :: Ptr SwimsimT -> Ptr Word64 -> CSize -> IO CInt
 foreign import ccall safe   "swimsim_digest"         c_digest :: Ptr SwimsimT -> Ptr Word64 -> IO CInt
+-- sharded clusters (one handle per GPU; include/swimsim.h "sharded clusters"): the caller moves the
+-- records of the two exchange rounds between the handles (MPI / RCCL binding of the embedder's choice;
+-- swim_amd/shard.py is the worked example over torch.distributed).
+foreign import ccall unsafe "swimsim_shard_info"    c_shard_info    :: Ptr SwimsimT -> Ptr Word32 -> Ptr Word32 -> Ptr Word32 -> Ptr Word32 -> Ptr Word32 -> IO CInt
+foreign import ccall unsafe "swimsim_shard_buffers" c_shard_buffers :: Ptr SwimsimT -> Ptr (Ptr ()) -> Ptr (Ptr ()) -> IO CInt
+foreign import ccall safe   "swimsim_shard_phase1"  c_shard_phase1  :: Ptr SwimsimT -> Ptr Word32 -> IO CInt
+foreign import ccall safe   "swimsim_shard_phase2"  c_shard_phase2  :: Ptr SwimsimT -> Ptr Word32 -> Ptr Word32 -> IO CInt
+foreign import ccall safe   "swimsim_shard_phase3"  c_shard_phase3  :: Ptr SwimsimT -> Ptr Word32 -> Ptr Word32 -> IO CInt
 
 defaultSimConfig :: Config -> SimConfig
 defaultSimConfig c = SimConfig c 128 1 0 0 0 0 0
