@@ -524,13 +524,6 @@ int swimsim_k_random_members(swimsim_t* h, uint32_t observer, uint32_t n, const 
   return SWIMSIM_OK;
 }
 
-#ifdef SWIM_STATS
-extern "C" int swimsim_debug_globals(swimsim_t* h, uint32_t* out) {
-  return hipMemcpy(out, h->d.g, G_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
-}
-#endif
-
-
 /* ---- sharded stepping: one tick = phase1 -> [exchange requests] -> phase2 -> [exchange payloads] -> phase3 ---- */
 
 int swimsim_shard_info(const swimsim_t* h, uint32_t* lo, uint32_t* n_local, uint32_t* r_cap, uint32_t* p_cap, uint32_t* x_cap) {

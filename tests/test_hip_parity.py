@@ -164,3 +164,22 @@ def test_one_process_per_shard_on_one_gpu():
            "--master-port", "29655", os.path.join(root, "tests", "dist_worker.py"), "8192", "3", "50000", "4", "40"]
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "DIST-OK world=2" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+def test_million_members_sharded_digest_equals_unsharded(hip_abi):
+    """BASELINE size, no oracle: the saturated 1 M-member run must give the same state digest, counters
+    and first-detection ticks whether it is one handle or 2 / 8 shards (several handles on this GPU).
+    Size-independent property of the exchange -- and a race detector for it."""
+    from swim_amd.shard import LocalFabric, ShardedSim
+    n, ticks = 1 << 20, 40
+    sc, crashes, _ = workloads.saturated(n, ticks, crashes_per_tick=2.0, t0=2)
+    results = []
+    for shards in (1, 2, 8):
+        s = Sim.create(hip_abi, sc) if shards == 1 else ShardedSim(hip_abi, sc, LocalFabric(shards), device="cuda:0")
+        workloads.apply_crashes(s, crashes)
+        s.step(ticks)
+        c = s.counters()
+        results.append((s.digest(), c, s.firstDetection()))
+        s.close()
+    assert results[0][1]["changes"] > 10 * n                      # the run really disseminates
+    assert results[1] == results[0] and results[2] == results[0]
