@@ -83,9 +83,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # SWIM_BENCH_SHARE_GPU=1 (test hook, not a reporting mode): all ranks share GPU 0 over gloo with
+    # host-staged records, to exercise this file's multi-rank flow on a one-GPU box
+    share_gpu = os.environ.get("SWIM_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("cpu:gloo,cuda:nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("cpu:gloo,cuda:nccl", device_id=torch.device("cuda", local_rank))
 
     from swim_amd import Sim, _lib, workloads
     total = args.warmup + args.steps
@@ -103,12 +111,13 @@ def main():
         sim = Sim.create(_lib.load(), sc)
     else:
         from swim_amd.shard import DistFabric, ShardedSim
-        fabric = DistFabric("cuda:%d" % local_rank)
+        fabric = DistFabric("cuda:%d" % local_rank, transport="host" if share_gpu else "auto")
         sim = ShardedSim(_lib.load(), sc, fabric, device="cuda:%d" % local_rank)
         exchange = "torch.distributed p2p, transport=%s%s" % (fabric.transport, (" [" + fabric.note + "]") if fabric.note else "")
     workloads.apply_crashes(sim, crashes)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -124,7 +133,7 @@ def main():
     kt = sim.kernelTiming()
     c1 = sim.counters()
     if world > 1:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device="cpu" if share_gpu else "cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -133,8 +142,8 @@ def main():
         P = sim.resolved.probes_per_tick
         K = sim.resolved.indirect_k
         a_by, rates = algorithmic_bytes(c0, c1, nt, args.steps, P, K)
-        nt = max(1, kt["ticks"])
-        secs = {"probe_kernel": kt["probe_ms"] / 1e3 / nt, "merge_kernel": kt["merge_ms"] / 1e3 / nt}
+        nk = max(1, kt["ticks"])
+        secs = {"probe_kernel": kt["probe_ms"] / 1e3 / nk, "merge_kernel": kt["merge_ms"] / 1e3 / nk}
         per_kernel = {k: {"algorithmic_bytes_per_member_tick": a_by[k], "avg_launch_us": secs[k] * 1e6,
                           "achieved_GBs": (a_by[k] * n / secs[k] / 1e9) if secs[k] > 0 else 0.0} for k in secs}
         dom = "probe_kernel"
