@@ -6,11 +6,13 @@
 // position-major so that a wave's accesses share sectors, and only cross-member deliveries go
 // through atomics.
 // Three launches per tick:
+//   begin_kernel : one thread: scheduled faults, rumour-id window head (+ the tick's id dictionary).
 //   probe_kernel : one period of failureDetector / probeNode' per member (src/Core.hs:233-269),
 //                  closed form of the message exchange; delivers the piggyback payloads as masks.
-//   begin_kernel : one thread: scheduled faults, rumour-id window head.
 //   merge_kernel : owner-computes end of tick: delivered rumours, timers, state rule, piggyback queue
 //                  (src/Core.hs:89-117, 127-138, 142-218).
+// Sharded clusters add split_kernel / xlat_kernel + serve_kernel / ingest_kernel around the two
+// exchange rounds.
 #pragma once
 #include "swim_device.h"
 
@@ -91,7 +93,7 @@ __device__ inline uint32_t get_slot(const DevState& s, uint32_t j) {
 // ================================================================================================
 // "dst merges src's start-of-tick queue" for a LOCAL source and a LOCAL destination: the mask by
 // atomicOr, filtered by what dst already knows, plus an explicit record when the mask cannot carry all
-// of it (swim_device.h).  dst_known = pk[dst].y if the caller has it, else it is fetched.
+// of it (swim_device.h).
 __device__ inline void deliver_local(const DevState& s, uint32_t t, bool use_mask, unsigned long long stale,
                                      uint32_t dst_li, uint32_t src_li, uint32_t msrc, unsigned long long srcmask) {
   if (use_mask) {
