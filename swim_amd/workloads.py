@@ -75,8 +75,10 @@ def saturated(n_members, total_ticks, seed=1, crashes_per_tick=1.0, t0=10):
     want = max(1, int(round(span * crashes_per_tick)))
     den = 1 << 20
     num = max(1, int(round(want * den / n_members)))
+    # pending suspicion timers per member ~ crashes per tick x suspicion ticks (3 log2 N), with headroom
+    timer_cap = max(256, int(crashes_per_tick * 3 * max(1, (n_members - 1).bit_length()) * 2) + 64)
     sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n_members, seed=seed,
-                   maxSubjects=min(n_members, max(256, 2 * want + 64)), timerCap=256)
+                   maxSubjects=min(n_members, max(256, 2 * want + 64)), timerCap=timer_cap)
     return sc, hashed_crashes(n_members, seed, num, den, t0, t0 + span), total_ticks
 
 
