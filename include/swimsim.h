@@ -247,15 +247,19 @@ int swimsim_get_config(const swimsim_t* h, swimsim_config_t* out);
  *   phase3
  * on every shard in lock step (swim_amd/shard.py does the exchange with torch.distributed:
  * RCCL over xGMI on GPUs).  Buffers are [n_shards][cap] records owned by the library, three kinds:
- *   0  8 bytes   this tick's id dictionary (64 x {subject, incarnation<<2|state}, one per mask
- *                position), then pull requests {dst, src} for the owner of src
- *   1  16 bytes  {dst, -, 64-bit mask over the SENDER's dictionary}: a queue as it travels normally
+ *   0  16 bytes  this tick's id dictionary (64 x {subject, incarnation<<2|state}, one per mask
+ *                position = 32 records), then round-1 records {dst | tag<<27, src | flags<<27, mask}:
+ *                pull requests (tag 0, to the owner of src) and fused direct probes of remote targets
+ *                (tag = probe index + 1, to the owner of dst: the Ping's payload as a mask and the
+ *                request for the Ack's payload in one record)
+ *   1  16 bytes  {dst | tag<<27, -, 64-bit mask over the SENDER's dictionary}: a queue as it travels
+ *                normally (tag: the answer to the receiver's own probe `tag-1`, stored without an atomic)
  *   2  72 bytes  {dst, n, n x {subject, incarnation<<2|state}}: the exact fallback
  * counts[] arrays hold n_shards entries per kind (kind-major, 3 * n_shards).  swimsim_step is refused
  * on sharded handles; digest / counters / events return this shard's part (the parts add up /
  * concatenate); view and member reads are answered by the owner only; first-detection ticks must be
  * combined (element-wise minimum) and set back before digest or first_detect are read. */
-#define SWIMSIM_RREC_BYTES 8u
+#define SWIMSIM_RREC_BYTES 16u
 #define SWIMSIM_PREC_BYTES 16u
 #define SWIMSIM_XREC_BYTES 72u
 int swimsim_shard_info(const swimsim_t* h, uint32_t* lo, uint32_t* n_local, uint32_t* r_cap,

@@ -39,5 +39,5 @@ if os.environ.get("PHASES", "1") == "1":
         for j, d in enumerate((t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
             acc[j] += d
     print(json.dumps({"per_tick_us_both_shards": {k: round(v / TICKS * 1e6, 1) for k, v in zip(("phase1", "round1", "phase2", "round2", "phase3"), acc)},
-                      "records_per_shard": {"requests": c1[0][0][1] - 64, "mask_payloads": c2[0][1][1], "explicit_payloads": c2[0][2][1]}}), flush=True)
+                      "records_per_shard": {"round1_records": c1[0][0][1] - 32, "mask_payloads": c2[0][1][1], "explicit_payloads": c2[0][2][1]}}), flush=True)
     s.close()

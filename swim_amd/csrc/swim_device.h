@@ -101,20 +101,28 @@ struct DevState {
   uint4* events;           // {tick, observer, subject, key<<8|cause}
   uint64_t* blk;           // [nblocks+1][C_COUNT] per-block counter rows (no atomics)
   // ---- cross-shard exchange (n_shards > 1) --------------------------------------
-  uint2* ord;              // [nblocks][ord_cap] deliveries {dst, src} (global ids) the probe could not do locally
+  uint4* ord;              // [nblocks][ord_cap] deliveries the probe could not do locally (order format below)
   uint32_t* ord_cnt;       // [nblocks]
   uint32_t ord_cap;
-  uint2* r_send; uint2* r_recv;         // [n_shards][DICT_RECS + r_cap]: this tick's id dictionary (position ->
-                                        //   {subject, key}), then pull requests {dst, src} for the owner of src
-  uint4* p_send; uint4* p_recv;         // [n_shards][p_cap] mask payloads {dst, -, mask over MY dictionary}
+  uint4* r_send; uint4* r_recv;         // [n_shards][DICT_RECS + r_cap]: this tick's id dictionary (64 x {subject,
+                                        //   key}, one per mask position), then round-1 records (order format)
+  uint4* p_send; uint4* p_recv;         // [n_shards][p_cap] mask payloads {dst | tag<<27, -, mask over MY dictionary}
   uint32_t* x_send; uint32_t* x_recv;   // [n_shards][x_cap][XREC_WORDS] explicit payload records (exact fallback)
   uint32_t r_cap, p_cap, x_cap;
   uint32_t* send_cnt;      // = g + G_SEND: [3][MAX_SHARDS] records appended per peer: requests, mask payloads,
                            //   explicit payloads (inside g so that ONE small copy brings flags and counts to the host)
-  uint2* xl;               // [n_shards][DICT_RECS] a peer's dictionary in MY numbering {slot | rid<<16, key}
-  uint4* fl;               // [n_shards * (x_cap + p_cap)][4] "foreign lines": received entries my masks cannot carry
+  uint2* xl;               // [n_shards][64] a peer's dictionary in MY numbering {slot | rid<<16, key}
+  uint4* fl;               // [n_shards * (x_cap + p_cap + r_cap)][4] "foreign lines": received entries my masks cannot carry
+  unsigned long long* ackslot;  // [N][P] Ack payloads pulled from remote targets: one slot per probe, plain stores
 };
-constexpr uint32_t DICT_RECS = 64;      // one entry per ring position
+constexpr uint32_t DICT_ENTRIES = 64;   // one dictionary entry per ring position ...
+constexpr uint32_t DICT_RECS = 32;      // ... = 32 sixteen-byte records at the head of every round-1 segment
+// Orders and round-1 records, 16 bytes: {x = dst | tag<<27, y = src | flags<<27, z/w = 64-bit mask}.
+//   tag = 0 : "dst merges src's queue", src on another shard than this record's reader: a pull request.
+//   tag = p+1: the direct probe p of member src at REMOTE target dst, fused: flags bit 0 = the mask is src's
+//             queue (deliver it to dst), bit 1 = dst's Ack arrived: send its queue back into src's slot p.
+constexpr uint32_t ID_BITS = 27, ID_MASK = (1u << ID_BITS) - 1u;   // sharded runs: n_members <= 2^27
+constexpr uint32_t OF_PAYLOAD = 1u, OF_WANTS_ACK = 2u;
 constexpr int MAX_SHARDS = 16;
 struct PeerCounts { uint32_t v[MAX_SHARDS]; };   // received records per peer, passed to kernels by value
 

@@ -130,11 +130,12 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
     uint32_t nfail = 0, nack = 0;
     unsigned payloads = 0, rumors = 0, dfail = 0, preqs = 0, susp = 0, fsusp = 0;
     // a delivery this shard cannot complete alone: the exchange routes it
-    auto emit_order = [&](uint32_t dst, uint32_t src) {
+    auto emit_raw = [&](uint32_t x, uint32_t y, unsigned long long m) {
       const uint32_t pos = atomicAdd(&ordn, 1u);
-      if (pos < s.ord_cap) s.ord[(size_t)blockIdx.x * s.ord_cap + pos] = make_uint2(dst, src);
+      if (pos < s.ord_cap) s.ord[(size_t)blockIdx.x * s.ord_cap + pos] = make_uint4(x, y, (uint32_t)m, (uint32_t)(m >> 32));
       else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_OVF);
     };
+    auto emit_order = [&](uint32_t dst, uint32_t src) { emit_raw(dst, src, 0ull); };
     // "dst merges src's start-of-tick queue", any dst / src (global ids); msrc = minfo[src]
     auto deliver = [&](uint32_t dst, uint32_t src, uint32_t msrc) {
       if (!is_local(s, src)) { emit_order(dst, src); return; }       // the owner of src knows its queue
@@ -186,8 +187,8 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
             const unsigned long long m = mymask & ~(tk2[p].y & ~stale);   // only what the target does not know
             if (m) atomicOr(&s.inmask[dl], m);
             if (expl) pos[p] = atomicAdd(&s.inbox_cnt[dl], 1u);
-          } else {
-            emit_order(picks[p], i);
+          } else if (expl) {
+            emit_order(picks[p], i);                 // my queue as an explicit payload record
           }
         }
       }
@@ -197,11 +198,19 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
           if (ping_ok[p] && is_local(s, picks[p])) push_commit(s, t, picks[p] - s.lo, mi_src(li, mi), pos[p]);
       }
     }
+    // remote targets: ONE record per probe carries my queue's mask (if it says everything) and the request
+    // for the target's queue (if its Ack arrived); the answer lands in my slot p without an atomic
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p) {
+      if (!ping_ok[p] || is_local(s, picks[p])) continue;
+      const uint32_t fl = ((mymask && !(mi & MI_OOW)) ? OF_PAYLOAD : 0u) | (ack_ok[p] ? OF_WANTS_ACK : 0u);
+      if (fl) emit_raw(picks[p] | ((uint32_t)(p + 1) << ID_BITS), i | (fl << ID_BITS), (fl & OF_PAYLOAD) ? mymask : 0ull);
+    }
     // pass 4: the Acks' payloads, pulled by the prober itself
 #pragma unroll
     for (int p = 0; p < PMAX; ++p) {
       if (!ack_ok[p]) continue;
-      if (!is_local(s, picks[p])) { emit_order(i, picks[p]); continue; }   // its owner serves the pull
+      if (!is_local(s, picks[p])) continue;          // asked for above
       const uint32_t pj = mi_pbn(pinfo[p]);
       if (pj) {
         ackacc |= tk2[p].x;
@@ -367,7 +376,13 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     const uint32_t po = s.probe_out[li];
     const uint32_t nsent = po & 31u, nfail = (po >> 5) & 31u, nack = po >> 10;
     const uint32_t cnt = s.inbox_cnt[li];
-    const unsigned long long pushed = s.inmask[li], pulled = s.ackmask[li];
+    const unsigned long long pushed = s.inmask[li];
+    unsigned long long pulled = s.ackmask[li];
+    if (s.n_shards > 1)                              // Ack payloads of remote targets: one slot per probe
+      for (uint32_t p = 0; p < s.P; ++p) {
+        const unsigned long long v = s.ackslot[(size_t)li * s.P + p];
+        if (v) { pulled |= v; s.ackslot[(size_t)li * s.P + p] = 0; }
+      }
     const uint4 hot0 = s.hot[li];
     uint32_t self_inc = hot0.x, thead = hot0.y & 0xFFFFu, tcount = hot0.y >> 16, tnext = hot0.w;
     const uint32_t pcount = mi_pbn(mi), cur = mi_buf(mi);
@@ -630,25 +645,72 @@ __device__ inline void write_xrec(const DevState& s, uint32_t* rec, uint32_t dst
   rec[0] = dst; rec[1] = n;
 }
 
-// What one order {dst, src} needs.  kind 0: pull request to the owner of src (src remote); 1: mask
-// payload / 2: explicit payload to the owner of dst (src local, queue not empty); -1: nothing to send
-// (dropped, or delivered here by do_local).
-struct OrderPlan { int kind; uint32_t peer; bool local; uint32_t msrc; };
-__device__ inline OrderPlan plan_order(const DevState& s, bool use_mask, uint32_t dst, uint32_t src) {
-  OrderPlan pl{-1, 0u, false, 0u};
+// translate a mask over a PEER's dictionary (xls = that dictionary in my numbering, LDS) into my ring
+// positions; entries my masks cannot carry this tick (ids younger than the head) go to a foreign line
+__device__ inline void translate_mask(const uint2* xls, unsigned long long m, bool use_mask, uint32_t H,
+                                      unsigned long long* bits, uint32_t* fl, uint32_t* nf) {
+  while (m) {
+    const uint32_t p = (uint32_t)__ffsll((unsigned long long)m) - 1u;
+    m &= m - 1ull;
+    const uint2 e = xls[p];                          // {slot | rid<<16, key} in my numbering
+    if (e.x == NONE32) continue;                     // cannot happen: the sender set the bit from an entry
+    const uint32_t rid = pe_rid(e.x);
+    if (use_mask && rid_in_ring(rid, H)) *bits |= rid_bit(rid);
+    else if (*nf < (uint32_t)PB_SLOTS) { fl[2 * *nf] = e.x; fl[2 * *nf + 1] = pe_hi(e.y, 1u); (*nf)++; }
+  }
+}
+
+// hand a received payload to local member dst_li: what my masks can carry goes in as a mask -- into the
+// member's Ack slot `tag-1` with a plain store when it answers its own probe, else by atomicOr --, the
+// rest becomes a "foreign line" read through an explicit record
+__device__ inline void ingest_finish(const DevState& s, uint32_t t, unsigned long long stale, uint32_t dst_li, uint32_t tag,
+                                     unsigned long long bits, uint32_t* fl, uint32_t nf, uint32_t fl_index) {
+  if (tag) {
+    if (bits) s.ackslot[(size_t)dst_li * s.P + (tag - 1u)] = bits;
+  } else if (bits) {
+    const unsigned long long m = bits & ~(s.pk[dst_li].y & ~stale);
+    if (m) atomicOr(&s.inmask[dst_li], m);
+  }
+  if (nf) {
+    for (uint32_t e = nf; e < (uint32_t)PB_SLOTS; ++e) { fl[2 * e] = 0; fl[2 * e + 1] = 0; }
+    push(s, t, dst_li, SRC_FOREIGN | fl_index);
+  }
+}
+
+// What one order / round-1 record needs (format: swim_device.h).  kind 0: round-1 record (a pull request
+// to the owner of src, or a fused probe record to the owner of dst); 1: mask payload / 2: explicit payload
+// to `peer` about local member `who`; -1: nothing to send.  local: deliver who's queue to local dst here.
+struct OrderPlan { int kind; uint32_t peer, who, out_dst; bool local, fused_in; uint32_t mwho; };
+__device__ inline OrderPlan plan_order(const DevState& s, bool use_mask, uint4 o) {
+  OrderPlan pl{-1, 0u, 0u, 0u, false, false, 0u};
+  const uint32_t tag = o.x >> ID_BITS, dst = o.x & ID_MASK, src = o.y & ID_MASK, fl = o.y >> ID_BITS;
+  if (tag) {
+    if (is_local(s, src)) { pl.kind = 0; pl.peer = owner_of(s, dst); return pl; }   // my probe of a remote target
+    // a peer's probe of MY member dst: its payload is delivered by the caller; the Ack's payload goes back
+    pl.fused_in = true;
+    if (!(fl & OF_WANTS_ACK)) return pl;
+    pl.who = dst; pl.mwho = s.minfo[dst];
+    if (!mi_pbn(pl.mwho)) return pl;
+    pl.kind = (use_mask && !(pl.mwho & MI_OOW)) ? 1 : 2;
+    pl.peer = owner_of(s, src);
+    pl.out_dst = src | (tag << ID_BITS);
+    return pl;
+  }
   if (!is_local(s, src)) { pl.kind = 0; pl.peer = owner_of(s, src); return pl; }
-  pl.msrc = s.minfo[src];
-  if (!mi_pbn(pl.msrc)) return pl;                  // empty payload: nothing travels
+  pl.who = src; pl.mwho = s.minfo[src];
+  if (!mi_pbn(pl.mwho)) return pl;                  // empty payload: nothing travels
   if (is_local(s, dst)) { pl.local = true; return pl; }
-  pl.kind = (use_mask && !(pl.msrc & MI_OOW)) ? 1 : 2;
+  pl.kind = (use_mask && !(pl.mwho & MI_OOW)) ? 1 : 2;
   pl.peer = owner_of(s, dst);
+  pl.out_dst = dst;
   return pl;
 }
 
-// One block routes the orders [first, first + n) of `list`: pass 1 counts, pass 2 writes.  count = this
-// shard accounts for the payloads (the prober could not: orders that came in as pull requests).
-__device__ inline void route_block(const DevState& s, uint32_t t, AppendCtx* a, BlockCounters* sh, const uint2* list,
-                                   uint32_t n, bool count) {
+// One block routes the records [0, n) of `list`: pass 1 counts, pass 2 writes.  served = the list came in
+// from peer `from` (round 1): this shard accounts for the payloads it serves, and xls holds that peer's
+// dictionary for the masks of fused records.
+__device__ inline void route_block(const DevState& s, uint32_t t, AppendCtx* a, BlockCounters* sh, const uint4* list,
+                                   uint32_t n, bool served, uint32_t from, size_t list_index0, const uint2* xls) {
   const uint32_t Hprev = s.g[G_PREV], H = s.g[G_HEAD];
   const bool use_mask = H - Hprev <= MASK_SLACK;
   const unsigned long long stale = stale_positions(Hprev, H);
@@ -657,8 +719,7 @@ __device__ inline void route_block(const DevState& s, uint32_t t, AppendCtx* a, 
   if (threadIdx.x < 3 * MAX_SHARDS) a->cnt[threadIdx.x / MAX_SHARDS][threadIdx.x % MAX_SHARDS] = 0;
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < n; k += BLOCK) {
-    const uint2 o = list[k];
-    const OrderPlan pl = plan_order(s, use_mask, o.x, o.y);
+    const OrderPlan pl = plan_order(s, use_mask, list[k]);
     if (pl.kind >= 0) atomicAdd(&a->cnt[pl.kind][pl.peer], 1u);
   }
   __syncthreads();
@@ -669,11 +730,19 @@ __device__ inline void route_block(const DevState& s, uint32_t t, AppendCtx* a, 
   }
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < n; k += BLOCK) {
-    const uint2 o = list[k];
-    const OrderPlan pl = plan_order(s, use_mask, o.x, o.y);
-    const uint32_t src_li = o.y - s.lo;
-    if (count && is_local(s, o.y) && mi_pbn(pl.msrc)) { ctr_add(sh, C_PAYLOADS, 1u); ctr_add(sh, C_RUMORS_SEEN, mi_pbn(pl.msrc)); }
-    if (pl.local) deliver_local(s, t, use_mask, stale, o.x - s.lo, src_li, pl.msrc, use_mask ? s.pk[src_li].x : 0ull);
+    const uint4 o = list[k];
+    const OrderPlan pl = plan_order(s, use_mask, o);
+    if (pl.fused_in && ((o.y >> ID_BITS) & OF_PAYLOAD)) {
+      // the Ping's payload of a peer's probe, as a mask over ITS dictionary
+      const size_t fi = (size_t)s.n_shards * ((size_t)s.x_cap + s.p_cap) + (size_t)from * s.r_cap + list_index0 + k;
+      uint32_t* fl = reinterpret_cast<uint32_t*>(s.fl + fi * 4);
+      unsigned long long bits = 0; uint32_t nf = 0;
+      translate_mask(xls, ((unsigned long long)o.w << 32) | o.z, use_mask, H, &bits, fl, &nf);
+      ingest_finish(s, t, stale, (o.x & ID_MASK) - s.lo, 0u, bits, fl, nf, (uint32_t)fi);
+    }
+    const uint32_t who_li = pl.who - s.lo;
+    if (served && mi_pbn(pl.mwho)) { ctr_add(sh, C_PAYLOADS, 1u); ctr_add(sh, C_RUMORS_SEEN, mi_pbn(pl.mwho)); }
+    if (pl.local) deliver_local(s, t, use_mask, stale, (o.x & ID_MASK) - s.lo, who_li, pl.mwho, use_mask ? s.pk[who_li].x : 0ull);
     if (pl.kind < 0) continue;
     const uint32_t pos = a->base[pl.kind][pl.peer] + atomicAdd(&a->cnt[pl.kind][pl.peer], 1u);
     if (pl.kind == 0) {
@@ -681,39 +750,42 @@ __device__ inline void route_block(const DevState& s, uint32_t t, AppendCtx* a, 
       else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_OVF);
     } else if (pl.kind == 1) {
       if (pos < s.p_cap) {
-        const unsigned long long m = s.pk[src_li].x;
-        s.p_send[(size_t)pl.peer * s.p_cap + pos] = make_uint4(o.x, 0u, (uint32_t)m, (uint32_t)(m >> 32));
+        const unsigned long long m = s.pk[who_li].x;
+        s.p_send[(size_t)pl.peer * s.p_cap + pos] = make_uint4(pl.out_dst, 0u, (uint32_t)m, (uint32_t)(m >> 32));
       } else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_OVF);
     } else {
-      if (pos < s.x_cap) write_xrec(s, s.x_send + ((size_t)pl.peer * s.x_cap + pos) * XREC_WORDS, o.x, src_li, pl.msrc);
+      if (pos < s.x_cap) write_xrec(s, s.x_send + ((size_t)pl.peer * s.x_cap + pos) * XREC_WORDS, pl.out_dst, who_li, pl.mwho);
       else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_OVF);
     }
   }
 }
 
-// after probe_kernel: the orders it left.  Source remote -> pull request to its owner; source local ->
-// payload record to the owner of dst.  One block per probe block (its own order region).
+// after probe_kernel: the orders it left.  Fused probe records and pull requests go out in round 1,
+// payloads of local sources for remote members in round 2.  One block per probe block (its own region).
 __global__ __launch_bounds__(BLOCK) void split_kernel(DevState s, uint32_t t) {
   __shared__ BlockCounters sh;
   __shared__ AppendCtx a;
   ctr_init(&sh);
-  route_block(s, t, &a, &sh, s.ord + (size_t)blockIdx.x * s.ord_cap, s.ord_cnt[blockIdx.x], false);
+  route_block(s, t, &a, &sh, s.ord + (size_t)blockIdx.x * s.ord_cap, s.ord_cnt[blockIdx.x], false, 0u, 0, nullptr);
   ctr_flush(s, &sh, blockIdx.x);
 }
 
-// after round 1: the pull requests other shards sent me (their source is mine).  Fixed grid (= nblocks)
-// so that every block owns a counter row; each block takes one contiguous chunk of each peer's list.
+// after round 1: the records other shards sent me.  Fixed grid (= nblocks) so that every block owns a
+// counter row; each block takes one contiguous chunk of each peer's list.
 __global__ __launch_bounds__(BLOCK) void serve_kernel(DevState s, uint32_t t, PeerCounts r_counts) {
   __shared__ BlockCounters sh;
   __shared__ AppendCtx a;
+  __shared__ uint2 xls[DICT_ENTRIES];
   ctr_init(&sh);
   const size_t rstride = DICT_RECS + s.r_cap;
   for (uint32_t peer = 0; peer < s.n_shards; ++peer) {
-    const uint32_t got = r_counts.v[peer];          // dictionary + requests
+    const uint32_t got = r_counts.v[peer];          // dictionary + records
     const uint32_t n = got > DICT_RECS ? min(got - DICT_RECS, s.r_cap) : 0u;
     const uint32_t chunk = (n + gridDim.x - 1) / gridDim.x;
     const uint32_t first = min(n, blockIdx.x * chunk), cnt = min(n - first, chunk);
-    route_block(s, t, &a, &sh, s.r_recv + (size_t)peer * rstride + DICT_RECS + first, cnt, true);
+    __syncthreads();
+    if (threadIdx.x < DICT_ENTRIES) xls[threadIdx.x] = s.xl[(size_t)peer * DICT_ENTRIES + threadIdx.x];
+    route_block(s, t, &a, &sh, s.r_recv + (size_t)peer * rstride + DICT_RECS + first, cnt, true, peer, first, xls);
   }
   ctr_flush(s, &sh, blockIdx.x);
 }
@@ -723,35 +795,21 @@ __global__ __launch_bounds__(BLOCK) void serve_kernel(DevState s, uint32_t t, Pe
 // head, so ingest hands them over through foreign lines until the next tick.
 __global__ void xlat_kernel(DevState s, PeerCounts r_counts) {
   const uint32_t peer = blockIdx.x, p = threadIdx.x;
-  if (p >= DICT_RECS) return;
+  if (p >= DICT_ENTRIES) return;
   uint2 out = make_uint2(NONE32, 0u);
   if (peer != s.shard && r_counts.v[peer] >= DICT_RECS) {
-    const uint2 e = s.r_recv[(size_t)peer * (DICT_RECS + s.r_cap) + p];       // {subject, key}
+    const uint2 e = reinterpret_cast<const uint2*>(s.r_recv + (size_t)peer * (DICT_RECS + s.r_cap))[p];   // {subject, key}
     if (e.x != NONE32) {
       const uint32_t slot = get_slot(s, e.x);
       out = make_uint2(pe_lo(slot, find_rid(s, slot, e.y)), e.y);
     }
   }
-  s.xl[(size_t)peer * DICT_RECS + p] = out;
-}
-
-// hand a received payload to local member dst_li: what my masks can carry is pushed as a mask, the rest
-// becomes a "foreign line" read through an explicit record
-__device__ inline void ingest_finish(const DevState& s, uint32_t t, unsigned long long stale, uint32_t dst_li,
-                                     unsigned long long bits, uint32_t* fl, uint32_t nf, uint32_t fl_index) {
-  if (bits) {
-    const unsigned long long m = bits & ~(s.pk[dst_li].y & ~stale);
-    if (m) atomicOr(&s.inmask[dst_li], m);
-  }
-  if (nf) {
-    for (uint32_t e = nf; e < (uint32_t)PB_SLOTS; ++e) { fl[2 * e] = 0; fl[2 * e + 1] = 0; }
-    push(s, t, dst_li, SRC_FOREIGN | fl_index);
-  }
+  s.xl[(size_t)peer * DICT_ENTRIES + p] = out;
 }
 
 // after round 2: payload records for my members, as masks over the sender's dictionary or as explicit ids
 __global__ __launch_bounds__(BLOCK) void ingest_kernel(DevState s, uint32_t t, PeerCounts p_counts, PeerCounts x_counts) {
-  __shared__ uint2 xls[DICT_RECS];
+  __shared__ uint2 xls[DICT_ENTRIES];
   const uint32_t Hprev = s.g[G_PREV], H = s.g[G_HEAD];
   const bool use_mask = H - Hprev <= MASK_SLACK;
   const unsigned long long stale = stale_positions(Hprev, H);
@@ -760,24 +818,15 @@ __global__ __launch_bounds__(BLOCK) void ingest_kernel(DevState s, uint32_t t, P
     // ---- mask records
     const uint32_t np = min(p_counts.v[peer], s.p_cap);
     __syncthreads();
-    if (threadIdx.x < DICT_RECS) xls[threadIdx.x] = s.xl[(size_t)peer * DICT_RECS + threadIdx.x];
+    if (threadIdx.x < DICT_ENTRIES) xls[threadIdx.x] = s.xl[(size_t)peer * DICT_ENTRIES + threadIdx.x];
     __syncthreads();
     for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < np; k += gridDim.x * BLOCK) {
       const size_t ri = (size_t)peer * s.p_cap + k;
       const uint4 rec = s.p_recv[ri];
-      unsigned long long m = ((unsigned long long)rec.w << 32) | rec.z, bits = 0;
       uint32_t* fl = reinterpret_cast<uint32_t*>(s.fl + (fl_x + ri) * 4);
-      uint32_t nf = 0;
-      while (m) {
-        const uint32_t p = (uint32_t)__ffsll((unsigned long long)m) - 1u;
-        m &= m - 1ull;
-        const uint2 e = xls[p];                                // {slot | rid<<16, key} in my numbering
-        if (e.x == NONE32) continue;                           // cannot happen: the sender set the bit from an entry
-        const uint32_t rid = pe_rid(e.x);
-        if (use_mask && rid_in_ring(rid, H)) bits |= rid_bit(rid);
-        else if (nf < (uint32_t)PB_SLOTS) { fl[2 * nf] = e.x; fl[2 * nf + 1] = pe_hi(e.y, 1u); nf++; }
-      }
-      ingest_finish(s, t, stale, rec.x - s.lo, bits, fl, nf, (uint32_t)(fl_x + ri));
+      unsigned long long bits = 0; uint32_t nf = 0;
+      translate_mask(xls, ((unsigned long long)rec.w << 32) | rec.z, use_mask, H, &bits, fl, &nf);
+      ingest_finish(s, t, stale, (rec.x & ID_MASK) - s.lo, rec.x >> ID_BITS, bits, fl, nf, (uint32_t)(fl_x + ri));
     }
     // ---- explicit records
     const uint32_t nx = min(x_counts.v[peer], s.x_cap);
@@ -795,7 +844,7 @@ __global__ __launch_bounds__(BLOCK) void ingest_kernel(DevState s, uint32_t t, P
         if (use_mask && rid_in_ring(rid, H)) bits |= rid_bit(rid);     // an id of an earlier tick
         else { fl[2 * nf] = pe_lo(slot, rid); fl[2 * nf + 1] = pe_hi(key, 1u); nf++; }
       }
-      ingest_finish(s, t, stale, rec[0] - s.lo, bits, fl, nf, (uint32_t)ri);
+      ingest_finish(s, t, stale, (rec[0] & ID_MASK) - s.lo, 0u, bits, fl, nf, (uint32_t)ri);
     }
   }
 }
@@ -879,11 +928,12 @@ __global__ void begin_kernel(DevState s, uint32_t t, const FaultRec* faults, uin
     for (int k = 0; k < 3 * MAX_SHARDS; ++k) s.send_cnt[k] = 0;
     // this tick's dictionary for the peers: ring position -> {subject, key} of the id that owns it
     const size_t rstride = DICT_RECS + s.r_cap;
-    for (uint32_t p = 0; p < DICT_RECS; ++p) {
+    for (uint32_t p = 0; p < DICT_ENTRIES; ++p) {
       const uint32_t rid = rid_at(p, H);
       uint2 e = make_uint2(NONE32, 0u);
       if (rid < H) { const uint2 r = s.rum[rid & RID_MASK]; e = make_uint2(s.subject_of[r.x], r.y); }   // else: no such id yet
-      for (uint32_t g = 0; g < s.n_shards; ++g) if (g != s.shard) s.r_send[(size_t)g * rstride + p] = e;
+      for (uint32_t g = 0; g < s.n_shards; ++g)
+        if (g != s.shard) reinterpret_cast<uint2*>(s.r_send + (size_t)g * rstride)[p] = e;
     }
   }
 }

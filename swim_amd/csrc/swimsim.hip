@@ -117,6 +117,7 @@ int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, std::string*
   if (c->n_shards == 0) c->n_shards = 1;
   if (c->n_shards > 16 || c->shard_index >= c->n_shards) { *err = "n_shards must be <= 16 and shard_index < n_shards"; return SWIMSIM_ERR_INVALID; }
   if (c->n_members % c->n_shards) { *err = "n_members must be a multiple of n_shards"; return SWIMSIM_ERR_INVALID; }
+  if (c->n_shards > 1 && c->n_members > (1u << 27)) { *err = "sharded clusters: n_members must be <= 2^27"; return SWIMSIM_ERR_INVALID; }
   return SWIMSIM_OK;
 }
 
@@ -286,8 +287,9 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     CK(dev_alloc(h, &d.p_recv, (size_t)d.n_shards * d.p_cap, 0));
     CK(dev_alloc(h, &d.x_send, (size_t)d.n_shards * d.x_cap * XREC_WORDS, 0));
     CK(dev_alloc(h, &d.x_recv, (size_t)d.n_shards * d.x_cap * XREC_WORDS, 0));
-    CK(dev_alloc(h, &d.xl, (size_t)d.n_shards * DICT_RECS, 0xFF));
-    CK(dev_alloc(h, &d.fl, (size_t)d.n_shards * ((size_t)d.x_cap + d.p_cap) * 4, 0));
+    CK(dev_alloc(h, &d.xl, (size_t)d.n_shards * DICT_ENTRIES, 0xFF));
+    CK(dev_alloc(h, &d.fl, (size_t)d.n_shards * ((size_t)d.x_cap + d.p_cap + d.r_cap) * 4, 0));
+    CK(dev_alloc(h, &d.ackslot, (size_t)N * std::max(1u, d.P), 0));
   }
   hipLaunchKernelGGL(init_members_kernel, dim3((std::max(N, NT) + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, d.hot, d.minfo, N, NT);
   HK(hipGetLastError());
@@ -611,7 +613,7 @@ int swimsim_shard_phase2(swimsim_t* h, const uint32_t* r_counts_in, uint32_t* co
   if (!r_counts_in || !counts) return SWIMSIM_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
   const PeerCounts rc_in = peer_counts(h, r_counts_in);
-  hipLaunchKernelGGL(xlat_kernel, dim3(h->d.n_shards), dim3(DICT_RECS), 0, h->stream, h->d, rc_in);
+  hipLaunchKernelGGL(xlat_kernel, dim3(h->d.n_shards), dim3(DICT_ENTRIES), 0, h->stream, h->d, rc_in);
   hipLaunchKernelGGL(serve_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, (uint32_t)h->tick, rc_in);
   rc = finish_phase(h, counts);
   if (rc) return rc;

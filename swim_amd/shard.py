@@ -26,7 +26,7 @@ from .sim import Sim, SwimError
 from .types import SimConfig
 
 _M64 = (1 << 64) - 1
-REC_BYTES = (8, 16, 72)          # record kinds: requests (+dictionary), mask payloads, explicit payloads
+REC_BYTES = (16, 16, 72)         # record kinds: round-1 records (+dictionary), mask payloads, explicit payloads
 
 
 def _wrap(ptr: int, nbytes: int, device):

@@ -183,3 +183,30 @@ def test_million_members_sharded_digest_equals_unsharded(hip_abi):
         s.close()
     assert results[0][1]["changes"] > 10 * n                      # the run really disseminates
     assert results[1] == results[0] and results[2] == results[0]
+
+
+@pytest.mark.parametrize("n", [1 << 10, 1 << 15, 1 << 20])
+def test_dissemination_is_logarithmic(hip_abi, n):
+    """SURVEY 8c known-answer check: infection-style dissemination reaches everybody in O(log N) periods.
+    One member crashes; from its first detection on, count the periods until every live member has
+    changed its entry (Suspect) -- with 2P = 6 payloads per member-period the epidemic needs about
+    log_7 N + a few periods; 2 log2 N is a generous bound that a broken piggyback path cannot meet."""
+    import math
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=7, maxSubjects=16, timerCap=16)
+    s = Sim.create(hip_abi, sc)
+    s.crash(n // 3, 2)
+    s.step(2)
+    detected_at = None
+    for t in range(2, 2 + 4 * int(math.log2(n))):
+        s.step(1)
+        c = s.counters()
+        if detected_at is None and c["suspects"] > 0:
+            detected_at = t
+        if c["changes"] >= n - 1:
+            break
+    else:
+        raise AssertionError("rumour did not reach all %d members" % n)
+    assert detected_at is not None
+    assert t - detected_at <= 2 * math.log2(n), (t, detected_at)
+    assert s.counters()["false_suspects"] == 0
+    s.close()

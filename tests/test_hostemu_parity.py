@@ -65,3 +65,25 @@ def test_explicit_record_paths(oracle_abi):
     faults = [(45, m, True) for (_, m) in crashes[:20]]
     a, b = make_pair(oracle_abi, emu, sc, crashes, faults)
     run_lockstep(a, b, 70, 5, observers=(0, 1, n - 1), members=(0, 1, n - 1))
+
+
+def test_dissemination_is_logarithmic_small(emu_abi):
+    """The O(log N) dissemination check of tests/test_hip_parity.py at a size the emulation handles."""
+    import math
+    n = 2048
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=7, maxSubjects=16, timerCap=16)
+    s = Sim.create(emu_abi, sc)
+    s.crash(n // 3, 2)
+    s.step(2)
+    detected_at, t = None, 2
+    while t < 2 + 4 * int(math.log2(n)):
+        s.step(1)
+        c = s.counters()
+        if detected_at is None and c["suspects"] > 0:
+            detected_at = t
+        if c["changes"] >= n - 1:
+            break
+        t += 1
+    assert detected_at is not None and c["changes"] >= n - 1
+    assert t - detected_at <= 2 * math.log2(n)
+    s.close()
