@@ -73,6 +73,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=150)
     ap.add_argument("--members", type=int, default=N_MEMBERS, help="members per GPU")
     ap.add_argument("--regime", default="saturated", choices=["saturated", "quiescent"])
+    ap.add_argument("--scheme", default="random", choices=["random", "robust"],
+                    help="target scheme of the direct probes: random = the reference's kRandomMembers (the headline); "
+                         "robust = round-robin rotation (src/Core.hs:232 FIXME), reported separately")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -106,6 +109,7 @@ def main():
     else:
         sc, crashes, _ = workloads.quiescent(nt, total, seed=1)
     sc.device = local_rank
+    sc.targetScheme = 1 if args.scheme == "robust" else 0
     exchange = "none (one shard)"
     if world == 1:
         sim = Sim.create(_lib.load(), sc)
@@ -167,7 +171,7 @@ def main():
             "config": {"workload": "config3(%s): %d members/GPU, k=3, ~1 crash per tick (hashed schedule), "
                                    "suspicion %d ticks, retransmit %dx log2 N" % (
                                        args.regime, n, sim.resolved.suspicion_ticks, sim.resolved.retransmit_mult),
-                       "members_per_gpu": n, "num_to_gossip": sim.resolved.num_to_gossip,
+                       "members_per_gpu": n, "num_to_gossip": sim.resolved.num_to_gossip, "target_scheme": args.scheme,
                        "parallelism": "1 GPU" if world == 1 else "ONE cluster of %d members in %d shards (contiguous id ranges, one per GPU); piggyback payloads cross shards in two rounds per tick (%s)" % (nt, world, exchange)},
             "ticks_per_s": args.steps / dt,
             "mean_first_detection_latency_ticks": lat, "crashes_measured": nlat,

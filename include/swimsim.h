@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SWIMSIM_ABI_VERSION 1u
+#define SWIMSIM_ABI_VERSION 2u
 
 /* ---- status codes ------------------------------------------------------ */
 typedef enum swimsim_status {
@@ -98,7 +98,22 @@ typedef struct swimsim_config {
   uint32_t shard_index;        /* this handle owns members [shard_index*n_members/n_shards,
                                   ...) of the population; n_members is the WHOLE population */
   uint32_t n_shards;           /* 0/1 -> unsharded; <= 16, must divide n_members      */
+  uint32_t target_scheme;      /* SWIMSIM_TARGETS_RANDOM (the reference: kRandomMembers,
+                                  src/Core.hs:239) or SWIMSIM_TARGETS_ROBUST (the FIXME at
+                                  src/Core.hs:232 "move from random to robust scheme")   */
 } swimsim_config_t;
+
+/* Target schemes for the direct probes of a period.
+ * RANDOM: numToGossip members drawn uniformly among those Alive in the prober's view (the reference).
+ * ROBUST: the round-robin selection of the SWIM paper (section 4.3) as a population-wide rotation:
+ *   in period t probe p of member i goes to (i + o(t,p)) mod N, where the offsets o run through a
+ *   pseudo-random permutation of 1..N-1 in rounds of ceil((N-1)/numToGossip) periods (DESIGN.md
+ *   section 9).  Every member is probed by exactly numToGossip members per period and every member
+ *   probes every other one once per round: detection time is bounded, and since the pingers of a
+ *   member are computable its Ping payloads are pulled instead of pushed (no atomics).  Targets that
+ *   are not Alive in the prober's view are skipped, proxies stay uniformly random.  Not available on
+ *   sharded handles yet. */
+enum { SWIMSIM_TARGETS_RANDOM = 0, SWIMSIM_TARGETS_ROBUST = 1 };
 
 typedef struct swimsim swimsim_t; /* opaque; owned by the library */
 

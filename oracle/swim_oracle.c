@@ -384,8 +384,49 @@ static void probe_node(swimoracle_t* o, uint32_t i, uint32_t p, uint32_t j) {
     o->first_suspect[j] = (uint32_t)o->tick;
 }
 
+/* The "robust scheme" the reference asks for (FIXME at src/Core.hs:232): the round-robin target
+ * selection of the SWIM paper (section 4.3) as a population-wide rotation (include/swimsim.h,
+ * DESIGN.md section 9).  Rounds of R = ceil((N-1)/P) periods; round r uses a pseudo-random permutation
+ * pi_r of 0..N-2 and probe p of period u of the round has offset 1 + pi_r(u*P + p) (no probe once
+ * u*P + p >= N-1).  pi_r = a keyed bijection on ceil(log2(N-1))-bit words (xor, odd multiplications,
+ * xor-shifts, one addition: each step is invertible) restricted to [0, N-1) by cycle walking.  An
+ * arithmetic progression of offsets would be a permutation too, but its sums barely expand and the
+ * gossip then spreads polynomially instead of exponentially. */
+static uint32_t perm_bits(uint32_t x, uint32_t k1, uint32_t k2, uint32_t bits) {
+  const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : (1u << bits) - 1u, sh = bits / 2 ? bits / 2 : 1;
+  x = (x ^ k1) & mask;
+  x = (x * 0x9E3779B1u) & mask; x ^= x >> sh;
+  x = (x * 0x85EBCA6Bu) & mask; x ^= x >> sh;
+  x = (x + k2) & mask;
+  x = (x * 0xC2B2AE35u) & mask; x ^= x >> sh;
+  return x;
+}
+static void robust_offsets(const swimoracle_t* o, uint32_t t, uint32_t* out) {
+  uint32_t M = o->N - 1, P = o->P ? o->P : 1, R = (M + P - 1) / P, r = t / R, u = t % R;
+  uint32_t rk = tick_key(o->cfg.seed, r);
+  uint32_t k1 = hash_h(rk, 0x524F4255u, 1, 0), k2 = hash_h(rk, 0x524F4255u, 2, 0), bits = ceil_log2(M);
+  for (uint32_t p = 0; p < o->P; p++) {
+    uint64_t k = (uint64_t)u * P + p;
+    if (k >= M) { out[p] = 0; continue; }
+    uint32_t x = (uint32_t)k;
+    if (bits) do x = perm_bits(x, k1, k2, bits); while (x >= M);
+    out[p] = 1 + x;
+  }
+}
+
 /* one period of failureDetector for member i (src/Core.hs:236-240; D14) */
 static void failure_detector(swimoracle_t* o, uint32_t i) {
+  if (o->cfg.target_scheme == SWIMSIM_TARGETS_ROBUST) {
+    uint32_t off[16], n = 0;
+    robust_offsets(o, (uint32_t)o->tick, off);
+    for (uint32_t p = 0; p < o->P; p++) if (off[p] && is_alive_in_view(o, i, (i + off[p]) % o->N)) n++;
+    o->nsent[i] = (uint8_t)n;
+    for (uint32_t p = 0; p < o->P; p++) {
+      uint32_t j = (i + off[p]) % o->N;
+      if (off[p] && is_alive_in_view(o, i, j)) probe_node(o, i, p, j);   /* probe index = rotation index */
+    }
+    return;
+  }
   uint32_t ms[256];
   uint32_t n = k_random_members(o, i, o->P, NULL, 0, P_SELECT, 0, ms);   /* :239 */
   o->nsent[i] = (uint8_t)n;
@@ -663,6 +704,7 @@ static int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, char*
   if (c->event_mask == 0) c->event_mask = SWIMSIM_EVMASK_DEFAULT;
   if (c->n_shards == 0) c->n_shards = 1;
   if (c->n_shards != 1 || c->shard_index != 0) { snprintf(err, errn, "oracle: sharding is driven from outside (n_shards must be 1)"); return SWIMSIM_ERR_INVALID; }
+  if (c->target_scheme > SWIMSIM_TARGETS_ROBUST) { snprintf(err, errn, "unknown target_scheme"); return SWIMSIM_ERR_INVALID; }
   return SWIMSIM_OK;
 }
 

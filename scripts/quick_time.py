@@ -11,6 +11,7 @@ for path in libs:
     abi = _abi.bind(C.CDLL(os.path.abspath(path)), "swimsim_")
     mk = workloads.saturated if REGIME == 'saturated' else workloads.quiescent
     sc, crashes, _ = mk(N, WARM + TICKS)
+    sc.targetScheme = 1 if os.environ.get('SCHEME') == 'robust' else 0
     s = Sim.create(abi, sc); workloads.apply_crashes(s, crashes)
     s.step(WARM)
     s.kernelTimingEnable(True)

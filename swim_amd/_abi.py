@@ -8,11 +8,12 @@ that loading happens in tests/ only, never in this package.
 """
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK = 0
 ERR_INVALID, ERR_DEVICE, ERR_NOMEM, ERR_CAPACITY, ERR_STATE, ERR_BUFFER = -1, -2, -3, -4, -5, -6
 ALIVE, SUSPECT, DEAD = 0, 1, 2
+TARGETS_RANDOM, TARGETS_ROBUST = 0, 1
 CAUSE_PROBE, CAUSE_TIMER, CAUSE_GOSSIP, CAUSE_REFUTE, CAUSE_JOIN = 0, 1, 2, 3, 4
 EVMASK_ALL = 0x1F
 EVMASK_DEFAULT = (1 << CAUSE_PROBE) | (1 << CAUSE_REFUTE) | (1 << CAUSE_JOIN)
@@ -38,6 +39,7 @@ class Config(C.Structure):
         ("timer_cap", C.c_uint32), ("event_cap", C.c_uint32), ("event_mask", C.c_uint32),
         ("inbox_cap", C.c_uint32),
         ("device", C.c_int32), ("shard_index", C.c_uint32), ("n_shards", C.c_uint32),
+        ("target_scheme", C.c_uint32),
     ]
 
 

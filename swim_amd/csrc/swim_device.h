@@ -67,6 +67,7 @@ struct DevState {
   // id (ground truth and the subject -> slot table are replicated on every shard); every other
   // per-member array by LOCAL index.  Hashes, events and digests always use global ids.
   uint32_t N, NT, lo, n_shards, shard;
+  uint32_t scheme;         // SWIMSIM_TARGETS_*: how the direct probes of a period pick their targets
   uint32_t P, K, S, L, loss_thr, R_max, timer_cap, event_cap, event_mask, nblocks;
   uint32_t inbox_cap, ovf_cap;  // per-member delivery slots; exact overflow list capacity
   uint32_t* minfo;         // per member, ONE gather per probe target:
@@ -125,6 +126,7 @@ constexpr uint32_t ID_BITS = 27, ID_MASK = (1u << ID_BITS) - 1u;   // sharded ru
 constexpr uint32_t OF_PAYLOAD = 1u, OF_WANTS_ACK = 2u;
 constexpr int MAX_SHARDS = 16;
 struct PeerCounts { uint32_t v[MAX_SHARDS]; };   // received records per peer, passed to kernels by value
+struct Offsets { uint32_t o[16]; };              // robust scheme: this period's rotation per probe index (0 = none)
 
 // payload record on the wire: {dst (global id), n, n x {subject, key}} -- ids, not slots: every shard
 // has its own slot and rumour-id numbering

@@ -104,7 +104,7 @@ __device__ inline void deliver_local(const DevState& s, uint32_t t, bool use_mas
 }
 
 template <int PMAX>
-__global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, uint32_t tk) {
+__global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, uint32_t tk, Offsets off) {
   __shared__ BlockCounters sh;
   __shared__ uint32_t ordn;                        // deliveries left to the exchange (sharded runs)
   if (threadIdx.x == 0) ordn = 0;
@@ -124,9 +124,31 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
     const uint32_t mycnt = mi_pbn(mi);
     const unsigned long long mymask = (mycnt && use_mask) ? s.pk[li].x : 0ull;
     uint32_t picks[PMAX], pinfo[PMAX];
-    // ms <- kRandomMembers store (numToGossip cfg) []        (src/Core.hs:239)
-    const uint32_t np = select_members<PMAX>(s, mk, i, s.P, P_SELECT, 0, nullptr, 0, picks, pinfo);
-    n_pings = np;
+    bool valid[PMAX];                               // probe index p is in use this period
+    const bool robust = s.scheme == 1u;
+    uint32_t np;                                    // probe indices in play
+    if (!robust) {
+      // ms <- kRandomMembers store (numToGossip cfg) []        (src/Core.hs:239)
+      np = select_members<PMAX>(s, mk, i, s.P, P_SELECT, 0, nullptr, 0, picks, pinfo);
+      n_pings = np;
+#pragma unroll
+      for (int p = 0; p < PMAX; ++p) valid[p] = (uint32_t)p < np;
+    } else {
+      // the "robust scheme" (FIXME at src/Core.hs:232): probe p goes to (i + o(t,p)) mod N -- a rotation
+      // shared by everybody, so that a member's pingers are known to it; targets that are not Alive in
+      // my view are skipped (include/swimsim.h)
+      np = s.P;
+#pragma unroll
+      for (int p = 0; p < PMAX; ++p) {
+        valid[p] = false; picks[p] = 0; pinfo[p] = 0;
+        if ((uint32_t)p < np && off.o[p]) {
+          uint32_t c = i + off.o[p]; if (c >= s.NT) c -= s.NT;
+          picks[p] = c; pinfo[p] = s.minfo[c];
+          valid[p] = view_alive(s, li, pinfo[p]);
+          n_pings += valid[p] ? 1u : 0u;
+        }
+      }
+    }
     uint32_t nfail = 0, nack = 0;
     unsigned payloads = 0, rumors = 0, dfail = 0, preqs = 0, susp = 0, fsusp = 0;
     // a delivery this shard cannot complete alone: the exchange routes it
@@ -159,7 +181,7 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
 #pragma unroll
     for (int p = 0; p < PMAX; ++p) {
       ping_ok[p] = false; ack_ok[p] = false;
-      if ((uint32_t)p < np) {
+      if (valid[p]) {
         ping_ok[p] = mi_up(pinfo[p]) && !lost(s, tk, P_L_PING, i, picks[p], p);
         ack_ok[p] = ping_ok[p] && !lost(s, tk, P_L_ACK, picks[p], i, p);
       }
@@ -182,6 +204,7 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
         pos[p] = 0;
         if (ping_ok[p]) {
           payloads++; rumors += mycnt;
+          if (robust) continue;                      // the target pulls it (below): its pingers are computable
           if (is_local(s, picks[p])) {
             const uint32_t dl = picks[p] - s.lo;
             const unsigned long long m = mymask & ~(tk2[p].y & ~stale);   // only what the target does not know
@@ -192,17 +215,30 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
           }
         }
       }
-      if (expl) {
+      if (expl && !robust) {
 #pragma unroll
         for (int p = 0; p < PMAX; ++p)
           if (ping_ok[p] && is_local(s, picks[p])) push_commit(s, t, picks[p] - s.lo, mi_src(li, mi), pos[p]);
+      }
+    }
+    if (robust) {
+      // the Pings that reach ME this period: probe p of member q = i - o(t,p), if q is up, sees me Alive
+      // and the Ping is not lost.  I merge q's queue: a gather instead of q's atomicOr.
+#pragma unroll
+      for (int p = 0; p < PMAX; ++p) {
+        if ((uint32_t)p >= s.P || !off.o[p]) continue;
+        uint32_t q = i + s.NT - off.o[p]; if (q >= s.NT) q -= s.NT;
+        const uint32_t mq = s.minfo[q];
+        if (!mi_up(mq) || !mi_pbn(mq) || !view_alive(s, q - s.lo, mi) || lost(s, tk, P_L_PING, q, i, p)) continue;
+        if (use_mask) ackacc |= s.pk[q - s.lo].x;
+        if (!use_mask || (mq & MI_OOW)) push(s, t, li, mi_src(q - s.lo, mq));
       }
     }
     // remote targets: ONE record per probe carries my queue's mask (if it says everything) and the request
     // for the target's queue (if its Ack arrived); the answer lands in my slot p without an atomic
 #pragma unroll
     for (int p = 0; p < PMAX; ++p) {
-      if (!ping_ok[p] || is_local(s, picks[p])) continue;
+      if (robust || !ping_ok[p] || is_local(s, picks[p])) continue;
       const uint32_t fl = ((mymask && !(mi & MI_OOW)) ? OF_PAYLOAD : 0u) | (ack_ok[p] ? OF_WANTS_ACK : 0u);
       if (fl) emit_raw(picks[p] | ((uint32_t)(p + 1) << ID_BITS), i | (fl << ID_BITS), (fl & OF_PAYLOAD) ? mymask : 0ull);
     }
@@ -221,7 +257,7 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
     // pass 5 (rare): probes without an ack -> k indirect probes -> maybe Suspect
     for (int p = 0; p < PMAX; ++p) {
       if ((uint32_t)p >= np) break;
-      if (ack_ok[p]) continue;                               // unlessAck (D2, D3)
+      if (!valid[p] || ack_ok[p]) continue;                  // unlessAck (D2, D3)
       const uint32_t j = picks[p], mj = pinfo[p];
       const bool upj = mi_up(mj);
       dfail++;
@@ -258,7 +294,7 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
       if (upj) fsusp++;
       else atomicMin(&s.first_suspect[j], t);
     }
-    s.probe_out[li] = (uint16_t)(np | (nfail << 5) | (nack << 10));
+    s.probe_out[li] = (uint16_t)(n_pings | (nfail << 5) | (nack << 10));
     ctr_add(&sh, C_PAYLOADS, payloads);
     ctr_add(&sh, C_RUMORS_SEEN, rumors);
     ctr_add(&sh, C_DIRECT_FAILED, dfail);

@@ -117,6 +117,8 @@ int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, std::string*
   if (c->n_shards == 0) c->n_shards = 1;
   if (c->n_shards > 16 || c->shard_index >= c->n_shards) { *err = "n_shards must be <= 16 and shard_index < n_shards"; return SWIMSIM_ERR_INVALID; }
   if (c->n_members % c->n_shards) { *err = "n_members must be a multiple of n_shards"; return SWIMSIM_ERR_INVALID; }
+  if (c->target_scheme > SWIMSIM_TARGETS_ROBUST) { *err = "unknown target_scheme"; return SWIMSIM_ERR_INVALID; }
+  if (c->n_shards > 1 && c->target_scheme != SWIMSIM_TARGETS_RANDOM) { *err = "the robust target scheme is not available on sharded handles yet"; return SWIMSIM_ERR_INVALID; }
   if (c->n_shards > 1 && c->n_members > (1u << 27)) { *err = "sharded clusters: n_members must be <= 2^27"; return SWIMSIM_ERR_INVALID; }
   return SWIMSIM_OK;
 }
@@ -173,10 +175,39 @@ int pull_events(swimsim* h) {
   return SWIMSIM_OK;
 }
 
+// The robust scheme's rotations for period t (include/swimsim.h): rounds of
+// R = ceil((N-1)/P) periods; round r uses a pseudo-random permutation pi_r of 0..N-2 (a keyed bijection on
+// ceil(log2(N-1))-bit words -- xor, odd multiplications, xor-shifts, one addition -- restricted to
+// [0, N-1) by cycle walking); probe p of period u of the round has offset 1 + pi_r(u P + p).
+uint32_t perm_bits(uint32_t x, uint32_t k1, uint32_t k2, uint32_t bits) {
+  const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : (1u << bits) - 1u, sh = bits / 2 ? bits / 2 : 1;
+  x = (x ^ k1) & mask;
+  x = (x * 0x9E3779B1u) & mask; x ^= x >> sh;
+  x = (x * 0x85EBCA6Bu) & mask; x ^= x >> sh;
+  x = (x + k2) & mask;
+  x = (x * 0xC2B2AE35u) & mask; x ^= x >> sh;
+  return x;
+}
+Offsets robust_offsets(const swimsim* h, uint32_t t) {
+  Offsets off{};
+  if (h->d.scheme != SWIMSIM_TARGETS_ROBUST) return off;
+  const uint32_t M = h->d.NT - 1, P = std::max(1u, h->d.P), R = (M + P - 1) / P, r = t / R, u = t % R;
+  const uint32_t mk = mix32(tick_key(h->cfg.seed, r) ^ 0x524F4255u);
+  const uint32_t k1 = hash_mk(mk, 1, 0), k2 = hash_mk(mk, 2, 0), bits = ceil_log2(M);
+  for (uint32_t p = 0; p < h->d.P; ++p) {
+    const uint64_t k = (uint64_t)u * P + p;
+    if (k >= M) continue;
+    uint32_t x = (uint32_t)k;
+    if (bits) do x = perm_bits(x, k1, k2, bits); while (x >= M);
+    off.o[p] = 1u + x;
+  }
+  return off;
+}
+
 template <int PMAX>
 void launch_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev) {
   if (ev) (void)hipEventRecord(ev[0], h->stream);
-  hipLaunchKernelGGL((probe_kernel<PMAX>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk);
+  hipLaunchKernelGGL((probe_kernel<PMAX>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, robust_offsets(h, t));
   if (ev) (void)hipEventRecord(ev[1], h->stream);
   hipLaunchKernelGGL(merge_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
   if (ev) (void)hipEventRecord(ev[2], h->stream);
@@ -234,6 +265,7 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   DevState& d = h->d;
   const uint32_t NT = c.n_members, N = NT / c.n_shards;   // N = members owned by this handle
   d.N = N; d.NT = NT; d.lo = c.shard_index * N; d.n_shards = c.n_shards; d.shard = c.shard_index;
+  d.scheme = c.target_scheme;
   d.P = (uint32_t)c.probes_per_tick; d.K = (uint32_t)c.indirect_k; d.S = c.suspicion_ticks;
   d.L = c.retransmit_mult * ceil_log2((uint64_t)NT + 1);
   {
@@ -595,9 +627,9 @@ int swimsim_shard_phase1(swimsim_t* h, uint32_t* counts) {
   const uint32_t tk = tick_key(h->cfg.seed, t);
   if (h->timing) (void)hipEventRecord(h->tick_ev[0], h->stream);
   if (h->d.P <= 4 && h->d.K <= 4)
-    hipLaunchKernelGGL((probe_kernel<4>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk);
+    hipLaunchKernelGGL((probe_kernel<4>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, Offsets{});
   else
-    hipLaunchKernelGGL((probe_kernel<16>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk);
+    hipLaunchKernelGGL((probe_kernel<16>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, Offsets{});
   if (h->timing) (void)hipEventRecord(h->tick_ev[1], h->stream);
   hipLaunchKernelGGL(split_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
   rc = finish_phase(h, counts);

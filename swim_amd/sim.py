@@ -41,6 +41,7 @@ def _to_c_config(sc: SimConfig, shard_index: int = 0, n_shards: int = 1) -> _abi
     c.device = sc.device
     c.shard_index = shard_index
     c.n_shards = n_shards
+    c.target_scheme = sc.targetScheme
     return c
 
 

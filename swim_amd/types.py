@@ -59,6 +59,7 @@ class SimConfig:
     eventMask: int = 0
     inboxCap: int = 0
     device: int = 0
+    targetScheme: int = 0         # 0 = kRandomMembers (reference), 1 = robust round-robin (src/Core.hs:232)
 
 
 def memberName(member_id: int) -> str:

@@ -210,3 +210,17 @@ def test_dissemination_is_logarithmic(hip_abi, n):
     assert t - detected_at <= 2 * math.log2(n), (t, detected_at)
     assert s.counters()["false_suspects"] == 0
     s.close()
+
+
+@pytest.mark.parametrize("n,p,loss,seed", [(777, 3, 0, 1), (4096, 3, 50000, 2), (1000, 10, 150000, 3), (65536, 3, 5000, 4)])
+def test_robust_target_scheme_parity(oracle_abi, hip_abi, n, p, loss, seed):
+    """the robust (round-robin) target scheme (src/Core.hs:232), Ping payloads pulled by
+    the target instead of pushed with atomics: bit-exact against the oracle."""
+    sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, targetScheme=1, eventMask=0x1F if n <= 4096 else 0,
+                   suspicionTicks=7, maxSubjects=min(n, 2048), timerCap=512)
+    crashes = workloads.hashed_crashes(n, seed, 1, 128, 3, 33)
+    a, b = make_pair(oracle_abi, hip_abi, sc, crashes, [(45, crashes[0][1], True)])
+    run_lockstep(a, b, 70, 10, observers=(0, n - 1, crashes[0][1]), members=(0, n - 1, crashes[0][1]))
+    fd = b.firstDetection()
+    if loss == 0:
+        assert all(fd[m] == t for (t, m) in crashes[1:])  # detected in the period of the crash (crashes[0] rejoined)
