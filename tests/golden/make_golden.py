@@ -19,6 +19,9 @@ SPECS = {
                      "faults": [[4, 10, 0], [9, 50, 0]]},
     "churn_n64_k2": {"n": 64, "k": 2, "seed": 9, "loss_ppm": 50000, "suspicion": 6, "ticks": 150, "every": 10,
                      "faults": [[3, 5, 0], [30, 5, 1], [60, 5, 0], [90, 5, 1], [20, 33, 0]]},
+    # the robust (round-robin) target scheme, with loss, a crash and a rejoin
+    "robust_n96_k3": {"n": 96, "k": 3, "seed": 11, "loss_ppm": 100000, "suspicion": 7, "ticks": 120, "every": 10, "scheme": 1,
+                      "faults": [[4, 10, 0], [9, 50, 0], [60, 10, 1]]},
 }
 
 if __name__ == "__main__":
