@@ -44,7 +44,8 @@ typedef enum swimsim_status {
   SWIMSIM_ERR_NOMEM = -3,     /* host or device allocation failed               */
   SWIMSIM_ERR_CAPACITY = -4,  /* a bounded table overflowed (max_subjects,
                                  timer_cap, inbox overflow list, incarnation
-                                 bits); the handle is poisoned afterwards       */
+                                 bits, shard exchange buffers); the handle is
+                                 poisoned afterwards                            */
   SWIMSIM_ERR_STATE = -5,     /* call not valid in this state (poisoned handle) */
   SWIMSIM_ERR_BUFFER = -6     /* caller buffer too small (n_out has the need)   */
 } swimsim_status;

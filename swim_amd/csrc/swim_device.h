@@ -26,7 +26,7 @@ enum : uint64_t { TAG_SELF = 0x53454c46u, TAG_VIEW = 0x56494557u, TAG_PB = 0x504
 // globals word indices (DevState::g)
 enum { G_NSLOTS = 0, G_ERR = 1, G_EVCUR = 2, G_OVF0 = 3, G_OVF1 = 4, G_NRUM = 5, G_HEAD = 6, G_PREV = 7,
        G_SEND = 16 /* [3][16] exchange records appended per peer (send_cnt) */, G_WORDS = 64 };
-enum { ERRF_SUBJECTS = 1, ERRF_TIMERS = 2, ERRF_OVF = 4, ERRF_INC = 8 };
+enum { ERRF_SUBJECTS = 1, ERRF_TIMERS = 2, ERRF_OVF = 4, ERRF_INC = 8, ERRF_XCHG = 16 };
 
 // counter slots (same order as SWIMSIM_CTR_* in include/swimsim.h)
 enum { C_PINGS = 0, C_DIRECT_FAILED, C_PING_REQS, C_SUSPECTS, C_FALSE_SUSPECTS, C_PAYLOADS,

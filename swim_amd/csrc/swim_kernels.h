@@ -155,7 +155,7 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
     auto emit_raw = [&](uint32_t x, uint32_t y, unsigned long long m) {
       const uint32_t pos = atomicAdd(&ordn, 1u);
       if (pos < s.ord_cap) s.ord[(size_t)blockIdx.x * s.ord_cap + pos] = make_uint4(x, y, (uint32_t)m, (uint32_t)(m >> 32));
-      else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_OVF);
+      else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG);
     };
     auto emit_order = [&](uint32_t dst, uint32_t src) { emit_raw(dst, src, 0ull); };
     // "dst merges src's start-of-tick queue", any dst / src (global ids); msrc = minfo[src]
@@ -783,15 +783,15 @@ __device__ inline void route_block(const DevState& s, uint32_t t, AppendCtx* a, 
     const uint32_t pos = a->base[pl.kind][pl.peer] + atomicAdd(&a->cnt[pl.kind][pl.peer], 1u);
     if (pl.kind == 0) {
       if (pos < s.r_cap) s.r_send[(size_t)pl.peer * rstride + DICT_RECS + pos] = o;
-      else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_OVF);
+      else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG);
     } else if (pl.kind == 1) {
       if (pos < s.p_cap) {
         const unsigned long long m = s.pk[who_li].x;
         s.p_send[(size_t)pl.peer * s.p_cap + pos] = make_uint4(pl.out_dst, 0u, (uint32_t)m, (uint32_t)(m >> 32));
-      } else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_OVF);
+      } else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG);
     } else {
       if (pos < s.x_cap) write_xrec(s, s.x_send + ((size_t)pl.peer * s.x_cap + pos) * XREC_WORDS, pl.out_dst, who_li, pl.mwho);
-      else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_OVF);
+      else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG);
     }
   }
 }

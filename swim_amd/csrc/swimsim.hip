@@ -132,6 +132,7 @@ int check_device_errors(swimsim* h) {
     if (g[G_ERR] & ERRF_TIMERS) m += " timer_cap";
     if (g[G_ERR] & ERRF_OVF) m += " inbox-overflow-list";
     if (g[G_ERR] & ERRF_INC) m += " incarnation-bits";
+    if (g[G_ERR] & ERRF_XCHG) m += " shard-exchange-buffers";
     return set_err(h, SWIMSIM_ERR_CAPACITY, m);
   }
   return SWIMSIM_OK;
