@@ -172,7 +172,9 @@ enum {
   SWIMSIM_CTR_PB_WRITES = 8,      /* c: piggyback buffers rewritten                      */
   SWIMSIM_CTR_TIMERS_FIRED = 9,   /* Suspect -> Dead by timeout                          */
   SWIMSIM_CTR_REFUTES = 10,       /* incarnation bumps (src/Core.hs:155-166)             */
-  SWIMSIM_CTR_EVENTS_DROPPED = 11,/* events lost to a full ring                          */
+  SWIMSIM_CTR_EVENTS_DROPPED = 11,/* events lost to a full ring (counted before the per-(tick,
+                                     observer, subject) collapse: once the ring overflows the
+                                     exact count is implementation-defined, not protocol state) */
   SWIMSIM_CTR_ACTIVE_MEMBERS = 12,/* up-member ticks actually processed                  */
   SWIMSIM_CTR_EVDIGEST = 13,      /* running digest of every view / incarnation change   */
   SWIMSIM_CTR_COUNT = 16
