@@ -127,6 +127,8 @@ def main():
         torch.cuda.synchronize()
 
     sim.step(args.warmup)
+    if world > 1:
+        sim.phaseBreakdown(reset=True)
     c0 = sim.counters()
     sim.kernelTimingEnable(True)
     barrier()
@@ -186,6 +188,8 @@ def main():
                                         "achieved_GBs": a_tot * n / t_tot / 1e9 if t_tot > 0 else 0.0,
                                         "frac": (a_tot * n / t_tot / 1e9 / HBM_PEAK_GBS) if t_tot > 0 else 0.0}},
         }
+        if world > 1:
+            out["shard_tick_breakdown_us_rank0"] = sim.phaseBreakdown()      # where a sharded tick goes (host view)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -225,6 +225,8 @@ class ShardedSim:
         self.n_local = self.shards[0].n_local
         self.resolved = self.shards[0].sim.resolved
         self._fd_synced_at = -1
+        self.phase_seconds = [0.0] * 5          # host-side wall time per step part: phase1, round1, phase2, round2, phase3
+        self.timed_ticks = 0
 
     def close(self):
         for s in self.shards:
@@ -241,13 +243,33 @@ class ShardedSim:
     # -- the hot path ------------------------------------------------------------------------------------
     def step(self, nticks: int = 1):
         f, sh = self.fabric, self.shards
+        import time
+        acc = self.phase_seconds
         for _ in range(nticks):
+            t0 = time.perf_counter()
             c1 = [s.phase1() for s in sh]
+            t1 = time.perf_counter()
             r_in = f.exchange(sh, (0,), [[c[0]] for c in c1])                       # round 1
+            t2 = time.perf_counter()
             c2 = [s.phase2(r_in[k][0]) for k, s in enumerate(sh)]
+            t3 = time.perf_counter()
             px_in = f.exchange(sh, (1, 2), [[c[1], c[2]] for c in c2])              # round 2
+            t4 = time.perf_counter()
             for k, s in enumerate(sh):
                 s.phase3(px_in[k][0], px_in[k][1])
+            t5 = time.perf_counter()
+            for j, d in enumerate((t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
+                acc[j] += d
+            self.timed_ticks += 1
+
+    def phaseBreakdown(self, reset=False):
+        """Mean host-side wall time (us) per tick of phase1 / round 1 / phase2 / round 2 / phase3 since the last reset."""
+        n = max(1, self.timed_ticks)
+        out = {k: round(v / n * 1e6, 1) for k, v in zip(("phase1", "round1", "phase2", "round2", "phase3"), self.phase_seconds)}
+        if reset:
+            self.phase_seconds = [0.0] * 5
+            self.timed_ticks = 0
+        return out
 
     @property
     def tick(self) -> int:
