@@ -50,6 +50,7 @@ data SimConfig = SimConfig
   , simRetransmitMult :: Word32   -- 0 = 3
   , simMaxSubjects    :: Word32
   , simDevice         :: Int32
+  , simTargetScheme   :: Word32   -- 0 = kRandomMembers (the reference), 1 = robust round-robin (src/Core.hs:232 FIXME)
   }
 
 data SwimsimT
@@ -79,7 +80,7 @@ foreign import ccall safe   "swimsim_shard_phase2"  c_shard_phase2  :: Ptr Swims
 foreign import ccall safe   "swimsim_shard_phase3"  c_shard_phase3  :: Ptr SwimsimT -> Ptr Word32 -> Ptr Word32 -> IO CInt
 
 defaultSimConfig :: Config -> SimConfig
-defaultSimConfig c = SimConfig c 128 1 0 0 0 0 0
+defaultSimConfig c = SimConfig c 128 1 0 0 0 0 0 0
 
 memberNameOf :: Word32 -> String
 memberNameOf i = 'm' : show i
@@ -98,6 +99,7 @@ configureSim SimConfig{..} =
     pokeByteOff p 56 simRetransmitMult
     pokeByteOff p 60 simMaxSubjects
     pokeByteOff p 80 simDevice
+    pokeByteOff p 92 simTargetScheme
     rc <- c_create p ph
     if rc /= 0
       then Left <$> (c_last_error nullPtr >>= peekCString)
