@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SWIMSIM_ABI_VERSION 2u
+#define SWIMSIM_ABI_VERSION 3u
 
 /* ---- status codes ------------------------------------------------------ */
 typedef enum swimsim_status {
@@ -43,9 +43,9 @@ typedef enum swimsim_status {
   SWIMSIM_ERR_DEVICE = -2,    /* no GPU, HIP error                              */
   SWIMSIM_ERR_NOMEM = -3,     /* host or device allocation failed               */
   SWIMSIM_ERR_CAPACITY = -4,  /* a bounded table overflowed (max_subjects,
-                                 timer_cap, inbox overflow list, incarnation
-                                 bits, shard exchange buffers); the handle is
-                                 poisoned afterwards                            */
+                                 inbox overflow list, incarnation bits, shard
+                                 exchange buffers); the handle is poisoned
+                                 afterwards                                     */
   SWIMSIM_ERR_STATE = -5,     /* call not valid in this state (poisoned handle) */
   SWIMSIM_ERR_BUFFER = -6     /* caller buffer too small (n_out has the need)   */
 } swimsim_status;
@@ -88,8 +88,14 @@ typedef struct swimsim_config {
   uint32_t loss_ppm;           /* per-message loss probability, parts per million     */
   uint32_t suspicion_ticks;    /* Suspect -> Dead timeout (D4); 0 -> 3*ceil(log2 N)   */
   uint32_t retransmit_mult;    /* piggyback budget L = mult*ceil(log2(N+1)) (D5); 0->3 */
-  uint32_t max_subjects;       /* capacity of the rumour-subject table; 0 -> default  */
-  uint32_t timer_cap;          /* pending suspicion timers per member; 0 -> 64        */
+  uint32_t max_subjects;       /* subjects with a live view column at one time (columns are
+                                  reclaimed by settling, gc_ticks); 0 -> min(N, 1024)    */
+  uint32_t gc_ticks;           /* settling horizon G (`removeDeadNodes`, src/Core.hs:65-67, plus
+                                  the push-pull anti-entropy the reference leaves commented out,
+                                  src/Types.hs:165,177): a subject nobody has changed its mind
+                                  about for G periods is reconciled and its view column
+                                  reclaimed.  0 -> off, SWIMSIM_GC_AUTO -> the minimum
+                                  suspicion_ticks + L + 2; smaller values are refused         */
   uint32_t event_cap;          /* event ring capacity; 0 -> 1<<20                     */
   uint32_t event_mask;         /* bit per SWIMSIM_CAUSE_*; 0 -> SWIMSIM_EVMASK_DEFAULT */
   uint32_t inbox_cap;          /* per-member delivery slots per tick; 0 -> sized from the
@@ -103,6 +109,20 @@ typedef struct swimsim_config {
                                   src/Core.hs:239) or SWIMSIM_TARGETS_ROBUST (the FIXME at
                                   src/Core.hs:232 "move from random to robust scheme")   */
 } swimsim_config_t;
+
+#define SWIMSIM_GC_AUTO 0xFFFFFFFFu
+
+/* Settling (gc_ticks = G > 0).  At the end of tick t, every subject s with a
+ * view column whose last change in ANY view (or last announcement: refutation, join) is older than
+ * t - G is settled: k* = the largest entry about s among the members that are up (the value their
+ * views would converge to under push-pull anti-entropy), base(s) := max(base(s), k*), and every
+ * member's entry about s returns to the default -- which from then on means base(s), not Alive@0.  A
+ * settled Dead subject is thereby removed from every member map (`removeDeadNodes`) and survives only
+ * as a population-wide tombstone (never picked, rumours at its incarnation ignored, an Alive at a
+ * higher incarnation re-adds it); a settled Alive@i subject stays listed with since_tick = the settling
+ * tick.  Nothing is settled while a member that is up still holds it Suspect.  The column is reusable
+ * two ticks later.  G >= suspicion_ticks + L + 2 guarantees that no piggyback queue and no pending
+ * timer of an up member refers to s any more.  Not available on sharded handles yet. */
 
 /* Target schemes for the direct probes of a period.
  * RANDOM: numToGossip members drawn uniformly among those Alive in the prober's view (the reference).
@@ -177,6 +197,7 @@ enum {
                                      exact count is implementation-defined, not protocol state) */
   SWIMSIM_CTR_ACTIVE_MEMBERS = 12,/* up-member ticks actually processed                  */
   SWIMSIM_CTR_EVDIGEST = 13,      /* running digest of every view / incarnation change   */
+  SWIMSIM_CTR_SETTLED = 15,       /* subjects settled (view columns reclaimed; gc_ticks) */
   SWIMSIM_CTR_COUNT = 16
 };
 
@@ -199,8 +220,12 @@ const char* swimsim_last_error(const swimsim_t* h);
 /* ---- fault injection (the simulator owns ground truth) */
 
 /* Member `member` is down (up=0) / up again (up=1) FOR tick `tick` and after.
- * `tick` must be >= the current tick.  Coming back up bumps the member's
- * incarnation and announces Alive (cause JOIN). */
+ * `tick` must be >= the current tick.  Going down loses the process's volatile
+ * protocol state: its piggyback queue is dropped (the member map and its
+ * suspicion deadlines are kept -- they stand for the state a restarted node
+ * pulls from its join host).  Coming back up bumps the member's incarnation,
+ * announces Alive (cause JOIN) and fires the suspicion deadlines that passed
+ * while it was down. */
 int swimsim_schedule_fault(swimsim_t* h, uint64_t tick, uint32_t member, uint8_t up);
 
 /* ---- the hot path -------------------------------------------------------- */
@@ -222,7 +247,8 @@ int swimsim_tick(const swimsim_t* h, uint64_t* tick);
 int swimsim_drain_events(swimsim_t* h, swimsim_event_t* buf, size_t cap, size_t* n_out);
 
 /* Non-default entries of `observer`'s member map, sorted by subject: replaces
- * `members` (src/Core.hs:76-77) / `readTVar storeMembers`. */
+ * `members` (src/Core.hs:76-77) / `readTVar storeMembers`.  Every member not
+ * listed is Alive at incarnation 0 -- or was removed as Dead by settling. */
 int swimsim_read_view(swimsim_t* h, uint32_t observer, swimsim_view_entry_t* buf,
                       size_t cap, size_t* n_out);
 

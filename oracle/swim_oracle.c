@@ -18,11 +18,14 @@
  *      this phase order: suspicion timers, own failed probes, received rumours;
  *      each applied with the commutative merge `max (incarnation, state)`.
  *   3. changed entries become rumours in the member's piggyback buffer.
+ *   4. settling (gc_ticks; `removeDeadNodes`, src/Core.hs:65-67): subjects nobody has changed its mind
+ *      about for G ticks are reconciled and their view columns reclaimed (settle()).
  * The outcome of a tick does not depend on the order in which members or
  * messages are processed (property-tested via swimoracle_set_shuffle).
  */
 #include "swim_oracle.h"
 
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -39,7 +42,8 @@ enum { P_SELECT = 1, P_PROXY = 2, P_L_PING = 3, P_L_ACK = 4, P_L_REQ = 5,
 
 enum { TAG_SELF = 0x53454c46u, TAG_VIEW = 0x56494557u, TAG_PB = 0x50425546u,
        TAG_TIMER = 0x54494d52u, TAG_FD = 0x46444554u, TAG_EV = 0x45564e54u,
-       TAG_INC = 0x494e4352u, TAG_TICK = 0x5449434bu, TAG_MEMBER = 0x4d454d42u };
+       TAG_INC = 0x494e4352u, TAG_TICK = 0x5449434bu, TAG_MEMBER = 0x4d454d42u,
+       TAG_BASE = 0x42415345u };
 
 #define NONE32 0xFFFFFFFFu
 
@@ -92,6 +96,25 @@ typedef struct {
   int via_proxy;      /* hop class: 0 = direct ping/ack, 1 = proxied               */
 } omsg_t;
 
+typedef struct { opend_t* v; size_t n, cap; } opendv_t;
+
+/* Worker context.  A tick is two parallel phases over contiguous member ranges (Jacobi semantics make
+ * both embarrassingly parallel): A = every up member's failureDetector period (reads start-of-tick
+ * state only; delivered rumours are appended to per-destination-range lists), B = every member's end of
+ * tick (touches only its own state).  One worker = the single-threaded oracle; swimoracle_set_threads
+ * adds workers for the CPU baseline and for oracle-checked runs at full size.  Results do not depend on
+ * the number of workers (tests/test_oracle_semantics.py). */
+typedef struct octx {
+  struct swimoracle* o;
+  uint32_t w, lo, hi;       /* worker index, member range [lo, hi) */
+  uint64_t counters[SWIMSIM_CTR_COUNT];
+  opendv_t* out;            /* [nworkers] rumours delivered this tick, by destination range */
+  ofail_t* fails; size_t nfails, fails_cap;
+  swimsim_event_t* events; size_t nevents, events_cap;
+  opend_t* sorted; size_t sorted_cap; uint32_t* off;   /* phase B: this range's rumours by receiver */
+  int ctx_acked;            /* probe context (processing is synchronous, depth first) */
+} octx_t;
+
 struct swimoracle {
   swimsim_config_t cfg;     /* resolved */
   uint32_t N, P, K, S, L, loss_thr;
@@ -103,25 +126,31 @@ struct swimoracle {
   otimerq_t* timers;
   uint8_t* nsent;
   /* sparse views: slot-major columns over the subjects anyone ever gossiped about */
-  uint32_t* slot_of;        /* subject -> slot+1, 0 = none (view entry = Alive@0)  */
+  uint32_t* slot_of;        /* subject -> slot+1, 0 = none (view entry = the default)   */
   uint32_t* subject_of;
   oentry_t** cols;
   uint32_t nslots, slots_cap;
+  uint32_t nlive;           /* columns in use (max_subjects bounds this)               */
+  uint32_t* free_at;        /* [slot] NONE32 = in use, else the tick from which the column may be reused */
+  /* settling (gc_ticks): the default entry about s is base[s] (0 = Alive@0), settled at base_since[s] */
+  uint32_t G;
+  uint32_t* base; uint32_t* base_since;
+  uint32_t* last_change;    /* [subject] last tick any view entry about it changed / it announced itself */
+  int literal_rule;         /* oracle-only: apply the LITERAL suspectOrDeadNode' instead of the merge */
+  uint64_t d13_hits;        /* proposals on which the literal rule and the merge disagree            */
   /* fault schedule */
   ofault_t* faults; size_t nfaults, faults_cap; uint32_t fault_order;
   uint32_t* first_suspect;  /* NONE32 = never */
   uint32_t* crash_tick;
-  /* per-tick scratch */
-  opend_t* pend; size_t npend, pend_cap;
-  opend_t* pend_sorted; size_t pend_sorted_cap;
-  uint32_t* pend_off;       /* N+1 */
-  ofail_t* fails; size_t nfails, fails_cap;
+  /* workers */
+  octx_t* ctx; uint32_t nworkers, chunk;      /* member m belongs to worker m / chunk */
+  pthread_t* threads; pthread_barrier_t bar; int phase; int quit;
+  pthread_mutex_t mu;       /* slot allocation, error text */
   /* events */
   swimsim_event_t* events; size_t nevents, events_cap_alloc;
   uint64_t counters[SWIMSIM_CTR_COUNT];
   uint64_t shuffle_seed;
-  /* probe / capture context (processing is synchronous, depth first) */
-  int ctx_acked;
+  /* capture mode (unit-level hook swimoracle_process) */
   int capture; int capture_literal_d8;
   swimoracle_msg_t* cap_out; size_t cap_cap, cap_n;
   int poisoned;
@@ -131,8 +160,12 @@ struct swimoracle {
 static char g_create_err[256];
 
 static int fail(swimoracle_t* o, int code, const char* msg) {
-  if (o) { snprintf(o->err, sizeof o->err, "%s", msg); if (code == SWIMSIM_ERR_CAPACITY) o->poisoned = 1; }
-  else snprintf(g_create_err, sizeof g_create_err, "%s", msg);
+  if (o) {
+    pthread_mutex_lock(&o->mu);
+    snprintf(o->err, sizeof o->err, "%s", msg);
+    if (code == SWIMSIM_ERR_CAPACITY) __atomic_store_n(&o->poisoned, 1, __ATOMIC_RELAXED);
+    pthread_mutex_unlock(&o->mu);
+  } else snprintf(g_create_err, sizeof g_create_err, "%s", msg);
   return code;
 }
 
@@ -154,27 +187,42 @@ int swimoracle_default_config(swimsim_config_t* cfg) {
 /* ------------------------------------------------------------------------- */
 /* views                                                                      */
 /* ------------------------------------------------------------------------- */
+/* member i's entry about s; the default (no column, or an untouched cell) is the settled base --
+ * Alive@0 until s is settled for the first time */
 static inline oentry_t view_get(const swimoracle_t* o, uint32_t i, uint32_t s) {
-  oentry_t z = {0, 0};
-  uint32_t sl = o->slot_of[s];
-  return sl ? o->cols[sl - 1][i] : z;
+  oentry_t z = {o->base[s], 0};
+  uint32_t sl = __atomic_load_n(&o->slot_of[s], __ATOMIC_ACQUIRE);
+  if (!sl) return z;
+  oentry_t e = o->cols[sl - 1][i];
+  return e.key ? e : z;
 }
 
+/* cell of member i about subject s, the subject's column created on first use (cols / subject_of are
+ * allocated once for every possible column, so readers never see them move).  A cell with key 0 is
+ * "default": callers compare against view_get. */
 static oentry_t* view_ref(swimoracle_t* o, uint32_t i, uint32_t s) {
-  uint32_t sl = o->slot_of[s];
+  uint32_t sl = __atomic_load_n(&o->slot_of[s], __ATOMIC_ACQUIRE);
   if (!sl) {
-    if (o->nslots >= o->cfg.max_subjects) { fail(o, SWIMSIM_ERR_CAPACITY, "max_subjects exceeded"); return NULL; }
-    if (o->nslots == o->slots_cap) {
-      uint32_t nc = o->slots_cap ? o->slots_cap * 2 : 16;
-      o->cols = (oentry_t**)realloc(o->cols, nc * sizeof *o->cols);
-      o->subject_of = (uint32_t*)realloc(o->subject_of, nc * sizeof *o->subject_of);
-      o->slots_cap = nc;
+    pthread_mutex_lock(&o->mu);
+    sl = o->slot_of[s];
+    if (!sl && o->nlive < o->cfg.max_subjects) {
+      uint32_t t = (uint32_t)o->tick, pick = NONE32;
+      for (uint32_t r = 0; r < o->nslots; r++)             /* a reclaimed column, if one is reusable */
+        if (o->free_at[r] != NONE32 && o->free_at[r] <= t) { pick = r; break; }
+      if (pick == NONE32 && o->nslots < o->slots_cap) {
+        oentry_t* col = (oentry_t*)calloc(o->N, sizeof(oentry_t));
+        if (col) { pick = o->nslots++; o->cols[pick] = col; }
+      }
+      if (pick != NONE32) {
+        o->free_at[pick] = NONE32;
+        o->subject_of[pick] = s;
+        o->nlive++;
+        sl = pick + 1;
+        __atomic_store_n(&o->slot_of[s], sl, __ATOMIC_RELEASE);
+      }
     }
-    o->cols[o->nslots] = (oentry_t*)calloc(o->N, sizeof(oentry_t));
-    if (!o->cols[o->nslots]) { fail(o, SWIMSIM_ERR_NOMEM, "out of memory (view column)"); return NULL; }
-    o->subject_of[o->nslots] = s;
-    o->slot_of[s] = ++o->nslots;
-    sl = o->nslots;
+    pthread_mutex_unlock(&o->mu);
+    if (!sl) { fail(o, SWIMSIM_ERR_CAPACITY, "max_subjects exceeded"); return NULL; }
   }
   return &o->cols[sl - 1][i];
 }
@@ -235,25 +283,27 @@ static inline int lost(const swimoracle_t* o, uint32_t purpose, uint32_t src, ui
   return hash_h(o->tk, src, (purpose << 24) | idx, dst) < o->loss_thr;
 }
 
-static void pend_add(swimoracle_t* o, uint32_t dst, uint32_t subject, uint32_t key) {
-  if (o->npend == o->pend_cap) {
-    o->pend_cap = o->pend_cap ? o->pend_cap * 2 : 1024;
-    o->pend = (opend_t*)realloc(o->pend, o->pend_cap * sizeof *o->pend);
+static void pend_add(octx_t* c, uint32_t dst, uint32_t subject, uint32_t key) {
+  opendv_t* q = &c->out[dst / c->o->chunk];
+  if (q->n == q->cap) {
+    q->cap = q->cap ? q->cap * 2 : 1024;
+    q->v = (opend_t*)realloc(q->v, q->cap * sizeof *q->v);
   }
-  o->pend[o->npend].dst = dst; o->pend[o->npend].subject = subject; o->pend[o->npend].key = key;
-  o->npend++;
+  q->v[q->n].dst = dst; q->v[q->n].subject = subject; q->v[q->n].key = key;
+  q->n++;
 }
 
-static void process(swimoracle_t* o, uint32_t self, uint32_t sender, const omsg_t* msg);
+static void process(octx_t* c, uint32_t self, uint32_t sender, const omsg_t* msg);
 
 /* A datagram src -> dst: the control message plus the sender's start-of-tick
  * piggyback buffer as a compound envelope (src/Types.hs:96-119; D5, D11). */
-static int deliver(swimoracle_t* o, uint32_t purpose, uint32_t src, uint32_t dst, const omsg_t* msg) {
+static int deliver(octx_t* c, uint32_t purpose, uint32_t src, uint32_t dst, const omsg_t* msg) {
+  swimoracle_t* o = c->o;
   if (lost(o, purpose, src, dst, msg->lidx)) return 0;
   if (!o->up[dst]) return 0;                      /* nobody listening */
   const opb_t* pb = &o->pb[src];
   if (pb->n > 0) {
-    o->counters[SWIMSIM_CTR_PAYLOADS]++;
+    c->counters[SWIMSIM_CTR_PAYLOADS]++;
     for (int s = 0; s < pb->n; s++) {             /* handleUDPMessage: CC.concat over the envelope */
       omsg_t r; memset(&r, 0, sizeof r);
       uint32_t st = key_state(pb->r[s].key);
@@ -261,11 +311,11 @@ static int deliver(swimoracle_t* o, uint32_t purpose, uint32_t src, uint32_t dst
       r.m.incarnation = key_inc(pb->r[s].key);
       r.m.node = pb->r[s].subject;
       r.relay_to = NONE32;
-      o->counters[SWIMSIM_CTR_RUMORS_SEEN]++;
-      process(o, dst, src, &r);
+      c->counters[SWIMSIM_CTR_RUMORS_SEEN]++;
+      process(c, dst, src, &r);
     }
   }
-  process(o, dst, src, msg);
+  process(c, dst, src, msg);
   return 1;
 }
 
@@ -274,19 +324,20 @@ static void emit(swimoracle_t* o, const swimoracle_msg_t* m) {
   o->cap_n++;
 }
 
-static int accept_key(swimoracle_t* o, uint32_t i, uint32_t s, uint32_t key, uint8_t cause,
+static int accept_key(octx_t* c, uint32_t i, uint32_t s, uint32_t key, uint8_t cause,
                       uint32_t* refute_inc, opb_t* cand, uint32_t self_inc_start);
 
 /* `process sender msg` (src/Core.hs:89-117) */
-static void process(swimoracle_t* o, uint32_t self, uint32_t sender, const omsg_t* msg) {
+static void process(octx_t* c, uint32_t self, uint32_t sender, const omsg_t* msg) {
+  swimoracle_t* o = c->o;
   switch (msg->m.type) {
     case SWIMO_MSG_ACK:                                    /* src/Core.hs:92-94 */
       if (o->capture) return;                              /* `return []` */
       if (msg->relay_to != NONE32) {                       /* proxy relays the ack (D9) */
         omsg_t a = *msg; a.relay_to = NONE32;
-        deliver(o, P_L_RELAY, self, msg->relay_to, &a);
+        deliver(c, P_L_RELAY, self, msg->relay_to, &a);
       } else {
-        o->ctx_acked = 1;                                  /* invokeAckHandler (src/Core.hs:220-221) */
+        c->ctx_acked = 1;                                  /* invokeAckHandler (src/Core.hs:220-221) */
       }
       return;
     case SWIMO_MSG_PING:                                   /* src/Core.hs:97-101 */
@@ -295,7 +346,7 @@ static void process(swimoracle_t* o, uint32_t self, uint32_t sender, const omsg_
         a.m.type = SWIMO_MSG_ACK; a.m.seq_no = msg->m.seq_no; a.m.to = sender;
         a.relay_to = msg->relay_to; a.lidx = msg->lidx; a.via_proxy = msg->via_proxy;
         if (o->capture) { emit(o, &a.m); return; }
-        deliver(o, msg->via_proxy ? P_L_BACK : P_L_ACK, self, sender, &a);
+        deliver(c, msg->via_proxy ? P_L_BACK : P_L_ACK, self, sender, &a);
       }
       return;                                              /* not for us: [] */
     case SWIMO_MSG_INDIRECT_PING: {                        /* src/Core.hs:105-108 */
@@ -310,7 +361,7 @@ static void process(swimoracle_t* o, uint32_t self, uint32_t sender, const omsg_
       }
       p.relay_to = sender; p.lidx = msg->lidx; p.via_proxy = 1;
       if (o->capture) { emit(o, &p.m); return; }
-      deliver(o, P_L_FWD, self, msg->m.target, &p);
+      deliver(c, P_L_FWD, self, msg->m.target, &p);
       return;
     }
     case SWIMO_MSG_SUSPECT:                                /* src/Core.hs:110-117 */
@@ -321,7 +372,7 @@ static void process(swimoracle_t* o, uint32_t self, uint32_t sender, const omsg_
       uint32_t key = key_make(msg->m.incarnation, st);
       if (o->capture) {                                    /* maybeBroadcast, applied now */
         uint32_t refute = NONE32; opb_t cand = o->pb[self];
-        int ch = accept_key(o, self, msg->m.node, key, SWIMSIM_CAUSE_GOSSIP, &refute, &cand, o->self_inc[self]);
+        int ch = accept_key(c, self, msg->m.node, key, SWIMSIM_CAUSE_GOSSIP, &refute, &cand, o->self_inc[self]);
         if (refute != NONE32) {                            /* src/Core.hs:155-166 */
           o->self_inc[self] = refute + 1;
           swimoracle_msg_t a; memset(&a, 0, sizeof a);
@@ -333,7 +384,7 @@ static void process(swimoracle_t* o, uint32_t self, uint32_t sender, const omsg_
         o->pb[self] = cand;
         return;
       }
-      pend_add(o, self, msg->m.node, key);                 /* lands at end of tick */
+      pend_add(c, self, msg->m.node, key);                 /* lands at end of tick */
       return;
     }
     default: return;
@@ -343,24 +394,25 @@ static void process(swimoracle_t* o, uint32_t self, uint32_t sender, const omsg_
 /* ------------------------------------------------------------------------- */
 /* active side: failureDetector / probeNode' (src/Core.hs:233-269)             */
 /* ------------------------------------------------------------------------- */
-static void fails_add(swimoracle_t* o, uint32_t i, uint32_t j) {
-  if (o->nfails == o->fails_cap) {
-    o->fails_cap = o->fails_cap ? o->fails_cap * 2 : 256;
-    o->fails = (ofail_t*)realloc(o->fails, o->fails_cap * sizeof *o->fails);
+static void fails_add(octx_t* c, uint32_t i, uint32_t j) {
+  if (c->nfails == c->fails_cap) {
+    c->fails_cap = c->fails_cap ? c->fails_cap * 2 : 256;
+    c->fails = (ofail_t*)realloc(c->fails, c->fails_cap * sizeof *c->fails);
   }
-  o->fails[o->nfails].i = i; o->fails[o->nfails].j = j; o->nfails++;
+  c->fails[c->nfails].i = i; c->fails[c->nfails].j = j; c->nfails++;
 }
 
 /* probeNode' store currSeqNo m (src/Core.hs:243-254) */
-static void probe_node(swimoracle_t* o, uint32_t i, uint32_t p, uint32_t j) {
+static void probe_node(octx_t* c, uint32_t i, uint32_t p, uint32_t j) {
+  swimoracle_t* o = c->o;
   omsg_t ping; memset(&ping, 0, sizeof ping);
   ping.m.type = SWIMO_MSG_PING; ping.m.seq_no = (uint32_t)o->tick + 1; ping.m.node = j; ping.m.to = j;
   ping.relay_to = NONE32; ping.lidx = p; ping.via_proxy = 0;
-  o->counters[SWIMSIM_CTR_PINGS]++;
-  o->ctx_acked = 0;
-  deliver(o, P_L_PING, i, j, &ping);                       /* yield Direct (Ping ...) :246 */
-  if (o->ctx_acked) return;                                /* unlessAck (D2, D3)          */
-  o->counters[SWIMSIM_CTR_DIRECT_FAILED]++;
+  c->counters[SWIMSIM_CTR_PINGS]++;
+  c->ctx_acked = 0;
+  deliver(c, P_L_PING, i, j, &ping);                       /* yield Direct (Ping ...) :246 */
+  if (c->ctx_acked) return;                                /* unlessAck (D2, D3)          */
+  c->counters[SWIMSIM_CTR_DIRECT_FAILED]++;
   /* kRandomMembers store (numToGossip cfg) [] :249 -- D7: exclude the target */
   uint32_t qs[256];
   uint32_t nq = k_random_members(o, i, o->K, &j, 1, P_PROXY, p, qs);
@@ -370,18 +422,21 @@ static void probe_node(swimoracle_t* o, uint32_t i, uint32_t p, uint32_t j) {
     ip.m.type = SWIMO_MSG_INDIRECT_PING; ip.m.seq_no = (uint32_t)o->tick + 1;
     ip.m.target = j; ip.m.node = j;                        /* D12: node = member id        */
     ip.relay_to = NONE32; ip.lidx = (p << 8) | k; ip.via_proxy = 1;
-    o->counters[SWIMSIM_CTR_PING_REQS]++;
-    o->ctx_acked = 0;
-    deliver(o, P_L_REQ, i, qs[k], &ip);
-    acked |= o->ctx_acked;                                 /* any of the k relays (D9)     */
+    c->counters[SWIMSIM_CTR_PING_REQS]++;
+    c->ctx_acked = 0;
+    deliver(c, P_L_REQ, i, qs[k], &ip);
+    acked |= c->ctx_acked;                                 /* any of the k relays (D9)     */
   }
   if (acked) return;                                       /* second unlessAck :251        */
   /* suspectNode store (Suspect (memberIncarnation m) name) :253 -- lands at end of tick */
-  fails_add(o, i, j);
-  o->counters[SWIMSIM_CTR_SUSPECTS]++;
-  if (o->up[j]) o->counters[SWIMSIM_CTR_FALSE_SUSPECTS]++;
-  else if (o->first_suspect[j] == NONE32 || (uint32_t)o->tick < o->first_suspect[j])
-    o->first_suspect[j] = (uint32_t)o->tick;
+  fails_add(c, i, j);
+  c->counters[SWIMSIM_CTR_SUSPECTS]++;
+  if (o->up[j]) c->counters[SWIMSIM_CTR_FALSE_SUSPECTS]++;
+  else {                                                   /* min over the probers of j (any order) */
+    uint32_t t = (uint32_t)o->tick, cur = __atomic_load_n(&o->first_suspect[j], __ATOMIC_RELAXED);
+    while ((cur == NONE32 || t < cur) &&
+           !__atomic_compare_exchange_n(&o->first_suspect[j], &cur, t, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  }
 }
 
 /* The "robust scheme" the reference asks for (FIXME at src/Core.hs:232): the round-robin target
@@ -415,7 +470,8 @@ static void robust_offsets(const swimoracle_t* o, uint32_t t, uint32_t* out) {
 }
 
 /* one period of failureDetector for member i (src/Core.hs:236-240; D14) */
-static void failure_detector(swimoracle_t* o, uint32_t i) {
+static void failure_detector(octx_t* c, uint32_t i) {
+  swimoracle_t* o = c->o;
   if (o->cfg.target_scheme == SWIMSIM_TARGETS_ROBUST) {
     uint32_t off[16], n = 0;
     robust_offsets(o, (uint32_t)o->tick, off);
@@ -423,14 +479,14 @@ static void failure_detector(swimoracle_t* o, uint32_t i) {
     o->nsent[i] = (uint8_t)n;
     for (uint32_t p = 0; p < o->P; p++) {
       uint32_t j = (i + off[p]) % o->N;
-      if (off[p] && is_alive_in_view(o, i, j)) probe_node(o, i, p, j);   /* probe index = rotation index */
+      if (off[p] && is_alive_in_view(o, i, j)) probe_node(c, i, p, j);   /* probe index = rotation index */
     }
     return;
   }
   uint32_t ms[256];
   uint32_t n = k_random_members(o, i, o->P, NULL, 0, P_SELECT, 0, ms);   /* :239 */
   o->nsent[i] = (uint8_t)n;
-  for (uint32_t p = 0; p < n; p++) probe_node(o, i, p, ms[p]);           /* mapM_ :240 */
+  for (uint32_t p = 0; p < n; p++) probe_node(c, i, p, ms[p]);           /* mapM_ :240 */
 }
 
 /* ------------------------------------------------------------------------- */
@@ -438,7 +494,6 @@ static void failure_detector(swimoracle_t* o, uint32_t i) {
 /* ------------------------------------------------------------------------- */
 static void timer_push(swimoracle_t* o, uint32_t i, uint32_t s, uint32_t deadline) {
   otimerq_t* q = &o->timers[i];
-  if (q->n >= o->cfg.timer_cap) { fail(o, SWIMSIM_ERR_CAPACITY, "timer_cap exceeded"); return; }
   if (q->n == q->cap) {
     uint32_t nc = q->cap ? q->cap * 2 : 4;
     otimer_t* nv = (otimer_t*)malloc(nc * sizeof *nv);
@@ -468,14 +523,14 @@ static void cand_insert(opb_t* c, uint32_t subject, uint32_t key, uint8_t tx) {
   if (rumor_better(&r, &c->r[worst])) c->r[worst] = r;
 }
 
-static void event_add(swimoracle_t* o, uint32_t t, uint32_t i, uint32_t s, uint32_t key, uint8_t cause) {
-  if (!(o->cfg.event_mask & (1u << cause))) return;
-  if (o->nevents >= o->cfg.event_cap) { o->counters[SWIMSIM_CTR_EVENTS_DROPPED]++; return; }
-  if (o->nevents == o->events_cap_alloc) {
-    o->events_cap_alloc = o->events_cap_alloc ? o->events_cap_alloc * 2 : 1024;
-    o->events = (swimsim_event_t*)realloc(o->events, o->events_cap_alloc * sizeof *o->events);
+/* events are collected per worker and appended to the handle's list after the tick (events_fold) */
+static void event_add(octx_t* c, uint32_t t, uint32_t i, uint32_t s, uint32_t key, uint8_t cause) {
+  if (!(c->o->cfg.event_mask & (1u << cause))) return;
+  if (c->nevents == c->events_cap) {
+    c->events_cap = c->events_cap ? c->events_cap * 2 : 1024;
+    c->events = (swimsim_event_t*)realloc(c->events, c->events_cap * sizeof *c->events);
   }
-  swimsim_event_t* e = &o->events[o->nevents++];
+  swimsim_event_t* e = &c->events[c->nevents++];
   memset(e, 0, sizeof *e);
   e->tick = t; e->observer = i; e->subject = s; e->incarnation = key_inc(key);
   e->state = (uint8_t)key_state(key); e->cause = cause;
@@ -489,8 +544,9 @@ static void event_add(swimoracle_t* o, uint32_t t, uint32_t i, uint32_t s, uint3
  *   - i < inc  => ignore      : same (:151).
  *   - about self => refute    : same (:155-166), with D10's counter fix.
  * Returns 1 if i's entry for s changed. */
-static int accept_key(swimoracle_t* o, uint32_t i, uint32_t s, uint32_t key, uint8_t cause,
+static int accept_key(octx_t* c, uint32_t i, uint32_t s, uint32_t key, uint8_t cause,
                       uint32_t* refute_inc, opb_t* cand, uint32_t self_inc_start) {
+  swimoracle_t* o = c->o;
   uint32_t t = (uint32_t)o->tick;
   if (s == i) {
     /* `name == memberName storeSelf` -> refute (:155); old incarnations ignored (:151) */
@@ -498,30 +554,42 @@ static int accept_key(swimoracle_t* o, uint32_t i, uint32_t s, uint32_t key, uin
       if (*refute_inc == NONE32 || key_inc(key) > *refute_inc) *refute_inc = key_inc(key);
     return 0;
   }
+  const oentry_t cur = view_get(o, i, s);
+  if (o->literal_rule) {                           /* oracle-only mode: the literal rule (D13) */
+    const uint32_t mrg = key > cur.key ? key : cur.key;
+    const uint32_t lit = key_state(key) == SWIMSIM_ALIVE ? mrg          /* aliveNode is unwritten (D6) */
+                                                         : swimoracle_reference_rule(cur.key, key);
+    if (lit != mrg) __atomic_fetch_add(&o->d13_hits, 1, __ATOMIC_RELAXED);
+    if (lit == cur.key) return 0;
+    key = lit;
+  } else if (key <= cur.key) return 0;             /* old incarnation / weaker state: ignore */
   oentry_t* e = view_ref(o, i, s);
   if (!e) return 0;
-  if (key <= e->key) return 0;                     /* old incarnation / weaker state: ignore */
-  o->counters[SWIMSIM_CTR_EVDIGEST] += h4(TAG_EV, ((uint64_t)t << 32) | i, s, key)
-                                     - h4(TAG_EV, ((uint64_t)t << 32) | i, s, e->key);
-  if (e->since1 != t + 1) o->counters[SWIMSIM_CTR_CHANGES]++;
+  c->counters[SWIMSIM_CTR_EVDIGEST] += h4(TAG_EV, ((uint64_t)t << 32) | i, s, key)
+                                     - h4(TAG_EV, ((uint64_t)t << 32) | i, s, cur.key);
+  __atomic_store_n(&o->last_change[s], t, __ATOMIC_RELAXED);
+  if (e->since1 != t + 1) c->counters[SWIMSIM_CTR_CHANGES]++;
   e->key = key; e->since1 = t + 1;                 /* memberLastChange = now (:176) */
-  if (cause == SWIMSIM_CAUSE_TIMER) o->counters[SWIMSIM_CTR_TIMERS_FIRED]++;
+  if (cause == SWIMSIM_CAUSE_TIMER) c->counters[SWIMSIM_CTR_TIMERS_FIRED]++;
   if (key_state(key) == SWIMSIM_SUSPECT) timer_push(o, i, s, t + o->S);   /* D4 */
   cand_insert(cand, s, key, (uint8_t)o->L);        /* `Just msg` -> Broadcast -> enqueue (D5) */
-  event_add(o, t, i, s, key, cause);
+  event_add(c, t, i, s, key, cause);
   return 1;
 }
 
-static void end_of_tick(swimoracle_t* o, uint32_t i, const opend_t* pend, uint32_t npend,
+static void end_of_tick(octx_t* c, uint32_t i, const opend_t* pend, uint32_t npend,
                         const ofail_t* fails, uint32_t nfails) {
+  swimoracle_t* o = c->o;
   uint32_t t = (uint32_t)o->tick;
   const opb_t* old = &o->pb[i];
   uint32_t self_inc_start = o->self_inc[i];
   uint32_t refute = NONE32;
-  /* age the queue: every ping sent this tick carried every slot (D5) */
+  /* age the queue: every ping sent this tick carried every slot (D5); a period without a single
+   * ping still costs one transmission, so that a rumour is retired after at most L periods */
   opb_t cand; cand.n = 0;
+  const uint32_t age = o->nsent[i] ? o->nsent[i] : 1u;
   for (int s = 0; s < old->n; s++)
-    if (old->r[s].tx > o->nsent[i]) { cand.r[cand.n] = old->r[s]; cand.r[cand.n].tx = (uint8_t)(old->r[s].tx - o->nsent[i]); cand.n++; }
+    if (old->r[s].tx > age) { cand.r[cand.n] = old->r[s]; cand.r[cand.n].tx = (uint8_t)(old->r[s].tx - age); cand.n++; }
   /* phase 1: suspicion timers (the FIXME at src/Core.hs:141; D4), evaluated on the
    * start-of-tick view */
   otimerq_t* q = &o->timers[i];
@@ -531,19 +599,19 @@ static void end_of_tick(swimoracle_t* o, uint32_t i, const opend_t* pend, uint32
     oentry_t e = view_get(o, i, tm.subject);
     if (key_state(e.key) == SWIMSIM_SUSPECT && e.since1 - 1 + o->S == tm.deadline) {
       if (ntp == 64) { /* flush */
-        for (uint32_t x = 0; x < ntp; x++) accept_key(o, i, tprop[x], tkey[x], SWIMSIM_CAUSE_TIMER, &refute, &cand, self_inc_start);
+        for (uint32_t x = 0; x < ntp; x++) accept_key(c, i, tprop[x], tkey[x], SWIMSIM_CAUSE_TIMER, &refute, &cand, self_inc_start);
         ntp = 0;
       }
       tprop[ntp] = tm.subject; tkey[ntp] = key_make(key_inc(e.key), SWIMSIM_DEAD); ntp++;
     }
   }
-  for (uint32_t x = 0; x < ntp; x++) accept_key(o, i, tprop[x], tkey[x], SWIMSIM_CAUSE_TIMER, &refute, &cand, self_inc_start);
+  for (uint32_t x = 0; x < ntp; x++) accept_key(c, i, tprop[x], tkey[x], SWIMSIM_CAUSE_TIMER, &refute, &cand, self_inc_start);
   /* phase 2: own probes that ended without any ack: suspectNode (src/Core.hs:253) with
    * the incarnation of the start-of-tick view entry (`memberIncarnation m`) */
   for (uint32_t f = 0; f < nfails; f++) {
     uint32_t j = fails[f].j;
     uint32_t key = key_make(key_inc(view_get(o, i, j).key), SWIMSIM_SUSPECT);
-    accept_key(o, i, j, key, SWIMSIM_CAUSE_PROBE, &refute, &cand, self_inc_start);
+    accept_key(c, i, j, key, SWIMSIM_CAUSE_PROBE, &refute, &cand, self_inc_start);
   }
   /* phase 3: rumours received this tick (any order: the merge is commutative) */
   if (o->shuffle_seed && npend > 1) {
@@ -554,23 +622,24 @@ static void end_of_tick(swimoracle_t* o, uint32_t i, const opend_t* pend, uint32
       uint32_t tmp = perm[x]; perm[x] = perm[r]; perm[r] = tmp;
     }
     for (uint32_t x = 0; x < npend; x++)
-      accept_key(o, i, pend[perm[x]].subject, pend[perm[x]].key, SWIMSIM_CAUSE_GOSSIP, &refute, &cand, self_inc_start);
+      accept_key(c, i, pend[perm[x]].subject, pend[perm[x]].key, SWIMSIM_CAUSE_GOSSIP, &refute, &cand, self_inc_start);
     free(perm);
   } else {
     for (uint32_t x = 0; x < npend; x++)
-      accept_key(o, i, pend[x].subject, pend[x].key, SWIMSIM_CAUSE_GOSSIP, &refute, &cand, self_inc_start);
+      accept_key(c, i, pend[x].subject, pend[x].key, SWIMSIM_CAUSE_GOSSIP, &refute, &cand, self_inc_start);
   }
   /* refutation: bump own incarnation past the rumour's (src/Core.hs:155-166; D10) */
   if (refute != NONE32) {
     uint32_t ni = refute + 1;
     if (ni > INC_MAX) { fail(o, SWIMSIM_ERR_CAPACITY, "incarnation overflow"); return; }
     o->self_inc[i] = ni;
-    o->counters[SWIMSIM_CTR_EVDIGEST] += h4(TAG_INC, ((uint64_t)t << 32) | i, ni, 0);
-    o->counters[SWIMSIM_CTR_REFUTES]++;
+    c->counters[SWIMSIM_CTR_EVDIGEST] += h4(TAG_INC, ((uint64_t)t << 32) | i, ni, 0);
+    c->counters[SWIMSIM_CTR_REFUTES]++;
     cand_insert(&cand, i, key_make(ni, SWIMSIM_ALIVE), (uint8_t)o->L);   /* Just Alive{..} :163 */
-    event_add(o, t, i, i, key_make(ni, SWIMSIM_ALIVE), SWIMSIM_CAUSE_REFUTE);
+    __atomic_store_n(&o->last_change[i], t, __ATOMIC_RELAXED);
+    event_add(c, t, i, i, key_make(ni, SWIMSIM_ALIVE), SWIMSIM_CAUSE_REFUTE);
   }
-  if (old->n > 0 || cand.n > 0) o->counters[SWIMSIM_CTR_PB_WRITES]++;
+  if (old->n > 0 || cand.n > 0) c->counters[SWIMSIM_CTR_PB_WRITES]++;
   o->pb[i] = cand;
 }
 
@@ -590,7 +659,7 @@ static void apply_faults(swimoracle_t* o, uint32_t t) {
     uint32_t m = f.member;
     if (f.up == o->up[m]) continue;
     o->up[m] = f.up;
-    if (!f.up) { o->crash_tick[m] = t; o->first_suspect[m] = NONE32; }
+    if (!f.up) { o->crash_tick[m] = t; o->first_suspect[m] = NONE32; o->pb[m].n = 0; /* the process's queue is lost */ }
     else {
       /* (re)join: new incarnation + announce Alive (memberlist-style; the reference's
        * joinHosts is dead config, src/Util.hs:46) */
@@ -599,7 +668,8 @@ static void apply_faults(swimoracle_t* o, uint32_t t) {
       o->self_inc[m] = ni;
       o->counters[SWIMSIM_CTR_EVDIGEST] += h4(TAG_INC, ((uint64_t)t << 32) | m, ni, 0);
       cand_insert(&o->pb[m], m, key_make(ni, SWIMSIM_ALIVE), (uint8_t)o->L);
-      event_add(o, t, m, m, key_make(ni, SWIMSIM_ALIVE), SWIMSIM_CAUSE_JOIN);
+      o->last_change[m] = t;
+      event_add(&o->ctx[0], t, m, m, key_make(ni, SWIMSIM_ALIVE), SWIMSIM_CAUSE_JOIN);
       o->first_suspect[m] = NONE32;
     }
   }
@@ -623,42 +693,182 @@ int swimoracle_schedule_fault(swimoracle_t* o, uint64_t tick, uint32_t member, u
 /* ------------------------------------------------------------------------- */
 /* the tick                                                                   */
 /* ------------------------------------------------------------------------- */
-static int one_tick(swimoracle_t* o) {
-  uint32_t t = (uint32_t)o->tick;
-  uint32_t N = o->N;
-  apply_faults(o, t);
-  if (o->poisoned) return SWIMSIM_ERR_CAPACITY;
-  o->tk = tick_key(o->cfg.seed, t);
-  o->npend = 0; o->nfails = 0;
-  for (uint32_t i = 0; i < N; i++) {
+/* phase A for one worker: one period of failureDetector for each of its up members */
+static void phase_probe(octx_t* c) {
+  swimoracle_t* o = c->o;
+  c->nfails = 0;
+  for (uint32_t g = 0; g < o->nworkers; g++) c->out[g].n = 0;
+  for (uint32_t i = c->lo; i < c->hi; i++) {
     o->nsent[i] = 0;
-    if (o->up[i]) { failure_detector(o, i); o->counters[SWIMSIM_CTR_ACTIVE_MEMBERS]++; }
+    if (o->up[i]) { failure_detector(c, i); c->counters[SWIMSIM_CTR_ACTIVE_MEMBERS]++; }
   }
-  /* bucket the pending rumours by receiver (stable: arrival order kept) */
-  memset(o->pend_off, 0, (N + 1) * sizeof *o->pend_off);
-  for (size_t x = 0; x < o->npend; x++) o->pend_off[o->pend[x].dst + 1]++;
-  for (uint32_t i = 0; i < N; i++) o->pend_off[i + 1] += o->pend_off[i];
-  if (o->npend > o->pend_sorted_cap) {
-    o->pend_sorted_cap = o->npend * 2;
-    o->pend_sorted = (opend_t*)realloc(o->pend_sorted, o->pend_sorted_cap * sizeof *o->pend_sorted);
+}
+
+/* phase B for one worker: the rumours delivered to its members (from every worker's lists), bucketed
+ * by receiver (stable: arrival order kept), then every up member's end of tick */
+static void phase_merge(octx_t* c) {
+  swimoracle_t* o = c->o;
+  const uint32_t n = c->hi - c->lo;
+  size_t total = 0;
+  for (uint32_t g = 0; g < o->nworkers; g++) total += o->ctx[g].out[c->w].n;
+  if (total > c->sorted_cap) {
+    c->sorted_cap = total * 2;
+    c->sorted = (opend_t*)realloc(c->sorted, c->sorted_cap * sizeof *c->sorted);
   }
+  memset(c->off, 0, ((size_t)n + 1) * sizeof *c->off);
+  for (uint32_t g = 0; g < o->nworkers; g++) {
+    const opendv_t* q = &o->ctx[g].out[c->w];
+    for (size_t x = 0; x < q->n; x++) c->off[q->v[x].dst - c->lo + 1]++;
+  }
+  for (uint32_t i = 0; i < n; i++) c->off[i + 1] += c->off[i];
   {
-    uint32_t* cur = (uint32_t*)malloc(N * sizeof *cur);
-    memcpy(cur, o->pend_off, N * sizeof *cur);
-    for (size_t x = 0; x < o->npend; x++) o->pend_sorted[cur[o->pend[x].dst]++] = o->pend[x];
+    uint32_t* cur = (uint32_t*)malloc(((size_t)n + 1) * sizeof *cur);
+    memcpy(cur, c->off, (size_t)n * sizeof *cur);
+    for (uint32_t g = 0; g < o->nworkers; g++) {
+      const opendv_t* q = &o->ctx[g].out[c->w];
+      for (size_t x = 0; x < q->n; x++) c->sorted[cur[q->v[x].dst - c->lo]++] = q->v[x];
+    }
     free(cur);
   }
   size_t fc = 0;
-  for (uint32_t i = 0; i < N; i++) {
+  for (uint32_t i = c->lo; i < c->hi; i++) {
     size_t f0 = fc;
-    while (fc < o->nfails && o->fails[fc].i == i) fc++;
+    while (fc < c->nfails && c->fails[fc].i == i) fc++;
     if (!o->up[i]) continue;
-    end_of_tick(o, i, o->pend_sorted + o->pend_off[i], o->pend_off[i + 1] - o->pend_off[i],
-                o->fails + f0, (uint32_t)(fc - f0));
-    if (o->poisoned) return SWIMSIM_ERR_CAPACITY;
+    end_of_tick(c, i, c->sorted + c->off[i - c->lo], c->off[i - c->lo + 1] - c->off[i - c->lo],
+                c->fails + f0, (uint32_t)(fc - f0));
+    if (__atomic_load_n(&o->poisoned, __ATOMIC_RELAXED)) return;
   }
+}
+
+static void run_phase(octx_t* c, int phase) { if (phase == 0) phase_probe(c); else phase_merge(c); }
+
+static void* worker_main(void* arg) {
+  octx_t* c = (octx_t*)arg;
+  swimoracle_t* o = c->o;
+  for (;;) {
+    pthread_barrier_wait(&o->bar);                /* phase published */
+    if (o->quit) return NULL;
+    run_phase(c, o->phase);
+    pthread_barrier_wait(&o->bar);                /* phase done */
+  }
+}
+
+static void parallel_phase(swimoracle_t* o, int phase) {
+  if (o->nworkers == 1) { run_phase(&o->ctx[0], phase); return; }
+  o->phase = phase;
+  pthread_barrier_wait(&o->bar);
+  run_phase(&o->ctx[0], phase);                   /* the calling thread is worker 0 */
+  pthread_barrier_wait(&o->bar);
+}
+
+/* counters add up; events are appended in worker order (drain sorts them) */
+static void fold_workers(swimoracle_t* o) {
+  for (uint32_t g = 0; g < o->nworkers; g++) {
+    octx_t* c = &o->ctx[g];
+    for (int k = 0; k < SWIMSIM_CTR_COUNT; k++) { o->counters[k] += c->counters[k]; c->counters[k] = 0; }
+    for (size_t x = 0; x < c->nevents; x++) {
+      if (o->nevents >= o->cfg.event_cap) { o->counters[SWIMSIM_CTR_EVENTS_DROPPED]++; continue; }
+      if (o->nevents == o->events_cap_alloc) {
+        o->events_cap_alloc = o->events_cap_alloc ? o->events_cap_alloc * 2 : 1024;
+        o->events = (swimsim_event_t*)realloc(o->events, o->events_cap_alloc * sizeof *o->events);
+      }
+      o->events[o->nevents++] = c->events[x];
+    }
+    c->nevents = 0;
+  }
+}
+
+/* Settling at the end of tick t (include/swimsim.h): `removeDeadNodes` (src/Core.hs:65-67)
+ * + the anti-entropy the reference leaves commented out (PushPullMsg, src/Types.hs:165,177). */
+static void settle(swimoracle_t* o, uint32_t t) {
+  if (!o->G) return;
+  for (uint32_t sl = 0; sl < o->nslots; sl++) {
+    if (o->free_at[sl] != NONE32) continue;
+    const uint32_t s = o->subject_of[sl];
+    const uint32_t lc = o->last_change[s];
+    if (lc != NONE32 && t - lc < o->G) continue;       /* lc == NONE32: column made by set_view only */
+    uint32_t k = 0;
+    oentry_t* col = o->cols[sl];
+    for (uint32_t i = 0; i < o->N; i++) if (o->up[i] && i != s && col[i].key > k) k = col[i].key;
+    if (key_state(k) == SWIMSIM_SUSPECT) continue;     /* somebody's timer is still running */
+    if (o->N <= 4096)                                  /* the invariant G >= S + L + 2 buys (checked where cheap) */
+      for (uint32_t i = 0; i < o->N; i++)
+        for (int q = 0; q < o->pb[i].n; q++)
+          if (o->pb[i].r[q].subject == s) { fail(o, SWIMSIM_ERR_STATE, "settle: a queue still holds the subject"); return; }
+    if (k > o->base[s]) o->base[s] = k;
+    o->base_since[s] = t;
+    memset(col, 0, (size_t)o->N * sizeof *col);
+    o->slot_of[s] = 0;
+    o->free_at[sl] = t + 2;
+    o->nlive--;
+    o->counters[SWIMSIM_CTR_SETTLED]++;
+  }
+}
+
+static int one_tick(swimoracle_t* o) {
+  uint32_t t = (uint32_t)o->tick;
+  apply_faults(o, t);
+  fold_workers(o);                                /* JOIN events */
+  if (o->poisoned) return SWIMSIM_ERR_CAPACITY;
+  o->tk = tick_key(o->cfg.seed, t);
+  parallel_phase(o, 0);
+  parallel_phase(o, 1);
+  fold_workers(o);
+  if (o->poisoned) return SWIMSIM_ERR_CAPACITY;
+  settle(o, t);
+  if (o->poisoned) return SWIMSIM_ERR_CAPACITY;
   o->tick++;
   return SWIMSIM_OK;
+}
+
+static void workers_stop(swimoracle_t* o) {
+  if (o->nworkers > 1) {
+    o->quit = 1;
+    pthread_barrier_wait(&o->bar);
+    for (uint32_t g = 1; g < o->nworkers; g++) pthread_join(o->threads[g], NULL);
+    pthread_barrier_destroy(&o->bar);
+    o->quit = 0;
+  }
+  free(o->threads); o->threads = NULL;
+  for (uint32_t g = 0; g < o->nworkers; g++) {
+    octx_t* c = &o->ctx[g];
+    for (uint32_t d = 0; c->out && d < o->nworkers; d++) free(c->out[d].v);
+    free(c->out); free(c->fails); free(c->events); free(c->sorted); free(c->off);
+  }
+  free(o->ctx); o->ctx = NULL; o->nworkers = 0;
+}
+
+/* (re)partition the members over n workers; n-1 threads are started (the caller is worker 0) */
+static int workers_start(swimoracle_t* o, uint32_t n) {
+  if (n < 1) n = 1;
+  if (n > o->N) n = o->N;
+  uint32_t chunk = (o->N + n - 1) / n;
+  n = (o->N + chunk - 1) / chunk;
+  o->ctx = (octx_t*)calloc(n, sizeof *o->ctx);
+  if (!o->ctx) return SWIMSIM_ERR_NOMEM;
+  o->nworkers = n; o->chunk = chunk;
+  for (uint32_t g = 0; g < n; g++) {
+    octx_t* c = &o->ctx[g];
+    c->o = o; c->w = g; c->lo = g * chunk; c->hi = c->lo + chunk > o->N ? o->N : c->lo + chunk;
+    c->out = (opendv_t*)calloc(n, sizeof *c->out);
+    c->off = (uint32_t*)calloc((size_t)(c->hi - c->lo) + 1, sizeof *c->off);
+    if (!c->out || !c->off) return SWIMSIM_ERR_NOMEM;
+  }
+  if (n > 1) {
+    o->threads = (pthread_t*)calloc(n, sizeof *o->threads);
+    if (!o->threads || pthread_barrier_init(&o->bar, NULL, n)) return SWIMSIM_ERR_NOMEM;
+    for (uint32_t g = 1; g < n; g++)
+      if (pthread_create(&o->threads[g], NULL, worker_main, &o->ctx[g])) return SWIMSIM_ERR_NOMEM;
+  }
+  return SWIMSIM_OK;
+}
+
+int swimoracle_set_threads(swimoracle_t* o, uint32_t n) {
+  if (!o) return SWIMSIM_ERR_INVALID;
+  fold_workers(o);
+  workers_stop(o);
+  return workers_start(o, n) ? fail(o, SWIMSIM_ERR_NOMEM, "out of memory (workers)") : SWIMSIM_OK;
 }
 
 int swimoracle_step(swimoracle_t* o, uint32_t nticks) {
@@ -698,8 +908,11 @@ static int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, char*
     snprintf(err, errn, "retransmit budget exceeds 255"); return SWIMSIM_ERR_INVALID; }
   if (c->max_subjects == 0) c->max_subjects = c->n_members < 1024 ? c->n_members : 1024;
   if (c->max_subjects > 65534u) { snprintf(err, errn, "max_subjects must be <= 65534"); return SWIMSIM_ERR_INVALID; }
-  if (c->timer_cap == 0) c->timer_cap = 64;
-  if (c->timer_cap > 32768u) { snprintf(err, errn, "timer_cap must be <= 32768"); return SWIMSIM_ERR_INVALID; }
+  {
+    uint32_t gmin = c->suspicion_ticks + c->retransmit_mult * ceil_log2((uint64_t)c->n_members + 1) + 2;
+    if (c->gc_ticks == SWIMSIM_GC_AUTO) c->gc_ticks = gmin;
+    if (c->gc_ticks && c->gc_ticks < gmin) { snprintf(err, errn, "gc_ticks must be 0, SWIMSIM_GC_AUTO or >= suspicion_ticks + L + 2 = %u", gmin); return SWIMSIM_ERR_INVALID; }
+  }
   if (c->event_cap == 0) c->event_cap = 1u << 20;
   if (c->event_mask == 0) c->event_mask = SWIMSIM_EVMASK_DEFAULT;
   if (c->n_shards == 0) c->n_shards = 1;
@@ -729,10 +942,20 @@ int swimoracle_create(const swimsim_config_t* cfg, swimoracle_t** out) {
   o->pb = (opb_t*)calloc(N, sizeof(opb_t)); o->timers = (otimerq_t*)calloc(N, sizeof(otimerq_t));
   o->nsent = (uint8_t*)calloc(N, 1); o->slot_of = (uint32_t*)calloc(N, 4);
   o->first_suspect = (uint32_t*)malloc((size_t)N * 4); o->crash_tick = (uint32_t*)malloc((size_t)N * 4);
-  o->pend_off = (uint32_t*)calloc((size_t)N + 1, 4);
-  if (!o->up || !o->self_inc || !o->pb || !o->timers || !o->nsent || !o->slot_of || !o->first_suspect || !o->crash_tick || !o->pend_off) {
+  /* settled columns wait two ticks before reuse, so a few more than max_subjects may exist */
+  o->slots_cap = c.max_subjects + (c.gc_ticks ? c.max_subjects : 0);
+  o->cols = (oentry_t**)calloc(o->slots_cap, sizeof *o->cols);
+  o->subject_of = (uint32_t*)calloc(o->slots_cap, sizeof *o->subject_of);
+  o->free_at = (uint32_t*)malloc((size_t)o->slots_cap * 4);
+  o->G = c.gc_ticks;
+  o->base = (uint32_t*)calloc(N, 4); o->base_since = (uint32_t*)calloc(N, 4);
+  o->last_change = (uint32_t*)malloc((size_t)N * 4);
+  pthread_mutex_init(&o->mu, NULL);
+  if (!o->up || !o->self_inc || !o->pb || !o->timers || !o->nsent || !o->slot_of || !o->first_suspect || !o->crash_tick ||
+      !o->cols || !o->subject_of || !o->free_at || !o->base || !o->base_since || !o->last_change || workers_start(o, 1)) {
     swimoracle_destroy(o); return fail(NULL, SWIMSIM_ERR_NOMEM, "out of memory");
   }
+  memset(o->free_at, 0xFF, (size_t)o->slots_cap * 4); memset(o->last_change, 0xFF, (size_t)N * 4);
   memset(o->up, 1, N);
   memset(o->first_suspect, 0xFF, (size_t)N * 4); memset(o->crash_tick, 0xFF, (size_t)N * 4);
   *out = o;
@@ -741,11 +964,14 @@ int swimoracle_create(const swimsim_config_t* cfg, swimoracle_t** out) {
 
 void swimoracle_destroy(swimoracle_t* o) {
   if (!o) return;
+  workers_stop(o);
   for (uint32_t s = 0; s < o->nslots; s++) free(o->cols[s]);
   if (o->timers) for (uint32_t i = 0; i < o->N; i++) free(o->timers[i].v);
+  free(o->free_at); free(o->base); free(o->base_since); free(o->last_change);
   free(o->cols); free(o->subject_of); free(o->slot_of); free(o->up); free(o->self_inc); free(o->pb);
   free(o->timers); free(o->nsent); free(o->faults); free(o->first_suspect); free(o->crash_tick);
-  free(o->pend); free(o->pend_sorted); free(o->pend_off); free(o->fails); free(o->events);
+  free(o->events);
+  pthread_mutex_destroy(&o->mu);
   free(o);
 }
 
@@ -803,6 +1029,18 @@ int swimoracle_read_view(swimoracle_t* o, uint32_t observer, swimsim_view_entry_
     }
     n++;
   }
+  /* settled subjects: Alive@i (i > 0) stays a listed member, Dead ones were removed (removeDeadNodes) */
+  for (uint32_t s = 0; s < o->N; s++) {
+    if (!o->base[s] || key_state(o->base[s]) != SWIMSIM_ALIVE || s == observer) continue;
+    uint32_t sl = o->slot_of[s];
+    if (sl && o->cols[sl - 1][observer].key) continue;      /* listed above with its own entry */
+    if (n < cap && buf) {
+      memset(&buf[n], 0, sizeof buf[n]);
+      buf[n].subject = s; buf[n].incarnation = key_inc(o->base[s]);
+      buf[n].state = SWIMSIM_ALIVE; buf[n].since_tick = o->base_since[s];
+    }
+    n++;
+  }
   *n_out = n;
   if (n > cap || (n && !buf)) return SWIMSIM_ERR_BUFFER;
   qsort(buf, n, sizeof *buf, ventry_cmp);
@@ -846,6 +1084,7 @@ int swimoracle_digest(swimoracle_t* o, uint64_t* out) {
     for (int s = 0; s < o->pb[i].n; s++) mh += h4(TAG_PB, o->pb[i].r[s].subject, o->pb[i].r[s].key, o->pb[i].r[s].tx);
     D += mix64(mh + mix64((uint64_t)TAG_MEMBER + i));
     if (o->first_suspect[i] != NONE32) D += h4(TAG_FD, i, o->first_suspect[i], 0);
+    if (o->base[i]) D += h4(TAG_BASE, i, o->base[i], o->base_since[i]);
   }
   *out = D;
   return SWIMSIM_OK;
@@ -888,7 +1127,8 @@ int swimoracle_process(swimoracle_t* o, uint32_t self, uint32_t sender, const sw
   omsg_t m; memset(&m, 0, sizeof m);
   m.m = *msg; m.relay_to = NONE32;
   o->capture = 1; o->capture_literal_d8 = literal_d8; o->cap_out = out; o->cap_cap = out ? cap : 0; o->cap_n = 0;
-  process(o, self, sender, &m);
+  process(&o->ctx[0], self, sender, &m);
+  fold_workers(o);
   o->capture = 0;
   *n_out = o->cap_n;
   return o->cap_n > o->cap_cap ? SWIMSIM_ERR_BUFFER : SWIMSIM_OK;
@@ -915,6 +1155,15 @@ size_t swimoracle_remove_dead_nodes(swimsim_view_entry_t* entries, size_t n) {
   for (size_t x = 0; x < n; x++) if (entries[x].state != SWIMSIM_DEAD) entries[w++] = entries[x];
   return w;
 }
+
+/* oracle-only: step under the LITERAL suspectOrDeadNode' (src/Core.hs:151-152,182-184) instead of the
+ * commutative merge; *hits = proposals on which the two rules disagreed so far (D13).  While it stays 0 a
+ * run is identical to the merge run -- which is how the tests narrow "parity unpinned". */
+int swimoracle_set_literal_rule(swimoracle_t* o, int on) {
+  if (!o) return SWIMSIM_ERR_INVALID;
+  o->literal_rule = on != 0; return SWIMSIM_OK;
+}
+uint64_t swimoracle_d13_hits(const swimoracle_t* o) { return o ? o->d13_hits : 0; }
 
 int swimoracle_set_shuffle(swimoracle_t* o, uint64_t shuffle_seed) {
   if (!o) return SWIMSIM_ERR_INVALID;

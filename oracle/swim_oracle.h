@@ -1,7 +1,7 @@
 /*
  * swim_oracle.h -- CPU ORACLE for the SWIM tick (TEST INFRASTRUCTURE, NOT PRODUCT).
  *
- * A plain-C, single-threaded, message-level restatement of the reference's
+ * A plain-C, message-level restatement (sequential by default; member-range threads on request) of the reference's
  * per-member protocol rules (src/Core.hs, src/Util.hs, src/Types.hs of
  * jpfuentes2/swim) as a bulk-synchronous tick.  Only tests/, __graft_entry__.smoke()
  * and bench.py's cpu_baseline leg may load this library.  The product
@@ -97,8 +97,19 @@ uint32_t swimoracle_merge_rule(uint32_t cur_key, uint32_t msg_key);
  * returns the new length. */
 size_t swimoracle_remove_dead_nodes(swimsim_view_entry_t* entries, size_t n);
 
+/* Step under the literal rule above instead of the merge (Alive messages keep the merge: aliveNode is
+ * unwritten, D6).  d13_hits counts the proposals on which the two rules disagree; while it is 0 the run
+ * equals the merge run in every observable. */
+int swimoracle_set_literal_rule(swimoracle_t* h, int on);
+uint64_t swimoracle_d13_hits(const swimoracle_t* h);
+
 /* Spec hash H(seed, tick, a, b, c) -> u32. */
 uint32_t swimoracle_hash(uint64_t seed, uint32_t tick, uint32_t a, uint32_t b, uint32_t c);
+
+/* Split the members into n contiguous ranges stepped by n threads (the caller's thread included).
+ * Every observable is independent of n; n = 1 (the default) is the plain sequential oracle.  Used by
+ * bench.py's cpu_baseline ("all host cores") and by oracle-checked runs at full size. */
+int swimoracle_set_threads(swimoracle_t* h, uint32_t n);
 
 /* Permute the order in which each member applies its pending rumours / timers
  * (0 = canonical arrival order).  Results must not depend on it (property test). */

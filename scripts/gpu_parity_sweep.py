@@ -21,7 +21,7 @@ while time.time()-t0 < 150:
         shards=rng.choice([g for g in (2,3,4,8) if n%g==0] or [1])
     seed=rng.randrange(1,1<<30)
     sc=SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, eventMask=0x1F if n<=4096 else 0, suspicionTicks=rng.choice([3,6,12]),
-                 maxSubjects=min(n,4096), timerCap=1024, targetScheme=scheme, inboxCap=rng.choice([0,0,1,2]) if n <= 4096 else 0)
+                 maxSubjects=min(n,4096), targetScheme=scheme, inboxCap=rng.choice([0,0,1,2]) if n <= 4096 else 0)
     print("cfg", n,p,loss,scheme,shards,seed, flush=True)
     a=Sim.create(orc, sc)
     b=Sim.create(emu, sc) if shards==1 else ShardedSim(emu, sc, LocalFabric(shards), device="cuda:0")

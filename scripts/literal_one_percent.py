@@ -9,7 +9,7 @@ n = 1 << 20
 WARM, TICKS = 150, 100
 crashes = workloads.hashed_crashes(n, 1, 10, 1000, 10, 1110)
 from swim_amd import Config, SimConfig
-sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=1, maxSubjects=16384, timerCap=2048)
+sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=1, maxSubjects=16384)
 s = Sim.create(abi, sc); workloads.apply_crashes(s, crashes)
 s.step(WARM); c0 = s.counters(); s.kernelTimingEnable(True)
 t0 = time.time(); s.step(TICKS); dt = time.time() - t0

@@ -8,7 +8,7 @@ that loading happens in tests/ only, never in this package.
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK = 0
 ERR_INVALID, ERR_DEVICE, ERR_NOMEM, ERR_CAPACITY, ERR_STATE, ERR_BUFFER = -1, -2, -3, -4, -5, -6
@@ -18,11 +18,12 @@ CAUSE_PROBE, CAUSE_TIMER, CAUSE_GOSSIP, CAUSE_REFUTE, CAUSE_JOIN = 0, 1, 2, 3, 4
 EVMASK_ALL = 0x1F
 EVMASK_DEFAULT = (1 << CAUSE_PROBE) | (1 << CAUSE_REFUTE) | (1 << CAUSE_JOIN)
 TICK_NONE = 0xFFFFFFFFFFFFFFFF
+GC_AUTO = 0xFFFFFFFF
 
 CTR_NAMES = [
     "pings", "direct_failed", "ping_reqs", "suspects", "false_suspects", "payloads",
     "rumors_seen", "changes", "pb_writes", "timers_fired", "refutes", "events_dropped",
-    "active_members", "evdigest", "_14", "_15",
+    "active_members", "evdigest", "_14", "settled",
 ]
 CTR_COUNT = 16
 
@@ -36,7 +37,7 @@ class Config(C.Structure):
         ("probes_per_tick", C.c_int32), ("indirect_k", C.c_int32),
         ("loss_ppm", C.c_uint32), ("suspicion_ticks", C.c_uint32),
         ("retransmit_mult", C.c_uint32), ("max_subjects", C.c_uint32),
-        ("timer_cap", C.c_uint32), ("event_cap", C.c_uint32), ("event_mask", C.c_uint32),
+        ("gc_ticks", C.c_uint32), ("event_cap", C.c_uint32), ("event_mask", C.c_uint32),
         ("inbox_cap", C.c_uint32),
         ("device", C.c_int32), ("shard_index", C.c_uint32), ("n_shards", C.c_uint32),
         ("target_scheme", C.c_uint32),

@@ -34,7 +34,7 @@ def _to_c_config(sc: SimConfig, shard_index: int = 0, n_shards: int = 1) -> _abi
     c.suspicion_ticks = sc.suspicionTicks
     c.retransmit_mult = sc.retransmitMult
     c.max_subjects = sc.maxSubjects
-    c.timer_cap = sc.timerCap
+    c.gc_ticks = sc.gcTicks
     c.event_cap = sc.eventCap
     c.event_mask = sc.eventMask
     c.inbox_cap = sc.inboxCap

@@ -54,7 +54,7 @@ class SimConfig:
     suspicionTicks: int = 0       # 0 -> 3*ceil(log2 N) (D4)
     retransmitMult: int = 0       # 0 -> 3 (D5)
     maxSubjects: int = 0
-    timerCap: int = 0
+    gcTicks: int = 0              # settling horizon (removeDeadNodes); 0 = off, GC_AUTO = S + L + 2
     eventCap: int = 0
     eventMask: int = 0
     inboxCap: int = 0

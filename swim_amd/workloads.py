@@ -48,7 +48,7 @@ def config1(seed=1):
 
 def config2(seed=1):
     """65 536 members, k=3, 1 % hashed crashes in ticks [10,110), 400 ticks."""
-    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=65536, seed=seed, maxSubjects=1024, timerCap=1024)
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=65536, seed=seed, maxSubjects=1024)
     return sc, hashed_crashes(65536, seed, 1, 100, 10, 110), 400
 
 
@@ -57,7 +57,7 @@ def config3(seed=1, crash_per_mille=1, t0=10, t1=1010, max_subjects=2048):
     hashed ticks in [t0,t1) (dissemination-loaded regime); crash_per_mille=0 -> one crash
     (quiescent regime)."""
     n = 1 << 20
-    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=seed, maxSubjects=max_subjects, timerCap=256)
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=seed, maxSubjects=max_subjects)
     if crash_per_mille == 0:
         return sc, [(t0, n // 2)], t1
     return sc, hashed_crashes(n, seed, crash_per_mille, 1000, t0, t1), t1
@@ -75,14 +75,12 @@ def saturated(n_members, total_ticks, seed=1, crashes_per_tick=1.0, t0=10):
     want = max(1, int(round(span * crashes_per_tick)))
     den = 1 << 20
     num = max(1, int(round(want * den / n_members)))
-    # pending suspicion timers per member ~ crashes per tick x suspicion ticks (3 log2 N), with headroom
-    timer_cap = max(256, int(crashes_per_tick * 3 * max(1, (n_members - 1).bit_length()) * 2) + 64)
     sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n_members, seed=seed,
-                   maxSubjects=min(n_members, max(256, 2 * want + 64)), timerCap=timer_cap)
+                   maxSubjects=min(n_members, max(256, 2 * want + 64)))
     return sc, hashed_crashes(n_members, seed, num, den, t0, t0 + span), total_ticks
 
 
 def quiescent(n_members, total_ticks, seed=1):
     """One crash early on; afterwards only probes and empty payloads (regime (q))."""
-    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n_members, seed=seed, maxSubjects=64, timerCap=64)
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n_members, seed=seed, maxSubjects=64)
     return sc, [(2, n_members // 2)], total_ticks

@@ -17,7 +17,7 @@ def main():
     from swim_amd.shard import DistFabric, ShardedSim
     from tests import hostemu_binding, oracle_binding
     sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, eventMask=0x1F,
-                   suspicionTicks=6, maxSubjects=min(n, 1024), timerCap=256)
+                   suspicionTicks=6, maxSubjects=min(n, 1024))
     if os.environ.get("SWIM_DIST_DEVICE", "cpu") == "cuda":
         # all ranks share GPU 0 (RCCL refuses two ranks on one device): the real HIP library, device
         # buffers wrapped zero-copy, records staged through host memory over gloo

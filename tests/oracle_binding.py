@@ -49,8 +49,20 @@ def load():
         lib.swimoracle_hash.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         lib.swimoracle_set_shuffle.restype = C.c_int
         lib.swimoracle_set_shuffle.argtypes = [H, C.c_uint64]
+        lib.swimoracle_set_literal_rule.restype = C.c_int
+        lib.swimoracle_set_literal_rule.argtypes = [H, C.c_int]
+        lib.swimoracle_d13_hits.restype = C.c_uint64
+        lib.swimoracle_d13_hits.argtypes = [H]
+        lib.swimoracle_set_threads.restype = C.c_int
+        lib.swimoracle_set_threads.argtypes = [H, C.c_uint32]
         _cached = ns
     return _cached
+
+
+def set_threads(sim, n):
+    """Step this oracle handle with n member-range threads (results do not depend on n)."""
+    rc = load().lib.swimoracle_set_threads(sim._h, n)
+    assert rc == 0, rc
 
 
 def process(sim, self_id, sender, msg, literal_d8=False):

@@ -31,7 +31,7 @@ def test_small_populations_with_loss(oracle_abi, hip_abi, n, p, loss, seed):
     """Ragged sizes (not multiples of 64/256), heavy loss => refutations, false suspicions,
     indirect probes; P up to the reference default numToGossip=10."""
     sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, eventMask=0x1F,
-                   suspicionTicks=6, maxSubjects=min(n, 1024), timerCap=256)
+                   suspicionTicks=6, maxSubjects=min(n, 1024))
     crashes = [(5, n // 2)] if n > 2 else []
     faults = [(40, n // 2, True)] if n > 2 else []
     a, b = make_pair(oracle_abi, hip_abi, sc, crashes, faults)
@@ -97,7 +97,7 @@ def test_million_members_properties(hip_abi):
     import math
     n = 1 << 20
     crashes = workloads.hashed_crashes(n, 3, 1, 20000, 2, 52)        # ~50 crashes, about one per tick
-    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=3, maxSubjects=128, timerCap=128, suspicionTicks=20)
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=3, maxSubjects=128, suspicionTicks=20)
     digests = []
     for rep in range(2):
         s = Sim.create(hip_abi, sc)
@@ -133,7 +133,7 @@ def test_sharded_cluster_on_one_gpu(oracle_abi, hip_abi, n, shards, loss, seed):
     # every gossip event is compared on the small clusters; on the large one only probe / refute / join
     # events (the per-handle event rings would overflow at different points, which is not protocol state)
     sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=seed, lossPpm=loss, eventMask=0x1F if n <= 4096 else 0,
-                   suspicionTicks=8, maxSubjects=min(n, 4096), timerCap=1024)
+                   suspicionTicks=8, maxSubjects=min(n, 4096))
     crashes = workloads.hashed_crashes(n, seed, 1, 256, 3, 23)
     a = Sim.create(oracle_abi, sc)
     b = ShardedSim(hip_abi, sc, LocalFabric(shards), device="cuda:0")
@@ -192,7 +192,7 @@ def test_dissemination_is_logarithmic(hip_abi, n):
     changed its entry (Suspect) -- with 2P = 6 payloads per member-period the epidemic needs about
     log_7 N + a few periods; 2 log2 N is a generous bound that a broken piggyback path cannot meet."""
     import math
-    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=7, maxSubjects=16, timerCap=16)
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=7, maxSubjects=16)
     s = Sim.create(hip_abi, sc)
     s.crash(n // 3, 2)
     s.step(2)
@@ -217,7 +217,7 @@ def test_robust_target_scheme_parity(oracle_abi, hip_abi, n, p, loss, seed):
     """the robust (round-robin) target scheme (src/Core.hs:232), Ping payloads pulled by
     the target instead of pushed with atomics: bit-exact against the oracle."""
     sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, targetScheme=1, eventMask=0x1F if n <= 4096 else 0,
-                   suspicionTicks=7, maxSubjects=min(n, 2048), timerCap=512)
+                   suspicionTicks=7, maxSubjects=min(n, 2048))
     crashes = workloads.hashed_crashes(n, seed, 1, 128, 3, 33)
     a, b = make_pair(oracle_abi, hip_abi, sc, crashes, [(45, crashes[0][1], True)])
     run_lockstep(a, b, 70, 10, observers=(0, n - 1, crashes[0][1]), members=(0, n - 1, crashes[0][1]))

@@ -27,7 +27,7 @@ def test_config1_every_tick(oracle_abi, emu_abi):
 ])
 def test_small_populations_with_loss(oracle_abi, emu_abi, n, p, loss, seed):
     sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, eventMask=0x1F,
-                   suspicionTicks=6, maxSubjects=min(n, 1024), timerCap=256)
+                   suspicionTicks=6, maxSubjects=min(n, 1024))
     crashes = [(5, n // 2)] if n > 2 else []
     faults = [(40, n // 2, True)] if n > 2 else []
     a, b = make_pair(oracle_abi, emu_abi, sc, crashes, faults)
@@ -39,7 +39,7 @@ def test_many_crashes_saturated_queue(oracle_abi, emu_abi):
     n = 2048
     crashes = workloads.hashed_crashes(n, 5, 1, 8, 3, 43)       # ~256 crashes over 40 ticks
     sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=5, eventMask=0x1F, suspicionTicks=7,
-                   maxSubjects=1024, timerCap=512)
+                   maxSubjects=1024)
     a, b = make_pair(oracle_abi, emu_abi, sc, crashes)
     run_lockstep(a, b, 70, 5, observers=(0, 1, n - 1), members=(0, 1, n - 1))
 
@@ -61,7 +61,7 @@ def test_explicit_record_paths(oracle_abi):
     n = 700
     crashes = workloads.hashed_crashes(n, 9, 1, 6, 3, 33)
     sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=9, lossPpm=30000, eventMask=0x1F, suspicionTicks=6,
-                   maxSubjects=700, timerCap=512, inboxCap=1)
+                   maxSubjects=700, inboxCap=1)
     faults = [(45, m, True) for (_, m) in crashes[:20]]
     a, b = make_pair(oracle_abi, emu, sc, crashes, faults)
     run_lockstep(a, b, 70, 5, observers=(0, 1, n - 1), members=(0, 1, n - 1))
@@ -71,7 +71,7 @@ def test_dissemination_is_logarithmic_small(emu_abi):
     """The O(log N) dissemination check of tests/test_hip_parity.py at a size the emulation handles."""
     import math
     n = 2048
-    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=7, maxSubjects=16, timerCap=16)
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=7, maxSubjects=16)
     s = Sim.create(emu_abi, sc)
     s.crash(n // 3, 2)
     s.step(2)

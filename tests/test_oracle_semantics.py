@@ -13,7 +13,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def run_fixture(abi, spec):
     sc = SimConfig(cfg=Config(numToGossip=spec["k"]), nMembers=spec["n"], seed=spec["seed"], lossPpm=spec["loss_ppm"],
-                   eventMask=0x1F, suspicionTicks=spec["suspicion"], timerCap=256, targetScheme=spec.get("scheme", 0))
+                   eventMask=0x1F, suspicionTicks=spec["suspicion"], targetScheme=spec.get("scheme", 0))
     s = Sim.create(abi, sc)
     for (tick, member, up) in spec["faults"]:
         s.scheduleFault(tick, member, bool(up))
@@ -42,7 +42,7 @@ def test_first_detection_latency_matches_analytic_mean(oracle_abi):
     1/(1-e^-P) periods for P probes per member per period."""
     for P, n_crash in ((1, 400), (3, 400)):
         n = 4096
-        sc = SimConfig(cfg=Config(numToGossip=P), nMembers=n, seed=11 + P, suspicionTicks=50, maxSubjects=1024, timerCap=1024)
+        sc = SimConfig(cfg=Config(numToGossip=P), nMembers=n, seed=11 + P, suspicionTicks=50, maxSubjects=1024)
         s = Sim.create(oracle_abi, sc)
         crashes = [(5 + (k % 40), (k * 10 + 3) % n) for k in range(n_crash)]
         crashes = sorted(set(crashes))
@@ -81,7 +81,7 @@ def test_refutation_keeps_live_members_alive_under_loss(oracle_abi):
     queue is overloaded -- ~12 new rumours per tick cluster-wide -- and refutations lose the race:
     protocol behaviour under overload, documented in DESIGN.md.)"""
     n = 256
-    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=5, lossPpm=50000, eventMask=0x1F, suspicionTicks=24, timerCap=512)
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=5, lossPpm=50000, eventMask=0x1F, suspicionTicks=24)
     s = Sim.create(oracle_abi, sc)
     s.step(300)
     c = s.counters()
@@ -112,7 +112,7 @@ def test_processing_order_does_not_matter(oracle_abi):
     """The merge is commutative: shuffling the order in which members apply received rumours
     leaves every observable unchanged."""
     def run(shuffle):
-        sc = SimConfig(cfg=Config(numToGossip=3), nMembers=300, seed=8, lossPpm=150000, eventMask=0x1F, suspicionTicks=10, timerCap=512)
+        sc = SimConfig(cfg=Config(numToGossip=3), nMembers=300, seed=8, lossPpm=150000, eventMask=0x1F, suspicionTicks=10)
         s = Sim.create(oracle_abi, sc)
         oracle_abi.lib.swimoracle_set_shuffle(s._h, shuffle)
         s.crash(5, 2); s.crash(100, 4); s.scheduleFault(30, 5, True)
@@ -153,3 +153,118 @@ def test_capacity_errors_are_loud(oracle_abi):
     assert ei.value.status == -4
     with pytest.raises(SwimError):
         s.step(1)                      # poisoned
+
+
+def test_threads_do_not_matter(oracle_abi):
+    """Member-range threads (swimoracle_set_threads: the CPU baseline's "all host cores" mode and the
+    checker for full-size runs) leave every observable unchanged."""
+    from tests import oracle_binding
+
+    def run(threads):
+        sc, crashes, _ = workloads.saturated(6000, 60)
+        sc.lossPpm = 30000
+        sc.eventMask = 0x1F
+        s = Sim.create(oracle_abi, sc)
+        workloads.apply_crashes(s, crashes)
+        s.scheduleFault(30, crashes[0][1], True)
+        if threads > 1:
+            oracle_binding.set_threads(s, threads)
+        out = []
+        for _ in range(6):
+            s.step(10)
+            out.append(s.digest())
+        return out, s.drainEventsRaw(), s.counters(), s.firstDetection(), s.members(17)
+    base = run(1)
+    for th in (2, 5, 16):
+        assert run(th) == base
+
+
+def test_literal_reference_rule_gives_the_same_run_where_d13_is_not_hit(oracle_abi):
+    """Narrowing "parity unpinned": whole clusters stepped under the LITERAL suspectOrDeadNode'
+    (src/Core.hs:151-152,182-184) instead of the commutative merge.  Without loss nothing is ever
+    suspected twice, the D13 difference set is never hit and the two runs are identical in every
+    observable; under loss the counter says exactly how often the rules part."""
+    lib = oracle_abi.lib
+
+    def run(literal, n, loss, crashes, ticks, susp):
+        sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=4, lossPpm=loss, eventMask=0x1F, suspicionTicks=susp,
+                       maxSubjects=min(n, 1024))
+        s = Sim.create(oracle_abi, sc)
+        lib.swimoracle_set_literal_rule(s._h, 1 if literal else 0)
+        workloads.apply_crashes(s, crashes)
+        out = []
+        for _ in range(ticks // 10):
+            s.step(10)
+            out.append(s.digest())
+        return (out, s.drainEventsRaw(), s.counters(), s.firstDetection()), lib.swimoracle_d13_hits(s._h)
+    for n, crashes, ticks, susp in ((128, [(10, 64)], 120, 21), (4096, [(5 + k, 37 * k + 1) for k in range(40)], 150, 12),
+                                    (1000, [(3, 1), (3, 2), (3, 3), (40, 500)], 100, 6)):
+        merge, h0 = run(False, n, 0, crashes, ticks, susp)
+        lit, h1 = run(True, n, 0, crashes, ticks, susp)
+        assert h0 == 0 and h1 == 0
+        assert lit == merge
+    # with loss: refutations race with re-suspicion, the literal rule ignores Suspect@i+1 on a Suspect entry
+    merge, _ = run(False, 300, 150000, [(5, 7)], 150, 8)
+    lit, hits = run(True, 300, 150000, [(5, 7)], 150, 8)
+    assert hits > 0 and lit != merge
+
+
+def _gc_config(n, G, **kw):
+    from swim_amd import _abi
+    return SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=6, eventMask=0x1F, suspicionTicks=8, gcTicks=G, **kw)
+
+
+def test_settling_is_removeDeadNodes_and_reclaims_columns(oracle_abi):
+    """gc_ticks (src/Core.hs:65-67 `removeDeadNodes` + anti-entropy): Dead members leave every member map
+    after G quiet periods, their view columns are reused (more subjects than max_subjects over the run),
+    they are still never probed, and a later rejoin is accepted and settles as a listed Alive@1."""
+    from swim_amd import _abi
+    n = 256
+    sc = _gc_config(n, _abi.GC_AUTO, maxSubjects=12)
+    s = Sim.create(oracle_abi, sc)
+    G = s.resolved.gc_ticks
+    assert G == s.resolved.suspicion_ticks + s.resolved.retransmit_mult * 9 + 2
+    crashes = [(5 + 12 * k, 10 + k) for k in range(40)]           # 40 subjects through 12 columns
+    workloads.apply_crashes(s, crashes)
+    s.scheduleFault(300, 10, True)                                 # rejoins long after it was settled Dead
+    s.step(250)
+    assert s.counters()["settled"] >= 8
+    v = s.members(0)
+    assert all(int(m.memberAlive) in (1, 2) for m in v)
+    assert "m10" not in [m.memberName for m in v]                  # removed, not merely Dead
+    p0 = s.counters()["pings"]
+    s.step(40)                                                     # live members keep 3 probes per tick: the
+    up = n - sum(1 for (t, _) in crashes if t < 290)               # removed ones are never picked
+    assert s.counters()["pings"] - p0 >= 3 * up * 40 - 3 * 40 * 4
+    s.step(5 + 12 * 40 + 3 * G + 330 - s.tick)
+    assert s.counters()["settled"] >= 41
+    for o in (0, 99, 255):
+        v = s.members(o)
+        assert [(m.memberName, int(m.memberAlive), m.memberIncarnation) for m in v] == [("m10", 0, 1)], (o, v)
+    assert s.counters()["false_suspects"] == 0
+
+
+def test_settling_does_not_change_what_the_protocol_decides(oracle_abi):
+    """Without loss dissemination completes long before the horizon: the event stream, the counters and
+    the first-detection ticks of a settled run equal those of the unsettled run.  (A member that comes
+    back after a long downtime is the exception by design: the settled state stands for what it pulls
+    from its join host, src/Types.hs:47 joinHosts -- it neither probes the removed members nor fires
+    timers it slept through.)"""
+    from swim_amd import _abi
+    out = []
+    for G in (0, _abi.GC_AUTO):
+        sc = _gc_config(512, G, maxSubjects=64)
+        s = Sim.create(oracle_abi, sc)
+        for k in range(30):
+            s.crash(20 + k, 4 + 3 * k)
+        s.step(400)
+        c = s.counters()
+        settled = c.pop("settled")
+        out.append((s.drainEventsRaw(), c, s.firstDetection()))
+        assert (settled > 0) == (G != 0)
+    assert out[0] == out[1]
+
+
+def test_gc_ticks_below_the_safe_horizon_are_refused(oracle_abi):
+    err, s = Sim.configure(oracle_abi, _gc_config(64, 5))
+    assert s is None and "gc_ticks" in err

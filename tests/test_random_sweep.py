@@ -25,7 +25,7 @@ def test_random_configurations(oracle_abi, block):
             shards = rng.choice([g for g in (2, 3, 4, 8) if n % g == 0] or [1])
         seed = rng.randrange(1, 1 << 30)
         sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, eventMask=0x1F,
-                       suspicionTicks=rng.choice([3, 6, 12]), maxSubjects=min(n, 1024), timerCap=1024,
+                       suspicionTicks=rng.choice([3, 6, 12]), maxSubjects=min(n, 1024),
                        targetScheme=scheme, inboxCap=rng.choice([0, 0, 1, 2]))
         a = Sim.create(oracle_abi, sc)
         b = Sim.create(emu, sc) if shards == 1 else ShardedSim(emu, sc, LocalFabric(shards))

@@ -52,7 +52,7 @@ def test_every_crash_is_detected_in_its_first_period(oracle_abi):
 
 @pytest.mark.parametrize("n,p,loss,seed", [(2, 1, 0, 1), (65, 3, 0, 2), (128, 3, 100000, 3), (300, 5, 200000, 4), (777, 3, 0, 5)])
 def test_robust_parity_hostemu(oracle_abi, emu_abi, n, p, loss, seed):
-    sc = robust(n, p, seed=seed, lossPpm=loss, eventMask=0x1F, suspicionTicks=6, maxSubjects=min(n, 1024), timerCap=256)
+    sc = robust(n, p, seed=seed, lossPpm=loss, eventMask=0x1F, suspicionTicks=6, maxSubjects=min(n, 1024))
     crashes = [(5, n // 2)] if n > 2 else []
     faults = [(40, n // 2, True)] if n > 2 else []
     a, b = make_pair(oracle_abi, emu_abi, sc, crashes, faults)
@@ -65,7 +65,7 @@ def test_robust_parity_hostemu_fallback_paths(oracle_abi):
     emu = hostemu_binding.load_variant("win4", ["SWIM_MASK_WIN=4", "SWIM_MASK_SLACK=2"])
     n = 500
     crashes = workloads.hashed_crashes(n, 9, 1, 6, 3, 33)
-    sc = robust(n, 3, seed=9, lossPpm=30000, eventMask=0x1F, suspicionTicks=6, maxSubjects=500, timerCap=512, inboxCap=1)
+    sc = robust(n, 3, seed=9, lossPpm=30000, eventMask=0x1F, suspicionTicks=6, maxSubjects=500, inboxCap=1)
     a, b = make_pair(oracle_abi, emu, sc, crashes, [(45, m, True) for (_, m) in crashes[:10]])
     run_lockstep(a, b, 60, 5, observers=(0, 1, n - 1), members=(0, 1, n - 1))
 

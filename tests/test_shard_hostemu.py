@@ -36,7 +36,7 @@ def lockstep(oracle, sharded, ticks, chunk, observers, members):
 ])
 def test_sharded_matches_oracle(oracle_abi, emu_abi, n, shards, p, loss, seed):
     sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, eventMask=0x1F,
-                   suspicionTicks=6, maxSubjects=min(n, 1024), timerCap=256)
+                   suspicionTicks=6, maxSubjects=min(n, 1024))
     a = Sim.create(oracle_abi, sc)
     b = ShardedSim(emu_abi, sc, LocalFabric(shards))
     for s in (a, b):
@@ -52,7 +52,7 @@ def test_sharded_saturated_queues(oracle_abi, emu_abi):
     n = 1024
     crashes = workloads.hashed_crashes(n, 5, 1, 8, 3, 33)
     sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=5, eventMask=0x1F, suspicionTicks=7,
-                   maxSubjects=512, timerCap=512)
+                   maxSubjects=512)
     a = Sim.create(oracle_abi, sc)
     b = ShardedSim(emu_abi, sc, LocalFabric(4))
     for s in (a, b):
@@ -69,7 +69,7 @@ def test_sharded_with_tiny_mask_window(oracle_abi):
     n = 384
     crashes = workloads.hashed_crashes(n, 11, 1, 8, 3, 33)
     sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=11, lossPpm=20000, eventMask=0x1F, suspicionTicks=6,
-                   maxSubjects=384, timerCap=512, inboxCap=2)
+                   maxSubjects=384, inboxCap=2)
     a = Sim.create(oracle_abi, sc)
     b = ShardedSim(emu, sc, LocalFabric(3))
     for s in (a, b):
