@@ -21,17 +21,22 @@ enum { P_SELECT = 1, P_PROXY = 2, P_L_PING = 3, P_L_ACK = 4, P_L_REQ = 5, P_L_FW
        P_L_RELAY = 8 };
 enum : uint64_t { TAG_SELF = 0x53454c46u, TAG_VIEW = 0x56494557u, TAG_PB = 0x50425546u,
                   TAG_TIMER = 0x54494d52u, TAG_FD = 0x46444554u, TAG_EV = 0x45564e54u,
-                  TAG_INC = 0x494e4352u, TAG_TICK = 0x5449434bu, TAG_MEMBER = 0x4d454d42u };
+                  TAG_INC = 0x494e4352u, TAG_TICK = 0x5449434bu, TAG_MEMBER = 0x4d454d42u,
+                  TAG_BASE = 0x42415345u };
 
 // globals word indices (DevState::g)
-enum { G_NSLOTS = 0, G_ERR = 1, G_EVCUR = 2, G_OVF0 = 3, G_OVF1 = 4, G_NRUM = 5, G_HEAD = 6, G_PREV = 7,
+enum { G_NSLOTS = 0 /* view rows ever handed out (high-water mark) */, G_ERR = 1, G_EVCUR = 2, G_OVF0 = 3, G_OVF1 = 4,
+       G_NRUM = 5, G_HEAD = 6, G_PREV = 7,
+       G_NFREE = 8 /* reclaimed rows on the free stack */, G_NLIVE = 9 /* subjects with a row (max_subjects bounds it) */,
+       G_SETTLE_N = 10 /* rows whose entries this tick's merge reduces */, G_ZERO_N = 11 /* rows it clears */,
+       G_SETTLE_PENDING = 12 /* the lists above still await settle_finish */, G_SETTLE_TICK = 13,
        G_SEND = 16 /* [3][16] exchange records appended per peer (send_cnt) */, G_WORDS = 64 };
-enum { ERRF_SUBJECTS = 1, ERRF_TIMERS = 2, ERRF_OVF = 4, ERRF_INC = 8, ERRF_XCHG = 16 };
+enum { ERRF_SUBJECTS = 1, ERRF_ROWS = 2, ERRF_OVF = 4, ERRF_INC = 8, ERRF_XCHG = 16 };
 
 // counter slots (same order as SWIMSIM_CTR_* in include/swimsim.h)
 enum { C_PINGS = 0, C_DIRECT_FAILED, C_PING_REQS, C_SUSPECTS, C_FALSE_SUSPECTS, C_PAYLOADS,
        C_RUMORS_SEEN, C_CHANGES, C_PB_WRITES, C_TIMERS_FIRED, C_REFUTES, C_EVENTS_DROPPED,
-       C_ACTIVE, C_EVDIGEST, C_EXAMINED /* view lookups by merge_kernel (internal) */, C_COUNT = 16 };
+       C_ACTIVE, C_EVDIGEST, C_EXAMINED /* view lookups by merge_kernel (internal) */, C_SETTLED, C_COUNT = 16 };
 
 // ---- hashes (replace the global StdGen of src/Util.hs:40, F7) -----------
 __host__ __device__ inline uint32_t mix32(uint32_t x) {
@@ -56,10 +61,11 @@ __host__ __device__ inline uint64_t h4(uint64_t tag, uint64_t a, uint64_t b, uin
 // ---- device state (struct of arrays) -----------------------------------------------------
 // Per-member arrays are indexed by member id so that a wave of 64 consecutive members
 // issues coalesced loads.  The tick is bound by the NUMBER of L2<->fabric requests (measured:
-// ~45 G requests/s for scattered 64-B accesses, profiles/), so the two big owner-private tables
-// are position-major: view entries V[slot][member] and timer rings ring[position][member].  The
-// members of a wave look at the same few rumour slots (the ones in circulation) and their FIFO
-// positions advance in step, so their accesses share 64-B sectors instead of costing one
+// ~45-55 G requests/s for scattered 64-B accesses, profiles/), so the two big owner-private tables
+// are row-major over members: view entries V[slot][member] and suspicion deadlines
+// trow[deadline mod S][member].  The members of a wave look at the same few rumour slots (the ones
+// in circulation) -- merge_kernel walks them in wave-uniform order -- and every member reads and
+// rewrites the SAME deadline row in a tick, so these accesses share sectors instead of costing one
 // request per member.
 struct DevState {
   // N = members owned by this handle (local index li in [0,N)), NT = whole population, lo = global id of
@@ -68,13 +74,15 @@ struct DevState {
   // per-member array by LOCAL index.  Hashes, events and digests always use global ids.
   uint32_t N, NT, lo, n_shards, shard;
   uint32_t scheme;         // SWIMSIM_TARGETS_*: how the direct probes of a period pick their targets
-  uint32_t P, K, S, L, loss_thr, R_max, timer_cap, event_cap, event_mask, nblocks;
+  uint32_t P, K, S, L, loss_thr, R_max /* max_subjects */, R_phys /* view rows allocated */, G /* settling horizon, 0 = off */;
+  uint32_t event_cap, event_mask, nblocks;
   uint32_t inbox_cap, ovf_cap;  // per-member delivery slots; exact overflow list capacity
   uint32_t* minfo;         // per member, ONE gather per probe target:
                            //   bits 0-15 rumour slot+1 of this member as a subject (0 none,
                            //   0xFFFF being allocated), 16-19 valid piggyback slots,
                            //   20 which pb buffer is current, 21 up (ground truth),
-                           //   22 the queue holds an entry its mask cannot express (MI_OOW)
+                           //   22 the queue holds an entry its mask cannot express (MI_OOW),
+                           //   23-24 state of the settled base entry about this member (everybody's default)
   uint16_t* probe_out;     // nsent | nfail<<5 | n explicit own-ack sources<<10, probe -> merge kernel
   ulonglong2* pk;          // per member {x: the queue as a 64-bit mask over rumour-id positions (rid & 63),
                            //   y: known-ring, bit (rid & 63) set => this member's view already dominates
@@ -89,11 +97,23 @@ struct DevState {
   uint32_t* ackfrom;       // [N][P] sources whose Ack reached this member with such a payload
   uint32_t* inbox_cnt;     // explicit deliveries to this member this tick
   uint32_t* inbox;         // [N][inbox_cap] source ids (bit31 = source's pb buffer)
-  uint4* hot;              // {storeIncarnation, timer ring head | count<<16, -, next deadline}
+  uint2* hot;              // {storeIncarnation, flags: bit 0 = came back up, deadlines slept through not fired yet}
   uint32_t* subject_of;    // slot -> subject
   uint32_t* fail;          // [N][P] targets whose probe ended without ack
-  uint2* ring;             // [timer_cap][N] {slot, deadline}: FIFO of suspicion timers
-  uint2* V;                // [R_max][N] {key = inc<<2|state, lastChange+1}
+  uint4* trow;             // [S][N] suspicion deadlines: row d mod S = 8 x 16-bit (slot+1) this member must
+                           //   look at in tick d (the FIXME at src/Core.hs:141; D4).  Every member reads and
+                           //   rewrites row t mod S in tick t: coalesced, no per-member FIFO.
+  uint2* V;                // [R_phys][N] {key = inc<<2|state, lastChange+1}; key 0 = default = slot_base[slot]
+  // ---- settling (gc_ticks; include/swimsim.h): removeDeadNodes (src/Core.hs:65-67)
+  uint32_t* slot_last;     // [R_phys] last tick any entry of the row changed / its subject announced itself
+  uint32_t* slot_base;     // [R_phys] base key of the row's subject (what a cell with key 0 means)
+  uint8_t* slot_used;      // [R_phys] 1 = the row belongs to subject_of[row]
+  uint32_t* base_key;      // [NT] settled entry about a member (0 = Alive@0), base_since its settling tick
+  uint32_t* base_since;
+  uint32_t* free_rows;     // [R_phys] stack of reclaimed rows (popped by ensure_slot, pushed by settle_finish)
+  uint32_t* settle_slots;  // [R_phys] rows eligible this tick; settle_key[k] = max entry among up members
+  uint32_t* settle_key;
+  uint32_t* zero_slots;    // [R_phys] rows settled at the end of the last tick: cleared by this tick's merge
   uint64_t* pb;            // [2][N][PB_SLOTS] {lo: slot | rid<<16, hi: key | tx<<24}, sorted by priority
   uint32_t* first_suspect;
   uint32_t* crash_tick;
@@ -216,7 +236,8 @@ __device__ inline bool rid_maskable(uint32_t rid, uint32_t H) {
 
 // minfo fields
 constexpr uint32_t MI_SLOT = 0xFFFFu, MI_PBN_SHIFT = 16, MI_PBN = 0xFu << 16, MI_BUF = 1u << 20,
-                   MI_UP = 1u << 21, MI_OOW = 1u << 22, MI_PB = MI_PBN | MI_BUF | MI_OOW;
+                   MI_UP = 1u << 21, MI_OOW = 1u << 22, MI_PB = MI_PBN | MI_BUF | MI_OOW,
+                   MI_BASE_SHIFT = 23, MI_BASE = 3u << MI_BASE_SHIFT;
 __device__ inline uint32_t mi_pbn(uint32_t mi) { return (mi >> MI_PBN_SHIFT) & 0xFu; }
 __device__ inline uint32_t mi_buf(uint32_t mi) { return (mi >> 20) & 1u; }
 __device__ inline bool mi_up(uint32_t mi) { return (mi & MI_UP) != 0; }
@@ -226,8 +247,28 @@ __device__ inline uint32_t mi_src(uint32_t id, uint32_t mi) { return id | (mi_bu
 // `isAlive` on local member li's view of c (src/Core.hs:33-34, 72-74); mc = minfo[c]
 __device__ inline bool view_alive(const DevState& s, uint32_t li, uint32_t mc) {
   const uint32_t sl = mc & MI_SLOT;
-  if (sl == 0 || sl == MI_SLOT) return true;       // nobody ever gossiped about c: Alive@0
-  return (s.V[vidx(s, li, sl - 1)].x & 3u) == ST_ALIVE;
+  if (sl == 0 || sl == MI_SLOT) return ((mc >> MI_BASE_SHIFT) & 3u) == ST_ALIVE;   // no row: the settled base (Alive@0 at first)
+  const uint32_t k = s.V[vidx(s, li, sl - 1)].x;
+  return ((k ? k : s.slot_base[sl - 1]) & 3u) == ST_ALIVE;
+}
+
+// ---- suspicion deadlines (trow) ---------------------------------------------------------------
+// One 16-byte cell per (deadline mod S, member): up to 8 halfwords slot+1, packed from halfword 0; a cell
+// that would need a ninth carries TR_FULL in its last halfword = "look at every row" (exact, slow, rare).
+constexpr uint32_t TR_SLOTS = 8, TR_FULL = 0xFFFFu;
+struct TimerCell { unsigned long long lo, hi; uint32_t n; };
+__device__ inline void tc_put(TimerCell& c, uint32_t slot1) {
+  if (c.n < 4u) c.lo |= (unsigned long long)slot1 << (16u * c.n);
+  else if (c.n < TR_SLOTS) c.hi |= (unsigned long long)slot1 << (16u * (c.n - 4u));
+  else c.hi |= (unsigned long long)TR_FULL << 48;
+  c.n++;
+}
+__device__ inline uint32_t tc_get(const uint4& v, uint32_t k) {
+  const uint32_t w = k < 2u ? v.x : k < 4u ? v.y : k < 6u ? v.z : v.w;
+  return (k & 1u) ? (w >> 16) : (w & 0xFFFFu);
+}
+__device__ inline uint4 tc_pack(const TimerCell& c) {
+  return make_uint4((uint32_t)c.lo, (uint32_t)(c.lo >> 32), (uint32_t)c.hi, (uint32_t)(c.hi >> 32));
 }
 
 // kRandomMembers (src/Core.hs:69-74) + shuffle (src/Util.hs:37-42) as n draws without

@@ -6,7 +6,7 @@
 // position-major so that a wave's accesses share sectors, and only cross-member deliveries go
 // through atomics.
 // Three launches per tick:
-//   begin_kernel : one thread: scheduled faults, rumour-id window head (+ the tick's id dictionary).
+//   begin_kernel : one block: settling bookkeeping, scheduled faults, rumour-id window head (+ id dictionary).
 //   probe_kernel : one period of failureDetector / probeNode' per member (src/Core.hs:233-269),
 //                  closed form of the message exchange; delivers the piggyback payloads as masks.
 //   merge_kernel : owner-computes end of tick: delivered rumours, timers, state rule, piggyback queue
@@ -36,6 +36,10 @@ __device__ inline void ctr_add(BlockCounters* sh, int which, unsigned x) {
 
 __device__ inline unsigned wave_sum(unsigned x) {
   for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+  return x;
+}
+__device__ inline unsigned wave_max(unsigned x) {            // lane 0 holds the result
+  for (int o = 32; o > 0; o >>= 1) { const unsigned y = __shfl_down(x, o, 64); x = y > x ? y : x; }
   return x;
 }
 
@@ -68,9 +72,20 @@ __device__ inline void ensure_slot(const DevState& s, uint32_t j) {
   while ((cur & MI_SLOT) == 0u) {
     const uint32_t seen = atomicCAS(&s.minfo[j], cur, cur | MI_SLOT);   // 0xFFFF = being allocated
     if (seen == cur) {
-      uint32_t r = atomicAdd(&s.g[G_NSLOTS], 1u);
-      if (r >= s.R_max) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_SUBJECTS); r = 0; }
+      // a reclaimed row if there is one (pushed only by settle_finish, between the tick kernels), else a new one
+      uint32_t r;
+      const int f = (int)atomicAdd(&s.g[G_NFREE], 0xFFFFFFFFu) - 1;
+      if (f >= 0) r = s.free_rows[f];
+      else {
+        atomicAdd(&s.g[G_NFREE], 1u);
+        r = atomicAdd(&s.g[G_NSLOTS], 1u);
+        if (r >= s.R_phys) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_ROWS); r = 0; }
+      }
+      if (atomicAdd(&s.g[G_NLIVE], 1u) >= s.R_max) atomicOr(&s.g[G_ERR], (uint32_t)ERRF_SUBJECTS);
       s.subject_of[r] = j;
+      s.slot_base[r] = s.base_key[j];
+      s.slot_last[r] = NONE32;
+      s.slot_used[r] = 1;
       __threadfence();
       atomicXor(&s.minfo[j], MI_SLOT ^ (r + 1u));
       return;
@@ -395,9 +410,25 @@ __device__ inline void group_put(NewGroup& c, uint32_t slot, uint32_t rid, uint3
 #ifndef SWIM_MERGE_WAVES
 #define SWIM_MERGE_WAVES 4
 #endif
+constexpr int ASM_STRIDE = BLOCK + 2;   // words per LDS column: keeps the transposed line store conflict-free
+
+// Settling, the per-member part (swim_device.h; begin_kernel builds the lists, settle_finish commits):
+// every member -- up or down -- shows its entry of each eligible row (the maximum over the members that
+// are up goes to settle_key) and clears its cell of every row settled at the end of the last tick.
+__device__ inline void settle_pass(const DevState& s, uint32_t li, bool up) {
+  const uint32_t ns = s.g[G_SETTLE_N], nz = s.g[G_ZERO_N];
+  for (uint32_t k = 0; k < ns; ++k) {
+    const uint32_t key = up ? s.V[vidx(s, li, s.settle_slots[k])].x : 0u;
+    const uint32_t m = wave_max(key);
+    if ((threadIdx.x & 63u) == 0u && m) atomicMax(&s.settle_key[k], m);
+  }
+  if (li < s.N)
+    for (uint32_t k = 0; k < nz; ++k) s.V[vidx(s, li, s.zero_slots[k])] = make_uint2(0u, 0u);
+}
+
 __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState s, uint32_t t) {
   __shared__ BlockCounters sh;
-  __shared__ uint32_t asm_[PB_SLOTS][2][BLOCK];   // the outgoing line is assembled here: [entry][word][thread]
+  __shared__ uint32_t asm_[PB_SLOTS * 2][ASM_STRIDE];   // the outgoing line is assembled here: [2 entry + word][thread]
   __shared__ uint32_t wfl[BLOCK];
   ctr_init(&sh);
   const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
@@ -405,238 +436,281 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
   const uint32_t tid = threadIdx.x;
   if (blockIdx.x == 0 && threadIdx.x == 0) s.g[G_OVF0 + ((t + 1) & 1u)] = 0;  // next tick's overflow list
   const uint32_t mi = li < s.N ? s.minfo[i] : 0u;
+  const bool up = mi_up(mi);
   const uint32_t H = s.g[G_HEAD];
   const unsigned long long stale = stale_positions(s.g[G_PREV], H);
-  uint32_t wflag = 0;                              // bit 0: my line was rebuilt in asm_, bit 1: into which buffer
-  if (mi_up(mi)) {
+  if (s.G) settle_pass(s, li, up);
+
+  // ---- this member's inputs of the tick (coalesced)
+  uint32_t nsent = 0, nfail = 0, nack = 0, cnt = 0;
+  unsigned long long pushed = 0, pulled = 0;
+  uint2 hot0 = make_uint2(0u, 0u);
+  uint4 due = make_uint4(0u, 0u, 0u, 0u);          // deadline row of this tick
+  const size_t trix = (size_t)(t % s.S) * s.N + li;
+  if (up) {
     const uint32_t po = s.probe_out[li];
-    const uint32_t nsent = po & 31u, nfail = (po >> 5) & 31u, nack = po >> 10;
-    const uint32_t cnt = s.inbox_cnt[li];
-    const unsigned long long pushed = s.inmask[li];
-    unsigned long long pulled = s.ackmask[li];
+    nsent = po & 31u; nfail = (po >> 5) & 31u; nack = po >> 10;
+    cnt = s.inbox_cnt[li];
+    pushed = s.inmask[li];
+    pulled = s.ackmask[li];
     if (s.n_shards > 1)                              // Ack payloads of remote targets: one slot per probe
       for (uint32_t p = 0; p < s.P; ++p) {
         const unsigned long long v = s.ackslot[(size_t)li * s.P + p];
         if (v) { pulled |= v; s.ackslot[(size_t)li * s.P + p] = 0; }
       }
-    const uint4 hot0 = s.hot[li];
-    uint32_t self_inc = hot0.x, thead = hot0.y & 0xFFFFu, tcount = hot0.y >> 16, tnext = hot0.w;
-    const uint32_t pcount = mi_pbn(mi), cur = mi_buf(mi);
-    const bool timer_due = tcount && tnext <= t;
-    if (!((pushed | pulled) != 0ull || (cnt | nack | nfail | pcount | (uint32_t)timer_due))) {
-      // idle this tick: only keep the ring valid (swim_device.h); nothing to write when no id was allocated
-      if (stale) { const ulonglong2 v = s.pk[li]; if (v.y & stale) s.pk[li] = make_ulonglong2(v.x, v.y & ~stale); }
-    } else {
-      // ---- known-ring: forget the positions of the ids allocated during the previous tick
-      unsigned long long kn = s.pk[li].y & ~stale;
-      // ---- own queue (sorted by priority; see swim_device.h): only the slot ids stay live (two per
-      // register) for the "superseded" test; the line itself is read again when the queue is rebuilt
-      NewGroup c; c.n = 0;
-#pragma unroll
-      for (int k = 0; k < PB_SLOTS; ++k) { c.w[k] = 0; c.key[k] = 0; c.subj[k] = 0; }
-      uint32_t killmask = 0;                        // own entries superseded by (or moved into) the new group
-      uint32_t oslot[PB_SLOTS / 2];
-#pragma unroll
-      for (int h = 0; h < PB_SLOTS / 2; ++h) oslot[h] = 0xFFFFFFFFu;   // no entry: matches no slot (< 0xFFFF)
-      const uint4* own_line = reinterpret_cast<const uint4*>(s.pb + ((size_t)cur * s.N + li) * PB_SLOTS);
-      if (pcount) {
-#pragma unroll
-        for (int h = 0; h < PB_SLOTS / 2; ++h) {
-          const uint4 v = own_line[h];
-          oslot[h] = (pe_tx(v.y) ? pe_slot(v.x) : 0xFFFFu) | ((pe_tx(v.w) ? pe_slot(v.z) : 0xFFFFu) << 16);
-        }
-      }
-      if (pcount && nsent == 0) {
-        // nothing was sent, nothing ages: entries still at tx == L tie with this tick's changes and
-        // are ordered with them by subject (the only case that needs the subjects of old entries)
-        const uint2* own = reinterpret_cast<const uint2*>(own_line);
-        for (uint32_t k = 0; k < pcount; ++k) {
-          const uint2 v = own[k];
-          if (pe_tx(v.y) != s.L) break;             // sorted: the tx == L entries come first
-          group_put(c, pe_slot(v.x), pe_rid(v.x), pe_key(v.y), s.subject_of[pe_slot(v.x)]);
-          killmask |= 1u << k;
-        }
-      }
-      const uint32_t my_slot1 = mi & MI_SLOT;       // slot+1 of rumours about me
-      uint32_t refute = NONE32;
-      unsigned changes = 0, timers_fired = 0, evdropped = 0, examined = 0;
-      unsigned long long evd = 0, ha = 0;
+    hot0 = s.hot[li];
+    due = s.trow[trix];
+  }
+  const uint32_t pcount = mi_pbn(mi), cur = mi_buf(mi);
+  const bool woke = (hot0.y & 1u) != 0;            // came back up: deadlines it slept through are still in trow
+  const bool timer_due = (due.x | due.y | due.z | due.w) != 0u;
+  const bool act = up && ((pushed | pulled) != 0ull || (cnt | nack | nfail | pcount | (uint32_t)timer_due | (uint32_t)woke));
+  // idle this tick: only keep the ring valid (swim_device.h); nothing to write when no id was allocated
+  if (up && !act && stale) { const ulonglong2 v = s.pk[li]; if (v.y & stale) s.pk[li] = make_ulonglong2(v.x, v.y & ~stale); }
 
-      auto kill_slot = [&](uint32_t slot) {
+  uint32_t wflag = 0;                              // bit 0: my line was rebuilt in asm_, bit 1: into which buffer
+  uint32_t self_inc = hot0.x;
+  unsigned long long kn = 0;                       // known-ring, positions of last tick's new ids forgotten
+  NewGroup c; c.n = 0;
 #pragma unroll
-        for (int h = 0; h < PB_SLOTS / 2; ++h) {
-          if ((oslot[h] & 0xFFFFu) == slot) killmask |= 1u << (2 * h);
-          if ((oslot[h] >> 16) == slot) killmask |= 1u << (2 * h + 1);
-        }
-      };
-      // The state rule on one proposal (slot, key).
-      auto examine = [&](uint32_t slot, uint32_t key, uint32_t cause, bool hasrid, uint32_t rid_in) {
-        if (slot + 1 == my_slot1) {
-          // about self -> refute (src/Core.hs:155-166): remember the largest non-Alive incarnation
-          if ((key & 3u) != ST_ALIVE) refute = (refute == NONE32 || (key >> 2) > refute) ? (key >> 2) : refute;
-          return;
-        }
-        examined++;
-        const uint2 e = s.V[vidx(s, li, slot)];
-        if (key <= e.x) return;                      // old incarnation / weaker state: ignore (:151)
-        s.V[vidx(s, li, slot)] = make_uint2(key, t + 1);                    // memberLastChange = now (:176)
-        const uint32_t subject = s.subject_of[slot];
-        if (!ha) ha = mix64(mix64((uint64_t)TAG_EV) + (((uint64_t)t << 32) | i));
-        const unsigned long long hx = mix64(ha + subject);                // h4(TAG_EV, a, subject, .) prefix
-        evd += mix64(hx + key) - mix64(hx + e.x);
-        changes += (e.y != t + 1) ? 1u : 0u;
-        if (cause == 1u) timers_fired++;
-        if ((key & 3u) == ST_SUSPECT) {              // start the suspicion timer (D4)
-          if (tcount >= s.timer_cap) atomicOr(&s.g[G_ERR], (uint32_t)ERRF_TIMERS);
-          else {
-            uint32_t pos = thead + tcount; if (pos >= s.timer_cap) pos -= s.timer_cap;
-            s.ring[ridx(s, li, pos)] = make_uint2(slot, t + s.S);
-            if (tcount == 0) tnext = t + s.S;
-            tcount++;
-          }
-        }
-        const uint32_t rid = hasrid ? rid_in : find_rid(s, slot, key);
-        kill_slot(slot);
-        group_put(c, slot, rid, key, subject);       // `Just msg` -> Broadcast -> enqueue (D5)
-        if (s.event_mask & (1u << cause)) {
-          const uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
-          if (pos < s.event_cap) s.events[pos] = make_uint4(t, i, subject, (key << 8) | cause);
-          else evdropped++;
-        }
-      };
+  for (int k = 0; k < PB_SLOTS; ++k) { c.w[k] = 0; c.key[k] = 0; c.subj[k] = 0; }
+  uint32_t killmask = 0;                           // own entries superseded by the new group
+  uint32_t oslot[PB_SLOTS / 2];                    // slot ids of the own queue, two per register
+#pragma unroll
+  for (int h = 0; h < PB_SLOTS / 2; ++h) oslot[h] = 0xFFFFFFFFu;   // no entry: matches no slot (< 0xFFFF)
+  const uint4* own_line = reinterpret_cast<const uint4*>(s.pb + ((size_t)cur * s.N + (li < s.N ? li : 0u)) * PB_SLOTS);
+  const uint32_t my_slot1 = mi & MI_SLOT;          // slot+1 of rumours about me
+  uint32_t refute = NONE32;
+  unsigned changes = 0, timers_fired = 0, evdropped = 0, examined = 0;
+  unsigned long long evd = 0, ha = 0;
+  TimerCell tnew; tnew.lo = 0; tnew.hi = 0; tnew.n = 0;   // deadlines t + S: go to the row just consumed
 
-      // phase 1: suspicion timers, evaluated on the start-of-tick view
-      if (timer_due)
-        while (tcount) {
-          const uint2 tm = s.ring[ridx(s, li, thead)];
-          if (tm.y > t) break;
-          thead = (thead + 1 == s.timer_cap) ? 0 : thead + 1;
-          tcount--;
-          const uint2 e = s.V[vidx(s, li, tm.x)];
-          if ((e.x & 3u) == ST_SUSPECT && e.y - 1 + s.S == tm.y) examine(tm.x, (e.x & ~3u) | ST_DEAD, 1u, false, 0u);
-        }
-      // phase 2: own probes that ended without any ack: Suspect at the viewed incarnation
-      for (uint32_t f = 0; f < nfail; ++f) {
-        const uint32_t j = s.fail[(size_t)li * s.P + f];
-        const uint32_t sl = (s.minfo[j] & MI_SLOT) - 1;
-        const uint2 e = s.V[vidx(s, li, sl)];
-        const uint32_t key = (e.x & ~3u) | ST_SUSPECT;
-        if (key > e.x) examine(sl, key, 0u, false, 0u);
-      }
-      // phase 3: rumours received this tick (any order: the merge is commutative)
-      {
-        unsigned long long fresh = (pushed | pulled) & ~kn;
-        kn |= fresh;
-        while (fresh) {
-          const uint32_t p = (uint32_t)__ffsll((unsigned long long)fresh) - 1u;
-          fresh &= fresh - 1ull;
-          const uint32_t rid = rid_at(p, H) & RID_MASK;
-          const uint2 r = s.rum[rid];
-          examine(r.x, r.y, 2u, true, rid);
-        }
-      }
-      if (cnt | nack) {
-        // explicit records: the sources' 64-B lines (queues the masks could not carry in full)
-        const uint32_t nin = cnt < s.inbox_cap ? cnt : s.inbox_cap;
-        const uint32_t novf = cnt > s.inbox_cap ? min(s.g[G_OVF0 + (t & 1u)], s.ovf_cap) : 0u;
-        for (uint32_t x = 0; x < nack + nin + novf; ++x) {
-          uint32_t srcw = NONE32;
-          if (x < nack) srcw = s.ackfrom[(size_t)li * s.P + x];
-          else if (x < nack + nin) srcw = s.inbox[(size_t)li * s.inbox_cap + (x - nack)];
-          else {
-            const uint2 o = s.ovf[(size_t)(t & 1u) * s.ovf_cap + (x - nack - nin)];
-            if (o.x == li) srcw = o.y;
-          }
-          if (srcw == NONE32) continue;
-          const uint4* line = (srcw & SRC_FOREIGN) ? s.fl + (size_t)(srcw & (SRC_FOREIGN - 1u)) * 4
-                                                   : line_ptr(s, srcw >> 31, srcw & 0x7FFFFFFFu);
-          for (int h = 0; h < PB_SLOTS / 2; ++h) {
-            const uint4 v = line[h];
+  if (act) {
+    kn = s.pk[li].y & ~stale;
+    if (pcount) {
 #pragma unroll
-            for (int w = 0; w < 2; ++w) {
-              const uint32_t lo = w ? v.z : v.x, hi = w ? v.w : v.y;
-              if (!pe_tx(hi)) continue;
-              const uint32_t rid = pe_rid(lo);
-              if (rid_in_ring(rid, H)) {
-                if (kn & rid_bit(rid)) continue;     // view already dominates it
-                kn |= rid_bit(rid);
-              }
-              examine(pe_slot(lo), pe_key(hi), 2u, true, rid);
-            }
-          }
-        }
+      for (int h = 0; h < PB_SLOTS / 2; ++h) {
+        const uint4 v = own_line[h];
+        oslot[h] = (pe_tx(v.y) ? pe_slot(v.x) : 0xFFFFu) | ((pe_tx(v.w) ? pe_slot(v.z) : 0xFFFFu) << 16);
       }
-      // ---- refutation: bump own incarnation past the rumour's (src/Core.hs:155-166; D10); rumours at
-      // an incarnation below my own are stale and ignored (:151)
-      unsigned refutes = 0;
-      if (refute != NONE32 && refute >= self_inc) {
-        uint32_t ni = refute + 1;
-        if (ni > INC_MAX) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_INC); ni = INC_MAX; }
-        self_inc = ni;
-        evd += h4(TAG_INC, ((uint64_t)t << 32) | i, ni, 0);
-        refutes = 1;
-        const uint32_t akey = (ni << 2) | ST_ALIVE;
-        kill_slot(my_slot1 - 1);
-        group_put(c, my_slot1 - 1, find_rid(s, my_slot1 - 1, akey), akey, i);   // Just Alive{..} (:163)
-        if (s.event_mask & (1u << 3)) {
-          const uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
-          if (pos < s.event_cap) s.events[pos] = make_uint4(t, i, i, (akey << 8) | 3u /*REFUTE*/);
-          else evdropped++;
-        }
-      }
-      // ---- rebuild the queue: [this tick's group, by subject][aged survivors, order kept], best 8 (D5),
-      // assembled in LDS columns, then written as one 64-B line together with its mask.
-      uint32_t nout = c.n;
-      unsigned long long qmask = 0;
-      uint32_t oow = 0;
-      auto publish = [&](uint32_t lo) -> uint32_t {  // mask bit or "cannot express", id parked if too old
-        const uint32_t rid = pe_rid(lo);
-        if (rid_maskable(rid, H)) qmask |= rid_bit(rid);
-        else oow = MI_OOW;
-        return park_rid(lo, H);
-      };
+    }
+  }
+  auto kill_slot = [&](uint32_t slot) {
 #pragma unroll
-      for (int k = 0; k < PB_SLOTS; ++k) {
-        const bool have = (uint32_t)k < c.n;
-        asm_[k][0][tid] = have ? publish(c.w[k]) : 0u;
-        asm_[k][1][tid] = have ? pe_hi(c.key[k], s.L) : 0u;
+    for (int h = 0; h < PB_SLOTS / 2; ++h) {
+      if ((oslot[h] & 0xFFFFu) == slot) killmask |= 1u << (2 * h);
+      if ((oslot[h] >> 16) == slot) killmask |= 1u << (2 * h + 1);
+    }
+  };
+  // The state rule on one proposal (slot, key).
+  auto examine = [&](uint32_t slot, uint32_t key, uint32_t cause, bool hasrid, uint32_t rid_in) {
+    if (slot + 1 == my_slot1) {
+      // about self -> refute (src/Core.hs:155-166): remember the largest non-Alive incarnation
+      if ((key & 3u) != ST_ALIVE) refute = (refute == NONE32 || (key >> 2) > refute) ? (key >> 2) : refute;
+      return;
+    }
+    examined++;
+    const uint2 e = s.V[vidx(s, li, slot)];
+    const uint32_t curk = e.x ? e.x : s.slot_base[slot];              // untouched cell: the settled base
+    if (key <= curk) return;                     // old incarnation / weaker state: ignore (:151)
+    s.V[vidx(s, li, slot)] = make_uint2(key, t + 1);                    // memberLastChange = now (:176)
+    if (s.G) s.slot_last[slot] = t;              // same value from every writer
+    const uint32_t subject = s.subject_of[slot];
+    if (!ha) ha = mix64(mix64((uint64_t)TAG_EV) + (((uint64_t)t << 32) | i));
+    const unsigned long long hx = mix64(ha + subject);                // h4(TAG_EV, a, subject, .) prefix
+    evd += mix64(hx + key) - mix64(hx + curk);
+    changes += (e.y != t + 1) ? 1u : 0u;
+    if (cause == 1u) timers_fired++;
+    if ((key & 3u) == ST_SUSPECT) tc_put(tnew, slot + 1);             // deadline t + S (D4)
+    const uint32_t rid = hasrid ? rid_in : find_rid(s, slot, key);
+    kill_slot(slot);
+    group_put(c, slot, rid, key, subject);       // `Just msg` -> Broadcast -> enqueue (D5)
+    if (s.event_mask & (1u << cause)) {
+      const uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
+      if (pos < s.event_cap) s.events[pos] = make_uint4(t, i, subject, (key << 8) | cause);
+      else evdropped++;
+    }
+  };
+  // one entry of a deadline cell: Suspect since t' with t' + S <= t => Dead at the same incarnation (D4);
+  // a deadline still ahead that belongs to this row goes back into the cell; anything else (refuted,
+  // already Dead, reclaimed, superseded by a later suspicion with its own cell) is dropped
+  TimerCell keep; keep.lo = 0; keep.hi = 0; keep.n = 0;
+  auto deadline = [&](uint32_t slot, uint32_t row) {
+    const uint2 e = s.V[vidx(s, li, slot)];
+    if ((e.x & 3u) != ST_SUSPECT) return;
+    if (e.y - 1 + s.S <= t) examine(slot, (e.x & ~3u) | ST_DEAD, 1u, false, 0u);
+    else if ((e.y - 1 + s.S) % s.S == row) tc_put(keep, slot + 1);
+  };
+  auto run_cell = [&](const uint4& cell, uint32_t row) {
+    for (uint32_t k = 0; k < TR_SLOTS; ++k) {
+      const uint32_t v = tc_get(cell, k);
+      if (!v) break;
+      if (v == TR_FULL) {                        // more than 8 deadlines in one cell: every row is a candidate
+        const uint32_t ns = min(s.g[G_NSLOTS], s.R_phys);
+        for (uint32_t r = 0; r < ns; ++r) {
+          const uint2 e = s.V[vidx(s, li, r)];
+          if ((e.x & 3u) == ST_SUSPECT && (e.y - 1 + s.S) % s.S == row && s.slot_used[r]) deadline(r, row);
+        }
+        break;
       }
-      if (pcount) {
-#pragma unroll
+      deadline(v - 1, row);
+    }
+  };
+  if (act) {
+    // phase 1: suspicion deadlines, evaluated on the start-of-tick view
+    if (woke) {
+      for (uint32_t row = 0; row < s.S; ++row) {
+        if (row == t % s.S) continue;
+        const size_t ix = (size_t)row * s.N + li;
+        const uint4 cell = s.trow[ix];
+        if (!(cell.x | cell.y | cell.z | cell.w)) continue;
+        keep.lo = 0; keep.hi = 0; keep.n = 0;
+        run_cell(cell, row);
+        const uint4 nc = tc_pack(keep);
+        if (nc.x != cell.x || nc.y != cell.y || nc.z != cell.z || nc.w != cell.w) s.trow[ix] = nc;
+      }
+      keep.lo = 0; keep.hi = 0; keep.n = 0;
+    }
+    if (timer_due) run_cell(due, t % s.S);
+    // deadlines that stay in this row (a fixture set by swimsim_set_view, a member that was down shortly)
+    for (uint32_t k = 0; k < keep.n && k < TR_SLOTS; ++k) {
+      const uint32_t v = k < 4u ? (uint32_t)(keep.lo >> (16u * k)) & 0xFFFFu : (uint32_t)(keep.hi >> (16u * (k - 4u))) & 0xFFFFu;
+      tc_put(tnew, v);
+    }
+    // phase 2: own probes that ended without any ack: Suspect at the viewed incarnation
+    for (uint32_t f = 0; f < nfail; ++f) {
+      const uint32_t j = s.fail[(size_t)li * s.P + f];
+      const uint32_t sl = (s.minfo[j] & MI_SLOT) - 1;
+      const uint2 e = s.V[vidx(s, li, sl)];
+      const uint32_t curk = e.x ? e.x : s.slot_base[sl];
+      const uint32_t key = (curk & ~3u) | ST_SUSPECT;
+      if (key > curk) examine(sl, key, 0u, false, 0u);
+    }
+  }
+  // phase 3: rumours received this tick (any order: the merge is commutative).  The wave walks the UNION
+  // of its members' new positions: every lane that has position p examines it in the same iteration, so the
+  // view accesses of a rumour are one contiguous row segment and rum[] is read once per wave.
+  {
+    unsigned long long fresh = act ? (pushed | pulled) & ~kn : 0ull;
+    kn |= fresh;
+    for (;;) {
+      const unsigned long long b = __ballot(fresh != 0ull);
+      if (!b) break;
+      const int leader = __ffsll(b) - 1;
+      const unsigned long long lf = ((unsigned long long)__shfl((uint32_t)(fresh >> 32), leader, 64) << 32) |
+                                    __shfl((uint32_t)fresh, leader, 64);
+      const uint32_t p = (uint32_t)__ffsll(lf) - 1u;
+      const uint32_t rid = rid_at(p, H) & RID_MASK;
+      if ((fresh >> p) & 1ull) {
+        fresh &= ~(1ull << p);
+        const uint2 r = s.rum[rid];
+        examine(r.x, r.y, 2u, true, rid);
+      }
+    }
+  }
+  if (act) {
+    if (cnt | nack) {
+      // explicit records: the sources' 64-B lines (queues the masks could not carry in full)
+      const uint32_t nin = cnt < s.inbox_cap ? cnt : s.inbox_cap;
+      const uint32_t novf = cnt > s.inbox_cap ? min(s.g[G_OVF0 + (t & 1u)], s.ovf_cap) : 0u;
+      for (uint32_t x = 0; x < nack + nin + novf; ++x) {
+        uint32_t srcw = NONE32;
+        if (x < nack) srcw = s.ackfrom[(size_t)li * s.P + x];
+        else if (x < nack + nin) srcw = s.inbox[(size_t)li * s.inbox_cap + (x - nack)];
+        else {
+          const uint2 o = s.ovf[(size_t)(t & 1u) * s.ovf_cap + (x - nack - nin)];
+          if (o.x == li) srcw = o.y;
+        }
+        if (srcw == NONE32) continue;
+        const uint4* line = (srcw & SRC_FOREIGN) ? s.fl + (size_t)(srcw & (SRC_FOREIGN - 1u)) * 4
+                                                 : line_ptr(s, srcw >> 31, srcw & 0x7FFFFFFFu);
         for (int h = 0; h < PB_SLOTS / 2; ++h) {
-          const uint4 v = own_line[h];
+          const uint4 v = line[h];
 #pragma unroll
           for (int w = 0; w < 2; ++w) {
-            const uint32_t lo = w ? v.z : v.x, hi = w ? v.w : v.y, tx = pe_tx(hi);
-            if (tx > nsent && !((killmask >> (2 * h + w)) & 1u) && nout < (uint32_t)PB_SLOTS) {
-              asm_[nout][0][tid] = publish(lo);
-              asm_[nout][1][tid] = pe_hi(pe_key(hi), tx - nsent);
-              nout++;
+            const uint32_t lo = w ? v.z : v.x, hi = w ? v.w : v.y;
+            if (!pe_tx(hi)) continue;
+            const uint32_t rid = pe_rid(lo);
+            if (rid_in_ring(rid, H)) {
+              if (kn & rid_bit(rid)) continue;     // view already dominates it
+              kn |= rid_bit(rid);
             }
+            examine(pe_slot(lo), pe_key(hi), 2u, true, rid);
           }
         }
       }
-      if (nout) {
-        wflag = 1u | ((cur ^ 1u) << 1);              // the line itself is stored below, a whole wave at a time
-        s.minfo[i] = (mi & ~MI_PB) | (nout << MI_PBN_SHIFT) | ((cur ^ 1u) << 20) | oow;
-      } else if (pcount) {
-        s.minfo[i] = mi & ~MI_PB;
-      }
-      s.pk[li] = make_ulonglong2(nout ? qmask : 0ull, kn);
-      if (pushed) s.inmask[li] = 0;
-      if (tcount == 0) tnext = NONE32;
-      else if (thead != (hot0.y & 0xFFFFu)) tnext = s.ring[ridx(s, li, thead)].y;
-      const uint4 hot1 = make_uint4(self_inc, thead | (tcount << 16), 0u, tnext);
-      if (hot1.x != hot0.x || hot1.y != hot0.y || hot1.w != hot0.w) s.hot[li] = hot1;
-      if (cnt) s.inbox_cnt[li] = 0;
-      ctr_add(&sh, C_CHANGES, changes);
-      ctr_add(&sh, C_PB_WRITES, (pcount || nout) ? 1u : 0u);
-      ctr_add(&sh, C_TIMERS_FIRED, timers_fired);
-      ctr_add(&sh, C_REFUTES, refutes);
-      ctr_add(&sh, C_EVENTS_DROPPED, evdropped);
-      ctr_add(&sh, C_EXAMINED, examined);
-      if (evd) atomicAdd(&sh.evd, evd);
     }
+    // ---- refutation: bump own incarnation past the rumour's (src/Core.hs:155-166; D10); rumours at
+    // an incarnation below my own are stale and ignored (:151)
+    unsigned refutes = 0;
+    if (refute != NONE32 && refute >= self_inc) {
+      uint32_t ni = refute + 1;
+      if (ni > INC_MAX) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_INC); ni = INC_MAX; }
+      self_inc = ni;
+      evd += h4(TAG_INC, ((uint64_t)t << 32) | i, ni, 0);
+      refutes = 1;
+      const uint32_t akey = (ni << 2) | ST_ALIVE;
+      if (s.G) s.slot_last[my_slot1 - 1] = t;
+      kill_slot(my_slot1 - 1);
+      group_put(c, my_slot1 - 1, find_rid(s, my_slot1 - 1, akey), akey, i);   // Just Alive{..} (:163)
+      if (s.event_mask & (1u << 3)) {
+        const uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
+        if (pos < s.event_cap) s.events[pos] = make_uint4(t, i, i, (akey << 8) | 3u /*REFUTE*/);
+        else evdropped++;
+      }
+    }
+    // ---- rebuild the queue: [this tick's group, by subject][aged survivors, order kept], best 8 (D5),
+    // assembled in LDS columns, then written as one 64-B line together with its mask.  Every period costs
+    // a rumour at least one transmission (age >= 1), so old entries never tie with this tick's group.
+    const uint32_t age = nsent ? nsent : 1u;
+    uint32_t nout = c.n;
+    unsigned long long qmask = 0;
+    uint32_t oow = 0;
+    auto publish = [&](uint32_t lo) -> uint32_t {  // mask bit or "cannot express", id parked if too old
+      const uint32_t rid = pe_rid(lo);
+      if (rid_maskable(rid, H)) qmask |= rid_bit(rid);
+      else oow = MI_OOW;
+      return park_rid(lo, H);
+    };
+#pragma unroll
+    for (int k = 0; k < PB_SLOTS; ++k) {
+      const bool have = (uint32_t)k < c.n;
+      asm_[2 * k][tid] = have ? publish(c.w[k]) : 0u;
+      asm_[2 * k + 1][tid] = have ? pe_hi(c.key[k], s.L) : 0u;
+    }
+    if (pcount) {
+#pragma unroll
+      for (int h = 0; h < PB_SLOTS / 2; ++h) {
+        const uint4 v = own_line[h];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const uint32_t lo = w ? v.z : v.x, hi = w ? v.w : v.y, tx = pe_tx(hi);
+          if (tx > age && !((killmask >> (2 * h + w)) & 1u) && nout < (uint32_t)PB_SLOTS) {
+            asm_[2 * nout][tid] = publish(lo);
+            asm_[2 * nout + 1][tid] = pe_hi(pe_key(hi), tx - age);
+            nout++;
+          }
+        }
+      }
+    }
+    if (nout) {
+      wflag = 1u | ((cur ^ 1u) << 1);              // the line itself is stored below, a whole wave at a time
+      s.minfo[i] = (mi & ~MI_PB) | (nout << MI_PBN_SHIFT) | ((cur ^ 1u) << 20) | oow;
+    } else if (pcount) {
+      s.minfo[i] = mi & ~MI_PB;
+    }
+    s.pk[li] = make_ulonglong2(nout ? qmask : 0ull, kn);
+    if (pushed) s.inmask[li] = 0;
+    if (timer_due || tnew.n) s.trow[trix] = tc_pack(tnew);     // consumed and refilled in one store
+    if (self_inc != hot0.x || woke) s.hot[li] = make_uint2(self_inc, hot0.y & ~1u);
+    if (cnt) s.inbox_cnt[li] = 0;
+    ctr_add(&sh, C_CHANGES, changes);
+    ctr_add(&sh, C_PB_WRITES, (pcount || nout) ? 1u : 0u);
+    ctr_add(&sh, C_TIMERS_FIRED, timers_fired);
+    ctr_add(&sh, C_REFUTES, refutes);
+    ctr_add(&sh, C_EVENTS_DROPPED, evdropped);
+    ctr_add(&sh, C_EXAMINED, examined);
+    if (evd) atomicAdd(&sh.evd, evd);
   }
   // ---- store the rebuilt lines.  L2 does not merge a lane's four 16-B pieces into one fabric write, so
   // the wave stores its 64 lines transposed: instruction k, lane l writes piece (l & 3) of the line of
@@ -652,7 +726,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
       if (fl & 1u) {
         const uint32_t gm = blockIdx.x * BLOCK + m;
         uint4* line = reinterpret_cast<uint4*>(s.pb + ((size_t)(fl >> 1) * s.N + gm) * PB_SLOTS);
-        line[q] = make_uint4(asm_[2 * q][0][m], asm_[2 * q][1][m], asm_[2 * q + 1][0][m], asm_[2 * q + 1][1][m]);
+        line[q] = make_uint4(asm_[4 * q][m], asm_[4 * q + 1][m], asm_[4 * q + 2][m], asm_[4 * q + 3][m]);
       }
     }
   }

@@ -1,7 +1,8 @@
 // swimsim.hip -- C ABI (include/swimsim.h) over the gfx950 tick kernels.
 //
 // Host side of libswimsim.so: owns device memory, the fault schedule and the launch
-// sequence (per tick: begin_kernel -> probe_kernel -> merge_kernel on one HIP stream).
+// sequence (per tick: begin_kernel -> probe_kernel -> merge_kernel on one HIP stream; no host
+// synchronisation inside swimsim_step).
 // There is no CPU implementation behind this ABI: without a HIP device swimsim_create fails.
 #include "../../include/swimsim.h"
 
@@ -100,9 +101,13 @@ int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, std::string*
   if ((uint64_t)c->retransmit_mult * ceil_log2((uint64_t)c->n_members + 1) > 255) {
     *err = "retransmit budget exceeds 255"; return SWIMSIM_ERR_INVALID; }
   if (c->max_subjects == 0) c->max_subjects = c->n_members < 1024 ? c->n_members : 1024;
-  if (c->max_subjects > 65534u) { *err = "max_subjects must be <= 65534"; return SWIMSIM_ERR_INVALID; }
-  if (c->timer_cap == 0) c->timer_cap = 64;
-  if (c->timer_cap > 32768u) { *err = "timer_cap must be <= 32768"; return SWIMSIM_ERR_INVALID; }
+  if (c->max_subjects > 60000u) { *err = "max_subjects must be <= 60000"; return SWIMSIM_ERR_INVALID; }
+  {
+    const uint32_t gmin = c->suspicion_ticks + c->retransmit_mult * ceil_log2((uint64_t)c->n_members + 1) + 2;
+    if (c->gc_ticks == SWIMSIM_GC_AUTO) c->gc_ticks = gmin;
+    if (c->gc_ticks && c->gc_ticks < gmin) {
+      *err = "gc_ticks must be 0, SWIMSIM_GC_AUTO or >= suspicion_ticks + L + 2 = " + std::to_string(gmin); return SWIMSIM_ERR_INVALID; }
+  }
   if (c->event_cap == 0) c->event_cap = 1u << 20;
   if (c->event_mask == 0) c->event_mask = SWIMSIM_EVMASK_DEFAULT;
   if (c->inbox_cap == 0) {
@@ -118,6 +123,7 @@ int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, std::string*
   if (c->n_shards > 16 || c->shard_index >= c->n_shards) { *err = "n_shards must be <= 16 and shard_index < n_shards"; return SWIMSIM_ERR_INVALID; }
   if (c->n_members % c->n_shards) { *err = "n_members must be a multiple of n_shards"; return SWIMSIM_ERR_INVALID; }
   if (c->target_scheme > SWIMSIM_TARGETS_ROBUST) { *err = "unknown target_scheme"; return SWIMSIM_ERR_INVALID; }
+  if (c->n_shards > 1 && c->gc_ticks) { *err = "settling (gc_ticks) is not available on sharded handles yet"; return SWIMSIM_ERR_INVALID; }
   if (c->n_shards > 1 && c->target_scheme != SWIMSIM_TARGETS_RANDOM) { *err = "the robust target scheme is not available on sharded handles yet"; return SWIMSIM_ERR_INVALID; }
   if (c->n_shards > 1 && c->n_members > (1u << 27)) { *err = "sharded clusters: n_members must be <= 2^27"; return SWIMSIM_ERR_INVALID; }
   return SWIMSIM_OK;
@@ -129,7 +135,7 @@ int check_device_errors(swimsim* h) {
   if (g[G_ERR]) {
     std::string m = "capacity exceeded:";
     if (g[G_ERR] & ERRF_SUBJECTS) m += " max_subjects";
-    if (g[G_ERR] & ERRF_TIMERS) m += " timer_cap";
+    if (g[G_ERR] & ERRF_ROWS) m += " view-rows-in-transit (settled rows wait two ticks before reuse)";
     if (g[G_ERR] & ERRF_OVF) m += " inbox-overflow-list";
     if (g[G_ERR] & ERRF_INC) m += " incarnation-bits";
     if (g[G_ERR] & ERRF_XCHG) m += " shard-exchange-buffers";
@@ -273,7 +279,10 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     uint64_t thr = ((uint64_t)c.loss_ppm << 32) / 1000000ull;
     d.loss_thr = thr > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)thr;
   }
-  d.R_max = c.max_subjects; d.timer_cap = c.timer_cap; d.event_cap = c.event_cap; d.event_mask = c.event_mask;
+  d.R_max = c.max_subjects; d.event_cap = c.event_cap; d.event_mask = c.event_mask;
+  d.G = c.gc_ticks;
+  // settled rows are cleared by the next merge and reusable the tick after: room for the rows in transit
+  d.R_phys = std::min<uint32_t>(65534u, d.R_max + (d.G ? std::min<uint32_t>(d.R_max, 1024u) : 0u));
   d.nblocks = (N + BLOCK - 1) / BLOCK;
   d.inbox_cap = c.inbox_cap;
   d.ovf_cap = std::max<uint32_t>(1u << 16, N / 8);
@@ -288,11 +297,20 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   CK(dev_alloc(h, &d.inmask, (size_t)N, 0));
   CK(dev_alloc(h, &d.ackmask, (size_t)N, 0));
   CK(dev_alloc(h, &d.rum, (size_t)65536, 0));
-  CK(dev_alloc(h, &d.rtab, (size_t)d.R_max * RT_WAYS, 0));
-  CK(dev_alloc(h, &d.subject_of, (size_t)d.R_max, 0));
+  CK(dev_alloc(h, &d.rtab, (size_t)d.R_phys * RT_WAYS, 0));
+  CK(dev_alloc(h, &d.subject_of, (size_t)d.R_phys, 0));
   CK(dev_alloc(h, &d.fail, (size_t)N * (d.P ? d.P : 1), 0));
-  CK(dev_alloc(h, &d.ring, (size_t)N * d.timer_cap, 0));
-  CK(dev_alloc(h, &d.V, (size_t)N * d.R_max, 0));
+  CK(dev_alloc(h, &d.trow, (size_t)N * d.S, 0));
+  CK(dev_alloc(h, &d.V, (size_t)N * d.R_phys, 0));
+  CK(dev_alloc(h, &d.slot_last, (size_t)d.R_phys, 0xFF));
+  CK(dev_alloc(h, &d.slot_base, (size_t)d.R_phys, 0));
+  CK(dev_alloc(h, &d.slot_used, (size_t)d.R_phys, 0));
+  CK(dev_alloc(h, &d.base_key, (size_t)NT, 0));
+  CK(dev_alloc(h, &d.base_since, (size_t)NT, 0));
+  CK(dev_alloc(h, &d.free_rows, (size_t)d.R_phys, 0));
+  CK(dev_alloc(h, &d.settle_slots, (size_t)d.R_phys, 0));
+  CK(dev_alloc(h, &d.settle_key, (size_t)d.R_phys, 0));
+  CK(dev_alloc(h, &d.zero_slots, (size_t)d.R_phys, 0));
   CK(dev_alloc(h, &d.pb, (size_t)2 * N * PB_SLOTS, 0));
   CK(dev_alloc(h, &d.first_suspect, NT, 0xFF));
   CK(dev_alloc(h, &d.crash_tick, NT, 0xFF));
@@ -324,7 +342,7 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     CK(dev_alloc(h, &d.fl, (size_t)d.n_shards * ((size_t)d.x_cap + d.p_cap + d.r_cap) * 4, 0));
     CK(dev_alloc(h, &d.ackslot, (size_t)N * std::max(1u, d.P), 0));
   }
-  hipLaunchKernelGGL(init_members_kernel, dim3((std::max(N, NT) + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, d.hot, d.minfo, N, NT);
+  hipLaunchKernelGGL(init_members_kernel, dim3((NT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, d.minfo, NT);
   HK(hipGetLastError());
   HK(hipStreamSynchronize(h->stream));
 #undef CK
@@ -355,8 +373,13 @@ static int upload_faults(swimsim* h, uint32_t nticks, size_t* fend_out) {
   size_t fend = 0;
   while (fend < h->faults.size() && (uint64_t)h->faults[fend].tick < h->tick + nticks) ++fend;
   if (fend) {
+    // within a tick the changes of one member stay in schedule order, members are grouped: begin_kernel
+    // applies the members in parallel (changes of different members commute)
+    std::vector<Fault> grouped(h->faults.begin(), h->faults.begin() + (long)fend);
+    std::stable_sort(grouped.begin(), grouped.end(), [](const Fault& x, const Fault& y) {
+      return x.tick != y.tick ? x.tick < y.tick : x.member < y.member; });
     std::vector<FaultRec> recs(fend);
-    for (size_t x = 0; x < fend; ++x) recs[x] = FaultRec{h->faults[x].member, h->faults[x].up};
+    for (size_t x = 0; x < fend; ++x) recs[x] = FaultRec{grouped[x].member, grouped[x].up};
     if (fend > h->d_faults_cap) {
       HIPCHK(h, hipStreamSynchronize(h->stream));
       if (h->d_faults) HIPCHK(h, hipFree(h->d_faults));
@@ -392,13 +415,15 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
     hipEvent_t* ev = h->timing ? &h->ev_pool[(size_t)k * 3] : nullptr;
     const size_t f0 = fpos;
     while (fpos < fend && h->faults[fpos].tick <= t) ++fpos;
-    hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(64), 0, h->stream, h->d, t, h->d_faults + f0, (uint32_t)(fpos - f0));
+    hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, h->d_faults + f0, (uint32_t)(fpos - f0));
     const uint32_t tk = tick_key(h->cfg.seed, t);
     if (h->d.P <= 4 && h->d.K <= 4) launch_tick<4>(h, t, tk, ev);
     else launch_tick<16>(h, t, tk, ev);
     h->tick++;
   }
   h->faults.erase(h->faults.begin(), h->faults.begin() + (long)fpos);
+  // the last tick's settling is committed before anybody reads state (between ticks begin_kernel does it)
+  if (h->d.G && nticks) hipLaunchKernelGGL(settle_flush_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (h->timing) {
@@ -432,17 +457,26 @@ int swimsim_drain_events(swimsim_t* h, swimsim_event_t* buf, size_t cap, size_t*
   return SWIMSIM_OK;
 }
 
+// one observer's cells of every view row in use (reclaimed rows read as empty) and the rows' subjects
 static int read_column(swimsim_t* h, uint32_t observer, std::vector<uint2>* col, std::vector<uint32_t>* subj) {
   uint32_t g[G_WORDS];
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(g, h->d.g, sizeof g, hipMemcpyDeviceToHost));
-  const uint32_t ns = std::min(g[G_NSLOTS], h->d.R_max);
+  const uint32_t ns = std::min(g[G_NSLOTS], h->d.R_phys);
   col->resize(ns); subj->resize(ns);
   if (!ns) return SWIMSIM_OK;
   // V is slot-major [slot][member]: one observer's entries are a strided column
   HIPCHK(h, hipMemcpy2D(col->data(), sizeof(uint2), h->d.V + observer, (size_t)h->d.N * sizeof(uint2),
                         sizeof(uint2), ns, hipMemcpyDeviceToHost));
   HIPCHK(h, hipMemcpy(subj->data(), h->d.subject_of, (size_t)ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  std::vector<uint8_t> used(ns);
+  HIPCHK(h, hipMemcpy(used.data(), h->d.slot_used, ns, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> sbase(ns);
+  HIPCHK(h, hipMemcpy(sbase.data(), h->d.slot_base, (size_t)ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  for (uint32_t r = 0; r < ns; ++r) {
+    if (!used[r]) { (*col)[r] = make_uint2(0u, 0u); (*subj)[r] = NONE32; }
+    else if ((*col)[r].x == 0) (*col)[r].y = sbase[r] | 0x80000000u;   // default cell: y carries the base key (flagged)
+  }
   return SWIMSIM_OK;
 }
 
@@ -453,11 +487,26 @@ int swimsim_read_view(swimsim_t* h, uint32_t observer, swimsim_view_entry_t* buf
   int rc = read_column(h, observer - h->d.lo, &col, &subj);
   if (rc) return rc;
   std::vector<swimsim_view_entry_t> ents;
+  std::vector<uint32_t> own;                       // subjects listed with the observer's own entry
   for (size_t r = 0; r < col.size(); ++r) {
     if (col[r].x == 0 || subj[r] == observer) continue;
     swimsim_view_entry_t e{};
     e.subject = subj[r]; e.incarnation = col[r].x >> 2; e.state = (uint8_t)(col[r].x & 3u); e.since_tick = col[r].y - 1;
     ents.push_back(e);
+    own.push_back(subj[r]);
+  }
+  if (h->d.G) {
+    // settled subjects: Alive@i (i > 0) stays a listed member, Dead ones were removed (removeDeadNodes)
+    std::vector<uint32_t> bk(h->d.NT), bs(h->d.NT);
+    HIPCHK(h, hipMemcpy(bk.data(), h->d.base_key, (size_t)h->d.NT * 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(bs.data(), h->d.base_since, (size_t)h->d.NT * 4, hipMemcpyDeviceToHost));
+    std::sort(own.begin(), own.end());
+    for (uint32_t sj = 0; sj < h->d.NT; ++sj) {
+      if (!bk[sj] || (bk[sj] & 3u) != ST_ALIVE || sj == observer || std::binary_search(own.begin(), own.end(), sj)) continue;
+      swimsim_view_entry_t e{};
+      e.subject = sj; e.incarnation = bk[sj] >> 2; e.state = ST_ALIVE; e.since_tick = bs[sj];
+      ents.push_back(e);
+    }
   }
   std::sort(ents.begin(), ents.end(), [](const swimsim_view_entry_t& a, const swimsim_view_entry_t& b) { return a.subject < b.subject; });
   *n_out = ents.size();
@@ -473,7 +522,7 @@ int swimsim_read_member(swimsim_t* h, uint32_t m, swimsim_member_t* out) {
   std::vector<uint2> col; std::vector<uint32_t> subj;
   int rc = read_column(h, ml, &col, &subj);
   if (rc) return rc;
-  uint4 hot; uint32_t mi;
+  uint2 hot; uint32_t mi;
   HIPCHK(h, hipMemcpy(&hot, h->d.hot + ml, sizeof hot, hipMemcpyDeviceToHost));
   HIPCHK(h, hipMemcpy(&mi, h->d.minfo + m, sizeof mi, hipMemcpyDeviceToHost));
   std::memset(out, 0, sizeof *out);
@@ -491,7 +540,7 @@ int swimsim_read_member(swimsim_t* h, uint32_t m, swimsim_member_t* out) {
     }
   }
   uint32_t nt = 0;
-  for (size_t r = 0; r < col.size(); ++r) if (subj[r] != m && (col[r].x & 3u) == ST_SUSPECT) nt++;
+  for (size_t r = 0; r < col.size(); ++r) if (subj[r] != m && col[r].x && (col[r].x & 3u) == ST_SUSPECT) nt++;
   out->n_timers = (uint16_t)nt;
   return SWIMSIM_OK;
 }
@@ -623,7 +672,7 @@ int swimsim_shard_phase1(swimsim_t* h, uint32_t* counts) {
   if (rc) return rc;
   if (h->timing && !h->tick_ev[0]) for (int k = 0; k < 3; ++k) HIPCHK(h, hipEventCreate(&h->tick_ev[k]));
   const uint32_t t = (uint32_t)h->tick;
-  hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(64), 0, h->stream, h->d, t, h->d_faults, (uint32_t)fend);
+  hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, h->d_faults, (uint32_t)fend);
   h->faults.erase(h->faults.begin(), h->faults.begin() + (long)fend);
   const uint32_t tk = tick_key(h->cfg.seed, t);
   if (h->timing) (void)hipEventRecord(h->tick_ev[0], h->stream);

@@ -7,8 +7,12 @@
 // loader (swim_amd/_lib.py) knows nothing about it and libswimsim.so has no CPU path.
 //
 // Execution model: blocks run one after another; the threads of a block are ucontext fibres run
-// round-robin, switching at __syncthreads() / wave intrinsics.  That reproduces barrier semantics and
-// LDS sharing exactly, and makes every run deterministic; it does NOT reproduce the GPU's memory
+// round-robin, switching at __syncthreads() / wave intrinsics.  A fibre waiting in __syncthreads() is
+// released only when every live fibre of the block waits there; a fibre inside a wave intrinsic is released
+// after one scheduler round (its wave's lanes have all deposited their values by then), so waves may run
+// loops of different lengths between two block barriers, as on the GPU.  Lanes that do not take part in a
+// wave intrinsic contribute 0.  That reproduces barrier semantics and LDS sharing exactly, and makes
+// every run deterministic; it does NOT reproduce the GPU's memory
 // model, scheduling or performance -- the `-m gpu` tests remain the parity tests proper.
 #pragma once
 #include <stdint.h>
@@ -87,7 +91,7 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t
 // ---- the fibre scheduler -------------------------------------------------------------------------
 namespace hostemu {
 constexpr size_t STACK_BYTES = 512 * 1024;
-struct Fibre { ucontext_t ctx; void* stack; int state; };   // 0 runnable, 1 at barrier, 2 done
+struct Fibre { ucontext_t ctx; void* stack; int state; };   // 0 runnable, 1 at block barrier, 2 done, 3 in a wave exchange
 struct Sched {
   ucontext_t main_ctx;
   std::vector<Fibre> f;
@@ -105,6 +109,12 @@ inline void barrier() {
   Sched& s = sched();
   Fibre& me = s.f[s.cur];
   me.state = 1;
+  swapcontext(&me.ctx, &s.main_ctx);
+}
+inline void wave_yield() {
+  Sched& s = sched();
+  Fibre& me = s.f[s.cur];
+  me.state = 3;
   swapcontext(&me.ctx, &s.main_ctx);
 }
 inline void trampoline() {
@@ -138,7 +148,10 @@ inline void run_block(uint32_t nthreads, void (*entry)(void*), void* arg) {
       tidx() = dim3(k, 0, 0);
       swapcontext(&s.main_ctx, &s.f[k].ctx);
     }
-    for (uint32_t k = 0; k < nthreads; ++k) if (s.f[k].state == 1) { s.f[k].state = 0; live++; }
+    uint32_t in_wave = 0;
+    for (uint32_t k = 0; k < nthreads; ++k) if (s.f[k].state == 3) { s.f[k].state = 0; in_wave++; live++; }
+    if (!in_wave)                                            // the block barrier opens when nobody is on the way to it
+      for (uint32_t k = 0; k < nthreads; ++k) if (s.f[k].state == 1) { s.f[k].state = 0; live++; }
     if (!live) break;                                        // all done (exited threads leave barriers)
   }
 }
@@ -185,10 +198,11 @@ static inline T __shfl_down(T x, int delta, int width = 64) {
   const uint32_t tid = hostemu::tidx().x;
   uint64_t v = 0; memcpy(&v, &x, sizeof(T) < 8 ? sizeof(T) : 8);
   s.exch[tid] = v;
-  hostemu::barrier();
+  hostemu::wave_yield();
   const uint32_t lane = tid % (uint32_t)width, src = lane + (uint32_t)delta < (uint32_t)width ? tid + (uint32_t)delta : tid;
   uint64_t r = src < s.nthreads ? s.exch[src] : v;
-  hostemu::barrier();
+  hostemu::wave_yield();
+  s.exch[tid] = 0;
   T out; memcpy(&out, &r, sizeof(T) < 8 ? sizeof(T) : 8);
   return out;
 }
@@ -198,10 +212,11 @@ static inline T __shfl(T x, int srcLane, int width = 64) {
   const uint32_t tid = hostemu::tidx().x;
   uint64_t v = 0; memcpy(&v, &x, sizeof(T) < 8 ? sizeof(T) : 8);
   s.exch[tid] = v;
-  hostemu::barrier();
+  hostemu::wave_yield();
   const uint32_t base = tid - tid % (uint32_t)width, src = base + ((uint32_t)srcLane % (uint32_t)width);
   uint64_t r = src < s.nthreads ? s.exch[src] : v;
-  hostemu::barrier();
+  hostemu::wave_yield();
+  s.exch[tid] = 0;
   T out; memcpy(&out, &r, sizeof(T) < 8 ? sizeof(T) : 8);
   return out;
 }
@@ -209,11 +224,12 @@ static inline unsigned long long __ballot(int pred) {
   auto& s = hostemu::sched();
   const uint32_t tid = hostemu::tidx().x;
   s.exch[tid] = pred ? 1u : 0u;
-  hostemu::barrier();
+  hostemu::wave_yield();
   const uint32_t base = tid - tid % 64u;
   unsigned long long m = 0;
   for (uint32_t l = 0; l < 64u && base + l < s.nthreads; ++l) if (s.exch[base + l]) m |= 1ull << l;
-  hostemu::barrier();
+  hostemu::wave_yield();
+  s.exch[tid] = 0;
   return m;
 }
 

@@ -87,3 +87,49 @@ def test_dissemination_is_logarithmic_small(emu_abi):
     assert detected_at is not None and c["changes"] >= n - 1
     assert t - detected_at <= 2 * math.log2(n)
     s.close()
+
+
+def test_settling_parity_with_churn(oracle_abi, emu_abi):
+    """gc_ticks: subjects settle, rows are reclaimed and reused (more subjects than max_subjects over the
+    run), members come back after their subject was removed, others sleep through their suspicion
+    deadlines -- every observable equals the oracle's after every block of ticks."""
+    from swim_amd import _abi
+    n = 320
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=12, lossPpm=20000, eventMask=0x1F, suspicionTicks=5,
+                   retransmitMult=1, maxSubjects=40, gcTicks=_abi.GC_AUTO)
+    crashes = [(3 + 4 * k, (7 * k + 11) % n) for k in range(70)]
+    faults = [(t + 9 + (k % 5) * 14, m, True) for k, (t, m) in enumerate(crashes) if k % 3 == 0]
+    faults += [(t + 2, (m + 1) % n, False) for (t, m) in crashes[::7]]            # neighbours that sleep through deadlines
+    faults += [(t + 12, (m + 1) % n, True) for (t, m) in crashes[::7]]
+    a, b = make_pair(oracle_abi, emu_abi, sc, crashes, faults)
+    run_lockstep(a, b, 420, 7, observers=(0, 12, n - 1), members=(0, 12, n - 1))
+    c = b.counters()
+    assert c["settled"] > 60 and c["timers_fired"] > 0
+
+
+def test_many_deadlines_in_one_cell_and_several_faults_of_one_member(oracle_abi, emu_abi):
+    """(a) 20 members crash in one tick and a 3-member... every observer fails probes of several of them in
+    the same tick: more than 8 suspicion deadlines land in one cell (the look-at-every-row path);
+    (b) one member goes down, up and down again within one tick (applied in schedule order), others flap
+    in the same tick (applied in parallel)."""
+    n = 40
+    sc = SimConfig(cfg=Config(numToGossip=12), nMembers=n, seed=3, eventMask=0x1F, suspicionTicks=5, maxSubjects=40)
+    crashes = [(4, m) for m in range(5, 33)]
+    faults = [(20, 6, True), (20, 6, False), (20, 6, True), (20, 7, True), (20, 8, True), (20, 8, False), (30, 8, True)]
+    a, b = make_pair(oracle_abi, emu_abi, sc, crashes, faults)
+    run_lockstep(a, b, 60, 1, observers=(0, 1, 6, 39), members=(0, 6, 8))
+
+
+def test_set_view_fixture_keeps_its_deadline(oracle_abi, emu_abi):
+    """swimsim_set_view(Suspect) starts a suspicion deadline like an accepted rumour does."""
+    outs = []
+    for abi in (oracle_abi, emu_abi):
+        s = Sim.create(abi, SimConfig(cfg=Config(numToGossip=2), nMembers=50, seed=4, eventMask=0x1F, suspicionTicks=4))
+        s.step(3)
+        s.setView(10, 20, 1, 0)
+        s.setView(10, 21, 1, 0)
+        s.step(12)
+        outs.append((s.digest(), s.drainEventsRaw(), s.counters(), s.members(10)))
+        s.close()
+    assert outs[0] == outs[1]
+    assert outs[0][2]["refutes"] >= 2          # members 20 and 21 are up: they refute
