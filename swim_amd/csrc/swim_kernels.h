@@ -964,77 +964,124 @@ __global__ __launch_bounds__(BLOCK) void ingest_kernel(DevState s, uint32_t t, P
 // ================================================================================================
 struct FaultRec { uint32_t member, up; };
 
-// Start of tick t, one thread: the ground-truth changes scheduled for t, in order (few per tick), then
-// the snapshot of the rumour-id counter that fixes the tick's window head H (no ids are allocated
-// between here and merge_kernel).
-__global__ void begin_kernel(DevState s, uint32_t t, const FaultRec* faults, uint32_t nfaults) {
-  if (blockIdx.x || threadIdx.x) return;
-  unsigned long long evd = 0; unsigned dropped = 0;
-  for (uint32_t k = 0; k < nfaults; ++k) {
-    const uint32_t mbr = faults[k].member, up = faults[k].up;
-    uint32_t mi = s.minfo[mbr];
-    if ((uint32_t)mi_up(mi) == up) continue;
-    s.first_suspect[mbr] = NONE32;
-    if (!up) { s.minfo[mbr] = mi & ~MI_UP; s.crash_tick[mbr] = t; continue; }
-    if (!is_local(s, mbr)) { s.minfo[mbr] = mi | MI_UP; continue; }   // its owner does the rest
-    // (re)join: new incarnation, announce Alive
-    const uint32_t ml = mbr - s.lo;
-    uint4 hot = s.hot[ml];
-    uint32_t ni = hot.x + 1;
-    if (ni > INC_MAX) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_INC); ni = INC_MAX; }
-    evd += h4(TAG_INC, ((uint64_t)t << 32) | mbr, ni, 0);
-    ensure_slot(s, mbr);
-    mi = s.minfo[mbr];
-    const uint32_t sl = (mi & MI_SLOT) - 1;
-    const uint32_t pcount = mi_pbn(mi), cur = mi_buf(mi);
-    const uint32_t akey = (ni << 2) | ST_ALIVE;
-    // queue := best 8 of (old entries not about self) + (self, Alive@ni, tx = L), priority order.
-    // The member slept through an unknown number of rumour ids: its old entries' ids are parked and
-    // its known-ring starts empty.
-    uint32_t lo[PB_SLOTS + 1], hi[PB_SLOTS + 1], sj[PB_SLOTS + 1], n = 0;
-    uint64_t* line = s.pb + ((size_t)cur * s.N + ml) * PB_SLOTS;
-    const uint32_t far = (s.g[G_NRUM] + RID_FAR) & RID_MASK;
-    if (pcount)
-      for (int q = 0; q < PB_SLOTS; ++q) {
-        const uint32_t l = (uint32_t)line[q], h = (uint32_t)(line[q] >> 32);
-        if (!pe_tx(h) || pe_slot(l) == sl) continue;
-        lo[n] = pe_lo(pe_slot(l), far); hi[n] = h; sj[n] = s.subject_of[pe_slot(l)]; n++;
-      }
-    const uint32_t arid = find_rid(s, sl, akey);
-    lo[n] = pe_lo(sl, arid); hi[n] = pe_hi(akey, s.L); sj[n] = mbr; n++;
-    for (uint32_t a = 1; a < n; ++a)                      // insertion sort by (tx desc, subject asc)
-      for (uint32_t b = a; b > 0 && rumor_better(pe_tx(hi[b]), sj[b], pe_tx(hi[b - 1]), sj[b - 1]); --b) {
-        uint32_t x;
-        x = lo[b]; lo[b] = lo[b - 1]; lo[b - 1] = x;
-        x = hi[b]; hi[b] = hi[b - 1]; hi[b - 1] = x;
-        x = sj[b]; sj[b] = sj[b - 1]; sj[b - 1] = x;
-      }
-    if (n > (uint32_t)PB_SLOTS) n = PB_SLOTS;
-    for (uint32_t q = 0; q < (uint32_t)PB_SLOTS; ++q)
-      line[q] = q < n ? (((uint64_t)hi[q] << 32) | lo[q]) : 0ull;
-    // mask: only the fresh announcement can be expressed (its id is the newest) -- if it made the cut;
-    // the rest is parked
-    unsigned long long jm = 0; uint32_t joow = 0;
-    for (uint32_t q = 0; q < n; ++q) {
-      if (pe_slot(lo[q]) == sl) jm = rid_bit(arid); else joow = MI_OOW;
-    }
-    s.pk[ml] = make_ulonglong2(jm, 0ull);         // and an empty known-ring
-    s.minfo[mbr] = (mi & ~(MI_PBN | MI_OOW)) | (n << MI_PBN_SHIFT) | MI_UP | joow;
-    s.inmask[ml] = 0;
-    hot.x = ni;
-    s.hot[ml] = hot;
-    if (s.event_mask & (1u << 4)) {
-      uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
-      if (pos < s.event_cap) s.events[pos] = make_uint4(t, mbr, mbr, (akey << 8) | 4u);
-      else dropped++;
-    }
+// Settling, the bookkeeping part (one block; include/swimsim.h).  After merge_kernel of
+// tick u: (a) the rows it cleared go to the free stack; (b) every row of its eligible list whose subject
+// was quiet during u as well is committed: base := max(base, largest entry among the members that were
+// up), the subject loses its row (minfo), the row joins the list the NEXT merge clears.  Nothing is
+// settled while an up member holds the subject Suspect.  Runs at the start of begin_kernel, or on its own
+// before state is read (digest, views) -- whichever comes first.
+__device__ inline void settle_finish(const DevState& s) {
+  if (!s.G || !s.g[G_SETTLE_PENDING]) return;     // uniform
+  __shared__ uint32_t nz_new, nfree;
+  const uint32_t u = s.g[G_SETTLE_TICK], ns = s.g[G_SETTLE_N], nz = s.g[G_ZERO_N];
+  if (threadIdx.x == 0) { nz_new = 0; nfree = s.g[G_NFREE]; }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < nz; k += blockDim.x) s.free_rows[nfree + k] = s.zero_slots[k];
+  __syncthreads();
+  unsigned settled = 0;
+  for (uint32_t k = threadIdx.x; k < ns; k += blockDim.x) {
+    const uint32_t slot = s.settle_slots[k], kmax = s.settle_key[k], last = s.slot_last[slot];
+    if (last != NONE32 && u - last < s.G) continue;          // somebody changed its mind during tick u
+    if ((kmax & 3u) == ST_SUSPECT) continue;                 // a timer is still running
+    const uint32_t subject = s.subject_of[slot];
+    const uint32_t nb = max(s.base_key[subject], kmax);
+    s.base_key[subject] = nb;
+    s.base_since[subject] = u;
+    s.minfo[subject] = (s.minfo[subject] & ~(MI_SLOT | MI_BASE)) | ((nb & 3u) << MI_BASE_SHIFT);
+    s.slot_used[slot] = 0;
+    for (int w = 0; w < RT_WAYS; ++w) s.rtab[(size_t)slot * RT_WAYS + w] = 0ull;
+    s.zero_slots[atomicAdd(&nz_new, 1u)] = slot;             // read above by this block only, behind the barrier
+    settled++;
   }
-  if (evd) s.blk[(size_t)s.nblocks * C_COUNT + C_EVDIGEST] += evd;
-  if (dropped) s.blk[(size_t)s.nblocks * C_COUNT + C_EVENTS_DROPPED] += dropped;
-  s.g[G_PREV] = s.g[G_HEAD];
-  const uint32_t H = s.g[G_NRUM];
-  s.g[G_HEAD] = H;
-  if (s.n_shards > 1) {
+  if (settled) {
+    atomicAdd(&s.g[G_NLIVE], 0u - settled);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&s.blk[(size_t)s.nblocks * C_COUNT + C_SETTLED]), (unsigned long long)settled);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s.g[G_NFREE] = nfree + nz; s.g[G_ZERO_N] = nz_new; s.g[G_SETTLE_N] = 0; s.g[G_SETTLE_PENDING] = 0;
+  }
+  __syncthreads();
+}
+__global__ __launch_bounds__(BLOCK) void settle_flush_kernel(DevState s) { settle_finish(s); }
+
+// Start of tick t, one block: settling bookkeeping of the tick before, then the ground-truth changes
+// scheduled for t (host-sorted by member within the tick: one thread applies all changes of one member in
+// order, members in parallel), then the snapshot of the rumour-id counter that fixes the tick's window head H
+// (no ids are allocated between here and merge_kernel), then the rows eligible for settling at the end of t.
+__global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, const FaultRec* faults, uint32_t nfaults) {
+  __shared__ unsigned long long evd_sh;
+  __shared__ unsigned dropped_sh, nset;
+  settle_finish(s);
+  if (threadIdx.x == 0) { evd_sh = 0; dropped_sh = 0; nset = 0; }
+  __syncthreads();
+  for (uint32_t k0 = threadIdx.x; k0 < nfaults; k0 += blockDim.x) {
+    if (k0 && faults[k0 - 1].member == faults[k0].member) continue;      // not the first change of its member
+    unsigned long long evd = 0; unsigned dropped = 0;
+    for (uint32_t k = k0; k < nfaults && faults[k].member == faults[k0].member; ++k) {
+      const uint32_t mbr = faults[k].member, up = faults[k].up;
+      uint32_t mi = s.minfo[mbr];
+      if ((uint32_t)mi_up(mi) == up) continue;
+      s.first_suspect[mbr] = NONE32;
+      if (!up) {
+        // the process is gone: its piggyback queue with it (member map and deadlines stay: swimsim.h)
+        s.crash_tick[mbr] = t;
+        if (is_local(s, mbr)) { s.minfo[mbr] = mi & ~(MI_UP | MI_PB); s.pk[mbr - s.lo].x = 0ull; }
+        else s.minfo[mbr] = mi & ~MI_UP;
+        continue;
+      }
+      if (!is_local(s, mbr)) { s.minfo[mbr] = mi | MI_UP; continue; }   // its owner does the rest
+      // (re)join: new incarnation, announce Alive: the queue holds exactly that rumour
+      const uint32_t ml = mbr - s.lo;
+      const uint2 hot = s.hot[ml];
+      uint32_t ni = hot.x + 1;
+      if (ni > INC_MAX) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_INC); ni = INC_MAX; }
+      evd += h4(TAG_INC, ((uint64_t)t << 32) | mbr, ni, 0);
+      const uint32_t sl = get_slot(s, mbr);
+      if (s.G) s.slot_last[sl] = t;
+      mi = s.minfo[mbr];
+      const uint32_t cur = mi_buf(mi);
+      const uint32_t akey = (ni << 2) | ST_ALIVE;
+      const uint32_t arid = find_rid(s, sl, akey);
+      uint64_t* line = s.pb + ((size_t)cur * s.N + ml) * PB_SLOTS;
+      line[0] = ((uint64_t)pe_hi(akey, s.L) << 32) | pe_lo(sl, arid);
+      for (int q = 1; q < PB_SLOTS; ++q) line[q] = 0ull;
+      s.pk[ml] = make_ulonglong2(rid_bit(arid), 0ull);       // its id is the newest: maskable; known-ring empty
+      s.minfo[mbr] = (mi & ~(MI_PBN | MI_OOW)) | (1u << MI_PBN_SHIFT) | MI_UP;
+      s.inmask[ml] = 0;
+      s.hot[ml] = make_uint2(ni, hot.y | 1u);                // merge_kernel fires the deadlines it slept through
+      if (s.event_mask & (1u << 4)) {
+        uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
+        if (pos < s.event_cap) s.events[pos] = make_uint4(t, mbr, mbr, (akey << 8) | 4u);
+        else dropped++;
+      }
+    }
+    if (evd) atomicAdd(&evd_sh, evd);
+    if (dropped) atomicAdd(&dropped_sh, dropped);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (evd_sh) s.blk[(size_t)s.nblocks * C_COUNT + C_EVDIGEST] += evd_sh;
+    if (dropped_sh) s.blk[(size_t)s.nblocks * C_COUNT + C_EVENTS_DROPPED] += dropped_sh;
+    s.g[G_PREV] = s.g[G_HEAD];
+    s.g[G_HEAD] = s.g[G_NRUM];
+  }
+  if (s.G) {
+    // rows whose subject nobody has changed its mind about for G ticks (counting this one, checked again by
+    // settle_finish): this tick's merge reduces their entries
+    const uint32_t nrows = min(s.g[G_NSLOTS], s.R_phys);
+    for (uint32_t r = threadIdx.x; r < nrows; r += blockDim.x) {
+      if (!s.slot_used[r]) continue;
+      const uint32_t last = s.slot_last[r];
+      if (last != NONE32 && t - last < s.G) continue;
+      const uint32_t k = atomicAdd(&nset, 1u);
+      s.settle_slots[k] = r; s.settle_key[k] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { s.g[G_SETTLE_N] = nset; s.g[G_SETTLE_TICK] = t; s.g[G_SETTLE_PENDING] = 1; }
+  }
+  if (s.n_shards > 1 && threadIdx.x == 0) {
+    const uint32_t H = s.g[G_NRUM];
     for (int k = 0; k < 3 * MAX_SHARDS; ++k) s.send_cnt[k] = 0;
     // this tick's dictionary for the peers: ring position -> {subject, key} of the id that owns it
     const size_t rstride = DICT_RECS + s.r_cap;
@@ -1056,11 +1103,12 @@ __global__ __launch_bounds__(BLOCK) void digest_kernel(DevState s, unsigned long
   const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
   const uint32_t i = s.lo + li;
   if (li < s.N) {
-    const uint4 hot = s.hot[li];
+    const uint2 hot = s.hot[li];
     const uint32_t mi = s.minfo[i];
     unsigned long long mh = h4(TAG_SELF, i, hot.x, mi_up(mi) ? 1u : 0u);
-    const uint32_t ns = min(s.g[G_NSLOTS], s.R_max);
+    const uint32_t ns = min(s.g[G_NSLOTS], s.R_phys);
     for (uint32_t r = 0; r < ns; ++r) {
+      if (!s.slot_used[r]) continue;                 // reclaimed (its cells are cleared by the next merge)
       const uint2 e = s.V[vidx(s, li, r)];
       if (e.x == 0) continue;
       const uint32_t subject = s.subject_of[r];
@@ -1078,6 +1126,8 @@ __global__ __launch_bounds__(BLOCK) void digest_kernel(DevState s, unsigned long
     unsigned long long d = mix64(mh + mix64((uint64_t)TAG_MEMBER + i));
     const uint32_t fs = s.first_suspect[i];
     if (fs != NONE32) d += h4(TAG_FD, i, fs, 0);
+    const uint32_t bk = s.base_key[i];
+    if (bk) d += h4(TAG_BASE, i, bk, s.base_since[i]);
     atomicAdd(&acc, d);
   }
   __syncthreads();
@@ -1101,21 +1151,18 @@ __global__ void set_view_kernel(DevState s, uint32_t t, uint32_t observer, uint3
   const uint32_t sl = (s.minfo[subject] & MI_SLOT) - 1;
   const uint32_t ol = observer - s.lo;
   s.V[vidx(s, ol, sl)] = make_uint2(key, t + 1);
-  if ((key & 3u) == ST_SUSPECT) {
-    uint4 hot = s.hot[ol];
-    const uint32_t thead = hot.y & 0xFFFFu, tcount = hot.y >> 16;
-    if (tcount >= s.timer_cap) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_TIMERS); return; }
-    uint32_t pos = thead + tcount; if (pos >= s.timer_cap) pos -= s.timer_cap;
-    s.ring[ridx(s, ol, pos)] = make_uint2(sl, t + s.S);
-    if (tcount == 0) hot.w = t + s.S;
-    hot.y = thead | ((tcount + 1) << 16);
-    s.hot[ol] = hot;
+  if ((key & 3u) == ST_SUSPECT) {                   // deadline t + S: row t mod S (merge_kernel carries it over)
+    const size_t ix = (size_t)(t % s.S) * s.N + ol;
+    const uint4 cell = s.trow[ix];
+    TimerCell c; c.lo = cell.x | ((unsigned long long)cell.y << 32); c.hi = cell.z | ((unsigned long long)cell.w << 32); c.n = 0;
+    while (c.n < TR_SLOTS && tc_get(cell, c.n)) c.n++;
+    tc_put(c, sl + 1);
+    s.trow[ix] = tc_pack(c);
   }
 }
 
-__global__ void init_members_kernel(uint4* hot, uint32_t* minfo, uint32_t n_local, uint32_t n_total) {
+__global__ void init_members_kernel(uint32_t* minfo, uint32_t n_total) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_local) hot[i] = make_uint4(0u, 0u, 0u, NONE32);
   if (i < n_total) minfo[i] = MI_UP;
 }
 
