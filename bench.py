@@ -7,11 +7,19 @@ dissemination-saturated regime: ~1 member crashes per
 every Ping/Ack carries a full 8-rumour piggyback payload and each member accepts ~2 view
 changes per tick.  State is resident in HBM before the timed region; faults are pre-scheduled.
 
+The regime does not depend on --warmup: before the W warm-up steps an untimed PRE-ROLL steps the
+cluster until the kernels' own counters show the saturated load (d >= 5.9 payloads delivered per
+member-tick over the last 10 ticks, and the suspicion timeout has passed so that Dead declarations
+circulate as well: r ~ 2), and the line reports the regime actually measured
+(`per_member_tick`).  `--regime quiescent` is the other regime of config 3 (one crash, empty payloads).
+
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     : dominant kernel (probe_kernel: it performs the 2P payload deliveries per member) algorithmic
-                 bytes / HIP-event duration vs 8 TB/s, plus the per-kernel and whole-tick figures
-  cpu_baseline : the CPU oracle (a "port": the Haskell reference cannot be built here, no GHC)
-                 timed on a bounded sample of the same workload on this box's host cores.
+  roofline     : whole-tick algorithmic bytes / HIP-event kernel time vs 8 TB/s (`frac`), plus each kernel's
+                 own figure; `kernel` names the one with the larger share of the time
+  cpu_baseline : the CPU oracle (a "port": the Haskell reference cannot be built here, no GHC) stepping the
+                 SAME cluster on this box's host cores (member-range threads, all cores) over a bounded
+                 window, plus its single-thread rate; the same replay checks the GPU's state digest and
+                 counters against the oracle at the end of the timed region (`verified_vs_oracle`).
 """
 import argparse
 import json
@@ -24,20 +32,24 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 N_MEMBERS = 1 << 20
+PREROLL_MAX = 400              # ticks; the saturated load is reached after ~60
+PREROLL_CHUNK = 10
+SATURATED_D = 5.9              # payloads delivered per member-tick (2P = 6 when every message carries one)
 
 
-def algorithmic_bytes(c0, c1, n_members, ticks, P, K):
-    """A = 16 + P + 64 d + 16 r + 128 c + f k  bytes per member-tick, from the
-    semantic event counters kept by the kernels (d payloads delivered, r view entries changed,
-    c piggyback lines rewritten, f failed direct probes), split by the kernel that moves them."""
+def rates(c0, c1, n_members, ticks):
+    """d payloads delivered, r view entries changed, c piggyback lines rewritten, f failed direct probes:
+    the semantic events per member-tick of SURVEY.md 8(d), from the kernels' counters."""
     mt = float(n_members) * ticks
-    d = (c1["payloads"] - c0["payloads"]) / mt
-    r = (c1["changes"] - c0["changes"]) / mt
-    c = (c1["pb_writes"] - c0["pb_writes"]) / mt
-    f = (c1["direct_failed"] - c0["direct_failed"]) / mt
-    a = {"probe_kernel": P + f * K + 64.0 * d,         # liveness gathers + delivered piggyback payloads
-         "merge_kernel": 16.0 + 16.0 * r + 128.0 * c}  # hot record, accepted rumours, own line read+write
-    return a, {"d": d, "r": r, "c": c, "f": f}
+    return {"d": (c1["payloads"] - c0["payloads"]) / mt, "r": (c1["changes"] - c0["changes"]) / mt,
+            "c": (c1["pb_writes"] - c0["pb_writes"]) / mt, "f": (c1["direct_failed"] - c0["direct_failed"]) / mt}
+
+
+def algorithmic_bytes(rt, P, K):
+    """A = 16 + P + 64 d + 16 r + 128 c + f k  bytes per member-tick, split by the kernel
+    that moves them."""
+    return {"probe_kernel": P + rt["f"] * K + 64.0 * rt["d"],         # liveness gathers + delivered payloads
+            "merge_kernel": 16.0 + 16.0 * rt["r"] + 128.0 * rt["c"]}  # hot record, accepted rumours, own line r+w
 
 
 def first_detection_latency(sim, crashes, lo_tick, hi_tick):
@@ -46,24 +58,38 @@ def first_detection_latency(sim, crashes, lo_tick, hi_tick):
     return (sum(lat) / len(lat), len(lat)) if lat else (None, 0)
 
 
-def cpu_baseline(budget_ticks=60, warm_ticks=150, n_members=65536):
-    """The oracle (oracle/swim_oracle.c, single thread) on a 65 536-member slice of the workload at
-    the same per-member rumour load (~1 crash per tick), warm-up excluded."""
+def oracle_replay(sc, crashes, t_window, t_end, gpu_digest, gpu_counters, budget_s=150.0):
+    """The CPU oracle (oracle/swim_oracle.c; checker and reported baseline, never the product) steps the
+    same cluster with the same schedule: all host cores up to t_end, timed over [t_window, t_end); digest
+    and counters must equal the GPU's; then a few more ticks on ONE thread for the single-core rate."""
     from swim_amd import Sim, workloads
     from tests import oracle_binding          # checker only: never the thing shipped
-    total = warm_ticks + budget_ticks
-    sc, crashes, _ = workloads.saturated(n_members, total)
+    cores = os.cpu_count() or 1
+    n = sc.nMembers
+    # rough cost model (1.0 M member-ticks/s per core, ~55 % parallel efficiency): skip what cannot finish
+    est = n * t_end / (1.0e6 * max(1.0, 0.55 * cores))
+    if est > budget_s:
+        return {"skipped": "oracle replay of %d ticks x %d members needs ~%.0f s on %d cores" % (t_end, n, est, cores)}, None
     s = Sim.create(oracle_binding.load(), sc)
     workloads.apply_crashes(s, crashes)
-    s.step(warm_ticks)
+    oracle_binding.set_threads(s, cores)
+    s.step(t_window)
     t0 = time.perf_counter()
-    s.step(budget_ticks)
-    dt = time.perf_counter() - t0
+    s.step(t_end - t_window)
+    dt_all = time.perf_counter() - t0
+    ok = (s.digest() == gpu_digest) and (s.counters() == gpu_counters)
+    oracle_binding.set_threads(s, 1)
+    k1 = max(1, min(8, int(6.0e6 / n)))
+    t0 = time.perf_counter()
+    s.step(k1)
+    dt_one = time.perf_counter() - t0
     s.close()
-    return {"value": n_members * budget_ticks / dt, "unit": "member-ticks/s", "cores": 1, "kind": "port",
-            "sample": "%d-member slice, same per-member load (~1 crash/tick), ticks %d-%d, oracle/swim_oracle.c "
-                      "single thread; reference Haskell not timed: no GHC in image" % (n_members, warm_ticks, total),
-            "host_cores_available": os.cpu_count()}
+    base = {"value": n * (t_end - t_window) / dt_all, "unit": "member-ticks/s", "cores": cores, "kind": "port",
+            "single_thread_value": n * k1 / dt_one,
+            "sample": "oracle/swim_oracle.c on the SAME %d-member cluster and fault schedule: ticks %d-%d with %d "
+                      "member-range threads (all host cores), then %d ticks on one thread; reference Haskell not "
+                      "timed: no GHC in image" % (n, t_window, t_end, cores, k1)}
+    return base, ok
 
 
 def main():
@@ -76,7 +102,10 @@ def main():
     ap.add_argument("--scheme", default="random", choices=["random", "robust"],
                     help="target scheme of the direct probes: random = the reference's kRandomMembers (the headline); "
                          "robust = round-robin rotation (src/Core.hs:232 FIXME), reported separately")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--loss-ppm", type=int, default=0, help="per-message loss (BASELINE config 5 uses 300000)")
+    ap.add_argument("--num-to-gossip", type=int, default=3, help="P = k (the reference's default config has 10)")
+    ap.add_argument("--gc", action="store_true", help="settling on (gc_ticks = auto): view rows are reclaimed")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle replay (baseline + verification)")
     args = ap.parse_args()
 
     import torch
@@ -98,18 +127,23 @@ def main():
         else:
             dist.init_process_group("cpu:gloo,cuda:nccl", device_id=torch.device("cuda", local_rank))
 
-    from swim_amd import Sim, _lib, workloads
-    total = args.warmup + args.steps
+    from swim_amd import Sim, _abi, _lib, workloads
     n = args.members                          # per GPU: weak scaling, ONE cluster of world * n members
     nt = n * world
-    # the same global failure rate at every size (~1 crash per tick): per-member rumour load, and so the
-    # per-GPU work, stays what it is on one GPU
-    if args.regime == "saturated":
-        sc, crashes, _ = workloads.saturated(nt, total, seed=1)
+    saturated = args.regime == "saturated"
+    horizon = (PREROLL_MAX if saturated else 0) + args.warmup + args.steps + 16
+    # the same global failure rate at every size (~1 crash per tick from tick 0 on): per-member rumour load,
+    # and so the per-GPU work, stays what it is on one GPU
+    if saturated:
+        sc, crashes, _ = workloads.saturated(nt, horizon, seed=1, t0=0, loss_ppm=args.loss_ppm, num_to_gossip=args.num_to_gossip)
     else:
-        sc, crashes, _ = workloads.quiescent(nt, total, seed=1)
+        sc, crashes, _ = workloads.quiescent(nt, horizon, seed=1)
+        sc.cfg.numToGossip = args.num_to_gossip
+        sc.lossPpm = args.loss_ppm
     sc.device = local_rank
     sc.targetScheme = 1 if args.scheme == "robust" else 0
+    if args.gc:
+        sc.gcTicks = _abi.GC_AUTO
     exchange = "none (one shard)"
     if world == 1:
         sim = Sim.create(_lib.load(), sc)
@@ -126,6 +160,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- pre-roll (untimed): step until the cluster carries the saturated load, whatever --warmup is
+    preroll = 0
+    if saturated:
+        cprev = sim.counters()
+        while True:
+            sim.step(PREROLL_CHUNK)
+            preroll += PREROLL_CHUNK
+            cnow = sim.counters()
+            d = rates(cprev, cnow, nt, PREROLL_CHUNK)["d"]       # counters() is collective on a sharded cluster
+            cprev = cnow
+            # every Ping and Ack that arrives carries a payload: d -> P (1-l) + P (1-l)^2 (+ proxied hops)
+            lv = 1.0 - args.loss_ppm / 1e6
+            # ... and the first Dead declarations (suspicion timeout) are circulating: r -> ~2
+            if d >= SATURATED_D / 6.0 * args.num_to_gossip * (lv + lv * lv) and preroll >= sim.resolved.suspicion_ticks + 20:
+                break
+            if preroll >= PREROLL_MAX:
+                raise SystemExit("bench: the cluster did not reach the saturated regime in %d ticks (d = %.2f)" % (preroll, d))
     sim.step(args.warmup)
     if world > 1:
         sim.phaseBreakdown(reset=True)
@@ -142,25 +193,31 @@ def main():
         tt = torch.tensor([dt], device="cpu" if share_gpu else "cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-
-    lat_all = first_detection_latency(sim, crashes, args.warmup, total - 2)   # collective on a sharded cluster
+    t_window, t_end = preroll + args.warmup, preroll + args.warmup + args.steps
+    lat_all = first_detection_latency(sim, crashes, t_window, t_end - 2)   # collective on a sharded cluster
+    gpu_digest = sim.digest() if world == 1 else None
     if rank == 0:
         P = sim.resolved.probes_per_tick
         K = sim.resolved.indirect_k
-        a_by, rates = algorithmic_bytes(c0, c1, nt, args.steps, P, K)
+        rt = rates(c0, c1, nt, args.steps)
+        a_by = algorithmic_bytes(rt, P, K)
         nk = max(1, kt["ticks"])
         secs = {"probe_kernel": kt["probe_ms"] / 1e3 / nk, "merge_kernel": kt["merge_ms"] / 1e3 / nk}
         per_kernel = {k: {"algorithmic_bytes_per_member_tick": a_by[k], "avg_launch_us": secs[k] * 1e6,
-                          "achieved_GBs": (a_by[k] * n / secs[k] / 1e9) if secs[k] > 0 else 0.0} for k in secs}
-        dom = "probe_kernel"
-        achieved = per_kernel[dom]["achieved_GBs"]
+                          "achieved_GBs": (a_by[k] * n / secs[k] / 1e9) if secs[k] > 0 else 0.0,
+                          "frac": (a_by[k] * n / secs[k] / 1e9 / HBM_PEAK_GBS) if secs[k] > 0 else 0.0} for k in secs}
+        dom = max(secs, key=lambda k: secs[k])               # the kernel with the larger share of the tick
         a_tot, t_tot = sum(a_by.values()), sum(secs.values())
-        traffic = None
+        whole = a_tot * n / t_tot / 1e9 if t_tot > 0 else 0.0
+        # HBM traffic of the dominant kernel: PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
+        # of THIS workload and regime, recorded by scripts/pmc_passes.sh -- a rocprof run cannot nest in here
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and saturated and not args.loss_ppm and args.num_to_gossip == 3 and args.scheme == "random":
             tj = json.load(open(tpath))
-            if tj.get("regime") == args.regime and tj.get("members") == n:
+            if tj.get("regime") == args.regime and tj.get("members") == n and tj.get("kernels_rev") == _abi.ABI_VERSION:
                 traffic = tj.get(dom + "_hbm_bytes_per_launch")
+                traffic_src = tj.get("source")
         lat, nlat = lat_all
         out = {
             "metric": "member-ticks/sec at N=1M simulated members; mean first-detection latency (ticks)",
@@ -170,28 +227,34 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "config3(%s): %d members/GPU, k=3, ~1 crash per tick (hashed schedule), "
-                                   "suspicion %d ticks, retransmit %dx log2 N" % (
-                                       args.regime, n, sim.resolved.suspicion_ticks, sim.resolved.retransmit_mult),
+            "config": {"workload": "config3(%s): %d members/GPU, k=%d, %s, loss %d ppm, suspicion %d ticks, retransmit %dx log2 N%s" % (
+                           args.regime, n, args.num_to_gossip,
+                           "~1 crash per tick from tick 0 (hashed schedule); untimed pre-roll of %d ticks until d >= %.1f and "
+                           "the suspicion timeout has passed, then the warm-up" % (preroll, SATURATED_D) if saturated else "one crash at tick 2",
+                           args.loss_ppm, sim.resolved.suspicion_ticks, sim.resolved.retransmit_mult,
+                           ", settling every %d quiet ticks" % sim.resolved.gc_ticks if sim.resolved.gc_ticks else ""),
                        "members_per_gpu": n, "num_to_gossip": sim.resolved.num_to_gossip, "target_scheme": args.scheme,
+                       "preroll_ticks": preroll, "timed_ticks": [t_window, t_end],
                        "parallelism": "1 GPU" if world == 1 else "ONE cluster of %d members in %d shards (contiguous id ranges, one per GPU); piggyback payloads cross shards in two rounds per tick (%s)" % (nt, world, exchange)},
             "ticks_per_s": args.steps / dt,
             "mean_first_detection_latency_ticks": lat, "crashes_measured": nlat,
-            "per_member_tick": rates,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_member_tick": a_by[dom],
-                         "avg_launch_us": secs[dom] * 1e6,
-                         "kernels": per_kernel,
-                         "whole_tick": {"algorithmic_bytes_per_member_tick": a_tot,
-                                        "kernel_us": t_tot * 1e6,
-                                        "achieved_GBs": a_tot * n / t_tot / 1e9 if t_tot > 0 else 0.0,
-                                        "frac": (a_tot * n / t_tot / 1e9 / HBM_PEAK_GBS) if t_tot > 0 else 0.0}},
+            "per_member_tick": rt,
+            "roofline": {"bound": "hbm", "kernel": dom, "scope": "whole tick (probe_kernel + merge_kernel)",
+                         "achieved": whole, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": whole / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_member_tick": a_tot, "kernel_us": t_tot * 1e6,
+                         "frac_of_wall": (a_tot * n / (dt / args.steps) / 1e9 / HBM_PEAK_GBS),
+                         "kernels": per_kernel},
         }
         if world > 1:
             out["shard_tick_breakdown_us_rank0"] = sim.phaseBreakdown()      # where a sharded tick goes (host view)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            base, ok = oracle_replay(sc, crashes, t_window, t_end, gpu_digest, c1)
+            out["cpu_baseline"] = base
+            out["verified_vs_oracle"] = ok       # digest + counters at the end of the timed region; None = replay skipped
+            if ok is False:
+                print(json.dumps(out))
+                raise SystemExit("bench: GPU state diverged from the oracle at tick %d" % t_end)
         print(json.dumps(out))
     sim.close()
     if world > 1:

@@ -68,15 +68,19 @@ def apply_crashes(sim, crashes):
         sim.crash(member, tick)
 
 
-def saturated(n_members, total_ticks, seed=1, crashes_per_tick=1.0, t0=10):
+def saturated(n_members, total_ticks, seed=1, crashes_per_tick=1.0, t0=10, loss_ppm=0, num_to_gossip=3):
     """Dissemination-saturated regime: about `crashes_per_tick` members crash per tick from t0 on,
-    so every message carries a full piggyback payload (regime (s))."""
+    so every message carries a full piggyback payload (regime (s)).  With message loss the
+    false suspicions add subjects of their own: the subject table is sized for them too."""
     span = max(1, total_ticks - t0)
     want = max(1, int(round(span * crashes_per_tick)))
     den = 1 << 20
     num = max(1, int(round(want * den / n_members)))
-    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n_members, seed=seed,
-                   maxSubjects=min(n_members, max(256, 2 * want + 64)))
+    loss = loss_ppm / 1e6
+    p_false = (1.0 - (1.0 - loss) ** 2) * (1.0 - (1.0 - loss) ** 4) ** num_to_gossip    # per probe
+    false_subjects = int(min(n_members, p_false * num_to_gossip * n_members * total_ticks))
+    sc = SimConfig(cfg=Config(numToGossip=num_to_gossip), nMembers=n_members, seed=seed, lossPpm=loss_ppm,
+                   maxSubjects=min(n_members, 60000, max(256, 2 * want + 64 + 2 * false_subjects)))
     return sc, hashed_crashes(n_members, seed, num, den, t0, t0 + span), total_ticks
 
 
