@@ -89,7 +89,9 @@ typedef struct swimsim_config {
   uint32_t suspicion_ticks;    /* Suspect -> Dead timeout (D4); 0 -> 3*ceil(log2 N)   */
   uint32_t retransmit_mult;    /* piggyback budget L = mult*ceil(log2(N+1)) (D5); 0->3 */
   uint32_t max_subjects;       /* subjects with a live view column at one time (columns are
-                                  reclaimed by settling, gc_ticks); 0 -> min(N, 1024)    */
+                                  reclaimed by settling, gc_ticks); 0 -> sized for the false
+                                  suspicions of ~256 periods at loss_ppm (>= 1024, <= N, <= 60000,
+                                  within 32 GB of columns)                                  */
   uint32_t gc_ticks;           /* settling horizon G (`removeDeadNodes`, src/Core.hs:65-67, plus
                                   the push-pull anti-entropy the reference leaves commented out,
                                   src/Types.hs:165,177): a subject nobody has changed its mind

@@ -906,8 +906,20 @@ static int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, char*
   if (c->retransmit_mult == 0) c->retransmit_mult = 3;
   if ((uint64_t)c->retransmit_mult * ceil_log2((uint64_t)c->n_members + 1) > 255) {
     snprintf(err, errn, "retransmit budget exceeds 255"); return SWIMSIM_ERR_INVALID; }
-  if (c->max_subjects == 0) c->max_subjects = c->n_members < 1024 ? c->n_members : 1024;
-  if (c->max_subjects > 65534u) { snprintf(err, errn, "max_subjects must be <= 65534"); return SWIMSIM_ERR_INVALID; }
+  if (c->max_subjects == 0) {
+    /* enough view columns for the subjects of ~256 periods of false suspicions (all in parts per million,
+     * integers only: the oracle and the product must agree on the number), within 32 GB of columns */
+    uint64_t q = 1000000u - c->loss_ppm, q2 = q * q / 1000000u, q4 = q2 * q2 / 1000000u;
+    uint64_t pf = 1000000u - q2;                                   /* the direct probe fails ... */
+    for (int k = 0; k < c->indirect_k; k++) pf = pf * (1000000u - q4) / 1000000u;   /* ... and every proxy chain */
+    uint64_t est = pf * (uint64_t)c->probes_per_tick * c->n_members / 1000000u * 512u + 1024u;
+    uint64_t mem = 32000000000ull / (8ull * c->n_members);
+    if (est > mem) est = mem < 64 ? 64 : mem;
+    if (est > 60000u) est = 60000u;
+    if (est > c->n_members) est = c->n_members;
+    c->max_subjects = (uint32_t)est;
+  }
+  if (c->max_subjects > 60000u) { snprintf(err, errn, "max_subjects must be <= 60000"); return SWIMSIM_ERR_INVALID; }
   {
     uint32_t gmin = c->suspicion_ticks + c->retransmit_mult * ceil_log2((uint64_t)c->n_members + 1) + 2;
     if (c->gc_ticks == SWIMSIM_GC_AUTO) c->gc_ticks = gmin;

@@ -11,6 +11,14 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libswimsim.so")
 _cached = None
 
 
+def load_variant(tag):
+    """A test build of the same sources with a compile-time knob shrunk (__graft_entry__.VARIANTS)."""
+    path = os.path.join(_HERE, "csrc", "libswimsim_%s.so" % tag)
+    if not os.path.exists(path):
+        raise ImportError("%s not built: run __graft_entry__.build()" % path)
+    return _abi.bind(C.CDLL(path, mode=C.RTLD_LOCAL), "swimsim_")
+
+
 def load():
     """Return the bound ABI namespace of libswimsim.so (prefix swimsim_)."""
     global _cached

@@ -90,7 +90,7 @@ struct DevState {
                            //   (x) and the "anything new for you?" test before a push (y)
   unsigned long long* inmask;   // OR of the masks pushed to this member this tick (atomicOr by the pingers)
   unsigned long long* ackmask;  // OR of the masks this member pulled with its Acks (plain store by the prober)
-  uint2* rum;              // [65536] rumour id -> {slot, key}
+  uint2* rum;              // [1 << RID_BITS] rumour id -> {slot, key}
   unsigned long long* rtab;// [R_max][RT_WAYS] (slot, key) -> rumour id: {key+1 : 32 | ready : 1 | rid : 16}
   // explicit delivery records "dst merges src's 64-B line": the exact fallback for queues with
   // entries outside the mask window, and for ticks that follow a burst of new rumour ids
@@ -210,8 +210,13 @@ __host__ __device__ inline uint32_t pe_hi(uint32_t key, uint32_t tx) { return ke
 #define SWIM_MASK_WIN 48
 #define SWIM_MASK_SLACK 16
 #endif
-constexpr uint32_t KN_BITS = 64, MASK_WIN = SWIM_MASK_WIN, MASK_SLACK = SWIM_MASK_SLACK, RID_MASK = 0xFFFFu, RID_FAR = 0x8000u;
+#ifndef SWIM_RID_BITS        // width of a rumour id (tests shrink it so that the id counter wraps every few ticks)
+#define SWIM_RID_BITS 16
+#endif
+constexpr uint32_t KN_BITS = 64, MASK_WIN = SWIM_MASK_WIN, MASK_SLACK = SWIM_MASK_SLACK, RID_BITS = SWIM_RID_BITS,
+                   RID_MASK = (1u << RID_BITS) - 1u, RID_FAR = 1u << (RID_BITS - 1), RID_NEAR = 1u << (RID_BITS - 2);
 static_assert(MASK_WIN + MASK_SLACK <= KN_BITS, "mask positions must be unambiguous");
+static_assert(RID_BITS <= 16 && KN_BITS + RID_NEAR < RID_FAR + 1 && KN_BITS <= RID_NEAR, "rumour ids: window < near range < parking distance");
 constexpr int RT_WAYS = 8;
 constexpr unsigned long long RT_READY = 1ull << 16;
 

@@ -118,8 +118,11 @@ __device__ inline void deliver_local(const DevState& s, uint32_t t, bool use_mas
   if (!use_mask || (msrc & MI_OOW)) push(s, t, dst_li, mi_src(src_li, msrc));
 }
 
+#ifndef SWIM_PROBE_WAVES
+#define SWIM_PROBE_WAVES 5
+#endif
 template <int PMAX>
-__global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, uint32_t tk, Offsets off) {
+__global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : 1) void probe_kernel(DevState s, uint32_t t, uint32_t tk, Offsets off) {
   __shared__ BlockCounters sh;
   __shared__ uint32_t ordn;                        // deliveries left to the exchange (sharded runs)
   if (threadIdx.x == 0) ordn = 0;
@@ -330,10 +333,6 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(DevState s, uint32_t t, ui
 // merge kernel
 // ================================================================================================
 
-__device__ inline bool rumor_better(uint32_t txa, uint32_t sa, uint32_t txb, uint32_t sb) {
-  return txa != txb ? txa > txb : sa < sb;
-}
-
 // (slot, key) -> rumour id, created by whoever states the rumour first (own probe, own timer,
 // refutation, join); everyone else learns the id from the piggyback entry that carries the rumour.
 // One way per (incarnation, state) combination, newer combinations evict older ones.  Duplicate ids
@@ -346,11 +345,18 @@ __device__ inline uint32_t find_rid(const DevState& s, uint32_t slot, uint32_t k
   for (int spin = 0; spin < 1024; ++spin) {
     const uint32_t ek = (uint32_t)(e >> 32);
     if (ek == key + 1u) {
-      if (e & RT_READY) return (uint32_t)e & RID_MASK;
-      e = atomicCAS(p, 0ull, 0ull);                 // being published by another lane: re-read at device scope
-      continue;
-    }
-    if (ek > key + 1u) break;                       // the way belongs to a newer rumour about this subject
+      if (e & RT_READY) {
+        // a published id is reused only while it still names this rumour and is recent: the id counter wraps
+        // (RID_BITS), and an id that another rumour took over -- or that is about to leave the near range --
+        // would set a foreign bit in somebody's mask.  A stale entry is re-claimed like a free one.
+        const uint32_t rid = (uint32_t)e & RID_MASK;
+        const uint2 r = s.rum[rid];
+        if (r.x == slot && r.y == key && ((s.g[G_NRUM] - rid) & RID_MASK) < RID_NEAR) return rid;
+      } else {
+        e = atomicCAS(p, 0ull, 0ull);               // being published by another lane: re-read at device scope
+        continue;
+      }
+    } else if (ek > key + 1u) break;                // the way belongs to a newer rumour about this subject
     const unsigned long long seen = atomicCAS(p, e, claim);
     if (seen == e) {
       const uint32_t rid = atomicAdd(&s.g[G_NRUM], 1u) & RID_MASK;
@@ -369,33 +375,7 @@ __device__ inline uint32_t find_rid(const DevState& s, uint32_t slot, uint32_t k
 // long-lived entry can never alias back into a later window (re-parked at every rewrite)
 __device__ inline uint32_t park_rid(uint32_t lo, uint32_t H) {
   const uint32_t above = (pe_rid(lo) - (H - KN_BITS)) & RID_MASK;     // distance above the window bottom
-  return above < KN_BITS + 0x4000u ? lo : pe_lo(pe_slot(lo), (H + RID_FAR) & RID_MASK);
-}
-
-// the tx == L group of the next piggyback line (this tick's changes), kept sorted by subject so
-// that the line's priority order (tx desc, subject asc) holds by construction (H3, D5)
-struct NewGroup {
-  uint32_t w[PB_SLOTS], key[PB_SLOTS], subj[PB_SLOTS];   // w = slot | rid<<16
-  uint32_t n;
-};
-
-__device__ inline void group_put(NewGroup& c, uint32_t slot, uint32_t rid, uint32_t key, uint32_t subj) {
-  bool hit = false;
-#pragma unroll
-  for (int k = 0; k < PB_SLOTS; ++k)
-    if ((uint32_t)k < c.n && pe_slot(c.w[k]) == slot) { c.w[k] = pe_lo(slot, rid); c.key[k] = key; hit = true; }
-  if (hit) return;
-  uint32_t pos = 0;
-#pragma unroll
-  for (int k = 0; k < PB_SLOTS; ++k) pos += ((uint32_t)k < c.n && c.subj[k] < subj) ? 1u : 0u;
-  if (pos >= (uint32_t)PB_SLOTS) return;                  // worse than the 8 kept (largest subjects drop)
-#pragma unroll
-  for (int k = PB_SLOTS - 1; k >= 1; --k)
-    if ((uint32_t)k > pos) { c.w[k] = c.w[k - 1]; c.key[k] = c.key[k - 1]; c.subj[k] = c.subj[k - 1]; }
-#pragma unroll
-  for (int k = 0; k < PB_SLOTS; ++k)
-    if ((uint32_t)k == pos) { c.w[k] = pe_lo(slot, rid); c.key[k] = key; c.subj[k] = subj; }
-  if (c.n < (uint32_t)PB_SLOTS) c.n++;
+  return above < KN_BITS + RID_NEAR ? lo : pe_lo(pe_slot(lo), (H + RID_FAR) & RID_MASK);
 }
 
 // One thread = one member's end of tick:
@@ -408,7 +388,7 @@ __device__ inline void group_put(NewGroup& c, uint32_t slot, uint32_t rid, uint3
 // Delivered rumours arrive as masks: new = (pushed | pulled) & ~known is the whole filter, and the
 // lanes of a wave walk their new bits in the same order, so their view / timer accesses coalesce.
 #ifndef SWIM_MERGE_WAVES
-#define SWIM_MERGE_WAVES 4
+#define SWIM_MERGE_WAVES 5
 #endif
 constexpr int ASM_STRIDE = BLOCK + 2;   // words per LDS column: keeps the transposed line store conflict-free
 
@@ -429,6 +409,7 @@ __device__ inline void settle_pass(const DevState& s, uint32_t li, bool up) {
 __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState s, uint32_t t) {
   __shared__ BlockCounters sh;
   __shared__ uint32_t asm_[PB_SLOTS * 2][ASM_STRIDE];   // the outgoing line is assembled here: [2 entry + word][thread]
+  __shared__ uint32_t gsubj[PB_SLOTS][ASM_STRIDE];      // subjects of this tick's group (its sort key)
   __shared__ uint32_t wfl[BLOCK];
   ctr_init(&sh);
   const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
@@ -471,9 +452,10 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
   uint32_t wflag = 0;                              // bit 0: my line was rebuilt in asm_, bit 1: into which buffer
   uint32_t self_inc = hot0.x;
   unsigned long long kn = 0;                       // known-ring, positions of last tick's new ids forgotten
-  NewGroup c; c.n = 0;
-#pragma unroll
-  for (int k = 0; k < PB_SLOTS; ++k) { c.w[k] = 0; c.key[k] = 0; c.subj[k] = 0; }
+  // this tick's changes = the tx == L group that heads the next piggyback line, kept sorted by subject so that
+  // the line's priority order (tx desc, subject asc) holds by construction (H3, D5).  It is built in place in
+  // the thread's LDS columns: entry k = {asm_[2k] = slot | rid<<16, asm_[2k+1] = key}, gsubj[k] its subject.
+  uint32_t gn = 0;
   uint32_t killmask = 0;                           // own entries superseded by the new group
   uint32_t oslot[PB_SLOTS / 2];                    // slot ids of the own queue, two per register
 #pragma unroll
@@ -502,6 +484,19 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
       if ((oslot[h] >> 16) == slot) killmask |= 1u << (2 * h + 1);
     }
   };
+  auto group_put = [&](uint32_t slot, uint32_t rid, uint32_t key, uint32_t subj) {
+    uint32_t pos = 0;
+    for (uint32_t k = 0; k < gn; ++k) {
+      if (pe_slot(asm_[2 * k][tid]) == slot) { asm_[2 * k][tid] = pe_lo(slot, rid); asm_[2 * k + 1][tid] = key; return; }
+      pos += gsubj[k][tid] < subj ? 1u : 0u;
+    }
+    if (pos >= (uint32_t)PB_SLOTS) return;                  // worse than the 8 kept (largest subjects drop)
+    for (uint32_t k = min(gn, (uint32_t)PB_SLOTS - 1u); k > pos; --k) {
+      asm_[2 * k][tid] = asm_[2 * k - 2][tid]; asm_[2 * k + 1][tid] = asm_[2 * k - 1][tid]; gsubj[k][tid] = gsubj[k - 1][tid];
+    }
+    asm_[2 * pos][tid] = pe_lo(slot, rid); asm_[2 * pos + 1][tid] = key; gsubj[pos][tid] = subj;
+    if (gn < (uint32_t)PB_SLOTS) gn++;
+  };
   // The state rule on one proposal (slot, key).
   auto examine = [&](uint32_t slot, uint32_t key, uint32_t cause, bool hasrid, uint32_t rid_in) {
     if (slot + 1 == my_slot1) {
@@ -524,7 +519,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     if ((key & 3u) == ST_SUSPECT) tc_put(tnew, slot + 1);             // deadline t + S (D4)
     const uint32_t rid = hasrid ? rid_in : find_rid(s, slot, key);
     kill_slot(slot);
-    group_put(c, slot, rid, key, subject);       // `Just msg` -> Broadcast -> enqueue (D5)
+    group_put(slot, rid, key, subject);          // `Just msg` -> Broadcast -> enqueue (D5)
     if (s.event_mask & (1u << cause)) {
       const uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
       if (pos < s.event_cap) s.events[pos] = make_uint4(t, i, subject, (key << 8) | cause);
@@ -652,7 +647,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
       const uint32_t akey = (ni << 2) | ST_ALIVE;
       if (s.G) s.slot_last[my_slot1 - 1] = t;
       kill_slot(my_slot1 - 1);
-      group_put(c, my_slot1 - 1, find_rid(s, my_slot1 - 1, akey), akey, i);   // Just Alive{..} (:163)
+      group_put(my_slot1 - 1, find_rid(s, my_slot1 - 1, akey), akey, i);   // Just Alive{..} (:163)
       if (s.event_mask & (1u << 3)) {
         const uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
         if (pos < s.event_cap) s.events[pos] = make_uint4(t, i, i, (akey << 8) | 3u /*REFUTE*/);
@@ -663,7 +658,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     // assembled in LDS columns, then written as one 64-B line together with its mask.  Every period costs
     // a rumour at least one transmission (age >= 1), so old entries never tie with this tick's group.
     const uint32_t age = nsent ? nsent : 1u;
-    uint32_t nout = c.n;
+    uint32_t nout = gn;
     unsigned long long qmask = 0;
     uint32_t oow = 0;
     auto publish = [&](uint32_t lo) -> uint32_t {  // mask bit or "cannot express", id parked if too old
@@ -672,11 +667,9 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
       else oow = MI_OOW;
       return park_rid(lo, H);
     };
-#pragma unroll
-    for (int k = 0; k < PB_SLOTS; ++k) {
-      const bool have = (uint32_t)k < c.n;
-      asm_[2 * k][tid] = have ? publish(c.w[k]) : 0u;
-      asm_[2 * k + 1][tid] = have ? pe_hi(c.key[k], s.L) : 0u;
+    for (uint32_t k = 0; k < gn; ++k) {
+      asm_[2 * k][tid] = publish(asm_[2 * k][tid]);
+      asm_[2 * k + 1][tid] = pe_hi(asm_[2 * k + 1][tid], s.L);
     }
     if (pcount) {
 #pragma unroll
@@ -693,6 +686,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
         }
       }
     }
+    for (uint32_t k = nout; k < (uint32_t)PB_SLOTS; ++k) { asm_[2 * k][tid] = 0u; asm_[2 * k + 1][tid] = 0u; }
     if (nout) {
       wflag = 1u | ((cur ^ 1u) << 1);              // the line itself is stored below, a whole wave at a time
       s.minfo[i] = (mi & ~MI_PB) | (nout << MI_PBN_SHIFT) | ((cur ^ 1u) << 20) | oow;

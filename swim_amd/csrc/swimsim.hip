@@ -100,7 +100,18 @@ int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, std::string*
   if (c->retransmit_mult == 0) c->retransmit_mult = 3;
   if ((uint64_t)c->retransmit_mult * ceil_log2((uint64_t)c->n_members + 1) > 255) {
     *err = "retransmit budget exceeds 255"; return SWIMSIM_ERR_INVALID; }
-  if (c->max_subjects == 0) c->max_subjects = c->n_members < 1024 ? c->n_members : 1024;
+  if (c->max_subjects == 0) {
+    // enough view columns for the subjects of ~256 periods of false suspicions (all in parts per million, integers only: the oracle and the product must agree on the number), within 32 GB of columns
+    uint64_t q = 1000000u - c->loss_ppm, q2 = q * q / 1000000u, q4 = q2 * q2 / 1000000u;
+    uint64_t pf = 1000000u - q2;                                   // the direct probe fails ...
+    for (int k = 0; k < c->indirect_k; k++) pf = pf * (1000000u - q4) / 1000000u;   // ... and every proxy chain
+    uint64_t est = pf * (uint64_t)c->probes_per_tick * c->n_members / 1000000u * 512u + 1024u;
+    uint64_t mem = 32000000000ull / (8ull * c->n_members);
+    if (est > mem) est = mem < 64 ? 64 : mem;
+    if (est > 60000u) est = 60000u;
+    if (est > c->n_members) est = c->n_members;
+    c->max_subjects = (uint32_t)est;
+  }
   if (c->max_subjects > 60000u) { *err = "max_subjects must be <= 60000"; return SWIMSIM_ERR_INVALID; }
   {
     const uint32_t gmin = c->suspicion_ticks + c->retransmit_mult * ceil_log2((uint64_t)c->n_members + 1) + 2;
@@ -296,7 +307,7 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   CK(dev_alloc(h, &d.pk, (size_t)N, 0));
   CK(dev_alloc(h, &d.inmask, (size_t)N, 0));
   CK(dev_alloc(h, &d.ackmask, (size_t)N, 0));
-  CK(dev_alloc(h, &d.rum, (size_t)65536, 0));
+  CK(dev_alloc(h, &d.rum, (size_t)1 << RID_BITS, 0));
   CK(dev_alloc(h, &d.rtab, (size_t)d.R_phys * RT_WAYS, 0));
   CK(dev_alloc(h, &d.subject_of, (size_t)d.R_phys, 0));
   CK(dev_alloc(h, &d.fail, (size_t)N * (d.P ? d.P : 1), 0));
@@ -471,12 +482,8 @@ static int read_column(swimsim_t* h, uint32_t observer, std::vector<uint2>* col,
   HIPCHK(h, hipMemcpy(subj->data(), h->d.subject_of, (size_t)ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
   std::vector<uint8_t> used(ns);
   HIPCHK(h, hipMemcpy(used.data(), h->d.slot_used, ns, hipMemcpyDeviceToHost));
-  std::vector<uint32_t> sbase(ns);
-  HIPCHK(h, hipMemcpy(sbase.data(), h->d.slot_base, (size_t)ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  for (uint32_t r = 0; r < ns; ++r) {
+  for (uint32_t r = 0; r < ns; ++r)
     if (!used[r]) { (*col)[r] = make_uint2(0u, 0u); (*subj)[r] = NONE32; }
-    else if ((*col)[r].x == 0) (*col)[r].y = sbase[r] | 0x80000000u;   // default cell: y carries the base key (flagged)
-  }
   return SWIMSIM_OK;
 }
 

@@ -224,3 +224,161 @@ def test_robust_target_scheme_parity(oracle_abi, hip_abi, n, p, loss, seed):
     fd = b.firstDetection()
     if loss == 0:
         assert all(fd[m] == t for (t, m) in crashes[1:])  # detected in the period of the crash (crashes[0] rejoined)
+
+
+def _oracle_threads(sim):
+    import os
+    from tests import oracle_binding
+    oracle_binding.set_threads(sim, os.cpu_count() or 1)
+
+
+def test_saturated_million_members_window_vs_oracle(oracle_abi, hip_abi):
+    """The BENCHMARKED regime against the oracle at full size: 1 048 576 members, ~1 crash per tick from
+    tick 0, through the pre-roll into the saturated steady state (d = 6, r ~ 2, c = 1) and 40 ticks of it:
+    state digest, every counter and the first-detection ticks must be identical (the oracle steps the
+    cluster on all host cores; same schedule as bench.py)."""
+    n = 1 << 20
+    sc, crashes, _ = workloads.saturated(n, 140, seed=1, t0=0)
+    a, b = make_pair(oracle_abi, hip_abi, sc, crashes)
+    _oracle_threads(a)
+    for stop in (60, 80, 100, 120):
+        a.step(stop - a.tick); b.step(stop - b.tick)
+        ca, cb = a.counters(), b.counters()
+        assert ca == cb, "counters differ at tick %d" % stop
+        assert a.digest() == b.digest(), "digest differs at tick %d" % stop
+    assert a.firstDetection() == b.firstDetection()
+    mt = float(n) * 20
+    # the window really is the saturated regime the bench times
+    a.step(20); b.step(20)
+    c2 = b.counters()
+    assert a.counters() == c2 and a.digest() == b.digest()
+    assert (c2["payloads"] - cb["payloads"]) / mt > 5.9 and (c2["changes"] - cb["changes"]) / mt > 1.2
+    for o in (0, 777777):
+        assert a.members(o) == b.members(o)
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_random_configurations_on_the_gpu(oracle_abi, hip_abi, block):
+    """Seeded randomised sweep (the generator of tests/test_random_sweep.py, sizes up to 65 536): sizes,
+    probe counts, loss, crashes and rejoins, both target schemes, 1-8 shards, tiny inboxes, settling."""
+    import random
+    from swim_amd import _abi
+    from swim_amd.shard import LocalFabric, ShardedSim
+    rng = random.Random(4200 + block)
+    for _ in range(8):
+        n = rng.choice([2, 3, 17, 64, 129, 300, 777, 1024, 4096, 10000, 65536])
+        p = rng.choice([1, 2, 3, 3, 3, 5, 10])
+        loss = rng.choice([0, 0, 0, 10000, 100000, 300000]) if n <= 4096 else rng.choice([0, 0, 2000])
+        scheme = rng.choice([0, 0, 1])
+        shards = 1
+        if scheme == 0 and n >= 64 and rng.random() < 0.4:
+            shards = rng.choice([g for g in (2, 3, 4, 8) if n % g == 0] or [1])
+        gc = _abi.GC_AUTO if shards == 1 and rng.random() < 0.5 else 0
+        seed = rng.randrange(1, 1 << 30)
+        sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, eventMask=0x1F if n <= 4096 else 0,
+                       suspicionTicks=rng.choice([3, 6, 12]), retransmitMult=rng.choice([1, 3]), maxSubjects=min(n, 4096),
+                       targetScheme=scheme, inboxCap=rng.choice([0, 0, 1, 2]) if n <= 4096 else 0, gcTicks=gc)
+        a = Sim.create(oracle_abi, sc)
+        _oracle_threads(a)
+        b = Sim.create(hip_abi, sc) if shards == 1 else ShardedSim(hip_abi, sc, LocalFabric(shards), device="cuda:0")
+        for _f in range(rng.randrange(0, min(256, max(1, n // 8)) + 1)):
+            m, t = rng.randrange(n), rng.randrange(1, 40)
+            for s in (a, b):
+                s.scheduleFault(t, m, False)
+            if rng.random() < 0.5:
+                t2 = t + rng.randrange(1, 30)
+                for s in (a, b):
+                    s.scheduleFault(t2, m, True)
+        what = (n, p, loss, scheme, shards, gc, seed)
+        for _t in range(rng.choice([3, 6, 12])):
+            a.step(10); b.step(10)
+            assert a.counters() == b.counters(), ("counters", what)
+            assert a.digest() == b.digest(), ("digest", what)
+            assert a.drainEventsRaw() == b.drainEventsRaw(), ("events", what)
+        assert a.firstDetection() == b.firstDetection(), ("first detection", what)
+        a.close(); b.close()
+
+
+def test_forced_fallback_paths_on_the_gpu(oracle_abi):
+    """The gfx950 build with a 4-id mask window and a 1-slot inbox: nearly every delivery takes the explicit
+    64-B-line records, the inbox overflow list and the "burst of new ids" fallback (the exact paths behind
+    the mask transport), at a size where they race for real."""
+    from swim_amd import _lib
+    hip = _lib.load_variant("win4")
+    n = 20000
+    crashes = workloads.hashed_crashes(n, 9, 1, 40, 3, 33)          # ~500 crashes over 30 ticks
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=9, lossPpm=30000, eventMask=0, suspicionTicks=6,
+                   maxSubjects=4096, inboxCap=1)
+    faults = [(45, m, True) for (_, m) in crashes[:100]]
+    a, b = make_pair(oracle_abi, hip, sc, crashes, faults)
+    _oracle_threads(a)
+    run_lockstep(a, b, 70, 10, observers=(0, 1, n - 1), members=(0, 1, n - 1), check_events=False)
+
+
+def test_rumour_id_counter_wraps_on_the_gpu(oracle_abi):
+    """The gfx950 build with 8-bit rumour ids: the id counter wraps every 256 rumours, dozens of times here."""
+    from swim_amd import _lib
+    hip = _lib.load_variant("rid8")
+    n = 30000
+    crashes = workloads.hashed_crashes(n, 4, 1, 30, 3, 103)         # ~1000 crashes over 100 ticks
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=4, lossPpm=5000, eventMask=0, suspicionTicks=6,
+                   maxSubjects=8192)
+    faults = [(t + 25, m, True) for (t, m) in crashes[:300]]
+    a, b = make_pair(oracle_abi, hip, sc, crashes, faults)
+    _oracle_threads(a)
+    run_lockstep(a, b, 150, 10, observers=(0, 1, n - 1), members=(0, 1, n - 1), check_events=False)
+
+
+def test_config5_loss_at_16k_members(oracle_abi, hip_abi):
+    """BASELINE config 5's message loss (30 %) at 16 384 members: about half of all direct probes escalate
+    to the k indirect probes, nearly every member is falsely suspected at some point (one view row per
+    member: the most a dense view holds), refutations everywhere.  Every observable, oracle-checked."""
+    n = 16384
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=21, lossPpm=300000, eventMask=0, suspicionTicks=10,
+                   maxSubjects=n)
+    crashes = workloads.hashed_crashes(n, 21, 1, 512, 3, 13)
+    a, b = make_pair(oracle_abi, hip_abi, sc, crashes)
+    _oracle_threads(a)
+    run_lockstep(a, b, 40, 10, observers=(0, n - 1), members=(0, n - 1), check_events=False)
+    c = b.counters()
+    assert c["direct_failed"] > 0.45 * c["pings"] and c["refutes"] > 1000
+
+
+def test_default_capacities_survive_a_lossy_run(oracle_abi, hip_abi):
+    """Library defaults (max_subjects = 0, no per-member timer capacity any more): 16 384 members at 5 % loss
+    used to fail with 'timer_cap exceeded' at tick 7."""
+    n = 16384
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=2, lossPpm=50000, eventMask=0)
+    a, b = make_pair(oracle_abi, hip_abi, sc, [(5, 100)])
+    _oracle_threads(a)
+    run_lockstep(a, b, 120, 20, observers=(0,), members=(0,), check_events=False)
+
+
+def test_settling_parity_and_bounded_rows(oracle_abi, hip_abi):
+    """gc_ticks on the GPU.  (a) 50 000 members with churn (crash, come back, crash again) and a little loss,
+    oracle-checked every 20 ticks through 3 settling horizons; (b) 262 144 members, one crash per tick for
+    4 000 ticks with room for 400 subjects: the run needs ten times as many, rows are reclaimed and reused."""
+    from swim_amd import _abi
+    n = 50000
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=31, lossPpm=2000, eventMask=0, suspicionTicks=6,
+                   retransmitMult=1, maxSubjects=1500, gcTicks=_abi.GC_AUTO)
+    crashes = workloads.hashed_crashes(n, 31, 1, 100, 2, 162)        # ~500 crashes over 160 ticks
+    faults = [(t + 20 + (m % 40), m, True) for (t, m) in crashes[::2]]
+    a, b = make_pair(oracle_abi, hip_abi, sc, crashes, faults)
+    _oracle_threads(a)
+    run_lockstep(a, b, 300, 20, observers=(0, n - 1, crashes[0][1]), members=(0, crashes[0][1]), check_events=False)
+    assert b.counters()["settled"] > 400
+    a.close(); b.close()
+    n, ticks = 1 << 18, 4000
+    sc, crashes, _ = workloads.saturated(n, ticks, seed=5, t0=0)
+    sc.maxSubjects = 400
+    sc.gcTicks = _abi.GC_AUTO
+    s = Sim.create(hip_abi, sc)
+    workloads.apply_crashes(s, crashes)
+    s.step(ticks)                                                    # SWIMSIM_ERR_CAPACITY would raise
+    c = s.counters()
+    assert c["settled"] > 3500 and c["false_suspects"] == 0
+    live = [o for o in (0, 5, n - 1) if o not in {m for (_, m) in crashes}]
+    for o in live:
+        assert len(s.members(o)) < 400                               # the removed ones are gone from the map
+    s.close()

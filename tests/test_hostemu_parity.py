@@ -133,3 +133,18 @@ def test_set_view_fixture_keeps_its_deadline(oracle_abi, emu_abi):
         s.close()
     assert outs[0] == outs[1]
     assert outs[0][2]["refutes"] >= 2          # members 20 and 21 are up: they refute
+
+
+def test_rumour_id_counter_wraps(oracle_abi):
+    """8-bit rumour ids (SWIM_RID_BITS=8): the id counter wraps every 256 rumours, several times in this
+    run -- parked ids, the (slot, key) -> id cache and the mask window must stay exact across the wrap."""
+    from tests import hostemu_binding
+    emu = hostemu_binding.load_variant("rid8", ["SWIM_RID_BITS=8"])
+    n = 900
+    crashes = workloads.hashed_crashes(n, 4, 1, 5, 3, 93)         # ~180 crashes over 90 ticks
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=4, lossPpm=20000, eventMask=0x1F, suspicionTicks=6,
+                   maxSubjects=900)
+    faults = [(t + 25, m, True) for (t, m) in crashes[:60]]          # long sleepers restate old rumours
+    a, b = make_pair(oracle_abi, emu, sc, crashes, faults)
+    run_lockstep(a, b, 140, 10, observers=(0, 1, n - 1), members=(0, 1, n - 1))
+    assert b.counters()["changes"] > 256 * 300                      # thousands of ids: many wraps
