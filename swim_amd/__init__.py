@@ -1,6 +1,6 @@
 """swim_amd -- MI355X-native SWIM tick simulator (host-side mirror of jpfuentes2/swim's
 Config / Liveness / Message surface over the C ABI in include/swimsim.h)."""
-from .types import (Alive, Broadcast, Config, Dead, Liveness, Member, MembershipEvent, SimConfig,
+from .types import (Ack, Alive, Broadcast, Config, Dead, IndirectPing, Liveness, Member, MembershipEvent, Ping, SimConfig,
                     Suspect, isAlive, isDead, memberId, memberName, milliseconds, notAlive,
                     parseConfig, removeDeadNodes)
 from .sim import Sim, SwimError

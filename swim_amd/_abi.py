@@ -106,7 +106,25 @@ _PRODUCT_ONLY = {
     "kernel_timing": (C.c_int, [_H, C.POINTER(C.c_double), C.c_size_t]),
 }
 
+
+
+class WireMsg(C.Structure):
+    """swimwire_msg_t (include/swimwire.h)"""
+    _fields_ = [("type", C.c_uint8), ("payload_len", C.c_uint8), ("port", C.c_uint16), ("seq_no", C.c_uint32),
+                ("target", C.c_uint32), ("addr", C.c_uint32), ("incarnation", C.c_int64),
+                ("node", C.c_char * 64), ("dead_from", C.c_char * 64), ("payload", C.c_uint8 * 255)]
+
+
+# include/swimwire.h: the wire codec (prefix swimwire_, product library only)
+_WIRE = {
+    "encode": (C.c_int, [C.POINTER(WireMsg), C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "decode": (C.c_int, [C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(WireMsg), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "size": (C.c_int, [C.POINTER(WireMsg), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "last_error": (C.c_char_p, []),
+}
+
 ENTRY_POINTS = tuple(_SIGS) + tuple(_PRODUCT_ONLY)
+WIRE_ENTRY_POINTS = tuple("swimwire_" + n for n in _WIRE)
 
 
 class Namespace:
@@ -126,6 +144,12 @@ def bind(lib, prefix):
         fn.restype = res
         fn.argtypes = args
         setattr(ns, name, fn)
+    if prefix == "swimsim_":
+        for name, (res, args) in _WIRE.items():
+            fn = getattr(lib, "swimwire_" + name)
+            fn.restype = res
+            fn.argtypes = args
+            setattr(ns, "wire_" + name, fn)
     ns.lib = lib
     ns.prefix = prefix
     return ns

@@ -6,7 +6,7 @@ src/Types.hs:62).
 """
 from dataclasses import dataclass, field
 from enum import IntEnum
-from typing import List, Optional, Tuple
+from typing import List, Optional, Tuple, Union
 
 
 class Liveness(IntEnum):
@@ -103,8 +103,28 @@ def removeDeadNodes(members: List[Member]) -> List[Member]:
     return [m for m in members if not isDead(m)]
 
 
-# --- Message (src/Types.hs:122-145): only the membership messages surface from a tick;
-# Ping / IndirectPing / Ack are internal to the round. ---
+# --- Message (src/Types.hs:122-145).  The membership messages surface from a tick as events; Ping /
+# IndirectPing / Ack are internal to the round and appear only on the wire (swim_amd.wire). ---
+
+@dataclass(frozen=True)
+class Ping:
+    seqNo: int
+    node: str
+
+
+@dataclass(frozen=True)
+class IndirectPing:
+    seqNo: int
+    target: int
+    port: int
+    node: str
+
+
+@dataclass(frozen=True)
+class Ack:
+    seqNo: int
+    payload: List[int] = field(default_factory=list)
+
 
 @dataclass(frozen=True)
 class Suspect:
@@ -125,6 +145,9 @@ class Dead:
     incarnation: int
     node: str
     deadFrom: str = ""
+
+
+Message = Union[Ping, IndirectPing, Ack, Suspect, Alive, Dead]
 
 
 @dataclass(frozen=True)

@@ -24,6 +24,25 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "missing export: " + name
 
 
+def test_wire_codec_symbols_are_exported_and_bound():
+    """include/swimwire.h: every declared entry point is exported by the same library and bound in _abi."""
+    import __graft_entry__ as g
+    from swim_amd import _abi
+    g.build()
+    text = open(os.path.join(ROOT, "include", "swimwire.h")).read()
+    syms = sorted(set(re.findall(r"\b(swimwire_[a-z_0-9]+)\s*\(", text)))
+    lib = C.CDLL(os.path.join(ROOT, "swim_amd", "csrc", "libswimsim.so"))
+    assert syms == sorted(_abi.WIRE_ENTRY_POINTS)
+    for name in syms:
+        assert hasattr(lib, name), "missing export: " + name
+    src = '#include <stdio.h>\n#include "swimwire.h"\nint main(){printf("%zu\\n", sizeof(swimwire_msg_t));return 0;}'
+    import subprocess, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        assert int(subprocess.check_output([os.path.join(d, "t")]).split()[0]) == C.sizeof(_abi.WireMsg)
+
+
 def test_python_binding_covers_the_header():
     from swim_amd import _abi
     declared = {s[len("swimsim_"):] for s in header_symbols()}

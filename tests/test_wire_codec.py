@@ -1,0 +1,132 @@
+"""The wire codec (include/swimwire.h) -- host-only code of libswimsim.so, so
+these tests need no GPU.  test/Spec.hs:77-96 restated (round trips of Ping / IndirectPing alone and of a
+4-message compound), the framing bytes of src/Types.hs:96-119 checked literally, the bodies cross-checked
+with an independent msgpack implementation (the `msgpack` Python package), the reference's decode failures,
+and the 255-message / 65 535-byte bounds of a piggybacked datagram."""
+import struct
+
+import msgpack
+import pytest
+
+import __graft_entry__ as g
+from swim_amd import Ack, Alive, Dead, IndirectPing, Ping, Suspect
+from swim_amd import wire
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    g.build()
+
+
+def back_and_forth(msgs):
+    """backAndForthForeverAndEver msgs = decode (encode $ envelope msgs)   (test/Spec.hs:64-65)"""
+    return wire.decode(wire.encode(msgs))
+
+
+def test_spec_hs_wire_protocol_encodes_and_decodes():
+    """test/Spec.hs:77-96, same values."""
+    ping = Ping(seqNo=1, node="a")
+    indirectPing = IndirectPing(seqNo=2, target=1, port=4000, node="b")
+    ack = Ack(seqNo=2, payload=[])
+    ping2 = Ping(seqNo=3, node="b")
+    ack2 = Ack(seqNo=4, payload=[])
+    msgs = [ping, ack, ping2, ack2]
+    assert back_and_forth([ping]) == (None, [ping])
+    assert back_and_forth([indirectPing]) == (None, [indirectPing])
+    assert back_and_forth(msgs) == (None, msgs)
+
+
+def test_framing_bytes_are_the_reference_layout():
+    """single: [msgIndex][body]; compound: [6][n][u16be lengths][bodies]   (src/Types.hs:96-103)"""
+    ping = Ping(1, "a")
+    one = wire.encode([ping])
+    assert one[0] == 0
+    body = one[1:]
+    assert msgpack.unpackb(body, raw=False) == {"tag": "Ping", "seqNo": 1, "node": "a"}
+    msgs = [ping, Ack(2, []), Suspect(7, "m12"), Alive(3, "m5", 5, 4000), Dead(9, "m77", "m1"),
+            IndirectPing(2, 1, 4000, "b")]
+    data = wire.encode(msgs)
+    assert data[0] == 6 and data[1] == len(msgs)
+    lens = struct.unpack(">%dH" % len(msgs), data[2:2 + 2 * len(msgs)])
+    off = 2 + 2 * len(msgs)
+    expect = [{"tag": "Ping", "seqNo": 1, "node": "a"}, {"tag": "Ack", "seqNo": 2, "payload": []},
+              {"tag": "Suspect", "incarnation": 7, "node": "m12"},
+              {"tag": "Alive", "incarnation": 3, "node": "m5", "addr": 5, "port": 4000},
+              {"tag": "Dead", "incarnation": 9, "node": "m77", "deadFrom": "m1"},
+              {"tag": "IndirectPing", "seqNo": 2, "target": 1, "port": 4000, "node": "b"}]
+    for ln, want in zip(lens, expect):
+        assert msgpack.unpackb(data[off:off + ln], raw=False) == want
+        off += ln
+    assert off == len(data)
+    assert wire.encode([msgs[2]])[0] == 3 and wire.encode([msgs[4]])[0] == 5       # msgIndex
+
+
+def test_decoder_accepts_what_another_msgpack_writer_produces():
+    """The reference's key order (a HashMap's) and integer widths are not reproducible here: any order, any
+    width, unknown extra fields must parse (packAeson / unpackAeson contract)."""
+    def body(d):
+        return msgpack.packb(d, use_bin_type=False)
+    for d, want in (
+        ({"node": "zeta", "seqNo": 70000, "tag": "Ping"}, Ping(70000, "zeta")),
+        ({"payload": [1, 2, 255], "tag": "Ack", "seqNo": 0, "extra": {"x": [1, None, True]}}, Ack(0, [1, 2, 255])),
+        ({"port": 1, "addr": 0xFFFFFFFF, "node": "m1", "incarnation": -5, "tag": "Alive"}, Alive(-5, "m1", 0xFFFFFFFF, 1)),
+        ({"deadFrom": "", "tag": "Dead", "node": "x" * 40, "incarnation": 2 ** 40}, Dead(2 ** 40, "x" * 40, "")),
+    ):
+        assert wire.decode(bytes([0]) + body(d)) == (None, [want])
+    # widest integer encodings for small values
+    b = b"\x83\xa3tag\xa4Ping\xa5seqNo\xcf" + struct.pack(">Q", 9) + b"\xa4node\xa1a"
+    assert wire.decode(b"\x00" + b) == (None, [Ping(9, "a")])
+    bodies = [body({"tag": "Suspect", "node": "m3", "incarnation": 1}), body({"seqNo": 5, "tag": "Ack", "payload": []})]
+    comp = bytes([6, 2]) + struct.pack(">HH", len(bodies[0]), len(bodies[1])) + bodies[0] + bodies[1]
+    assert wire.decode(comp) == (None, [Suspect(1, "m3"), Ack(5, [])])
+
+
+def test_decode_failures_of_the_reference():
+    """src/Types.hs:105-119: truncated compound, zero messages, unknown type, unparsable body."""
+    assert wire.decode(b"")[0]
+    assert "invalid message type" in wire.decode(b"\x09\x80")[0]
+    assert wire.decode(bytes([6, 3, 0, 1]))[0] == "compound message is truncated"
+    assert wire.decode(bytes([6, 0]))[0] == "compound mesage with zero messages"
+    assert "Could not parse" in wire.decode(b"\x00\x01\x02")[0]
+    assert "missing" in wire.decode(b"\x00" + msgpack.packb({"tag": "Ping", "seqNo": 1}))[0]
+    assert "out of bounds" in wire.decode(b"\x00" + msgpack.packb({"tag": "Ping", "seqNo": 2 ** 32, "node": "a"}))[0]
+    assert "unknown constructor" in wire.decode(b"\x00" + msgpack.packb({"tag": "PushPull"}))[0]
+    good = wire.encode([Ping(1, "a"), Ack(1, [])])
+    assert wire.decode(good[:-1])[0]                                   # isolate: body shorter than its length
+    body = msgpack.packb({"tag": "Ack", "seqNo": 1, "payload": []}) + b"\x00"
+    assert "trailing" in wire.decode(bytes([6, 1]) + struct.pack(">H", len(body)) + body)[0]
+
+
+def test_envelope_bounds_row_a18():
+    """<= 255 messages (numMsgs :: Word8), <= 65 535 bytes (src/Core.hs:280); an Envelope is NonEmpty."""
+    with pytest.raises(ValueError, match="at least one"):
+        wire.encode([])
+    many = [Suspect(k, "m%d" % k) for k in range(255)]
+    err, got = back_and_forth(many)
+    assert err is None and got == many
+    with pytest.raises(ValueError, match="255"):
+        wire.encode(many + [Suspect(1, "x")])
+    fat = [Ack(k, list(range(255))) for k in range(200)]               # ~410 bytes each
+    with pytest.raises(ValueError, match="65 535"):
+        wire.encode(fat)
+    # the simulator's piggybacked datagram: control message + 8 rumours at the widest values it can hold
+    # (27-bit member ids, 22-bit incarnations) stays two orders of magnitude below the limit
+    worst = [IndirectPing(2 ** 32 - 1, 2 ** 27 - 1, 65535, "m%d" % (2 ** 27 - 1))]
+    worst += [Dead(2 ** 22 - 1, "m%d" % (2 ** 27 - 1 - k), "m%d" % (2 ** 27 - 1)) for k in range(8)]
+    assert len(wire.encode(worst)) < 700
+
+
+def test_datagram_of_a_simulated_member(oracle_abi):
+    """Byte model of a tick: what a member puts on the wire = its control message + its piggyback queue
+    (the oracle handle stands in for the device handle: the codec itself is host code)."""
+    from swim_amd import Config, Sim, SimConfig
+    s = Sim.create(oracle_abi, SimConfig(cfg=Config(numToGossip=3), nMembers=64, seed=2, suspicionTicks=5))
+    s.crash(7, 1); s.crash(9, 1)
+    s.step(6)
+    m = s.readMember(0)
+    assert m["rumors"]
+    data = wire.datagram_of(s, 0, Ping(int(s.tick) + 1, "m3"))
+    err, msgs = wire.decode(data)
+    assert err is None and msgs[0] == Ping(int(s.tick) + 1, "m3") and len(msgs) == 1 + len(m["rumors"])
+    assert {(type(x).__name__, x.node) for x in msgs[1:]} <= {("Suspect", "m7"), ("Suspect", "m9"), ("Dead", "m7"), ("Dead", "m9")}
+    assert len(data) <= wire.MAX_DATAGRAM and len(msgs) <= wire.MAX_MSGS
