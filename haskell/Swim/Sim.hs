@@ -9,9 +9,13 @@
 --
 --   simulate :: SimConfig -> Source IO (Tick, Gossip)   -- events as `Broadcast (Suspect|Alive|Dead ..)`
 --   stepN, memberView, firstDetection
+--   encodeEnvelope / decodeEnvelope                      -- the wire codec of include/swimwire.h
+--
+-- Struct layouts come from Swim.Offsets, GENERATED from the C headers by scripts/gen_hs_offsets.py
+-- (the stand-in for hsc2hs in an image without GHC): no offset in this file is typed by hand.
 --
 -- Cabal stanza to add to swim.cabal's library:
---   exposed-modules: ..., Swim.Sim
+--   exposed-modules: ..., Swim.Sim, Swim.Offsets
 --   extra-libraries: swimsim
 --   include-dirs:    <repo>/include
 --   build-depends:   ..., conduit, stm
@@ -19,6 +23,7 @@ module Swim.Sim
   ( SimConfig(..), Sim, Tick
   , defaultSimConfig, configureSim, stepN, scheduleFault
   , drainEvents, simulate, memberView, firstDetection, digest
+  , encodeEnvelope, decodeEnvelope
   ) where
 
 import           Control.Concurrent.MVar (MVar, newMVar, withMVar)
@@ -27,14 +32,20 @@ import           Control.Monad.IO.Class (liftIO)
 import           Data.Conduit (Source, yield)
 import           Data.Int (Int32, Int64)
 import           Data.Word (Word16, Word32, Word64, Word8)
+import qualified Data.ByteString as BS
+import qualified Data.ByteString.Unsafe as BSU
+import           Data.Char (chr, ord)
 import           Foreign.C.String (CString, peekCString)
 import           Foreign.C.Types (CInt (..), CSize (..))
 import           Foreign.ForeignPtr (ForeignPtr, newForeignPtr, withForeignPtr)
 import           Foreign.Marshal.Alloc (alloca, allocaBytes)
-import           Foreign.Marshal.Array (allocaArray, peekArray)
+import           Foreign.Marshal.Array (allocaArray, peekArray, pokeArray)
+import           Foreign.Marshal.Utils (fillBytes)
 import           Foreign.Ptr (FunPtr, Ptr, nullPtr, plusPtr)
-import           Foreign.Storable (peek, peekByteOff, pokeByteOff)
+import qualified Foreign.Ptr
+import           Foreign.Storable (peek, peekByteOff, poke, pokeByteOff)
 
+import           Swim.Offsets
 import           Types  -- the reference's src/Types.hs, unchanged
 
 type Tick = Word64
@@ -49,6 +60,7 @@ data SimConfig = SimConfig
   , simSuspicionTicks :: Word32   -- 0 = 3 * ceil(log2 N)
   , simRetransmitMult :: Word32   -- 0 = 3
   , simMaxSubjects    :: Word32
+  , simGcTicks        :: Word32   -- settling horizon (`removeDeadNodes`, src/Core.hs:65-67): 0 = off, maxBound = auto
   , simDevice         :: Int32
   , simTargetScheme   :: Word32   -- 0 = kRandomMembers (the reference), 1 = robust round-robin (src/Core.hs:232 FIXME)
   }
@@ -56,12 +68,8 @@ data SimConfig = SimConfig
 data SwimsimT
 newtype Sim = Sim (MVar (ForeignPtr SwimsimT))   -- one handle = one logical thread of control
 
--- struct swimsim_config: field offsets as laid out by include/swimsim.h (LP64)
-cfgSize :: Int
-cfgSize = 96
-
 foreign import ccall unsafe "swimsim_default_config" c_default_config :: Ptr () -> IO CInt
-foreign import ccall safe   "swimsim_create"         c_create  :: Ptr () -> Ptr (Ptr SwimsimT) -> IO CInt
+foreign import ccall safe   "swimsim_create_msg"     c_create  :: Ptr () -> Ptr (Ptr SwimsimT) -> CString -> CSize -> IO CInt
 foreign import ccall unsafe "&swimsim_destroy"       p_destroy :: FunPtr (Ptr SwimsimT -> IO ())
 foreign import ccall unsafe "swimsim_last_error"     c_last_error :: Ptr SwimsimT -> IO CString
 foreign import ccall safe   "swimsim_step"           c_step :: Ptr SwimsimT -> Word32 -> IO CInt   -- long-running => safe
@@ -80,7 +88,7 @@ foreign import ccall safe   "swimsim_shard_phase2"  c_shard_phase2  :: Ptr Swims
 foreign import ccall safe   "swimsim_shard_phase3"  c_shard_phase3  :: Ptr SwimsimT -> Ptr Word32 -> Ptr Word32 -> IO CInt
 
 defaultSimConfig :: Config -> SimConfig
-defaultSimConfig c = SimConfig c 128 1 0 0 0 0 0 0
+defaultSimConfig c = SimConfig c 128 1 0 0 0 0 0 0 0
 
 memberNameOf :: Word32 -> String
 memberNameOf i = 'm' : show i
@@ -88,21 +96,24 @@ memberNameOf i = 'm' : show i
 -- | `configure :: IO (Either Error Store)` (src/Util.hs:103-107) for the whole population.
 configureSim :: SimConfig -> IO (Either Error Sim)
 configureSim SimConfig{..} =
-  allocaBytes cfgSize $ \p -> alloca $ \ph -> do
+  allocaBytes swimsimConfigSize $ \p -> alloca $ \ph -> allocaBytes 512 $ \perr -> do
     _ <- c_default_config p
-    pokeByteOff p 8  (fromIntegral (numToGossip simCfg) :: Int32)
-    pokeByteOff p 16 (fromIntegral (gossipInterval simCfg) :: Int64)
-    pokeByteOff p 24 simMembers
-    pokeByteOff p 32 simSeed
-    pokeByteOff p 48 simLossPpm
-    pokeByteOff p 52 simSuspicionTicks
-    pokeByteOff p 56 simRetransmitMult
-    pokeByteOff p 60 simMaxSubjects
-    pokeByteOff p 80 simDevice
-    pokeByteOff p 92 simTargetScheme
-    rc <- c_create p ph
+    pokeByteOff p swimsimConfig_num_to_gossip      (fromIntegral (numToGossip simCfg) :: Int32)
+    pokeByteOff p swimsimConfig_gossip_interval_us (fromIntegral (gossipInterval simCfg) :: Int64)
+    pokeByteOff p swimsimConfig_n_members          simMembers
+    pokeByteOff p swimsimConfig_seed               simSeed
+    pokeByteOff p swimsimConfig_loss_ppm           simLossPpm
+    pokeByteOff p swimsimConfig_suspicion_ticks    simSuspicionTicks
+    pokeByteOff p swimsimConfig_retransmit_mult    simRetransmitMult
+    pokeByteOff p swimsimConfig_max_subjects       simMaxSubjects
+    pokeByteOff p swimsimConfig_gc_ticks           simGcTicks
+    pokeByteOff p swimsimConfig_device             simDevice
+    pokeByteOff p swimsimConfig_target_scheme      simTargetScheme
+    -- the failure text comes back through OUR buffer: the library's per-thread text could belong to another
+    -- OS thread by the time a second `safe` call reads it
+    rc <- c_create p ph perr 512
     if rc /= 0
-      then Left <$> (c_last_error nullPtr >>= peekCString)
+      then Left <$> peekCString perr
       else do h <- peek ph
               fp <- newForeignPtr p_destroy h
               Right . Sim <$> newMVar fp
@@ -120,14 +131,13 @@ stepN s n = withSim s $ \h -> c_step h n >>= check h
 scheduleFault :: Sim -> Tick -> Word32 -> Bool -> IO ()
 scheduleFault s t m up = withSim s $ \h -> c_fault h t m (if up then 1 else 0) >>= check h
 
--- swimsim_event_t: tick u64 @0, observer u32 @8, subject @12, incarnation @16, state u8 @20, cause u8 @21; 24 bytes
 eventToGossip :: Ptr () -> IO (Tick, String, Gossip)
 eventToGossip p = do
-  t   <- peekByteOff p 0  :: IO Word64
-  obs <- peekByteOff p 8  :: IO Word32
-  sub <- peekByteOff p 12 :: IO Word32
-  inc <- peekByteOff p 16 :: IO Word32
-  st  <- peekByteOff p 20 :: IO Word8
+  t   <- peekByteOff p swimsimEvent_tick        :: IO Word64
+  obs <- peekByteOff p swimsimEvent_observer    :: IO Word32
+  sub <- peekByteOff p swimsimEvent_subject     :: IO Word32
+  inc <- peekByteOff p swimsimEvent_incarnation :: IO Word32
+  st  <- peekByteOff p swimsimEvent_state       :: IO Word8
   let name = memberNameOf sub
       msg = case st of
         1 -> Suspect { incarnation = fromIntegral inc, node = name }
@@ -138,13 +148,15 @@ eventToGossip p = do
 -- | The `Broadcast` gossip the members enqueued since the last drain (src/Core.hs:119-121,254).
 drainEvents :: Sim -> IO [(Tick, String, Gossip)]
 drainEvents s = withSim s $ \h -> alloca $ \pn -> do
-  rc0 <- c_drain h nullPtr 0 pn
+  poke pn 0
+  rc0 <- c_drain h nullPtr 0 pn          -- 0: nothing to drain; ERR_BUFFER: pn = how many; anything else: a real error
+  when (rc0 /= 0 && fromIntegral rc0 /= cSwimsimErrBuffer) $ check h rc0
   n <- peek pn
   if rc0 == 0 || n == 0 then return [] else
-    allocaBytes (fromIntegral n * 24) $ \buf -> do
+    allocaBytes (fromIntegral n * swimsimEventSize) $ \buf -> do
       c_drain h buf n pn >>= check h
       m <- peek pn
-      forM [0 .. fromIntegral m - 1] $ \k -> eventToGossip (buf `plusPtr` (k * 24))
+      forM [0 .. fromIntegral m - 1] $ \k -> eventToGossip (buf `plusPtr` (k * swimsimEventSize))
 
 -- | Stream of membership events, one tick at a time, in the reference's `Source IO Gossip` style
 -- (cf. `failureDetector :: Store -> Source IO Gossip`, src/Core.hs:233).
@@ -156,20 +168,21 @@ simulate s ticks = go ticks
                   go (k - 1)
 
 -- | `members store` (src/Core.hs:76-77) for one observer: the non-default entries of its map.
--- swimsim_view_entry_t: subject @0, incarnation @4, since_tick @8, state u8 @12; 16 bytes
 memberView :: Sim -> Word32 -> IO [(String, Liveness, Int, Tick)]
 memberView s obs = withSim s $ \h -> alloca $ \pn -> do
+  poke pn 0
   rc0 <- c_view h obs nullPtr 0 pn
+  when (rc0 /= 0 && fromIntegral rc0 /= cSwimsimErrBuffer) $ check h rc0
   n <- peek pn
   if rc0 == 0 || n == 0 then return [] else
-    allocaBytes (fromIntegral n * 16) $ \buf -> do
+    allocaBytes (fromIntegral n * swimsimViewEntrySize) $ \buf -> do
       c_view h obs buf n pn >>= check h
       forM [0 .. fromIntegral n - 1] $ \k -> do
-        let p = buf `plusPtr` (k * 16)
-        sub <- peekByteOff p 0 :: IO Word32
-        inc <- peekByteOff p 4 :: IO Word32
-        since <- peekByteOff p 8 :: IO Word32
-        st <- peekByteOff p 12 :: IO Word8
+        let p = buf `plusPtr` (k * swimsimViewEntrySize)
+        sub <- peekByteOff p swimsimViewEntry_subject :: IO Word32
+        inc <- peekByteOff p swimsimViewEntry_incarnation :: IO Word32
+        since <- peekByteOff p swimsimViewEntry_since_tick :: IO Word32
+        st <- peekByteOff p swimsimViewEntry_state :: IO Word8
         return (memberNameOf sub, toEnum (fromIntegral st), fromIntegral inc, fromIntegral since)
 
 firstDetection :: Sim -> Word32 -> IO [Maybe Tick]
@@ -179,3 +192,68 @@ firstDetection s n = withSim s $ \h -> allocaArray (fromIntegral n) $ \buf -> do
 
 digest :: Sim -> IO Word64
 digest s = withSim s $ \h -> alloca $ \p -> c_digest h p >>= check h >> peek p
+
+-- ---------------------------------------------------------------------------------------------------
+-- The wire codec (include/swimwire.h): `encode` / `decode` of `Envelope` (src/Types.hs:96-119) by the same
+-- library -- for replaying simulated traffic into a live node, or parsing a live node's datagrams.
+foreign import ccall unsafe "swimwire_encode"     c_wire_encode :: Ptr () -> CSize -> Ptr Word8 -> CSize -> Ptr CSize -> IO CInt
+foreign import ccall unsafe "swimwire_decode"     c_wire_decode :: Ptr Word8 -> CSize -> Ptr () -> CSize -> Ptr CSize -> IO CInt
+foreign import ccall unsafe "swimwire_last_error" c_wire_error  :: IO CString
+
+pokeName :: Ptr () -> Int -> String -> IO ()
+pokeName p off str = pokeArray (p `plusPtr` off) (map (fromIntegral . ord) (take (fromIntegral cSwimwireNameMax) str) ++ [0 :: Word8])
+
+peekName :: Ptr () -> Int -> IO String
+peekName p off = map (chr . fromIntegral) . takeWhile (/= 0) <$> peekArray (fromIntegral cSwimwireNameMax + 1) (p `plusPtr` off :: Ptr Word8)
+
+pokeMessage :: Ptr () -> Message -> IO ()
+pokeMessage p m = do
+  fillBytes p 0 swimwireMsgSize
+  pokeByteOff p swimwireMsg_type (msgIndex m :: Word8)
+  case m of
+    Ping{..}         -> pokeByteOff p swimwireMsg_seq_no seqNo >> pokeName p swimwireMsg_node node
+    IndirectPing{..} -> do pokeByteOff p swimwireMsg_seq_no seqNo; pokeByteOff p swimwireMsg_target target
+                           pokeByteOff p swimwireMsg_port port; pokeName p swimwireMsg_node node
+    Ack{..}          -> do pokeByteOff p swimwireMsg_seq_no seqNo
+                           pokeByteOff p swimwireMsg_payload_len (fromIntegral (length payload) :: Word8)
+                           pokeArray (p `plusPtr` swimwireMsg_payload) payload
+    Suspect{..}      -> pokeByteOff p swimwireMsg_incarnation (fromIntegral incarnation :: Int64) >> pokeName p swimwireMsg_node node
+    Alive{..}        -> do pokeByteOff p swimwireMsg_incarnation (fromIntegral incarnation :: Int64); pokeName p swimwireMsg_node node
+                           pokeByteOff p swimwireMsg_addr addr; pokeByteOff p swimwireMsg_port port
+    Dead{..}         -> do pokeByteOff p swimwireMsg_incarnation (fromIntegral incarnation :: Int64); pokeName p swimwireMsg_node node
+                           pokeName p swimwireMsg_dead_from deadFrom
+
+peekMessage :: Ptr () -> IO Message
+peekMessage p = do
+  ty  <- peekByteOff p swimwireMsg_type :: IO Word8
+  sq  <- peekByteOff p swimwireMsg_seq_no
+  inc <- fromIntegral <$> (peekByteOff p swimwireMsg_incarnation :: IO Int64)
+  nd  <- peekName p swimwireMsg_node
+  case ty of
+    0 -> return (Ping sq nd)
+    1 -> IndirectPing sq <$> peekByteOff p swimwireMsg_target <*> peekByteOff p swimwireMsg_port <*> pure nd
+    2 -> do n <- peekByteOff p swimwireMsg_payload_len :: IO Word8
+            Ack sq <$> peekArray (fromIntegral n) (p `plusPtr` swimwireMsg_payload)
+    3 -> return (Suspect inc nd)
+    4 -> Alive inc nd <$> peekByteOff p swimwireMsg_addr <*> peekByteOff p swimwireMsg_port
+    _ -> Dead inc nd <$> peekName p swimwireMsg_dead_from
+
+-- | `encode . Envelope` (src/Types.hs:96-103); Left = the codec's reason (more than 255 messages, > 65 535 bytes ..).
+encodeEnvelope :: [Message] -> IO (Either String BS.ByteString)
+encodeEnvelope msgs =
+  allocaBytes (max 1 (length msgs) * swimwireMsgSize) $ \arr -> allocaBytes (fromIntegral cSwimwireMaxDatagram) $ \buf -> alloca $ \pn -> do
+    forM_' (zip [0 ..] msgs) $ \(k, m) -> pokeMessage (arr `plusPtr` (k * swimwireMsgSize)) m
+    rc <- c_wire_encode arr (fromIntegral (length msgs)) buf (fromIntegral cSwimwireMaxDatagram) pn
+    if rc /= 0 then Left <$> (c_wire_error >>= peekCString)
+               else do n <- peek pn; Right <$> BS.packCStringLen (castPtr' buf, fromIntegral n)
+  where forM_' xs f = mapM_ f xs
+        castPtr' = Foreign.Ptr.castPtr
+
+-- | `decode :: ByteString -> Either String Envelope` (src/Types.hs:105-119).
+decodeEnvelope :: BS.ByteString -> IO (Either String [Message])
+decodeEnvelope bytes = BSU.unsafeUseAsCStringLen bytes $ \(src, len) ->
+  allocaBytes (fromIntegral cSwimwireMaxMsgs * swimwireMsgSize) $ \arr -> alloca $ \pn -> do
+    rc <- c_wire_decode (Foreign.Ptr.castPtr src) (fromIntegral len) arr (fromIntegral cSwimwireMaxMsgs) pn
+    if rc /= 0 then Left <$> (c_wire_error >>= peekCString)
+               else do n <- peek pn
+                       Right <$> forM [0 .. fromIntegral n - 1] (\k -> peekMessage (arr `plusPtr` (k * swimwireMsgSize)))

@@ -216,6 +216,10 @@ int swimsim_default_config(swimsim_config_t* cfg);
  * empty piggyback buffers, tick 0.  On failure *out is NULL and the message is
  * available via swimsim_last_error(NULL). */
 int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out);
+/* The same with the failure text copied into the caller's buffer (NUL-terminated, truncated to errcap): for
+ * hosts whose runtime may move a thread between two foreign calls (GHC's `safe` calls), where the per-thread
+ * text of swimsim_last_error(NULL) could be somebody else's by the time it is read. */
+int swimsim_create_msg(const swimsim_config_t* cfg, swimsim_t** out, char* err, size_t errcap);
 void swimsim_destroy(swimsim_t* h);
 const char* swimsim_last_error(const swimsim_t* h);
 

@@ -974,6 +974,12 @@ int swimoracle_create(const swimsim_config_t* cfg, swimoracle_t** out) {
   return SWIMSIM_OK;
 }
 
+int swimoracle_create_msg(const swimsim_config_t* cfg, swimoracle_t** out, char* err, size_t errcap) {
+  int rc = swimoracle_create(cfg, out);
+  if (err && errcap) snprintf(err, errcap, "%s", rc ? g_create_err : "");
+  return rc;
+}
+
 void swimoracle_destroy(swimoracle_t* o) {
   if (!o) return;
   workers_stop(o);

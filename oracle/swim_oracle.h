@@ -34,6 +34,7 @@ typedef struct swimoracle swimoracle_t;
 
 int swimoracle_default_config(swimsim_config_t* cfg);
 int swimoracle_create(const swimsim_config_t* cfg, swimoracle_t** out);
+int swimoracle_create_msg(const swimsim_config_t* cfg, swimoracle_t** out, char* err, size_t errcap);
 void swimoracle_destroy(swimoracle_t* h);
 const char* swimoracle_last_error(const swimoracle_t* h);
 int swimoracle_schedule_fault(swimoracle_t* h, uint64_t tick, uint32_t member, uint8_t up);

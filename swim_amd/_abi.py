@@ -74,6 +74,7 @@ _H = C.c_void_p
 _SIGS = {
     "default_config": (C.c_int, [C.POINTER(Config)]),
     "create": (C.c_int, [C.POINTER(Config), C.POINTER(_H)]),
+    "create_msg": (C.c_int, [C.POINTER(Config), C.POINTER(_H), C.c_char_p, C.c_size_t]),
     "destroy": (None, [_H]),
     "last_error": (C.c_char_p, [_H]),
     "schedule_fault": (C.c_int, [_H, C.c_uint64, C.c_uint32, C.c_uint8]),

@@ -362,6 +362,12 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   return SWIMSIM_OK;
 }
 
+int swimsim_create_msg(const swimsim_config_t* cfg, swimsim_t** out, char* err, size_t errcap) {
+  const int rc = swimsim_create(cfg, out);
+  if (err && errcap) { std::snprintf(err, errcap, "%s", rc ? g_create_err.c_str() : ""); }
+  return rc;
+}
+
 int swimsim_get_config(const swimsim_t* h, swimsim_config_t* out) {
   if (!h || !out) return SWIMSIM_ERR_INVALID;
   *out = h->cfg;

@@ -43,6 +43,17 @@ def test_wire_codec_symbols_are_exported_and_bound():
         assert int(subprocess.check_output([os.path.join(d, "t")]).split()[0]) == C.sizeof(_abi.WireMsg)
 
 
+def test_generated_haskell_offsets_are_current():
+    """haskell/Swim/Offsets.hs is generated from the headers (scripts/gen_hs_offsets.py); a stale file fails
+    here, so the uncompiled shim cannot drift from the ABI."""
+    import subprocess, sys
+    assert subprocess.call([sys.executable, os.path.join(ROOT, "scripts", "gen_hs_offsets.py"), "--check"]) == 0
+    shim = open(os.path.join(ROOT, "haskell", "Swim", "Sim.hs")).read()
+    assert not re.search(r"(peek|poke)ByteOff \w+ \d", shim), "hand-typed offset in the Haskell shim"
+    for name in re.findall(r"\bswim(?:sim|wire)[A-Z]\w*|\bcSwim\w+", shim):
+        assert name in open(os.path.join(ROOT, "haskell", "Swim", "Offsets.hs")).read(), name
+
+
 def test_python_binding_covers_the_header():
     from swim_amd import _abi
     declared = {s[len("swimsim_"):] for s in header_symbols()}
