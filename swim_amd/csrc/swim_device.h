@@ -113,6 +113,7 @@ struct DevState {
   uint32_t* free_rows;     // [R_phys] stack of reclaimed rows (popped by ensure_slot, pushed by settle_finish)
   uint32_t* settle_slots;  // [R_phys] rows eligible this tick; settle_key[k] = max entry among up members
   uint32_t* settle_key;
+  uint32_t* settle_part;   // [R_phys][nblocks] merge_kernel's per-block maxima of the eligible rows (no atomics)
   uint32_t* zero_slots;    // [R_phys] rows settled at the end of the last tick: cleared by this tick's merge
   uint64_t* pb;            // [2][N][PB_SLOTS] {lo: slot | rid<<16, hi: key | tx<<24}, sorted by priority
   uint32_t* first_suspect;

@@ -322,6 +322,7 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   CK(dev_alloc(h, &d.settle_slots, (size_t)d.R_phys, 0));
   CK(dev_alloc(h, &d.settle_key, (size_t)d.R_phys, 0));
   CK(dev_alloc(h, &d.zero_slots, (size_t)d.R_phys, 0));
+  CK(dev_alloc(h, &d.settle_part, d.G ? (size_t)d.R_phys * d.nblocks : 1, 0));
   CK(dev_alloc(h, &d.pb, (size_t)2 * N * PB_SLOTS, 0));
   CK(dev_alloc(h, &d.first_suspect, NT, 0xFF));
   CK(dev_alloc(h, &d.crash_tick, NT, 0xFF));
