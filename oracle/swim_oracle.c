@@ -113,7 +113,8 @@ typedef struct octx {
   swimsim_event_t* events; size_t nevents, events_cap;
   opend_t* sorted; size_t sorted_cap; uint32_t* off;   /* phase B: this range's rumours by receiver */
   int ctx_acked;            /* probe context (processing is synchronous, depth first) */
-} octx_t;
+  char pad_[128];           /* workers' contexts sit in one array: keep their hot counters on separate cache lines */
+} __attribute__((aligned(128))) octx_t;
 
 struct swimoracle {
   swimsim_config_t cfg;     /* resolved */
@@ -567,7 +568,8 @@ static int accept_key(octx_t* c, uint32_t i, uint32_t s, uint32_t key, uint8_t c
   if (!e) return 0;
   c->counters[SWIMSIM_CTR_EVDIGEST] += h4(TAG_EV, ((uint64_t)t << 32) | i, s, key)
                                      - h4(TAG_EV, ((uint64_t)t << 32) | i, s, cur.key);
-  __atomic_store_n(&o->last_change[s], t, __ATOMIC_RELAXED);
+  /* every worker writes the same tick into the same few words: look first, so that the line stays shared */
+  if (__atomic_load_n(&o->last_change[s], __ATOMIC_RELAXED) != t) __atomic_store_n(&o->last_change[s], t, __ATOMIC_RELAXED);
   if (e->since1 != t + 1) c->counters[SWIMSIM_CTR_CHANGES]++;
   e->key = key; e->since1 = t + 1;                 /* memberLastChange = now (:176) */
   if (cause == SWIMSIM_CAUSE_TIMER) c->counters[SWIMSIM_CTR_TIMERS_FIRED]++;
@@ -845,8 +847,9 @@ static int workers_start(swimoracle_t* o, uint32_t n) {
   if (n > o->N) n = o->N;
   uint32_t chunk = (o->N + n - 1) / n;
   n = (o->N + chunk - 1) / chunk;
-  o->ctx = (octx_t*)calloc(n, sizeof *o->ctx);
+  o->ctx = (octx_t*)aligned_alloc(128, (size_t)n * sizeof *o->ctx);
   if (!o->ctx) return SWIMSIM_ERR_NOMEM;
+  memset(o->ctx, 0, (size_t)n * sizeof *o->ctx);
   o->nworkers = n; o->chunk = chunk;
   for (uint32_t g = 0; g < n; g++) {
     octx_t* c = &o->ctx[g];

@@ -448,7 +448,6 @@ __device__ inline uint32_t park_rid(uint32_t lo, uint32_t H) {
 #define SWIM_MERGE_WAVES 5
 #endif
 constexpr int ASM_STRIDE = BLOCK + 2;   // words per LDS column: keeps the transposed line store conflict-free
-constexpr uint32_t ACC_CAP = 4;         // accepted proposals a member parks in LDS before their bookkeeping runs
 
 // Settling, the per-member part (swim_device.h; begin_kernel builds the lists, settle_finish commits):
 // every member -- up or down -- shows its entry of each eligible row (the maximum over the members that
@@ -475,7 +474,6 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
   __shared__ BlockCounters sh;
   __shared__ uint32_t asm_[PB_SLOTS * 2][ASM_STRIDE];   // the outgoing line is assembled here: [2 entry + word][thread]
   __shared__ uint32_t gsubj[PB_SLOTS][ASM_STRIDE];      // subjects of this tick's group (its sort key)
-  __shared__ uint32_t acc_[ACC_CAP * 3][ASM_STRIDE];    // accepted proposals parked until their bookkeeping runs
   __shared__ uint32_t wfl[BLOCK];
   __shared__ uint32_t wmax[BLOCK / 64];
   ctr_init(&sh);
@@ -564,141 +562,138 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     asm_[2 * pos][tid] = pe_lo(slot, rid); asm_[2 * pos + 1][tid] = key; gsubj[pos][tid] = subj;
     if (gn < (uint32_t)PB_SLOTS) gn++;
   };
-  // The state rule (suspectOrDeadNode' / aliveNode as the commutative merge) in two parts.  The candidate
-  // loop below is the part every delivered rumour pays: the view entry is compared and, if the proposal wins,
-  // overwritten (later proposals of this tick see it).  What follows an accepted change -- lastChange
-  // bookkeeping, digest, deadline, rumour id, queue, event -- is parked in LDS and done by bookkeep() in one
-  // loop per member: a wave executes that long body once per ACCEPTED change of its busiest lane instead of
-  // once per examined rumour.
-  uint32_t nacc = 0;
-  auto bookkeep = [&]() {
-    for (uint32_t k = 0; k < nacc; ++k) {
-      const uint32_t w0 = acc_[3 * k][tid], w1 = acc_[3 * k + 1][tid], curk = acc_[3 * k + 2][tid];
-      const uint32_t slot = w0 & 0xFFFFu, key = w1 & 0xFFFFFFu, cause = (w1 >> 24) & 7u;
-      const uint32_t subject = s.subject_of[slot];
-      if (!ha) ha = mix64(mix64((uint64_t)TAG_EV) + (((uint64_t)t << 32) | i));
-      const unsigned long long hx = mix64(ha + subject);                // h4(TAG_EV, a, subject, .) prefix
-      evd += mix64(hx + key) - mix64(hx + curk);
-      changes += (w1 >> 28) & 1u;
-      if (cause == 1u) timers_fired++;
-      if ((key & 3u) == ST_SUSPECT) tc_put(tnew, slot + 1);             // deadline t + S (D4)
-      const uint32_t rid = ((w1 >> 27) & 1u) ? (w0 >> 16) : find_rid(s, slot, key);
-      kill_slot(slot);
-      group_put(slot, rid, key, subject);        // `Just msg` -> Broadcast -> enqueue (D5)
-      if (s.event_mask & (1u << cause)) {
-        const uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
-        if (pos < s.event_cap) s.events[pos] = make_uint4(t, i, subject, (key << 8) | cause);
-        else evdropped++;
-      }
-    }
-    nacc = 0;
-  };
-
-  // ---- the candidates of this member, ONE per loop iteration whatever their source, so that the lanes of a
-  // wave share iterations across sources (a lane at a deadline and a lane at a gossiped rumour run the same
-  // compare-and-update code together).  Per member the order is the specification's:
-  //   stage 0  suspicion deadlines (the FIXME at src/Core.hs:141; D4), evaluated on the start-of-tick view:
-  //            the cell of this tick -- or, for a member that just came back up, every cell (deadlines it
-  //            slept through).  Suspect since t' with t' + S <= t => Dead at the same incarnation; a deadline
-  //            still ahead that belongs to the cell goes back into it; anything else (refuted, already Dead,
-  //            reclaimed, superseded by a later suspicion with its own cell) is dropped.
-  //   stage 1  own probes that ended without any ack: Suspect at the viewed incarnation (src/Core.hs:253)
-  //   stage 2  rumours delivered as mask bits (any order: the merge is commutative)
-  //   stage 3  rumours delivered as explicit records: the sources' 64-B lines (queues the masks could not carry)
-  const uint32_t row_now = t % s.S;
-  uint32_t stage = act ? 0u : 4u;
-  uint32_t row = woke ? 0u : row_now, rows_left = woke ? s.S : 1u;
-  uint4 cell = (woke && row_now != 0u && act) ? s.trow[li] : due;        // woke: start at row 0
-  uint32_t ck = 0, fs_r = 0, fs_n = 0;             // entry of the cell; "every view row" scan of a full cell
-  TimerCell keep; keep.lo = 0; keep.hi = 0; keep.n = 0;
-  uint32_t fi = 0;
-  unsigned long long fresh = 0;
-  uint32_t xi = 0, xq = 0, xsrc = NONE32;          // explicit records: source index, entry of its line
-  const uint32_t nin = cnt < s.inbox_cap ? cnt : s.inbox_cap;
-  const uint32_t novf = (act && cnt > s.inbox_cap) ? min(s.g[G_OVF0 + (t & 1u)], s.ovf_cap) : 0u;
-  if (act) { fresh = (pushed | pulled) & ~kn; kn |= fresh; }
-  while (stage < 4u) {
-    uint32_t slot = 0, key = 0, cause = 0, rid = 0;
-    bool have = false, hasrid = false;
-    if (stage == 0u) {
-      uint32_t v = 0;
-      if (fs_r < fs_n) { slot = fs_r++; cause = 1u; have = true; }
-      else if (ck < TR_SLOTS && (v = tc_get(cell, ck)) != 0u) {
-        ck++;
-        if (v == TR_FULL) { fs_r = 0; fs_n = min(s.g[G_NSLOTS], s.R_phys); ck = TR_SLOTS; }   // more than 8 deadlines in the cell
-        else { slot = v - 1u; cause = 1u; have = true; }
-      } else {
-        // cell done: deadlines that stay in it (a fixture of swimsim_set_view, a member that was down shortly)
-        if (row == row_now) {
-          for (uint32_t k = 0; k < keep.n && k < TR_SLOTS; ++k)
-            tc_put(tnew, k < 4u ? (uint32_t)(keep.lo >> (16u * k)) & 0xFFFFu : (uint32_t)(keep.hi >> (16u * (k - 4u))) & 0xFFFFu);
-        } else {
-          const uint4 nc = tc_pack(keep);
-          if (nc.x != cell.x || nc.y != cell.y || nc.z != cell.z || nc.w != cell.w) s.trow[(size_t)row * s.N + li] = nc;
-        }
-        keep.lo = 0; keep.hi = 0; keep.n = 0; ck = 0; fs_r = 0; fs_n = 0;
-        if (--rows_left) { row++; cell = row == row_now ? due : s.trow[(size_t)row * s.N + li]; }
-        else stage = 1u;
-      }
-    } else if (stage == 1u) {
-      if (fi < nfail) { slot = (s.minfo[s.fail[(size_t)li * s.P + fi]] & MI_SLOT) - 1u; fi++; cause = 0u; have = true; }
-      else stage = 2u;
-    } else if (stage == 2u) {
-      if (fresh) {
-        const uint32_t p = (uint32_t)__ffsll((unsigned long long)fresh) - 1u;
-        fresh &= fresh - 1ull;
-        rid = rid_at(p, H) & RID_MASK;
-        const uint2 r = s.rum[rid];
-        slot = r.x; key = r.y; cause = 2u; hasrid = true; have = true;
-      } else stage = (cnt | nack) ? 3u : 4u;
-    } else {
-      if (xsrc == NONE32) {                        // next source
-        if (xi >= nack + nin + novf) { stage = 4u; continue; }
-        if (xi < nack) xsrc = s.ackfrom[(size_t)li * s.P + xi];
-        else if (xi < nack + nin) xsrc = s.inbox[(size_t)li * s.inbox_cap + (xi - nack)];
-        else { const uint2 o = s.ovf[(size_t)(t & 1u) * s.ovf_cap + (xi - nack - nin)]; xsrc = o.x == li ? o.y : NONE32; }
-        xi++; xq = 0;
-      } else {
-        const uint2* line = reinterpret_cast<const uint2*>((xsrc & SRC_FOREIGN) ? s.fl + (size_t)(xsrc & (SRC_FOREIGN - 1u)) * 4
-                                                                                   : line_ptr(s, xsrc >> 31, xsrc & 0x7FFFFFFFu));
-        const uint2 en = line[xq];
-        if (++xq == (uint32_t)PB_SLOTS) xsrc = NONE32;
-        if (pe_tx(en.y)) {
-          rid = pe_rid(en.x);
-          bool known = false;
-          if (rid_in_ring(rid, H)) { known = (kn & rid_bit(rid)) != 0ull; kn |= rid_bit(rid); }   // known: view already dominates it
-          if (!known) { slot = pe_slot(en.x); key = pe_key(en.y); cause = 2u; hasrid = true; have = true; }
-        }
-      }
-    }
-    if (!have) continue;
-    if (cause == 2u && slot + 1u == my_slot1) {
+  // The state rule on one proposal (slot, key).
+  auto examine = [&](uint32_t slot, uint32_t key, uint32_t cause, bool hasrid, uint32_t rid_in) {
+    if (slot + 1 == my_slot1) {
       // about self -> refute (src/Core.hs:155-166): remember the largest non-Alive incarnation
       if ((key & 3u) != ST_ALIVE) refute = (refute == NONE32 || (key >> 2) > refute) ? (key >> 2) : refute;
-      continue;
-    }
-    const uint2 e = s.V[vidx(s, li, slot)];
-    if (cause == 1u) {
-      if ((e.x & 3u) != ST_SUSPECT) continue;
-      const uint32_t dl = e.y - 1u + s.S;          // its deadline
-      if (ck == TR_SLOTS && fs_n && (dl % s.S != row || !s.slot_used[slot])) continue;   // full scan: not of this cell
-      if (dl > t) { if (dl % s.S == row) tc_put(keep, slot + 1u); continue; }
-      key = (e.x & ~3u) | ST_DEAD;
+      return;
     }
     examined++;
+    const uint2 e = s.V[vidx(s, li, slot)];
     const uint32_t curk = e.x ? e.x : s.slot_base[slot];              // untouched cell: the settled base
-    if (cause == 0u) key = (curk & ~3u) | ST_SUSPECT;                   // `memberIncarnation m` of my own entry
-    if (key <= curk) continue;                     // old incarnation / weaker state: ignore (:151)
+    if (key <= curk) return;                     // old incarnation / weaker state: ignore (:151)
     s.V[vidx(s, li, slot)] = make_uint2(key, t + 1);                    // memberLastChange = now (:176)
-    if (s.G) s.slot_last[slot] = t;                // same value from every writer
-    if (nacc == ACC_CAP) bookkeep();
-    acc_[3 * nacc][tid] = slot | (hasrid ? rid << 16 : 0u);
-    acc_[3 * nacc + 1][tid] = key | (cause << 24) | ((hasrid ? 1u : 0u) << 27) | ((e.y != t + 1 ? 1u : 0u) << 28);
-    acc_[3 * nacc + 2][tid] = curk;
-    nacc++;
+    if (s.G) s.slot_last[slot] = t;              // same value from every writer
+    const uint32_t subject = s.subject_of[slot];
+    if (!ha) ha = mix64(mix64((uint64_t)TAG_EV) + (((uint64_t)t << 32) | i));
+    const unsigned long long hx = mix64(ha + subject);                // h4(TAG_EV, a, subject, .) prefix
+    evd += mix64(hx + key) - mix64(hx + curk);
+    changes += (e.y != t + 1) ? 1u : 0u;
+    if (cause == 1u) timers_fired++;
+    if ((key & 3u) == ST_SUSPECT) tc_put(tnew, slot + 1);             // deadline t + S (D4)
+    const uint32_t rid = hasrid ? rid_in : find_rid(s, slot, key);
+    kill_slot(slot);
+    group_put(slot, rid, key, subject);          // `Just msg` -> Broadcast -> enqueue (D5)
+    if (s.event_mask & (1u << cause)) {
+      const uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
+      if (pos < s.event_cap) s.events[pos] = make_uint4(t, i, subject, (key << 8) | cause);
+      else evdropped++;
+    }
+  };
+  // one entry of a deadline cell: Suspect since t' with t' + S <= t => Dead at the same incarnation (D4);
+  // a deadline still ahead that belongs to this row goes back into the cell; anything else (refuted,
+  // already Dead, reclaimed, superseded by a later suspicion with its own cell) is dropped
+  TimerCell keep; keep.lo = 0; keep.hi = 0; keep.n = 0;
+  auto deadline = [&](uint32_t slot, uint32_t row) {
+    const uint2 e = s.V[vidx(s, li, slot)];
+    if ((e.x & 3u) != ST_SUSPECT) return;
+    if (e.y - 1 + s.S <= t) examine(slot, (e.x & ~3u) | ST_DEAD, 1u, false, 0u);
+    else if ((e.y - 1 + s.S) % s.S == row) tc_put(keep, slot + 1);
+  };
+  auto run_cell = [&](const uint4& cell, uint32_t row) {
+    for (uint32_t k = 0; k < TR_SLOTS; ++k) {
+      const uint32_t v = tc_get(cell, k);
+      if (!v) break;
+      if (v == TR_FULL) {                        // more than 8 deadlines in one cell: every row is a candidate
+        const uint32_t ns = min(s.g[G_NSLOTS], s.R_phys);
+        for (uint32_t r = 0; r < ns; ++r) {
+          const uint2 e = s.V[vidx(s, li, r)];
+          if ((e.x & 3u) == ST_SUSPECT && (e.y - 1 + s.S) % s.S == row && s.slot_used[r]) deadline(r, row);
+        }
+        break;
+      }
+      deadline(v - 1, row);
+    }
+  };
+  if (act) {
+    // phase 1: suspicion deadlines, evaluated on the start-of-tick view
+    if (woke) {
+      for (uint32_t row = 0; row < s.S; ++row) {
+        if (row == t % s.S) continue;
+        const size_t ix = (size_t)row * s.N + li;
+        const uint4 cell = s.trow[ix];
+        if (!(cell.x | cell.y | cell.z | cell.w)) continue;
+        keep.lo = 0; keep.hi = 0; keep.n = 0;
+        run_cell(cell, row);
+        const uint4 nc = tc_pack(keep);
+        if (nc.x != cell.x || nc.y != cell.y || nc.z != cell.z || nc.w != cell.w) s.trow[ix] = nc;
+      }
+      keep.lo = 0; keep.hi = 0; keep.n = 0;
+    }
+    if (timer_due) run_cell(due, t % s.S);
+    // deadlines that stay in this row (a fixture set by swimsim_set_view, a member that was down shortly)
+    for (uint32_t k = 0; k < keep.n && k < TR_SLOTS; ++k) {
+      const uint32_t v = k < 4u ? (uint32_t)(keep.lo >> (16u * k)) & 0xFFFFu : (uint32_t)(keep.hi >> (16u * (k - 4u))) & 0xFFFFu;
+      tc_put(tnew, v);
+    }
+    // phase 2: own probes that ended without any ack: Suspect at the viewed incarnation
+    for (uint32_t f = 0; f < nfail; ++f) {
+      const uint32_t j = s.fail[(size_t)li * s.P + f];
+      const uint32_t sl = (s.minfo[j] & MI_SLOT) - 1;
+      const uint2 e = s.V[vidx(s, li, sl)];
+      const uint32_t curk = e.x ? e.x : s.slot_base[sl];
+      const uint32_t key = (curk & ~3u) | ST_SUSPECT;
+      if (key > curk) examine(sl, key, 0u, false, 0u);
+    }
+  }
+  // phase 3: rumours received this tick (any order: the merge is commutative).  Each lane walks its own new
+  // positions.  (Measured on MI355X, profiles/r02c_variants.txt: a wave-uniform walk over the UNION of the
+  // lanes' positions coalesces the view rows but triples the iterations -- 237 us against 188 us; one
+  // candidate loop shared by all sources with the bookkeeping parked in LDS -- 258 us.)
+  if (act) {
+    unsigned long long fresh = (pushed | pulled) & ~kn;
+    kn |= fresh;
+    while (fresh) {
+      const uint32_t p = (uint32_t)__ffsll((unsigned long long)fresh) - 1u;
+      fresh &= fresh - 1ull;
+      const uint32_t rid = rid_at(p, H) & RID_MASK;
+      const uint2 r = s.rum[rid];
+      examine(r.x, r.y, 2u, true, rid);
+    }
   }
   if (act) {
-    bookkeep();
+    if (cnt | nack) {
+      // explicit records: the sources' 64-B lines (queues the masks could not carry in full)
+      const uint32_t nin = cnt < s.inbox_cap ? cnt : s.inbox_cap;
+      const uint32_t novf = cnt > s.inbox_cap ? min(s.g[G_OVF0 + (t & 1u)], s.ovf_cap) : 0u;
+      for (uint32_t x = 0; x < nack + nin + novf; ++x) {
+        uint32_t srcw = NONE32;
+        if (x < nack) srcw = s.ackfrom[(size_t)li * s.P + x];
+        else if (x < nack + nin) srcw = s.inbox[(size_t)li * s.inbox_cap + (x - nack)];
+        else {
+          const uint2 o = s.ovf[(size_t)(t & 1u) * s.ovf_cap + (x - nack - nin)];
+          if (o.x == li) srcw = o.y;
+        }
+        if (srcw == NONE32) continue;
+        const uint4* line = (srcw & SRC_FOREIGN) ? s.fl + (size_t)(srcw & (SRC_FOREIGN - 1u)) * 4
+                                                 : line_ptr(s, srcw >> 31, srcw & 0x7FFFFFFFu);
+        for (int h = 0; h < PB_SLOTS / 2; ++h) {
+          const uint4 v = line[h];
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {
+            const uint32_t lo = w ? v.z : v.x, hi = w ? v.w : v.y;
+            if (!pe_tx(hi)) continue;
+            const uint32_t rid = pe_rid(lo);
+            if (rid_in_ring(rid, H)) {
+              if (kn & rid_bit(rid)) continue;     // view already dominates it
+              kn |= rid_bit(rid);
+            }
+            examine(pe_slot(lo), pe_key(hi), 2u, true, rid);
+          }
+        }
+      }
+    }
     // ---- refutation: bump own incarnation past the rumour's (src/Core.hs:155-166; D10); rumours at
     // an incarnation below my own are stale and ignored (:151)
     unsigned refutes = 0;
