@@ -67,8 +67,6 @@ __host__ __device__ inline uint64_t h4(uint64_t tag, uint64_t a, uint64_t b, uin
 // in circulation) -- merge_kernel walks them in wave-uniform order -- and every member reads and
 // rewrites the SAME deadline row in a tick, so these accesses share sectors instead of costing one
 // request per member.
-struct alignas(32) MemberRec { ulonglong2 pk; uint32_t mi; uint32_t pad_[3]; };
-
 struct DevState {
   // N = members owned by this handle (local index li in [0,N)), NT = whole population, lo = global id of
   // local member 0 (unsharded: lo = 0, NT = N).  minfo / first_suspect / crash_tick are indexed by GLOBAL
@@ -79,17 +77,17 @@ struct DevState {
   uint32_t P, K, S, L, loss_thr, R_max /* max_subjects */, R_phys /* view rows allocated */, G /* settling horizon, 0 = off */;
   uint32_t event_cap, event_mask, nblocks;
   uint32_t inbox_cap, ovf_cap;  // per-member delivery slots; exact overflow list capacity
-  MemberRec* mrec;         // per member (GLOBAL id), 32 bytes = what a prober gathers about a target in ONE fabric
-                           // request (two per 64-B line; the gathers are the probe kernel's bound, profiles/r02c):
-                           //   mi: bits 0-15 rumour slot+1 of this member as a subject (0 none, 0xFFFF being
-                           //     allocated), 16-19 valid piggyback slots, 20 which pb buffer is current, 21 up
-                           //     (ground truth), 22 the queue holds an entry its mask cannot express (MI_OOW),
-                           //     23-24 state of the settled base entry about this member (everybody's default).
-                           //     Replicated on every shard (ground truth and the subject -> slot table are global);
-                           //   pk (owner shard only) {x: the queue as a 64-bit mask over rumour-id positions (rid & 63),
-                           //     y: known-ring, bit (rid & 63) set => this member's view already dominates rumour rid}:
-                           //     serves the Ack's payload (x) and the "anything new for you?" test before a push (y)
+  uint32_t* minfo;         // per member, ONE gather per probe target:
+                           //   bits 0-15 rumour slot+1 of this member as a subject (0 none,
+                           //   0xFFFF being allocated), 16-19 valid piggyback slots,
+                           //   20 which pb buffer is current, 21 up (ground truth),
+                           //   22 the queue holds an entry its mask cannot express (MI_OOW),
+                           //   23-24 state of the settled base entry about this member (everybody's default)
   uint16_t* probe_out;     // nsent | nfail<<5 | n explicit own-ack sources<<10, probe -> merge kernel
+  ulonglong2* pk;          // per member {x: the queue as a 64-bit mask over rumour-id positions (rid & 63),
+                           //   y: known-ring, bit (rid & 63) set => this member's view already dominates
+                           //   rumour rid}: ONE 16-byte gather per probe target serves the Ack's payload
+                           //   (x) and the "anything new for you?" test before a push (y)
   unsigned long long* inmask;   // OR of the masks pushed to this member this tick (bin_reduce_kernel; atomicOr on the rare paths)
   uint4* bin_rec;          // [nbins][bin_cap] Ping payloads by destination bin {member & (BIN-1), -, mask}
   uint32_t* bin_cnt;       // [nbins]
@@ -302,7 +300,7 @@ __device__ inline uint32_t select_members(const DevState& s, uint32_t mk, uint32
       if ((uint32_t)p < n) {
         const uint32_t base = (purpose << 24) | (purpose == P_SELECT ? ((uint32_t)p << 8) : ((hi_idx << 16) | ((uint32_t)p << 8)));
         c0[p] = __umulhi(hash_mk(mk, base, 0), N);
-        m0[p] = s.mrec[c0[p]].mi;
+        m0[p] = s.minfo[c0[p]];
       }
     }
   }
@@ -317,7 +315,7 @@ __device__ inline uint32_t select_members(const DevState& s, uint32_t mk, uint32
       bool dup = false;
       for (int e = 0; e < MAXN; ++e) dup |= ((uint32_t)e < np) && (out[e] == cand);
       if (dup) return false;
-      mc = have ? mhave : s.mrec[cand].mi;
+      mc = have ? mhave : s.minfo[cand];
       return view_alive(s, i - s.lo, mc);
     };
     for (uint32_t a = 0; a < SEL_ATTEMPTS; ++a) {

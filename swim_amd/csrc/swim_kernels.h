@@ -68,9 +68,9 @@ __device__ inline void push(const DevState& s, uint32_t t, uint32_t dst, uint32_
 // make sure subject j (global id) has a rumour slot (first rumour about j); returns nothing: the slot
 // is usually only needed by the NEXT kernel (get_slot waits for it)
 __device__ inline void ensure_slot(const DevState& s, uint32_t j) {
-  uint32_t cur = s.mrec[j].mi;
+  uint32_t cur = s.minfo[j];
   while ((cur & MI_SLOT) == 0u) {
-    const uint32_t seen = atomicCAS(&s.mrec[j].mi, cur, cur | MI_SLOT);   // 0xFFFF = being allocated
+    const uint32_t seen = atomicCAS(&s.minfo[j], cur, cur | MI_SLOT);   // 0xFFFF = being allocated
     if (seen == cur) {
       // a reclaimed row if there is one (pushed only by settle_finish, between the tick kernels), else a new one
       uint32_t r;
@@ -87,7 +87,7 @@ __device__ inline void ensure_slot(const DevState& s, uint32_t j) {
       s.slot_last[r] = NONE32;
       s.slot_used[r] = 1;
       __threadfence();
-      atomicXor(&s.mrec[j].mi, MI_SLOT ^ (r + 1u));
+      atomicXor(&s.minfo[j], MI_SLOT ^ (r + 1u));
       return;
     }
     cur = seen;
@@ -97,8 +97,8 @@ __device__ inline void ensure_slot(const DevState& s, uint32_t j) {
 // slot of subject j, allocated if need be, for callers that need it at once (payload ingest)
 __device__ inline uint32_t get_slot(const DevState& s, uint32_t j) {
   ensure_slot(s, j);
-  uint32_t v = s.mrec[j].mi & MI_SLOT;
-  for (int spin = 0; spin < 4096 && (v == 0u || v == MI_SLOT); ++spin) v = atomicOr(&s.mrec[j].mi, 0u) & MI_SLOT;
+  uint32_t v = s.minfo[j] & MI_SLOT;
+  for (int spin = 0; spin < 4096 && (v == 0u || v == MI_SLOT); ++spin) v = atomicOr(&s.minfo[j], 0u) & MI_SLOT;
   if (v == 0u || v == MI_SLOT) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_SUBJECTS); return 0u; }
   return v - 1u;
 }
@@ -112,7 +112,7 @@ __device__ inline uint32_t get_slot(const DevState& s, uint32_t j) {
 __device__ inline void deliver_local(const DevState& s, uint32_t t, bool use_mask, unsigned long long stale,
                                      uint32_t dst_li, uint32_t src_li, uint32_t msrc, unsigned long long srcmask) {
   if (use_mask) {
-    const unsigned long long m = srcmask & ~(s.mrec[s.lo + (dst_li)].pk.y & ~stale);
+    const unsigned long long m = srcmask & ~(s.pk[dst_li].y & ~stale);
     if (m) atomicOr(&s.inmask[dst_li], m);
   }
   if (!use_mask || (msrc & MI_OOW)) push(s, t, dst_li, mi_src(src_li, msrc));
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(TPB, PMAX <= 4 ? (TPB >= 1024 ? 4 : SWIM_PROBE_WAVE
   ctr_init(&sh);
   const uint32_t li = blockIdx.x * TPB + threadIdx.x;
   const uint32_t i = s.lo + li;                    // global id
-  const uint32_t mi = li < s.N ? s.mrec[i].mi : 0u;
+  const uint32_t mi = li < s.N ? s.minfo[i] : 0u;
   const bool act = mi_up(mi);
   // masks are exact only if few rumour ids appeared since they were built (swim_device.h)
   const uint32_t Hprev = s.g[G_PREV], H = s.g[G_HEAD];
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(TPB, PMAX <= 4 ? (TPB >= 1024 ? 4 : SWIM_PROBE_WAVE
   if (act) {
     const uint32_t mk = mix32(tk ^ i);
     const uint32_t mycnt = mi_pbn(mi);
-    const unsigned long long mymask = (mycnt && use_mask) ? s.mrec[s.lo + (li)].pk.x : 0ull;
+    const unsigned long long mymask = (mycnt && use_mask) ? s.pk[li].x : 0ull;
     uint32_t picks[PMAX], pinfo[PMAX];
     bool valid[PMAX];                               // probe index p is in use this period
     const bool robust = s.scheme == 1u;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(TPB, PMAX <= 4 ? (TPB >= 1024 ? 4 : SWIM_PROBE_WAVE
         valid[p] = false; picks[p] = 0; pinfo[p] = 0;
         if ((uint32_t)p < np && off.o[p]) {
           uint32_t c = i + off.o[p]; if (c >= s.NT) c -= s.NT;
-          picks[p] = c; pinfo[p] = s.mrec[c].mi;
+          picks[p] = c; pinfo[p] = s.minfo[c];
           valid[p] = view_alive(s, li, pinfo[p]);
           n_pings += valid[p] ? 1u : 0u;
         }
@@ -199,10 +199,10 @@ __global__ __launch_bounds__(TPB, PMAX <= 4 ? (TPB >= 1024 ? 4 : SWIM_PROBE_WAVE
       payloads++; rumors += cnt;
       if (dst == i) {
         // pulled by myself: no atomics, a private word and (rarely) a private explicit list
-        if (use_mask) ackacc |= src == i ? mymask : s.mrec[s.lo + (src - s.lo)].pk.x;
+        if (use_mask) ackacc |= src == i ? mymask : s.pk[src - s.lo].x;
         if (!use_mask || (msrc & MI_OOW)) push(s, t, li, mi_src(src - s.lo, msrc));
       } else if (is_local(s, dst)) {
-        deliver_local(s, t, use_mask, stale, dst - s.lo, src - s.lo, msrc, src == i ? mymask : (use_mask ? s.mrec[s.lo + (src - s.lo)].pk.x : 0ull));
+        deliver_local(s, t, use_mask, stale, dst - s.lo, src - s.lo, msrc, src == i ? mymask : (use_mask ? s.pk[src - s.lo].x : 0ull));
       } else {
         emit_order(dst, src);
       }
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(TPB, PMAX <= 4 ? (TPB >= 1024 ? 4 : SWIM_PROBE_WAVE
     for (int p = 0; p < PMAX; ++p) {
       tk2[p] = make_ulonglong2(0ull, 0ull);
       if (use_mask && ping_ok[p] && is_local(s, picks[p]) && (mymask || (ack_ok[p] && mi_pbn(pinfo[p]))))
-        tk2[p] = s.mrec[picks[p]].pk;            // same 64-B line as the mi word gathered at selection: no new fabric request
+        tk2[p] = s.pk[picks[p] - s.lo];
     }
     // pass 3: the Pings' piggyback payloads: at most one atomicOr per target
     if (mycnt) {
@@ -264,9 +264,9 @@ __global__ __launch_bounds__(TPB, PMAX <= 4 ? (TPB >= 1024 ? 4 : SWIM_PROBE_WAVE
       for (int p = 0; p < PMAX; ++p) {
         if ((uint32_t)p >= s.P || !off.o[p]) continue;
         uint32_t q = i + s.NT - off.o[p]; if (q >= s.NT) q -= s.NT;
-        const uint32_t mq = s.mrec[q].mi;
+        const uint32_t mq = s.minfo[q];
         if (!mi_up(mq) || !mi_pbn(mq) || !view_alive(s, q - s.lo, mi) || lost(s, tk, P_L_PING, q, i, p)) continue;
-        if (use_mask) ackacc |= s.mrec[s.lo + (q - s.lo)].pk.x;
+        if (use_mask) ackacc |= s.pk[q - s.lo].x;
         if (!use_mask || (mq & MI_OOW)) push(s, t, li, mi_src(q - s.lo, mq));
       }
     }
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
   const uint32_t i = s.lo + li;                    // global id
   const uint32_t tid = threadIdx.x;
   if (blockIdx.x == 0 && threadIdx.x == 0) s.g[G_OVF0 + ((t + 1) & 1u)] = 0;  // next tick's overflow list
-  const uint32_t mi = li < s.N ? s.mrec[i].mi : 0u;
+  const uint32_t mi = li < s.N ? s.minfo[i] : 0u;
   const bool up = mi_up(mi);
   const uint32_t H = s.g[G_HEAD];
   const unsigned long long stale = stale_positions(s.g[G_PREV], H);
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
   const bool timer_due = (due.x | due.y | due.z | due.w) != 0u;
   const bool act = up && ((pushed | pulled) != 0ull || (cnt | nack | nfail | pcount | (uint32_t)timer_due | (uint32_t)woke));
   // idle this tick: only keep the ring valid (swim_device.h); nothing to write when no id was allocated
-  if (up && !act && stale) { const ulonglong2 v = s.mrec[i].pk; if (v.y & stale) s.mrec[i].pk = make_ulonglong2(v.x, v.y & ~stale); }
+  if (up && !act && stale) { const ulonglong2 v = s.pk[li]; if (v.y & stale) s.pk[li] = make_ulonglong2(v.x, v.y & ~stale); }
 
   uint32_t wflag = 0;                              // bit 0: my line was rebuilt in asm_, bit 1: into which buffer
   uint32_t self_inc = hot0.x;
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
   TimerCell tnew; tnew.lo = 0; tnew.hi = 0; tnew.n = 0;   // deadlines t + S: go to the row just consumed
 
   if (act) {
-    kn = s.mrec[s.lo + (li)].pk.y & ~stale;
+    kn = s.pk[li].y & ~stale;
     if (pcount) {
 #pragma unroll
       for (int h = 0; h < PB_SLOTS / 2; ++h) {
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     // phase 2: own probes that ended without any ack: Suspect at the viewed incarnation
     for (uint32_t f = 0; f < nfail; ++f) {
       const uint32_t j = s.fail[(size_t)li * s.P + f];
-      const uint32_t sl = (s.mrec[j].mi & MI_SLOT) - 1;
+      const uint32_t sl = (s.minfo[j] & MI_SLOT) - 1;
       const uint2 e = s.V[vidx(s, li, sl)];
       const uint32_t curk = e.x ? e.x : s.slot_base[sl];
       const uint32_t key = (curk & ~3u) | ST_SUSPECT;
@@ -748,11 +748,11 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     for (uint32_t k = nout; k < (uint32_t)PB_SLOTS; ++k) { asm_[2 * k][tid] = 0u; asm_[2 * k + 1][tid] = 0u; }
     if (nout) {
       wflag = 1u | ((cur ^ 1u) << 1);              // the line itself is stored below, a whole wave at a time
-      s.mrec[i].mi = (mi & ~MI_PB) | (nout << MI_PBN_SHIFT) | ((cur ^ 1u) << 20) | oow;
+      s.minfo[i] = (mi & ~MI_PB) | (nout << MI_PBN_SHIFT) | ((cur ^ 1u) << 20) | oow;
     } else if (pcount) {
-      s.mrec[i].mi = mi & ~MI_PB;
+      s.minfo[i] = mi & ~MI_PB;
     }
-    s.mrec[i].pk = make_ulonglong2(nout ? qmask : 0ull, kn);
+    s.pk[li] = make_ulonglong2(nout ? qmask : 0ull, kn);
     if (pushed) s.inmask[li] = 0;
     if (timer_due || tnew.n) s.trow[trix] = tc_pack(tnew);     // consumed and refilled in one store
     if (self_inc != hot0.x || woke) s.hot[li] = make_uint2(self_inc, hot0.y & ~1u);
@@ -831,7 +831,7 @@ __device__ inline void ingest_finish(const DevState& s, uint32_t t, unsigned lon
   if (tag) {
     if (bits) s.ackslot[(size_t)dst_li * s.P + (tag - 1u)] = bits;
   } else if (bits) {
-    const unsigned long long m = bits & ~(s.mrec[s.lo + (dst_li)].pk.y & ~stale);
+    const unsigned long long m = bits & ~(s.pk[dst_li].y & ~stale);
     if (m) atomicOr(&s.inmask[dst_li], m);
   }
   if (nf) {
@@ -852,7 +852,7 @@ __device__ inline OrderPlan plan_order(const DevState& s, bool use_mask, uint4 o
     // a peer's probe of MY member dst: its payload is delivered by the caller; the Ack's payload goes back
     pl.fused_in = true;
     if (!(fl & OF_WANTS_ACK)) return pl;
-    pl.who = dst; pl.mwho = s.mrec[dst].mi;
+    pl.who = dst; pl.mwho = s.minfo[dst];
     if (!mi_pbn(pl.mwho)) return pl;
     pl.kind = (use_mask && !(pl.mwho & MI_OOW)) ? 1 : 2;
     pl.peer = owner_of(s, src);
@@ -860,7 +860,7 @@ __device__ inline OrderPlan plan_order(const DevState& s, bool use_mask, uint4 o
     return pl;
   }
   if (!is_local(s, src)) { pl.kind = 0; pl.peer = owner_of(s, src); return pl; }
-  pl.who = src; pl.mwho = s.mrec[src].mi;
+  pl.who = src; pl.mwho = s.minfo[src];
   if (!mi_pbn(pl.mwho)) return pl;                  // empty payload: nothing travels
   if (is_local(s, dst)) { pl.local = true; return pl; }
   pl.kind = (use_mask && !(pl.mwho & MI_OOW)) ? 1 : 2;
@@ -905,7 +905,7 @@ __device__ inline void route_block(const DevState& s, uint32_t t, AppendCtx* a, 
     }
     const uint32_t who_li = pl.who - s.lo;
     if (served && mi_pbn(pl.mwho)) { ctr_add(sh, C_PAYLOADS, 1u); ctr_add(sh, C_RUMORS_SEEN, mi_pbn(pl.mwho)); }
-    if (pl.local) deliver_local(s, t, use_mask, stale, (o.x & ID_MASK) - s.lo, who_li, pl.mwho, use_mask ? s.mrec[s.lo + (who_li)].pk.x : 0ull);
+    if (pl.local) deliver_local(s, t, use_mask, stale, (o.x & ID_MASK) - s.lo, who_li, pl.mwho, use_mask ? s.pk[who_li].x : 0ull);
     if (pl.kind < 0) continue;
     const uint32_t pos = a->base[pl.kind][pl.peer] + atomicAdd(&a->cnt[pl.kind][pl.peer], 1u);
     if (pl.kind == 0) {
@@ -913,7 +913,7 @@ __device__ inline void route_block(const DevState& s, uint32_t t, AppendCtx* a, 
       else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG);
     } else if (pl.kind == 1) {
       if (pos < s.p_cap) {
-        const unsigned long long m = s.mrec[s.lo + (who_li)].pk.x;
+        const unsigned long long m = s.pk[who_li].x;
         s.p_send[(size_t)pl.peer * s.p_cap + pos] = make_uint4(pl.out_dst, 0u, (uint32_t)m, (uint32_t)(m >> 32));
       } else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG);
     } else {
@@ -1054,7 +1054,7 @@ __device__ inline void settle_finish(const DevState& s) {
     const uint32_t nb = max(s.base_key[subject], kmax);
     s.base_key[subject] = nb;
     s.base_since[subject] = u;
-    s.mrec[subject].mi = (s.mrec[subject].mi & ~(MI_SLOT | MI_BASE)) | ((nb & 3u) << MI_BASE_SHIFT);
+    s.minfo[subject] = (s.minfo[subject] & ~(MI_SLOT | MI_BASE)) | ((nb & 3u) << MI_BASE_SHIFT);
     s.slot_used[slot] = 0;
     for (int w = 0; w < RT_WAYS; ++w) s.rtab[(size_t)slot * RT_WAYS + w] = 0ull;
     s.zero_slots[atomicAdd(&nz_new, 1u)] = slot;             // read above by this block only, behind the barrier
@@ -1087,17 +1087,17 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, co
     unsigned long long evd = 0; unsigned dropped = 0;
     for (uint32_t k = k0; k < nfaults && faults[k].member == faults[k0].member; ++k) {
       const uint32_t mbr = faults[k].member, up = faults[k].up;
-      uint32_t mi = s.mrec[mbr].mi;
+      uint32_t mi = s.minfo[mbr];
       if ((uint32_t)mi_up(mi) == up) continue;
       s.first_suspect[mbr] = NONE32;
       if (!up) {
         // the process is gone: its piggyback queue with it (member map and deadlines stay: swimsim.h)
         s.crash_tick[mbr] = t;
-        if (is_local(s, mbr)) { s.mrec[mbr].mi = mi & ~(MI_UP | MI_PB); s.mrec[s.lo + (mbr - s.lo)].pk.x = 0ull; }
-        else s.mrec[mbr].mi = mi & ~MI_UP;
+        if (is_local(s, mbr)) { s.minfo[mbr] = mi & ~(MI_UP | MI_PB); s.pk[mbr - s.lo].x = 0ull; }
+        else s.minfo[mbr] = mi & ~MI_UP;
         continue;
       }
-      if (!is_local(s, mbr)) { s.mrec[mbr].mi = mi | MI_UP; continue; }   // its owner does the rest
+      if (!is_local(s, mbr)) { s.minfo[mbr] = mi | MI_UP; continue; }   // its owner does the rest
       // (re)join: new incarnation, announce Alive: the queue holds exactly that rumour
       const uint32_t ml = mbr - s.lo;
       const uint2 hot = s.hot[ml];
@@ -1106,15 +1106,15 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, co
       evd += h4(TAG_INC, ((uint64_t)t << 32) | mbr, ni, 0);
       const uint32_t sl = get_slot(s, mbr);
       if (s.G) s.slot_last[sl] = t;
-      mi = s.mrec[mbr].mi;
+      mi = s.minfo[mbr];
       const uint32_t cur = mi_buf(mi);
       const uint32_t akey = (ni << 2) | ST_ALIVE;
       const uint32_t arid = find_rid(s, sl, akey);
       uint64_t* line = s.pb + ((size_t)cur * s.N + ml) * PB_SLOTS;
       line[0] = ((uint64_t)pe_hi(akey, s.L) << 32) | pe_lo(sl, arid);
       for (int q = 1; q < PB_SLOTS; ++q) line[q] = 0ull;
-      s.mrec[mbr].pk = make_ulonglong2(rid_bit(arid), 0ull);    // its id is the newest: maskable; known-ring empty
-      s.mrec[mbr].mi = (mi & ~(MI_PBN | MI_OOW)) | (1u << MI_PBN_SHIFT) | MI_UP;
+      s.pk[ml] = make_ulonglong2(rid_bit(arid), 0ull);       // its id is the newest: maskable; known-ring empty
+      s.minfo[mbr] = (mi & ~(MI_PBN | MI_OOW)) | (1u << MI_PBN_SHIFT) | MI_UP;
       s.inmask[ml] = 0;
       s.hot[ml] = make_uint2(ni, hot.y | 1u);                // merge_kernel fires the deadlines it slept through
       if (s.event_mask & (1u << 4)) {
@@ -1171,7 +1171,7 @@ __global__ __launch_bounds__(BLOCK) void digest_kernel(DevState s, unsigned long
   const uint32_t i = s.lo + li;
   if (li < s.N) {
     const uint2 hot = s.hot[li];
-    const uint32_t mi = s.mrec[i].mi;
+    const uint32_t mi = s.minfo[i];
     unsigned long long mh = h4(TAG_SELF, i, hot.x, mi_up(mi) ? 1u : 0u);
     const uint32_t ns = min(s.g[G_NSLOTS], s.R_phys);
     for (uint32_t r = 0; r < ns; ++r) {
@@ -1215,7 +1215,7 @@ __global__ void select_debug_kernel(DevState s, uint32_t tk, uint32_t observer, 
 __global__ void set_view_kernel(DevState s, uint32_t t, uint32_t observer, uint32_t subject, uint32_t key) {
   if (blockIdx.x || threadIdx.x) return;
   ensure_slot(s, subject);
-  const uint32_t sl = (s.mrec[subject].mi & MI_SLOT) - 1;
+  const uint32_t sl = (s.minfo[subject] & MI_SLOT) - 1;
   const uint32_t ol = observer - s.lo;
   s.V[vidx(s, ol, sl)] = make_uint2(key, t + 1);
   if ((key & 3u) == ST_SUSPECT) {                   // deadline t + S: row t mod S (merge_kernel carries it over)
@@ -1228,9 +1228,9 @@ __global__ void set_view_kernel(DevState s, uint32_t t, uint32_t observer, uint3
   }
 }
 
-__global__ void init_members_kernel(MemberRec* mrec, uint32_t n_total) {
+__global__ void init_members_kernel(uint32_t* minfo, uint32_t n_total) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_total) mrec[i].mi = MI_UP;
+  if (i < n_total) minfo[i] = MI_UP;
 }
 
 }  // namespace swim

@@ -318,12 +318,13 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     if (lam > c.inbox_cap) d.ovf_cap = (uint32_t)std::min<double>(3.0e8, std::max<double>(d.ovf_cap, 2.0 * lam * N + 65536.0));
   }
   d.ord_cap = 0; d.r_cap = d.p_cap = d.x_cap = 0;
-  CK(dev_alloc(h, &d.mrec, NT, 0));
+  CK(dev_alloc(h, &d.minfo, NT, 0));
   CK(dev_alloc(h, &d.probe_out, N, 0));
   CK(dev_alloc(h, &d.ackfrom, (size_t)N * (d.P ? d.P : 1), 0));
   CK(dev_alloc(h, &d.inbox_cnt, N, 0));
   CK(dev_alloc(h, &d.inbox, (size_t)N * d.inbox_cap, 0));
   CK(dev_alloc(h, &d.hot, N, 0));
+  CK(dev_alloc(h, &d.pk, (size_t)N, 0));
   CK(dev_alloc(h, &d.inmask, (size_t)N, 0));
   CK(dev_alloc(h, &d.ackmask, (size_t)N, 0));
   // Ping payloads through per-bin record buffers (swim_kernels.h) when the table of bins fits the block's LDS
@@ -379,7 +380,7 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     CK(dev_alloc(h, &d.fl, (size_t)d.n_shards * ((size_t)d.x_cap + d.p_cap + d.r_cap) * 4, 0));
     CK(dev_alloc(h, &d.ackslot, (size_t)N * std::max(1u, d.P), 0));
   }
-  hipLaunchKernelGGL(init_members_kernel, dim3((NT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, d.mrec, NT);
+  hipLaunchKernelGGL(init_members_kernel, dim3((NT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, d.minfo, NT);
   HK(hipGetLastError());
   HK(hipStreamSynchronize(h->stream));
 #undef CK
@@ -563,7 +564,7 @@ int swimsim_read_member(swimsim_t* h, uint32_t m, swimsim_member_t* out) {
   if (rc) return rc;
   uint2 hot; uint32_t mi;
   HIPCHK(h, hipMemcpy(&hot, h->d.hot + ml, sizeof hot, hipMemcpyDeviceToHost));
-  HIPCHK(h, hipMemcpy(&mi, &h->d.mrec[m].mi, sizeof mi, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(&mi, h->d.minfo + m, sizeof mi, hipMemcpyDeviceToHost));
   std::memset(out, 0, sizeof *out);
   out->id = m; out->incarnation = hot.x; out->up = (mi >> 21) & 1u;
   if ((mi >> 16) & 15u) {
