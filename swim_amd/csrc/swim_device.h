@@ -88,10 +88,7 @@ struct DevState {
                            //   y: known-ring, bit (rid & 63) set => this member's view already dominates
                            //   rumour rid}: ONE 16-byte gather per probe target serves the Ack's payload
                            //   (x) and the "anything new for you?" test before a push (y)
-  unsigned long long* inmask;   // OR of the masks pushed to this member this tick (bin_reduce_kernel; atomicOr on the rare paths)
-  uint4* bin_rec;          // [nbins][bin_cap] Ping payloads by destination bin {member & (BIN-1), -, mask}
-  uint32_t* bin_cnt;       // [nbins]
-  uint32_t nbins, bin_cap; // nbins = 0: payloads go straight to inmask with one atomicOr each
+  unsigned long long* inmask;   // OR of the masks pushed to this member this tick (atomicOr by the pingers)
   unsigned long long* ackmask;  // OR of the masks this member pulled with its Acks (plain store by the prober)
   uint2* rum;              // [1 << RID_BITS] rumour id -> {slot, key}
   unsigned long long* rtab;// [R_max][RT_WAYS] (slot, key) -> rumour id: {key+1 : 32 | ready : 1 | rid : 16}

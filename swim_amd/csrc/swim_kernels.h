@@ -121,28 +121,13 @@ __device__ inline void deliver_local(const DevState& s, uint32_t t, bool use_mas
 #ifndef SWIM_PROBE_WAVES
 #define SWIM_PROBE_WAVES 5
 #endif
-// Ping payloads are PUSHED (a member does not know who pings it).  One atomicOr per payload runs at the chip's
-// memory-side atomic rate (~20 G/s whatever the table, profiles/): the whole probe kernel.  Instead the block
-// sorts its payloads by destination bin (BIN consecutive members) through an LDS histogram, reserves a range
-// of each bin's record buffer with ONE global atomic per (block, bin) and writes its records there as
-// contiguous runs; bin_reduce_kernel then ORs a bin's records into a BIN x 8-byte LDS array and stores the
-// result coalesced.  TPB = 1024 members per block so that a block has several payloads per bin (at 2^20
-// members: ~7 per bin and block, 8x fewer global atomics than payloads); commutative OR => any order is exact.
-constexpr uint32_t BIN = 4096, BIN_LOG2 = 12, MAX_BINS = 1024;
-template <int PMAX, int TPB>
-__global__ __launch_bounds__(TPB, PMAX <= 4 ? (TPB >= 1024 ? 4 : SWIM_PROBE_WAVES) : 1) void probe_kernel(DevState s, uint32_t t, uint32_t tk, Offsets off) {
+template <int PMAX>
+__global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : 1) void probe_kernel(DevState s, uint32_t t, uint32_t tk, Offsets off) {
   __shared__ BlockCounters sh;
   __shared__ uint32_t ordn;                        // deliveries left to the exchange (sharded runs)
-  __shared__ uint32_t bhist[MAX_BINS], bbase[MAX_BINS];
   if (threadIdx.x == 0) ordn = 0;
-  const bool binned = s.nbins != 0u;               // uniform
-  if (binned) for (uint32_t b = threadIdx.x; b < s.nbins; b += TPB) bhist[b] = 0;
-  unsigned long long pm[PMAX];                     // the payload of probe p if it goes through the bins
-  uint32_t pd[PMAX];
-#pragma unroll
-  for (int p = 0; p < PMAX; ++p) { pm[p] = 0ull; pd[p] = 0u; }
   ctr_init(&sh);
-  const uint32_t li = blockIdx.x * TPB + threadIdx.x;
+  const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
   const uint32_t i = s.lo + li;                    // global id
   const uint32_t mi = li < s.N ? s.minfo[i] : 0u;
   const bool act = mi_up(mi);
@@ -241,10 +226,7 @@ __global__ __launch_bounds__(TPB, PMAX <= 4 ? (TPB >= 1024 ? 4 : SWIM_PROBE_WAVE
           if (is_local(s, picks[p])) {
             const uint32_t dl = picks[p] - s.lo;
             const unsigned long long m = mymask & ~(tk2[p].y & ~stale);   // only what the target does not know
-            if (m) {
-              if (binned) { pm[p] = m; pd[p] = dl; atomicAdd(&bhist[dl >> BIN_LOG2], 1u); }
-              else atomicOr(&s.inmask[dl], m);
-            }
+            if (m) atomicOr(&s.inmask[dl], m);
             if (expl) pos[p] = atomicAdd(&s.inbox_cnt[dl], 1u);
           } else if (expl) {
             emit_order(picks[p], i);                 // my queue as an explicit payload record
@@ -339,51 +321,12 @@ __global__ __launch_bounds__(TPB, PMAX <= 4 ? (TPB >= 1024 ? 4 : SWIM_PROBE_WAVE
     ctr_add(&sh, C_FALSE_SUSPECTS, fsusp);
   }
   if (li < s.N) s.ackmask[li] = ackacc;
-  if (binned) {
-    // reserve: one global atomic per bin this block has payloads for; then the records, runs per bin
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < s.nbins; b += TPB) {
-      const uint32_t c = bhist[b];
-      if (c) bbase[b] = atomicAdd(&s.bin_cnt[b], c);
-      bhist[b] = 0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < PMAX; ++p) {
-      if (!pm[p]) continue;
-      const uint32_t b = pd[p] >> BIN_LOG2, pos = bbase[b] + atomicAdd(&bhist[b], 1u);
-      if (pos < s.bin_cap) s.bin_rec[(size_t)b * s.bin_cap + pos] = make_uint4(pd[p] & (BIN - 1u), 0u, (uint32_t)pm[p], (uint32_t)(pm[p] >> 32));
-      else atomicOr(&s.inmask[pd[p]], pm[p]);      // cannot happen below P payloads per member of the bin; exact anyway
-    }
-  }
   // the two always-nonzero counters: wave-reduce first
   unsigned wp = wave_sum(n_pings);
   unsigned wa = wave_sum(act ? 1u : 0u);
   if ((threadIdx.x & 63) == 0) { ctr_add(&sh, C_PINGS, wp); ctr_add(&sh, C_ACTIVE, wa); }
   ctr_flush(s, &sh, blockIdx.x);
   if (s.n_shards > 1 && threadIdx.x == 0) s.ord_cnt[blockIdx.x] = ordn < s.ord_cap ? ordn : s.ord_cap;
-}
-
-// the records of one bin, ORed per destination in LDS, then into inmask (nobody else touches it between
-// probe_kernel and merge_kernel except earlier, finished kernels: plain read-modify-write)
-__global__ __launch_bounds__(1024) void bin_reduce_kernel(DevState s) {
-  __shared__ unsigned long long acc[BIN];
-  const uint32_t b = blockIdx.x;
-  const uint32_t n = min(s.bin_cnt[b], s.bin_cap);
-  if (!n) return;                                  // uniform
-  for (uint32_t j = threadIdx.x; j < BIN; j += blockDim.x) acc[j] = 0ull;
-  __syncthreads();
-  for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
-    const uint4 r = s.bin_rec[(size_t)b * s.bin_cap + k];
-    atomicOr(&acc[r.x], ((unsigned long long)r.w << 32) | r.z);
-  }
-  __syncthreads();
-  for (uint32_t j = threadIdx.x; j < BIN; j += blockDim.x) {
-    const unsigned long long v = acc[j];
-    const uint32_t li = b * BIN + j;
-    if (v && li < s.N) s.inmask[li] |= v;
-  }
-  if (threadIdx.x == 0) s.bin_cnt[b] = 0;
 }
 
 // ================================================================================================

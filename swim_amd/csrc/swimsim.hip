@@ -11,7 +11,6 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -223,22 +222,10 @@ Offsets robust_offsets(const swimsim* h, uint32_t t) {
   return off;
 }
 
-// probe_kernel<4> runs 1024 members per block when its payloads go through the bins (swim_kernels.h)
-template <int PMAX>
-void launch_probe(swimsim* h, uint32_t t, uint32_t tk, const Offsets& off) {
-  constexpr int TPB = PMAX <= 4 ? 1024 : BLOCK;
-  if (h->d.nbins && h->d.n_shards == 1 && TPB != BLOCK)
-    hipLaunchKernelGGL((probe_kernel<PMAX, TPB>), dim3((h->d.N + TPB - 1) / TPB), dim3(TPB), 0, h->stream, h->d, t, tk, off);
-  else
-    hipLaunchKernelGGL((probe_kernel<PMAX, BLOCK>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, off);
-  if (h->d.nbins && h->d.scheme == SWIMSIM_TARGETS_RANDOM)
-    hipLaunchKernelGGL(bin_reduce_kernel, dim3(h->d.nbins), dim3(1024), 0, h->stream, h->d);
-}
-
 template <int PMAX>
 void launch_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev) {
   if (ev) (void)hipEventRecord(ev[0], h->stream);
-  launch_probe<PMAX>(h, t, tk, robust_offsets(h, t));
+  hipLaunchKernelGGL((probe_kernel<PMAX>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, robust_offsets(h, t));
   if (ev) (void)hipEventRecord(ev[1], h->stream);
   hipLaunchKernelGGL(merge_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
   if (ev) (void)hipEventRecord(ev[2], h->stream);
@@ -310,13 +297,6 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   d.nblocks = (N + BLOCK - 1) / BLOCK;
   d.inbox_cap = c.inbox_cap;
   d.ovf_cap = std::max<uint32_t>(1u << 16, N / 8);
-  {
-    // an inbox smaller than the expected fan-in (tests do that on purpose) sends the excess through the
-    // overflow list every tick: room for all of it
-    const double l = c.loss_ppm / 1e6, pf = 1.0 - (1.0 - l) * (1.0 - l);
-    const double lam = 2.0 * c.probes_per_tick + 4.0 * c.probes_per_tick * c.indirect_k * pf;
-    if (lam > c.inbox_cap) d.ovf_cap = (uint32_t)std::min<double>(3.0e8, std::max<double>(d.ovf_cap, 2.0 * lam * N + 65536.0));
-  }
   d.ord_cap = 0; d.r_cap = d.p_cap = d.x_cap = 0;
   CK(dev_alloc(h, &d.minfo, NT, 0));
   CK(dev_alloc(h, &d.probe_out, N, 0));
@@ -327,12 +307,6 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   CK(dev_alloc(h, &d.pk, (size_t)N, 0));
   CK(dev_alloc(h, &d.inmask, (size_t)N, 0));
   CK(dev_alloc(h, &d.ackmask, (size_t)N, 0));
-  // Ping payloads through per-bin record buffers (swim_kernels.h) when the table of bins fits the block's LDS
-  // histogram; SWIMSIM_NO_BINS=1 (measurement knob) keeps the one-atomic-per-payload path
-  d.nbins = (N + BIN - 1) / BIN; d.bin_cap = BIN * std::max(1u, d.P);
-  if (d.nbins > MAX_BINS || d.P == 0 || std::getenv("SWIMSIM_NO_BINS")) { d.nbins = 0; d.bin_cap = 0; }
-  CK(dev_alloc(h, &d.bin_rec, (size_t)d.nbins * d.bin_cap, 0));
-  CK(dev_alloc(h, &d.bin_cnt, (size_t)std::max(1u, d.nbins), 0));
   CK(dev_alloc(h, &d.rum, (size_t)1 << RID_BITS, 0));
   CK(dev_alloc(h, &d.rtab, (size_t)d.R_phys * RT_WAYS, 0));
   CK(dev_alloc(h, &d.subject_of, (size_t)d.R_phys, 0));
@@ -717,9 +691,9 @@ int swimsim_shard_phase1(swimsim_t* h, uint32_t* counts) {
   const uint32_t tk = tick_key(h->cfg.seed, t);
   if (h->timing) (void)hipEventRecord(h->tick_ev[0], h->stream);
   if (h->d.P <= 4 && h->d.K <= 4)
-    hipLaunchKernelGGL((probe_kernel<4, BLOCK>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, Offsets{});
+    hipLaunchKernelGGL((probe_kernel<4>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, Offsets{});
   else
-    hipLaunchKernelGGL((probe_kernel<16, BLOCK>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, Offsets{});
+    hipLaunchKernelGGL((probe_kernel<16>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, Offsets{});
   if (h->timing) (void)hipEventRecord(h->tick_ev[1], h->stream);
   hipLaunchKernelGGL(split_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
   rc = finish_phase(h, counts);
@@ -750,7 +724,6 @@ int swimsim_shard_phase3(swimsim_t* h, const uint32_t* p_counts_in, const uint32
   HIPCHK(h, hipSetDevice(h->device));
   const uint32_t t = (uint32_t)h->tick;
   hipLaunchKernelGGL(ingest_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, peer_counts(h, p_counts_in), peer_counts(h, x_counts_in));
-  if (h->d.nbins) hipLaunchKernelGGL(bin_reduce_kernel, dim3(h->d.nbins), dim3(1024), 0, h->stream, h->d);
   if (h->timing) (void)hipEventRecord(h->tick_ev[1], h->stream);
   hipLaunchKernelGGL(merge_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
   if (h->timing) (void)hipEventRecord(h->tick_ev[2], h->stream);
