@@ -387,6 +387,9 @@ __device__ inline uint32_t park_rid(uint32_t lo, uint32_t H) {
 //   digest; then the piggyback queue `disseminate` leaves as a FIXME (src/Core.hs:136-138; D5) is rebuilt.
 // Delivered rumours arrive as masks: new = (pushed | pulled) & ~known is the whole filter, and the
 // lanes of a wave walk their new bits in the same order, so their view / timer accesses coalesce.
+#ifndef SWIM_GOSSIP_BATCH       // rumours whose loads are issued together in merge_kernel
+#define SWIM_GOSSIP_BATCH 4
+#endif
 #ifndef SWIM_MERGE_WAVES
 #define SWIM_MERGE_WAVES 5
 #endif
@@ -506,19 +509,21 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     if (gn < (uint32_t)PB_SLOTS) gn++;
   };
   // The state rule on one proposal (slot, key).
-  auto examine = [&](uint32_t slot, uint32_t key, uint32_t cause, bool hasrid, uint32_t rid_in) {
+  // `pre` = the caller already holds the view cell, the row's base and its subject (loaded in a batch, below)
+  auto examine_with = [&](uint32_t slot, uint32_t key, uint32_t cause, bool hasrid, uint32_t rid_in, bool pre, uint2 e,
+                          uint32_t sbase, uint32_t subject) {
     if (slot + 1 == my_slot1) {
       // about self -> refute (src/Core.hs:155-166): remember the largest non-Alive incarnation
       if ((key & 3u) != ST_ALIVE) refute = (refute == NONE32 || (key >> 2) > refute) ? (key >> 2) : refute;
       return;
     }
     examined++;
-    const uint2 e = s.V[vidx(s, li, slot)];
-    const uint32_t curk = e.x ? e.x : s.slot_base[slot];              // untouched cell: the settled base
+    if (!pre) e = s.V[vidx(s, li, slot)];
+    const uint32_t curk = e.x ? e.x : (pre ? sbase : s.slot_base[slot]);   // untouched cell: the settled base
     if (key <= curk) return;                     // old incarnation / weaker state: ignore (:151)
     s.V[vidx(s, li, slot)] = make_uint2(key, t + 1);                    // memberLastChange = now (:176)
     if (s.G) s.slot_last[slot] = t;              // same value from every writer
-    const uint32_t subject = s.subject_of[slot];
+    if (!pre) subject = s.subject_of[slot];
     if (!ha) ha = mix64(mix64((uint64_t)TAG_EV) + (((uint64_t)t << 32) | i));
     const unsigned long long hx = mix64(ha + subject);                // h4(TAG_EV, a, subject, .) prefix
     evd += mix64(hx + key) - mix64(hx + curk);
@@ -533,6 +538,9 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
       if (pos < s.event_cap) s.events[pos] = make_uint4(t, i, subject, (key << 8) | cause);
       else evdropped++;
     }
+  };
+  auto examine = [&](uint32_t slot, uint32_t key, uint32_t cause, bool hasrid, uint32_t rid_in) {
+    examine_with(slot, key, cause, hasrid, rid_in, false, make_uint2(0u, 0u), 0u, 0u);
   };
   // one entry of a deadline cell: Suspect since t' with t' + S <= t => Dead at the same incarnation (D4);
   // a deadline still ahead that belongs to this row goes back into the cell; anything else (refuted,
@@ -594,15 +602,43 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
   // positions.  (Measured on MI355X, profiles/r02c_variants.txt: a wave-uniform walk over the UNION of the
   // lanes' positions coalesces the view rows but triples the iterations -- 237 us against 188 us; one
   // candidate loop shared by all sources with the bookkeeping parked in LDS -- 258 us.)
+  // The loads are batched: a member's next GB positions are decoded together -- their rum[] entries in one
+  // round of loads, then their view cells, row bases and subjects in a second one -- instead of three
+  // dependent loads per rumour (the kernel waits on such chains most of its time, profiles/r02a_pmc_summary.txt).
   if (act) {
+    constexpr int GB = SWIM_GOSSIP_BATCH;
     unsigned long long fresh = (pushed | pulled) & ~kn;
     kn |= fresh;
     while (fresh) {
-      const uint32_t p = (uint32_t)__ffsll((unsigned long long)fresh) - 1u;
-      fresh &= fresh - 1ull;
-      const uint32_t rid = rid_at(p, H) & RID_MASK;
-      const uint2 r = s.rum[rid];
-      examine(r.x, r.y, 2u, true, rid);
+      uint32_t rid[GB]; uint2 r[GB]; uint2 e[GB]; uint32_t sb[GB], sj[GB];
+      uint32_t n = 0;
+#pragma unroll
+      for (int k = 0; k < GB; ++k) {
+        rid[k] = 0; r[k] = make_uint2(0u, 0u); e[k] = make_uint2(0u, 0u); sb[k] = 0; sj[k] = 0;
+        if (fresh) {
+          const uint32_t p = (uint32_t)__ffsll((unsigned long long)fresh) - 1u;
+          fresh &= fresh - 1ull;
+          rid[k] = rid_at(p, H) & RID_MASK;
+          n = (uint32_t)k + 1u;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < GB; ++k) if ((uint32_t)k < n) r[k] = s.rum[rid[k]];
+#pragma unroll
+      for (int k = 0; k < GB; ++k)
+        if ((uint32_t)k < n && r[k].x + 1 != my_slot1) {
+          e[k] = s.V[vidx(s, li, r[k].x)]; sb[k] = s.slot_base[r[k].x]; sj[k] = s.subject_of[r[k].x];
+        }
+#pragma unroll
+      for (int k = 0; k < GB; ++k) {
+        if ((uint32_t)k >= n) continue;
+        // two rumours about one subject in a batch (Suspect and Dead arriving together): the later one looks at
+        // the cell again (this thread's own store is visible to it)
+        bool again = false;
+#pragma unroll
+        for (int j = 0; j < GB; ++j) again |= (j < k) && (r[j].x == r[k].x);
+        examine_with(r[k].x, r[k].y, 2u, true, rid[k], !again, e[k], sb[k], sj[k]);
+      }
     }
   }
   if (act) {
