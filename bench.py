@@ -64,7 +64,11 @@ def oracle_replay(sc, crashes, t_window, t_end, gpu_digest, gpu_counters, budget
     and counters must equal the GPU's; then a few more ticks on ONE thread for the single-core rate."""
     from swim_amd import Sim, workloads
     from tests import oracle_binding          # checker only: never the thing shipped
-    cores = os.cpu_count() or 1
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # member-range threads stop paying off at ~32 on the 256-core GPU box (random access to the view columns;
+    # measured 0.7 / 5.0 / 11.0 / 9.0 / 5.3 M member-ticks/s at 1 / 8 / 32 / 64 / 256 threads,
+    # profiles/r02d_oracle_thread_scaling.txt): use the best count, report what the box has
+    cores = min(avail, 32)
     n = sc.nMembers
     # rough cost model (1.0 M member-ticks/s per core, ~55 % parallel efficiency): skip what cannot finish
     est = n * t_end / (1.0e6 * max(1.0, 0.55 * cores))
@@ -87,8 +91,9 @@ def oracle_replay(sc, crashes, t_window, t_end, gpu_digest, gpu_counters, budget
     base = {"value": n * (t_end - t_window) / dt_all, "unit": "member-ticks/s", "cores": cores, "kind": "port",
             "single_thread_value": n * k1 / dt_one,
             "sample": "oracle/swim_oracle.c on the SAME %d-member cluster and fault schedule: ticks %d-%d with %d "
-                      "member-range threads (all host cores), then %d ticks on one thread; reference Haskell not "
-                      "timed: no GHC in image" % (n, t_window, t_end, cores, k1)}
+                      "member-range threads (the count that scales best; the box has %d cores), then %d ticks on one "
+                      "thread; reference Haskell not timed: no GHC in image" % (n, t_window, t_end, cores, avail, k1),
+            "host_cores_available": avail}
     return base, ok
 
 

@@ -122,7 +122,7 @@ __device__ inline void deliver_local(const DevState& s, uint32_t t, bool use_mas
 #define SWIM_PROBE_WAVES 5
 #endif
 template <int PMAX>
-__global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : 1) void probe_kernel(DevState s, uint32_t t, uint32_t tk, Offsets off) {
+__global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3 : PMAX <= 12 ? 2 : 1) void probe_kernel(DevState s, uint32_t t, uint32_t tk, Offsets off) {
   __shared__ BlockCounters sh;
   __shared__ uint32_t ordn;                        // deliveries left to the exchange (sharded runs)
   if (threadIdx.x == 0) ordn = 0;

@@ -435,7 +435,10 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
     while (fpos < fend && h->faults[fpos].tick <= t) ++fpos;
     hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, h->d_faults + f0, (uint32_t)(fpos - f0));
     const uint32_t tk = tick_key(h->cfg.seed, t);
-    if (h->d.P <= 4 && h->d.K <= 4) launch_tick<4>(h, t, tk, ev);
+    const uint32_t pk = std::max(h->d.P, h->d.K);   // registers follow the probe / proxy arrays: four sizes
+    if (pk <= 4) launch_tick<4>(h, t, tk, ev);
+    else if (pk <= 8) launch_tick<8>(h, t, tk, ev);
+    else if (pk <= 12) launch_tick<12>(h, t, tk, ev);   // the reference's default numToGossip = 10 (src/Util.hs:48)
     else launch_tick<16>(h, t, tk, ev);
     h->tick++;
   }
@@ -690,10 +693,11 @@ int swimsim_shard_phase1(swimsim_t* h, uint32_t* counts) {
   h->faults.erase(h->faults.begin(), h->faults.begin() + (long)fend);
   const uint32_t tk = tick_key(h->cfg.seed, t);
   if (h->timing) (void)hipEventRecord(h->tick_ev[0], h->stream);
-  if (h->d.P <= 4 && h->d.K <= 4)
-    hipLaunchKernelGGL((probe_kernel<4>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, Offsets{});
-  else
-    hipLaunchKernelGGL((probe_kernel<16>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, Offsets{});
+  const uint32_t pk = std::max(h->d.P, h->d.K);
+  if (pk <= 4) hipLaunchKernelGGL((probe_kernel<4>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, Offsets{});
+  else if (pk <= 8) hipLaunchKernelGGL((probe_kernel<8>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, Offsets{});
+  else if (pk <= 12) hipLaunchKernelGGL((probe_kernel<12>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, Offsets{});
+  else hipLaunchKernelGGL((probe_kernel<16>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, Offsets{});
   if (h->timing) (void)hipEventRecord(h->tick_ev[1], h->stream);
   hipLaunchKernelGGL(split_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
   rc = finish_phase(h, counts);

@@ -229,7 +229,7 @@ def test_robust_target_scheme_parity(oracle_abi, hip_abi, n, p, loss, seed):
 def _oracle_threads(sim):
     import os
     from tests import oracle_binding
-    oracle_binding.set_threads(sim, os.cpu_count() or 1)
+    oracle_binding.set_threads(sim, min(32, os.cpu_count() or 1))   # scales to ~32 threads (profiles/r02d_oracle_thread_scaling.txt)
 
 
 def test_saturated_million_members_window_vs_oracle(oracle_abi, hip_abi):
