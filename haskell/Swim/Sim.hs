@@ -24,6 +24,7 @@ module Swim.Sim
   , defaultSimConfig, configureSim, stepN, scheduleFault
   , drainEvents, simulate, memberView, firstDetection, digest
   , encodeEnvelope, decodeEnvelope
+  , stepShard
   ) where
 
 import           Control.Concurrent.MVar (MVar, newMVar, withMVar)
@@ -41,7 +42,7 @@ import           Foreign.ForeignPtr (ForeignPtr, newForeignPtr, withForeignPtr)
 import           Foreign.Marshal.Alloc (alloca, allocaBytes)
 import           Foreign.Marshal.Array (allocaArray, peekArray, pokeArray)
 import           Foreign.Marshal.Utils (fillBytes)
-import           Foreign.Ptr (FunPtr, Ptr, nullPtr, plusPtr)
+import           Foreign.Ptr (FunPtr, Ptr, freeHaskellFunPtr, nullPtr, plusPtr)
 import qualified Foreign.Ptr
 import           Foreign.Storable (peek, peekByteOff, poke, pokeByteOff)
 
@@ -86,6 +87,10 @@ foreign import ccall unsafe "swimsim_shard_buffers" c_shard_buffers :: Ptr Swims
 foreign import ccall safe   "swimsim_shard_phase1"  c_shard_phase1  :: Ptr SwimsimT -> Ptr Word32 -> IO CInt
 foreign import ccall safe   "swimsim_shard_phase2"  c_shard_phase2  :: Ptr SwimsimT -> Ptr Word32 -> Ptr Word32 -> IO CInt
 foreign import ccall safe   "swimsim_shard_phase3"  c_shard_phase3  :: Ptr SwimsimT -> Ptr Word32 -> Ptr Word32 -> IO CInt
+-- the tick loop of a shard inside the library, the embedder lending it the all-to-all-v (swimsim_exchange_fn)
+type ExchangeFn = Ptr () -> CInt -> Ptr Word32 -> Ptr Word32 -> IO CInt
+foreign import ccall "wrapper" mkExchange :: ExchangeFn -> IO (FunPtr ExchangeFn)
+foreign import ccall safe   "swimsim_shard_step"    c_shard_step    :: Ptr SwimsimT -> Word32 -> FunPtr ExchangeFn -> Ptr () -> IO CInt
 
 defaultSimConfig :: Config -> SimConfig
 defaultSimConfig c = SimConfig c 128 1 0 0 0 0 0 0 0
@@ -257,3 +262,19 @@ decodeEnvelope bytes = BSU.unsafeUseAsCStringLen bytes $ \(src, len) ->
     if rc /= 0 then Left <$> (c_wire_error >>= peekCString)
                else do n <- peek pn
                        Right <$> forM [0 .. fromIntegral n - 1] (\k -> peekMessage (arr `plusPtr` (k * swimwireMsgSize)))
+
+-- | `nticks` periods of this process's shard of a cluster of `nShards` handles (one per GPU / process), the
+-- tick loop running inside the library (swimsim_shard_step): no Python in the loop.  `exchange round out`
+-- is the embedder's all-to-all-v (MPI_Alltoallv, RCCL send/recv ..) over the buffers of
+-- swimsim_shard_buffers: `out` holds 3 * nShards record counts (kind-major) to deliver, the result the
+-- 3 * nShards counts that arrived.  Every shard of the cluster must make the same call.
+stepShard :: Sim -> Word32 -> Int -> (Int -> [Word32] -> IO [Word32]) -> IO ()
+stepShard s nticks nShards exchange = withSim s $ \h -> do
+  cb <- mkExchange $ \_ rnd pout pin -> do
+          out <- peekArray (3 * nShards) pout
+          got <- exchange (fromIntegral rnd) out
+          pokeArray pin (take (3 * nShards) (got ++ repeat 0))
+          return 0
+  rc <- c_shard_step h nticks cb nullPtr
+  freeHaskellFunPtr cb
+  check h rc

@@ -319,6 +319,17 @@ int swimsim_shard_phase1(swimsim_t* h, uint32_t* counts /*[3*n_shards] out*/);
 int swimsim_shard_phase2(swimsim_t* h, const uint32_t* r_counts_in /*[n_shards]*/,
                          uint32_t* counts /*[3*n_shards] out: kinds 1 and 2 now final*/);
 int swimsim_shard_phase3(swimsim_t* h, const uint32_t* p_counts_in, const uint32_t* x_counts_in);
+/* The same tick driven by the library: `nticks` times phase1 -> xchg(round 1) -> phase2 -> xchg(round 2) ->
+ * phase3.  `xchg` is the embedder's all-to-all-v: for every peer p != me and every kind k of the round
+ * (round 1: kind 0; round 2: kinds 1 and 2) it delivers send[k][p][0 .. counts_out[k*n_shards + p]) records to
+ * peer p's recv[k][me][..] and writes into counts_in[k*n_shards + p] how many records arrived from p (buffers:
+ * swimsim_shard_buffers; record sizes: SWIMSIM_*REC_BYTES).  It returns 0, or a non-zero value that aborts the
+ * step with SWIMSIM_ERR_STATE.  Every shard of the cluster must make the same call; this is what a host
+ * without swim_amd/shard.py binds (haskell/Swim/Sim.hs: stepShard) -- MPI_Alltoallv, RCCL send/recv or, as
+ * swim_amd/shard.py does, torch.distributed. */
+typedef int (*swimsim_exchange_fn)(void* ctx, int round, const uint32_t* counts_out /*[3*n_shards]*/,
+                                   uint32_t* counts_in /*[3*n_shards]*/);
+int swimsim_shard_step(swimsim_t* h, uint32_t nticks, swimsim_exchange_fn xchg, void* ctx);
 int swimsim_shard_get_first_suspect(swimsim_t* h, uint32_t* out, size_t n);
 int swimsim_shard_set_first_suspect(swimsim_t* h, const uint32_t* combined, size_t n);
 

@@ -94,6 +94,7 @@ _SIGS = {
 
 # entry points only the product library has (measurement plumbing, sharded stepping; no oracle counterpart)
 _U32P = C.POINTER(C.c_uint32)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32))   # swimsim_exchange_fn
 _VPP = C.POINTER(C.c_void_p)
 _PRODUCT_ONLY = {
     "shard_info": (C.c_int, [_H, _U32P, _U32P, _U32P, _U32P, _U32P]),
@@ -101,6 +102,7 @@ _PRODUCT_ONLY = {
     "shard_phase1": (C.c_int, [_H, _U32P]),
     "shard_phase2": (C.c_int, [_H, _U32P, _U32P]),
     "shard_phase3": (C.c_int, [_H, _U32P, _U32P]),
+    "shard_step": (C.c_int, [_H, C.c_uint32, C.c_void_p, C.c_void_p]),
     "shard_get_first_suspect": (C.c_int, [_H, _U32P, C.c_size_t]),
     "shard_set_first_suspect": (C.c_int, [_H, _U32P, C.c_size_t]),
     "kernel_timing_enable": (C.c_int, [_H, C.c_int]),

@@ -739,6 +739,25 @@ int swimsim_shard_phase3(swimsim_t* h, const uint32_t* p_counts_in, const uint32
   return SWIMSIM_OK;
 }
 
+int swimsim_shard_step(swimsim_t* h, uint32_t nticks, swimsim_exchange_fn xchg, void* ctx) {
+  if (!h || !xchg) return SWIMSIM_ERR_INVALID;
+  const uint32_t G = h->d.n_shards;
+  std::vector<uint32_t> out(3 * MAX_SHARDS), in(3 * MAX_SHARDS);
+  for (uint32_t k = 0; k < nticks; ++k) {
+    int rc = swimsim_shard_phase1(h, out.data());
+    if (rc) return rc;
+    std::fill(in.begin(), in.end(), 0u);
+    if (xchg(ctx, 1, out.data(), in.data())) return set_err(h, SWIMSIM_ERR_STATE, "shard_step: the exchange callback failed in round 1");
+    rc = swimsim_shard_phase2(h, in.data(), out.data());
+    if (rc) return rc;
+    std::fill(in.begin(), in.end(), 0u);
+    if (xchg(ctx, 2, out.data(), in.data())) return set_err(h, SWIMSIM_ERR_STATE, "shard_step: the exchange callback failed in round 2");
+    rc = swimsim_shard_phase3(h, in.data() + G, in.data() + 2 * G);
+    if (rc) return rc;
+  }
+  return SWIMSIM_OK;
+}
+
 /* First-detection ticks are recorded by the prober's shard: set the combined (element-wise minimum over
  * all shards) array back before digest / first_detect are read on a sharded cluster. */
 int swimsim_shard_set_first_suspect(swimsim_t* h, const uint32_t* combined, size_t n) {

@@ -241,8 +241,42 @@ class ShardedSim:
         self.scheduleFault(tick, member, False)
 
     # -- the hot path ------------------------------------------------------------------------------------
+    def _step_by_library(self, nticks: int):
+        """One shard per process: the tick loop runs inside libswimsim.so (swimsim_shard_step); this
+        process only lends it the all-to-all-v -- exactly what a host without this module would bind."""
+        import time
+        sh, f, G = self.shards[0], self.fabric, self.n_shards
+        acc = self.phase_seconds
+        state = {"t": time.perf_counter()}
+
+        def xchg(_ctx, rnd, c_out, c_in):
+            try:
+                t0 = time.perf_counter()
+                acc[0 if rnd == 1 else 2] += t0 - state["t"]          # the phase that just ended
+                kinds = (0,) if rnd == 1 else (1, 2)
+                counts = [[[c_out[k * G + p] for p in range(G)] for k in kinds]]
+                got = f.exchange([sh], kinds, counts)[0]
+                for j, k in enumerate(kinds):
+                    for p in range(G):
+                        c_in[k * G + p] = got[j][p]
+                state["t"] = time.perf_counter()
+                acc[1 if rnd == 1 else 3] += state["t"] - t0
+                return 0
+            except Exception:                                       # noqa: BLE001 -- must not unwind through C
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = _abi.EXCHANGE_FN(xchg)
+        for _ in range(nticks):
+            state["t"] = time.perf_counter()
+            sh.sim._check(sh.sim._abi.shard_step(sh.sim._h, 1, cb, None))
+            acc[4] += time.perf_counter() - state["t"]
+            self.timed_ticks += 1
+
     def step(self, nticks: int = 1):
         f, sh = self.fabric, self.shards
+        if len(sh) == 1 and self.n_shards > 1:
+            return self._step_by_library(nticks)
         import time
         acc = self.phase_seconds
         for _ in range(nticks):
