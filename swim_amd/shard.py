@@ -167,6 +167,17 @@ class DistFabric:
             self._cpug = self.dist.new_group(backend="gloo")
         return self._cpug
 
+    def _staging(self, sh, host):
+        """Persistent torch-allocated staging buffers (send, recv) shaped like the library's, so that the
+        collective backend only sees torch memory and a tick allocates nothing."""
+        if not hasattr(self, "_stage"):
+            torch = self.torch
+            dev = "cpu" if host else self.device
+            mk = lambda: [torch.empty(tuple(b.shape), dtype=torch.uint8, device=dev,
+                                      pin_memory=(host and self.on_gpu)) for b in sh.send]
+            self._stage = (mk(), mk())
+        return self._stage
+
     def exchange(self, shards, kinds, counts):
         """One round: the counts of every kind in ONE all_to_all, then all records in ONE batch of p2p ops."""
         torch, dist, G, me = self.torch, self.dist, self.n_shards, self.rank
@@ -180,16 +191,19 @@ class DistFabric:
         got = [int(v) for v in cr.tolist()]
         recv = [[got[p * nk + j] for p in range(G)] for j in range(nk)]
         ops, landing = [], []
+        stage = self._staging(sh, host)
         for p in range(G):
             if p == me:
                 continue
             for j, kind in enumerate(kinds):
                 n_out, n_in = counts[0][j][p], recv[j][p]
                 if n_out:
-                    src = sh.send[kind][p, : n_out * REC_BYTES[kind]]
-                    ops.append(dist.P2POp(dist.isend, src.cpu() if host else src.clone(), p, group=grp))
+                    nb = n_out * REC_BYTES[kind]
+                    out = stage[0][kind][p, :nb]
+                    out.copy_(sh.send[kind][p, :nb])
+                    ops.append(dist.P2POp(dist.isend, out, p, group=grp))
                 if n_in:
-                    tmp = torch.empty(n_in * REC_BYTES[kind], dtype=torch.uint8, device="cpu" if host else self.device)
+                    tmp = stage[1][kind][p, : n_in * REC_BYTES[kind]]
                     landing.append((kind, p, tmp))
                     ops.append(dist.P2POp(dist.irecv, tmp, p, group=grp))
         if ops:
