@@ -157,9 +157,19 @@ constexpr uint32_t SRC_FOREIGN = 1u << 30;      // explicit-record source word: 
 __device__ inline bool is_local(const DevState& s, uint32_t g) { return g - s.lo < s.N; }
 __device__ inline uint32_t owner_of(const DevState& s, uint32_t g) { return g / s.N; }   // equal-sized shards
 
-__device__ inline size_t vidx(const DevState& s, uint32_t li, uint32_t slot) {
-  return (size_t)slot * s.N + li;
+// View cell of local member li in row `slot`.  Rows are tiled over the members: all rows of VTILE consecutive
+// members are contiguous ([tile][slot][member in tile]), so a block's accesses to the ~30 rows in circulation
+// stay inside one few-MB region (address translation locality) while each row segment is still one contiguous
+// run.  SWIM_VTILE = 0 gives plain row-major [slot][member] (measurement knob).
+#ifndef SWIM_VTILE
+#define SWIM_VTILE 256
+#endif
+constexpr uint32_t VTILE = SWIM_VTILE;
+__host__ __device__ inline size_t vidx_of(uint32_t N, uint32_t R_phys, uint32_t li, uint32_t slot) {
+  if (VTILE == 0) return (size_t)slot * N + li;
+  return ((size_t)(li / (VTILE ? VTILE : 1u)) * R_phys + slot) * (VTILE ? VTILE : 1u) + (li % (VTILE ? VTILE : 1u));
 }
+__device__ inline size_t vidx(const DevState& s, uint32_t li, uint32_t slot) { return vidx_of(s.N, s.R_phys, li, slot); }
 __device__ inline size_t ridx(const DevState& s, uint32_t li, uint32_t pos) {
   return (size_t)pos * s.N + li;
 }

@@ -312,7 +312,7 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   CK(dev_alloc(h, &d.subject_of, (size_t)d.R_phys, 0));
   CK(dev_alloc(h, &d.fail, (size_t)N * (d.P ? d.P : 1), 0));
   CK(dev_alloc(h, &d.trow, (size_t)N * d.S, 0));
-  CK(dev_alloc(h, &d.V, (size_t)N * d.R_phys, 0));
+  CK(dev_alloc(h, &d.V, (size_t)(VTILE ? (N + VTILE - 1) / VTILE * VTILE : N) * d.R_phys, 0));
   CK(dev_alloc(h, &d.slot_last, (size_t)d.R_phys, 0xFF));
   CK(dev_alloc(h, &d.slot_base, (size_t)d.R_phys, 0));
   CK(dev_alloc(h, &d.slot_used, (size_t)d.R_phys, 0));
@@ -486,9 +486,9 @@ static int read_column(swimsim_t* h, uint32_t observer, std::vector<uint2>* col,
   const uint32_t ns = std::min(g[G_NSLOTS], h->d.R_phys);
   col->resize(ns); subj->resize(ns);
   if (!ns) return SWIMSIM_OK;
-  // V is slot-major [slot][member]: one observer's entries are a strided column
-  HIPCHK(h, hipMemcpy2D(col->data(), sizeof(uint2), h->d.V + observer, (size_t)h->d.N * sizeof(uint2),
-                        sizeof(uint2), ns, hipMemcpyDeviceToHost));
+  // one observer's entries are a strided column of V (stride = one row of its tile)
+  HIPCHK(h, hipMemcpy2D(col->data(), sizeof(uint2), h->d.V + vidx_of(h->d.N, h->d.R_phys, observer, 0),
+                        (VTILE ? (size_t)VTILE : (size_t)h->d.N) * sizeof(uint2), sizeof(uint2), ns, hipMemcpyDeviceToHost));
   HIPCHK(h, hipMemcpy(subj->data(), h->d.subject_of, (size_t)ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
   std::vector<uint8_t> used(ns);
   HIPCHK(h, hipMemcpy(used.data(), h->d.slot_used, ns, hipMemcpyDeviceToHost));
