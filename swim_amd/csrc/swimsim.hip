@@ -147,7 +147,7 @@ int check_device_errors(swimsim* h) {
     std::string m = "capacity exceeded:";
     if (g[G_ERR] & ERRF_SUBJECTS) m += " max_subjects";
     if (g[G_ERR] & ERRF_ROWS) m += " view-rows-in-transit (settled rows wait two ticks before reuse)";
-    if (g[G_ERR] & ERRF_OVF) m += " inbox-overflow-list";
+    if (g[G_ERR] & ERRF_OVF) m += " inbox-overflow-list (" + std::to_string(std::max(g[G_OVF0], g[G_OVF1])) + " entries, room for " + std::to_string(h->d.ovf_cap) + ")";
     if (g[G_ERR] & ERRF_INC) m += " incarnation-bits";
     if (g[G_ERR] & ERRF_XCHG) m += " shard-exchange-buffers";
     return set_err(h, SWIMSIM_ERR_CAPACITY, m);
@@ -297,6 +297,13 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   d.nblocks = (N + BLOCK - 1) / BLOCK;
   d.inbox_cap = c.inbox_cap;
   d.ovf_cap = std::max<uint32_t>(1u << 16, N / 8);
+  {
+    // an inbox smaller than the expected fan-in (tests do that on purpose) sends the excess through the
+    // overflow list every tick: room for all of it
+    const double l = c.loss_ppm / 1e6, pf = 1.0 - (1.0 - l) * (1.0 - l);
+    const double lam = 2.0 * c.probes_per_tick + 4.0 * c.probes_per_tick * c.indirect_k * pf;
+    if (lam > c.inbox_cap) d.ovf_cap = (uint32_t)std::min<double>(3.0e8, std::max<double>(d.ovf_cap, 2.0 * lam * N + 65536.0));
+  }
   d.ord_cap = 0; d.r_cap = d.p_cap = d.x_cap = 0;
   CK(dev_alloc(h, &d.minfo, NT, 0));
   CK(dev_alloc(h, &d.probe_out, N, 0));
