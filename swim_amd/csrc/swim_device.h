@@ -100,9 +100,12 @@ struct DevState {
   uint2* hot;              // {storeIncarnation, flags: bit 0 = came back up, deadlines slept through not fired yet}
   uint32_t* subject_of;    // slot -> subject
   uint32_t* fail;          // [N][P] targets whose probe ended without ack
-  uint4* trow;             // [S][N] suspicion deadlines: row d mod S = 8 x 16-bit (slot+1) this member must
+  uint4* trow;             // [S][N] suspicion deadlines: row d mod S = the rows (slot+1, 16 bit) this member must
                            //   look at in tick d (the FIXME at src/Core.hs:141; D4).  Every member reads and
                            //   rewrites row t mod S in tick t: coalesced, no per-member FIFO.
+  uint4* tovf;             // [S][2][tovf_cap] overflow cells of the deadline rows (chains, two pools per row)
+  uint32_t* tovf_n;        // [S][2] cells handed out
+  uint32_t tovf_cap;
   uint2* V;                // [R_phys][N] {key = inc<<2|state, lastChange+1}; key 0 = default = slot_base[slot]
   // ---- settling (gc_ticks; include/swimsim.h): removeDeadNodes (src/Core.hs:65-67)
   uint32_t* slot_last;     // [R_phys] last tick any entry of the row changed / its subject announced itself
@@ -269,13 +272,21 @@ __device__ inline bool view_alive(const DevState& s, uint32_t li, uint32_t mc) {
 }
 
 // ---- suspicion deadlines (trow) ---------------------------------------------------------------
-// One 16-byte cell per (deadline mod S, member): up to 8 halfwords slot+1, packed from halfword 0; a cell
-// that would need a ninth carries TR_FULL in its last halfword = "look at every row" (exact, slow, rare).
-constexpr uint32_t TR_SLOTS = 8, TR_FULL = 0xFFFFu;
+// One 16-byte cell per (deadline mod S, member): halfwords 0..6 = slot+1 of up to 7 deadlines, packed from 0;
+// halfword 7 = link: 0 none, TR_LINK | idx = the chain continues in overflow cell idx of the row's pool
+// (tovf; a member that accepts more than 7 suspicions in one tick -- heavy message loss), TR_FULL = "look at
+// every view row" (pool exhausted: exact, slow).  Pools alternate by cycle parity (t / S) & 1: tick t consumes
+// the chains written at t - S from pool parity^1 while it writes the chains for t + S into pool parity.
+constexpr uint32_t TR_PAY = 7, TR_FULL = 0xFFFFu, TR_LINK = 0x8000u;
 struct TimerCell { unsigned long long lo, hi; uint32_t n; };
-__device__ inline void tc_put(TimerCell& c, uint32_t slot1) {
-  if (c.n < 4u) c.lo |= (unsigned long long)slot1 << (16u * c.n);
-  else if (c.n < TR_SLOTS) c.hi |= (unsigned long long)slot1 << (16u * (c.n - 4u));
+__device__ inline void tc_clear(TimerCell& c) { c.lo = 0; c.hi = 0; c.n = 0; }
+__device__ inline void tc_set(TimerCell& c, uint32_t pos, uint32_t v) {       // pos 0..7
+  if (pos < 4u) c.lo |= (unsigned long long)v << (16u * pos);
+  else c.hi |= (unsigned long long)v << (16u * (pos - 4u));
+}
+// without a pool (fixtures, cells rebuilt after a downtime): the 8th deadline turns the cell into "look everywhere"
+__device__ inline void tc_put_simple(TimerCell& c, uint32_t slot1) {
+  if (c.n < TR_PAY) tc_set(c, c.n, slot1);
   else c.hi |= (unsigned long long)TR_FULL << 48;
   c.n++;
 }

@@ -509,6 +509,21 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     if (gn < (uint32_t)PB_SLOTS) gn++;
   };
   // The state rule on one proposal (slot, key).
+  // a deadline t + S for this tick's cell; the 8th spills the cell into the row's overflow pool and links it
+  const uint32_t row_now = t % s.S, par_now = (t / s.S) & 1u;
+  auto tput = [&](uint32_t slot1) {
+    if (tnew.n == TR_PAY) {
+      if (((uint32_t)(tnew.hi >> 48)) == TR_FULL) return;            // already "look everywhere"
+      const uint32_t idx = atomicAdd(&s.tovf_n[row_now * 2u + par_now], 1u);
+      if (idx < s.tovf_cap) {
+        s.tovf[((size_t)row_now * 2u + par_now) * s.tovf_cap + idx] = tc_pack(tnew);
+        tc_clear(tnew);
+        tnew.hi = (unsigned long long)(TR_LINK | idx) << 48;
+      } else { tnew.hi |= (unsigned long long)TR_FULL << 48; return; }
+    }
+    tc_set(tnew, tnew.n, slot1);
+    tnew.n++;
+  };
   // `pre` = the caller already holds the view cell, the row's base and its subject (loaded in a batch, below)
   auto examine_with = [&](uint32_t slot, uint32_t key, uint32_t cause, bool hasrid, uint32_t rid_in, bool pre, uint2 e,
                           uint32_t sbase, uint32_t subject) {
@@ -529,7 +544,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     evd += mix64(hx + key) - mix64(hx + curk);
     changes += (e.y != t + 1) ? 1u : 0u;
     if (cause == 1u) timers_fired++;
-    if ((key & 3u) == ST_SUSPECT) tc_put(tnew, slot + 1);             // deadline t + S (D4)
+    if ((key & 3u) == ST_SUSPECT) tput(slot + 1);                     // deadline t + S (D4)
     const uint32_t rid = hasrid ? rid_in : find_rid(s, slot, key);
     kill_slot(slot);
     group_put(slot, rid, key, subject);          // `Just msg` -> Broadcast -> enqueue (D5)
@@ -542,51 +557,50 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
   auto examine = [&](uint32_t slot, uint32_t key, uint32_t cause, bool hasrid, uint32_t rid_in) {
     examine_with(slot, key, cause, hasrid, rid_in, false, make_uint2(0u, 0u), 0u, 0u);
   };
-  // one entry of a deadline cell: Suspect since t' with t' + S <= t => Dead at the same incarnation (D4);
-  // a deadline still ahead that belongs to this row goes back into the cell; anything else (refuted,
-  // already Dead, reclaimed, superseded by a later suspicion with its own cell) is dropped
-  TimerCell keep; keep.lo = 0; keep.hi = 0; keep.n = 0;
-  auto deadline = [&](uint32_t slot, uint32_t row) {
+  // one entry of this tick's deadline cell: Suspect since t' with t' + S <= t => Dead at the same incarnation
+  // (D4); a deadline still ahead that belongs to this row goes back into the cell (a fixture of
+  // swimsim_set_view); anything else (refuted, already Dead, reclaimed, superseded by a later suspicion with
+  // its own cell) is dropped
+  auto deadline = [&](uint32_t slot) {
     const uint2 e = s.V[vidx(s, li, slot)];
     if ((e.x & 3u) != ST_SUSPECT) return;
     if (e.y - 1 + s.S <= t) examine(slot, (e.x & ~3u) | ST_DEAD, 1u, false, 0u);
-    else if ((e.y - 1 + s.S) % s.S == row) tc_put(keep, slot + 1);
-  };
-  auto run_cell = [&](const uint4& cell, uint32_t row) {
-    for (uint32_t k = 0; k < TR_SLOTS; ++k) {
-      const uint32_t v = tc_get(cell, k);
-      if (!v) break;
-      if (v == TR_FULL) {                        // more than 8 deadlines in one cell: every row is a candidate
-        const uint32_t ns = min(s.g[G_NSLOTS], s.R_phys);
-        for (uint32_t r = 0; r < ns; ++r) {
-          const uint2 e = s.V[vidx(s, li, r)];
-          if ((e.x & 3u) == ST_SUSPECT && (e.y - 1 + s.S) % s.S == row && s.slot_used[r]) deadline(r, row);
-        }
-        break;
-      }
-      deadline(v - 1, row);
-    }
+    else if ((e.y - 1 + s.S) % s.S == row_now) tput(slot + 1);
   };
   if (act) {
     // phase 1: suspicion deadlines, evaluated on the start-of-tick view
-    if (woke) {
-      for (uint32_t row = 0; row < s.S; ++row) {
-        if (row == t % s.S) continue;
-        const size_t ix = (size_t)row * s.N + li;
-        const uint4 cell = s.trow[ix];
-        if (!(cell.x | cell.y | cell.z | cell.w)) continue;
-        keep.lo = 0; keep.hi = 0; keep.n = 0;
-        run_cell(cell, row);
-        const uint4 nc = tc_pack(keep);
-        if (nc.x != cell.x || nc.y != cell.y || nc.z != cell.z || nc.w != cell.w) s.trow[ix] = nc;
+    if (woke || (uint32_t)(due.w >> 16) == TR_FULL) {
+      // a member that just came back up (its cells may be stale, their chains gone) or a cell that says "look
+      // everywhere": every view row is a candidate.  The member that came back also rebuilds its cells from
+      // what it finds: deadlines still ahead go to the cell of their tick.
+      if (woke) for (uint32_t row = 0; row < s.S; ++row) s.trow[(size_t)row * s.N + li] = make_uint4(0u, 0u, 0u, 0u);
+      const uint32_t ns = min(s.g[G_NSLOTS], s.R_phys);
+      for (uint32_t r = 0; r < ns; ++r) {
+        const uint2 e = s.V[vidx(s, li, r)];
+        if ((e.x & 3u) != ST_SUSPECT || !s.slot_used[r]) continue;
+        const uint32_t dl = e.y - 1 + s.S;
+        if (dl <= t) { if (woke || dl == t) examine(r, (e.x & ~3u) | ST_DEAD, 1u, false, 0u); }
+        else if (woke) {
+          const size_t ix = (size_t)(dl % s.S) * s.N + li;
+          const uint4 cell = s.trow[ix];
+          TimerCell c2; c2.lo = cell.x | ((unsigned long long)cell.y << 32); c2.hi = cell.z | ((unsigned long long)cell.w << 32); c2.n = 0;
+          while (c2.n < TR_PAY && tc_get(cell, c2.n)) c2.n++;
+          tc_put_simple(c2, r + 1);
+          s.trow[ix] = tc_pack(c2);
+        }
       }
-      keep.lo = 0; keep.hi = 0; keep.n = 0;
-    }
-    if (timer_due) run_cell(due, t % s.S);
-    // deadlines that stay in this row (a fixture set by swimsim_set_view, a member that was down shortly)
-    for (uint32_t k = 0; k < keep.n && k < TR_SLOTS; ++k) {
-      const uint32_t v = k < 4u ? (uint32_t)(keep.lo >> (16u * k)) & 0xFFFFu : (uint32_t)(keep.hi >> (16u * (k - 4u))) & 0xFFFFu;
-      tc_put(tnew, v);
+    } else if (timer_due) {
+      uint4 cell = due;
+      for (;;) {
+        for (uint32_t k = 0; k < TR_PAY; ++k) {
+          const uint32_t v = tc_get(cell, k);
+          if (!v) break;
+          deadline(v - 1);
+        }
+        const uint32_t link = cell.w >> 16;
+        if (!(link & TR_LINK) || link == TR_FULL) break;
+        cell = s.tovf[((size_t)row_now * 2u + (par_now ^ 1u)) * s.tovf_cap + (link & (TR_LINK - 1u))];
+      }
     }
     // phase 2: own probes that ended without any ack: Suspect at the viewed incarnation
     for (uint32_t f = 0; f < nfail; ++f) {
@@ -733,7 +747,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     }
     s.pk[li] = make_ulonglong2(nout ? qmask : 0ull, kn);
     if (pushed) s.inmask[li] = 0;
-    if (timer_due || tnew.n) s.trow[trix] = tc_pack(tnew);     // consumed and refilled in one store
+    if (timer_due || tnew.n || woke) s.trow[trix] = tc_pack(tnew);   // consumed and refilled in one store
     if (self_inc != hot0.x || woke) s.hot[li] = make_uint2(self_inc, hot0.y & ~1u);
     if (cnt) s.inbox_cnt[li] = 0;
     ctr_add(&sh, C_CHANGES, changes);
@@ -1111,6 +1125,7 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, co
     if (dropped_sh) s.blk[(size_t)s.nblocks * C_COUNT + C_EVENTS_DROPPED] += dropped_sh;
     s.g[G_PREV] = s.g[G_HEAD];
     s.g[G_HEAD] = s.g[G_NRUM];
+    if (t) s.tovf_n[((t - 1u) % s.S) * 2u + ((((t - 1u) / s.S) & 1u) ^ 1u)] = 0;   // the deadline chains tick t-1 consumed
   }
   if (s.G) {
     // rows whose subject nobody has changed its mind about for G ticks (counting this one, checked again by
@@ -1201,8 +1216,8 @@ __global__ void set_view_kernel(DevState s, uint32_t t, uint32_t observer, uint3
     const size_t ix = (size_t)(t % s.S) * s.N + ol;
     const uint4 cell = s.trow[ix];
     TimerCell c; c.lo = cell.x | ((unsigned long long)cell.y << 32); c.hi = cell.z | ((unsigned long long)cell.w << 32); c.n = 0;
-    while (c.n < TR_SLOTS && tc_get(cell, c.n)) c.n++;
-    tc_put(c, sl + 1);
+    while (c.n < TR_PAY && tc_get(cell, c.n)) c.n++;
+    tc_put_simple(c, sl + 1);
     s.trow[ix] = tc_pack(c);
   }
 }

@@ -319,6 +319,9 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   CK(dev_alloc(h, &d.subject_of, (size_t)d.R_phys, 0));
   CK(dev_alloc(h, &d.fail, (size_t)N * (d.P ? d.P : 1), 0));
   CK(dev_alloc(h, &d.trow, (size_t)N * d.S, 0));
+  d.tovf_cap = std::min<uint32_t>(0x7FFEu, std::max<uint32_t>(1024u, N / 4));
+  CK(dev_alloc(h, &d.tovf, (size_t)d.S * 2 * d.tovf_cap, 0));
+  CK(dev_alloc(h, &d.tovf_n, (size_t)d.S * 2, 0));
   CK(dev_alloc(h, &d.V, (size_t)(VTILE ? (N + VTILE - 1) / VTILE * VTILE : N) * d.R_phys, 0));
   CK(dev_alloc(h, &d.slot_last, (size_t)d.R_phys, 0xFF));
   CK(dev_alloc(h, &d.slot_base, (size_t)d.R_phys, 0));
