@@ -31,7 +31,7 @@ enum { G_NSLOTS = 0 /* view rows ever handed out (high-water mark) */, G_ERR = 1
        G_SETTLE_N = 10 /* rows whose entries this tick's merge reduces */, G_ZERO_N = 11 /* rows it clears */,
        G_SETTLE_PENDING = 12 /* the lists above still await settle_finish */, G_SETTLE_TICK = 13,
        G_SEND = 16 /* [3][16] exchange records appended per peer (send_cnt) */, G_WORDS = 64 };
-enum { ERRF_SUBJECTS = 1, ERRF_ROWS = 2, ERRF_OVF = 4, ERRF_INC = 8, ERRF_XCHG = 16 };
+enum { ERRF_SUBJECTS = 1, ERRF_ROWS = 2, ERRF_OVF = 4, ERRF_INC = 8, ERRF_XCHG = 16, ERRF_RIDS = 32 };
 
 // counter slots (same order as SWIMSIM_CTR_* in include/swimsim.h)
 enum { C_PINGS = 0, C_DIRECT_FAILED, C_PING_REQS, C_SUSPECTS, C_FALSE_SUSPECTS, C_PAYLOADS,
@@ -228,14 +228,15 @@ __host__ __device__ inline uint32_t pe_hi(uint32_t key, uint32_t tx) { return ke
 #define SWIM_RID_BITS 16
 #endif
 constexpr uint32_t KN_BITS = 64, MASK_WIN = SWIM_MASK_WIN, MASK_SLACK = SWIM_MASK_SLACK, RID_BITS = SWIM_RID_BITS,
-                   RID_MASK = (1u << RID_BITS) - 1u, RID_FAR = 1u << (RID_BITS - 1), RID_NEAR = 1u << (RID_BITS - 2);
+                   RID_MASK = (1u << RID_BITS) - 1u, RID_FAR = 1u << (RID_BITS - 1), RID_NEAR = 1u << (RID_BITS - 2),
+                   RID_PARKED = RID_MASK;   // "no id": never handed out, never in a window (an entry too old for the ring)
 static_assert(MASK_WIN + MASK_SLACK <= KN_BITS, "mask positions must be unambiguous");
 static_assert(RID_BITS <= 16 && KN_BITS + RID_NEAR < RID_FAR + 1 && KN_BITS <= RID_NEAR, "rumour ids: window < near range < parking distance");
 constexpr int RT_WAYS = 8;
 constexpr unsigned long long RT_READY = 1ull << 16;
 
 // ring / mask position arithmetic (H = head of the tick)
-__device__ inline bool rid_in_ring(uint32_t rid, uint32_t H) { return ((H - 1u - rid) & RID_MASK) < KN_BITS; }
+__device__ inline bool rid_in_ring(uint32_t rid, uint32_t H) { return rid != RID_PARKED && ((H - 1u - rid) & RID_MASK) < KN_BITS; }
 __device__ inline unsigned long long rid_bit(uint32_t rid) { return 1ull << (rid & 63u); }
 // the id in [H-64, H) that owns position p
 __device__ inline uint32_t rid_at(uint32_t p, uint32_t H) { return (H - 1u) - ((H - 1u - p) & 63u); }
@@ -250,7 +251,7 @@ __device__ inline unsigned long long stale_positions(uint32_t prev, uint32_t hea
 }
 // can an entry with this id be expressed in a mask built at head H?
 __device__ inline bool rid_maskable(uint32_t rid, uint32_t H) {
-  return ((rid - (H - MASK_WIN)) & RID_MASK) < MASK_WIN + MASK_SLACK;
+  return rid != RID_PARKED && ((rid - (H - MASK_WIN)) & RID_MASK) < MASK_WIN + MASK_SLACK;
 }
 
 // minfo fields

@@ -333,6 +333,13 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
 // merge kernel
 // ================================================================================================
 
+// a fresh rumour id (RID_PARKED is never handed out)
+__device__ inline uint32_t new_rid(const DevState& s) {
+  uint32_t rid;
+  do rid = atomicAdd(&s.g[G_NRUM], 1u) & RID_MASK; while (rid == RID_PARKED);
+  return rid;
+}
+
 // (slot, key) -> rumour id, created by whoever states the rumour first (own probe, own timer,
 // refutation, join); everyone else learns the id from the piggyback entry that carries the rumour.
 // One way per (incarnation, state) combination, newer combinations evict older ones.  Duplicate ids
@@ -359,24 +366,25 @@ __device__ inline uint32_t find_rid(const DevState& s, uint32_t slot, uint32_t k
     } else if (ek > key + 1u) break;                // the way belongs to a newer rumour about this subject
     const unsigned long long seen = atomicCAS(p, e, claim);
     if (seen == e) {
-      const uint32_t rid = atomicAdd(&s.g[G_NRUM], 1u) & RID_MASK;
+      const uint32_t rid = new_rid(s);
       s.rum[rid] = make_uint2(slot, key);           // read by other members from the next launch on
       atomicExch(p, claim | RT_READY | rid);
       return rid;
     }
     e = seen;
   }
-  const uint32_t rid = atomicAdd(&s.g[G_NRUM], 1u) & RID_MASK;
+  const uint32_t rid = new_rid(s);
   s.rum[rid] = make_uint2(slot, key);
   return rid;
 }
 
-// rumour ids that fell out of the known-ring window are parked half the id space away so that a
-// long-lived entry can never alias back into a later window (re-parked at every rewrite)
+// a rumour id that fell out of the known-ring window is replaced by RID_PARKED ("no id") at the next rewrite of
+// the line, so that a long-lived entry can never alias into a later window
 __device__ inline uint32_t park_rid(uint32_t lo, uint32_t H) {
   const uint32_t above = (pe_rid(lo) - (H - KN_BITS)) & RID_MASK;     // distance above the window bottom
-  return above < KN_BITS + RID_NEAR ? lo : pe_lo(pe_slot(lo), (H + RID_FAR) & RID_MASK);
+  return (pe_rid(lo) != RID_PARKED && above < KN_BITS + RID_NEAR) ? lo : pe_lo(pe_slot(lo), RID_PARKED);
 }
+
 
 // One thread = one member's end of tick:
 //   suspicion timers (the FIXME at src/Core.hs:141; D4), own probes that ended without an ack
@@ -1125,6 +1133,9 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, co
     if (dropped_sh) s.blk[(size_t)s.nblocks * C_COUNT + C_EVENTS_DROPPED] += dropped_sh;
     s.g[G_PREV] = s.g[G_HEAD];
     s.g[G_HEAD] = s.g[G_NRUM];
+    // an id must be seen by its holders' next rewrite while it is still inside [H - 64, H + RID_NEAR): more new
+    // ids than that in ONE tick would let an entry skip the zone unparked (2^14 per tick with 16-bit ids)
+    if (s.g[G_HEAD] - s.g[G_PREV] > RID_NEAR) atomicOr(&s.g[G_ERR], (uint32_t)ERRF_RIDS);
     if (t) s.tovf_n[((t - 1u) % s.S) * 2u + ((((t - 1u) / s.S) & 1u) ^ 1u)] = 0;   // the deadline chains tick t-1 consumed
   }
   if (s.G) {
