@@ -83,6 +83,11 @@ struct DevState {
                            //   20 which pb buffer is current, 21 up (ground truth),
                            //   22 the queue holds an entry its mask cannot express (MI_OOW),
                            //   23-24 state of the settled base entry about this member (everybody's default)
+  uint8_t* mb;             // [NT] the bits of minfo a prober needs about a target, in ONE byte (a 1-MB table at 2^20
+                           //   members stays resident in every XCD's L2, the 4-MB minfo table does not -- the
+                           //   gathers are the probe kernel's bound): bit 0 up, 1-4 queue length, 5 MI_OOW,
+                           //   6 the member has a view row (then, and on explicit-record ticks, the prober
+                           //   reads the full word), 7 its settled base is not Alive.  Written with every minfo.
   uint16_t* probe_out;     // nsent | nfail<<5 | n explicit own-ack sources<<10, probe -> merge kernel
   ulonglong2* pk;          // per member {x: the queue as a 64-bit mask over rumour-id positions (rid & 63),
                            //   y: known-ring, bit (rid & 63) set => this member's view already dominates
@@ -258,6 +263,28 @@ __device__ inline bool rid_maskable(uint32_t rid, uint32_t H) {
 constexpr uint32_t MI_SLOT = 0xFFFFu, MI_PBN_SHIFT = 16, MI_PBN = 0xFu << 16, MI_BUF = 1u << 20,
                    MI_UP = 1u << 21, MI_OOW = 1u << 22, MI_PB = MI_PBN | MI_BUF | MI_OOW,
                    MI_BASE_SHIFT = 23, MI_BASE = 3u << MI_BASE_SHIFT;
+constexpr uint32_t MB_UP = 1u, MB_PBN_SHIFT = 1, MB_OOW = 1u << 5, MB_ROW = 1u << 6, MB_BASE_NA = 1u << 7;
+__host__ __device__ inline uint32_t mb_of(uint32_t mi) {
+  return ((mi & MI_UP) ? MB_UP : 0u) | (((mi >> MI_PBN_SHIFT) & 0xFu) << MB_PBN_SHIFT) | ((mi & MI_OOW) ? MB_OOW : 0u) |
+         ((mi & MI_SLOT) ? MB_ROW : 0u) | ((mi & MI_BASE) ? MB_BASE_NA : 0u);
+}
+__device__ inline void set_mi(const DevState& s, uint32_t g, uint32_t v) { s.minfo[g] = v; s.mb[g] = (uint8_t)mb_of(v); }
+// the member now has a view row (minfo was updated with an atomic by whoever allocated it)
+__device__ inline void mb_set_row(const DevState& s, uint32_t g) {
+  atomicOr(reinterpret_cast<uint32_t*>(s.mb) + (g >> 2), MB_ROW << (8u * (g & 3u)));
+}
+// minfo of a probe target / proxy as far as the prober needs it: from the byte table, the full word only for
+// members with a view row or an unmaskable queue and on ticks that travel as explicit records (the line
+// buffer bit is needed then)
+__device__ inline uint32_t probe_mi(const DevState& s, uint32_t c, bool use_mask) {
+#ifdef SWIM_NO_MB            // measurement knob: always gather the full word
+  return s.minfo[c];
+#endif
+  const uint32_t b = s.mb[c];
+  if ((b & (MB_ROW | MB_OOW)) || !use_mask) return s.minfo[c];
+  return ((b & MB_UP) ? MI_UP : 0u) | (((b >> MB_PBN_SHIFT) & 0xFu) << MI_PBN_SHIFT) |
+         ((b & MB_BASE_NA) ? ((uint32_t)ST_DEAD << MI_BASE_SHIFT) : 0u);
+}
 __device__ inline uint32_t mi_pbn(uint32_t mi) { return (mi >> MI_PBN_SHIFT) & 0xFu; }
 __device__ inline uint32_t mi_buf(uint32_t mi) { return (mi >> 20) & 1u; }
 __device__ inline bool mi_up(uint32_t mi) { return (mi & MI_UP) != 0; }
@@ -306,7 +333,7 @@ template <int MAXN>
 __device__ inline uint32_t select_members(const DevState& s, uint32_t mk, uint32_t i, uint32_t n,
                                           uint32_t purpose, uint32_t hi_idx, const uint32_t* excl,
                                           uint32_t nexcl, uint32_t (&out)[MAXN],
-                                          uint32_t (&info)[MAXN]) {
+                                          uint32_t (&info)[MAXN], bool use_mask = false) {
   uint32_t np = 0;
   const uint32_t N = s.NT;
   // Issue the first-attempt gathers of all picks together (independent loads); eligibility is
@@ -319,7 +346,7 @@ __device__ inline uint32_t select_members(const DevState& s, uint32_t mk, uint32
       if ((uint32_t)p < n) {
         const uint32_t base = (purpose << 24) | (purpose == P_SELECT ? ((uint32_t)p << 8) : ((hi_idx << 16) | ((uint32_t)p << 8)));
         c0[p] = __umulhi(hash_mk(mk, base, 0), N);
-        m0[p] = s.minfo[c0[p]];
+        m0[p] = probe_mi(s, c0[p], use_mask);
       }
     }
   }
@@ -334,7 +361,7 @@ __device__ inline uint32_t select_members(const DevState& s, uint32_t mk, uint32
       bool dup = false;
       for (int e = 0; e < MAXN; ++e) dup |= ((uint32_t)e < np) && (out[e] == cand);
       if (dup) return false;
-      mc = have ? mhave : s.minfo[cand];
+      mc = have ? mhave : probe_mi(s, cand, use_mask);
       return view_alive(s, i - s.lo, mc);
     };
     for (uint32_t a = 0; a < SEL_ATTEMPTS; ++a) {

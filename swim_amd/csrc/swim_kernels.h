@@ -88,6 +88,7 @@ __device__ inline void ensure_slot(const DevState& s, uint32_t j) {
       s.slot_used[r] = 1;
       __threadfence();
       atomicXor(&s.minfo[j], MI_SLOT ^ (r + 1u));
+      mb_set_row(s, j);
       return;
     }
     cur = seen;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
     uint32_t np;                                    // probe indices in play
     if (!robust) {
       // ms <- kRandomMembers store (numToGossip cfg) []        (src/Core.hs:239)
-      np = select_members<PMAX>(s, mk, i, s.P, P_SELECT, 0, nullptr, 0, picks, pinfo);
+      np = select_members<PMAX>(s, mk, i, s.P, P_SELECT, 0, nullptr, 0, picks, pinfo, use_mask);
       n_pings = np;
 #pragma unroll
       for (int p = 0; p < PMAX; ++p) valid[p] = (uint32_t)p < np;
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
         valid[p] = false; picks[p] = 0; pinfo[p] = 0;
         if ((uint32_t)p < np && off.o[p]) {
           uint32_t c = i + off.o[p]; if (c >= s.NT) c -= s.NT;
-          picks[p] = c; pinfo[p] = s.minfo[c];
+          picks[p] = c; pinfo[p] = probe_mi(s, c, use_mask);
           valid[p] = view_alive(s, li, pinfo[p]);
           n_pings += valid[p] ? 1u : 0u;
         }
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
       for (int p = 0; p < PMAX; ++p) {
         if ((uint32_t)p >= s.P || !off.o[p]) continue;
         uint32_t q = i + s.NT - off.o[p]; if (q >= s.NT) q -= s.NT;
-        const uint32_t mq = s.minfo[q];
+        const uint32_t mq = probe_mi(s, q, use_mask);
         if (!mi_up(mq) || !mi_pbn(mq) || !view_alive(s, q - s.lo, mi) || lost(s, tk, P_L_PING, q, i, p)) continue;
         if (use_mask) ackacc |= s.pk[q - s.lo].x;
         if (!use_mask || (mq & MI_OOW)) push(s, t, li, mi_src(q - s.lo, mq));
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
       // kRandomMembers store (numToGossip cfg) [] for proxies (src/Core.hs:249), D7: not the target
       uint32_t qs[PMAX], qinfo[PMAX];
       const uint32_t excl = j;
-      const uint32_t nq = select_members<PMAX>(s, mk, i, s.K, P_PROXY, p, &excl, 1, qs, qinfo);
+      const uint32_t nq = select_members<PMAX>(s, mk, i, s.K, P_PROXY, p, &excl, 1, qs, qinfo, use_mask);
       preqs += nq;
       bool acked = false;
       for (int k = 0; k < PMAX; ++k) {
@@ -749,9 +750,9 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     for (uint32_t k = nout; k < (uint32_t)PB_SLOTS; ++k) { asm_[2 * k][tid] = 0u; asm_[2 * k + 1][tid] = 0u; }
     if (nout) {
       wflag = 1u | ((cur ^ 1u) << 1);              // the line itself is stored below, a whole wave at a time
-      s.minfo[i] = (mi & ~MI_PB) | (nout << MI_PBN_SHIFT) | ((cur ^ 1u) << 20) | oow;
+      set_mi(s, i, (mi & ~MI_PB) | (nout << MI_PBN_SHIFT) | ((cur ^ 1u) << 20) | oow);
     } else if (pcount) {
-      s.minfo[i] = mi & ~MI_PB;
+      set_mi(s, i, mi & ~MI_PB);
     }
     s.pk[li] = make_ulonglong2(nout ? qmask : 0ull, kn);
     if (pushed) s.inmask[li] = 0;
@@ -1055,7 +1056,7 @@ __device__ inline void settle_finish(const DevState& s) {
     const uint32_t nb = max(s.base_key[subject], kmax);
     s.base_key[subject] = nb;
     s.base_since[subject] = u;
-    s.minfo[subject] = (s.minfo[subject] & ~(MI_SLOT | MI_BASE)) | ((nb & 3u) << MI_BASE_SHIFT);
+    set_mi(s, subject, (s.minfo[subject] & ~(MI_SLOT | MI_BASE)) | ((nb & 3u) << MI_BASE_SHIFT));
     s.slot_used[slot] = 0;
     for (int w = 0; w < RT_WAYS; ++w) s.rtab[(size_t)slot * RT_WAYS + w] = 0ull;
     s.zero_slots[atomicAdd(&nz_new, 1u)] = slot;             // read above by this block only, behind the barrier
@@ -1094,11 +1095,11 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, co
       if (!up) {
         // the process is gone: its piggyback queue with it (member map and deadlines stay: swimsim.h)
         s.crash_tick[mbr] = t;
-        if (is_local(s, mbr)) { s.minfo[mbr] = mi & ~(MI_UP | MI_PB); s.pk[mbr - s.lo].x = 0ull; }
-        else s.minfo[mbr] = mi & ~MI_UP;
+        if (is_local(s, mbr)) { set_mi(s, mbr, mi & ~(MI_UP | MI_PB)); s.pk[mbr - s.lo].x = 0ull; }
+        else set_mi(s, mbr, mi & ~MI_UP);
         continue;
       }
-      if (!is_local(s, mbr)) { s.minfo[mbr] = mi | MI_UP; continue; }   // its owner does the rest
+      if (!is_local(s, mbr)) { set_mi(s, mbr, mi | MI_UP); continue; }   // its owner does the rest
       // (re)join: new incarnation, announce Alive: the queue holds exactly that rumour
       const uint32_t ml = mbr - s.lo;
       const uint2 hot = s.hot[ml];
@@ -1115,7 +1116,7 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, co
       line[0] = ((uint64_t)pe_hi(akey, s.L) << 32) | pe_lo(sl, arid);
       for (int q = 1; q < PB_SLOTS; ++q) line[q] = 0ull;
       s.pk[ml] = make_ulonglong2(rid_bit(arid), 0ull);       // its id is the newest: maskable; known-ring empty
-      s.minfo[mbr] = (mi & ~(MI_PBN | MI_OOW)) | (1u << MI_PBN_SHIFT) | MI_UP;
+      set_mi(s, mbr, (mi & ~(MI_PBN | MI_OOW)) | (1u << MI_PBN_SHIFT) | MI_UP);
       s.inmask[ml] = 0;
       s.hot[ml] = make_uint2(ni, hot.y | 1u);                // merge_kernel fires the deadlines it slept through
       if (s.event_mask & (1u << 4)) {
@@ -1233,9 +1234,9 @@ __global__ void set_view_kernel(DevState s, uint32_t t, uint32_t observer, uint3
   }
 }
 
-__global__ void init_members_kernel(uint32_t* minfo, uint32_t n_total) {
+__global__ void init_members_kernel(uint32_t* minfo, uint8_t* mb, uint32_t n_total) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_total) minfo[i] = MI_UP;
+  if (i < n_total) { minfo[i] = MI_UP; mb[i] = (uint8_t)mb_of(MI_UP); }
 }
 
 }  // namespace swim

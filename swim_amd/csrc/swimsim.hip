@@ -307,6 +307,7 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   }
   d.ord_cap = 0; d.r_cap = d.p_cap = d.x_cap = 0;
   CK(dev_alloc(h, &d.minfo, NT, 0));
+  CK(dev_alloc(h, &d.mb, ((size_t)NT + 3) & ~(size_t)3, 0));
   CK(dev_alloc(h, &d.probe_out, N, 0));
   CK(dev_alloc(h, &d.ackfrom, (size_t)N * (d.P ? d.P : 1), 0));
   CK(dev_alloc(h, &d.inbox_cnt, N, 0));
@@ -365,7 +366,7 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     CK(dev_alloc(h, &d.fl, (size_t)d.n_shards * ((size_t)d.x_cap + d.p_cap + d.r_cap) * 4, 0));
     CK(dev_alloc(h, &d.ackslot, (size_t)N * std::max(1u, d.P), 0));
   }
-  hipLaunchKernelGGL(init_members_kernel, dim3((NT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, d.minfo, NT);
+  hipLaunchKernelGGL(init_members_kernel, dim3((NT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, d.minfo, d.mb, NT);
   HK(hipGetLastError());
   HK(hipStreamSynchronize(h->stream));
 #undef CK
