@@ -350,7 +350,7 @@ __device__ inline uint32_t find_rid(const DevState& s, uint32_t slot, uint32_t k
   unsigned long long* p = s.rtab + (size_t)slot * RT_WAYS + way;
   const unsigned long long claim = (unsigned long long)(key + 1u) << 32;
   unsigned long long e = *p;                        // cached load: a published entry never reverts
-  for (int spin = 0; spin < 1024; ++spin) {
+  for (int spin = 0; spin < 64; ++spin) {           // a racing creator may sit in my own wave: do not wait for it long
     const uint32_t ek = (uint32_t)(e >> 32);
     if (ek == key + 1u) {
       if (e & RT_READY) {

@@ -316,11 +316,13 @@ def test_forced_fallback_paths_on_the_gpu(oracle_abi):
 
 
 def test_rumour_id_counter_wraps_on_the_gpu(oracle_abi):
-    """The gfx950 build with 8-bit rumour ids: the id counter wraps every 256 rumours, several times here.
-    (More than 64 new ids in ONE tick is more than an 8-bit id space tolerates: that is a loud
-    SWIMSIM_ERR_CAPACITY, 'rumour-ids-per-tick' -- 16 384 per tick with the product's 16-bit ids.)"""
+    """The gfx950 build with 10-bit rumour ids: the id counter wraps every 1 024 rumours, several times here
+    (racing creators of one rumour take spare ids on the GPU: ~100 new ids per tick in this run).  More than
+    2^(bits-2) new ids in ONE tick is more than an id space tolerates: that is a loud SWIMSIM_ERR_CAPACITY,
+    'rumour-ids-per-tick' -- 16 384 per tick with the product's 16-bit ids; the 8-bit build of the CPU
+    emulation test (tests/test_hostemu_parity.py) wraps an order of magnitude more often."""
     from swim_amd import _lib
-    hip = _lib.load_variant("rid8")
+    hip = _lib.load_variant("rid10")
     n = 30000
     crashes = workloads.hashed_crashes(n, 4, 1, 120, 3, 103)        # ~250 crashes over 100 ticks: ~10 new ids per
     sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=4, lossPpm=1000, eventMask=0, suspicionTicks=6,   # tick (an 8-bit id
