@@ -354,12 +354,13 @@ __device__ inline uint32_t find_rid(const DevState& s, uint32_t slot, uint32_t k
     const uint32_t ek = (uint32_t)(e >> 32);
     if (ek == key + 1u) {
       if (e & RT_READY) {
-        // a published id is reused only while it still names this rumour and is recent: the id counter wraps
-        // (RID_BITS), and an id that another rumour took over -- or that is about to leave the near range --
-        // would set a foreign bit in somebody's mask.  A stale entry is re-claimed like a free one.
+        // a published id is reused only while it still names this rumour and is younger than half the id space:
+        // the id counter wraps (RID_BITS), and an id that another rumour took over -- or one so old that it
+        // would read as an id just above the head -- would set a foreign bit in somebody's mask.  A stale entry
+        // is re-claimed like a free one.
         const uint32_t rid = (uint32_t)e & RID_MASK;
         const uint2 r = s.rum[rid];
-        if (r.x == slot && r.y == key && ((s.g[G_NRUM] - rid) & RID_MASK) < RID_NEAR) return rid;
+        if (r.x == slot && r.y == key && ((s.g[G_NRUM] - rid) & RID_MASK) < RID_FAR) return rid;
       } else {
         e = atomicCAS(p, 0ull, 0ull);               // being published by another lane: re-read at device scope
         continue;
@@ -1134,9 +1135,11 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, co
     if (dropped_sh) s.blk[(size_t)s.nblocks * C_COUNT + C_EVENTS_DROPPED] += dropped_sh;
     s.g[G_PREV] = s.g[G_HEAD];
     s.g[G_HEAD] = s.g[G_NRUM];
-    // an id must be seen by its holders' next rewrite while it is still inside [H - 64, H + RID_NEAR): more new
-    // ids than that in ONE tick would let an entry skip the zone unparked (2^14 per tick with 16-bit ids)
-    if (s.g[G_HEAD] - s.g[G_PREV] > RID_NEAR) atomicOr(&s.g[G_ERR], (uint32_t)ERRF_RIDS);
+    // a line is rewritten every tick and replaces ids outside [H - 64, H + RID_NEAR) by "no id"; an id born at
+    // distance r < RID_NEAR above the head sits at r - D one tick later (D = ids of the tick) and would wrap
+    // back INTO that zone only for D > 2^RID_BITS - RID_NEAR: beyond that (49 088 new rumours in ONE tick with
+    // 16-bit ids) the run stops loudly
+    if (s.g[G_HEAD] - s.g[G_PREV] > RID_MASK + 1u - RID_NEAR - KN_BITS) atomicOr(&s.g[G_ERR], (uint32_t)ERRF_RIDS);
     if (t) s.tovf_n[((t - 1u) % s.S) * 2u + ((((t - 1u) / s.S) & 1u) ^ 1u)] = 0;   // the deadline chains tick t-1 consumed
   }
   if (s.G) {
