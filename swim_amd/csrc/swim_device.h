@@ -30,8 +30,9 @@ enum { G_NSLOTS = 0 /* view rows ever handed out (high-water mark) */, G_ERR = 1
        G_NFREE = 8 /* reclaimed rows on the free stack */, G_NLIVE = 9 /* subjects with a row (max_subjects bounds it) */,
        G_SETTLE_N = 10 /* rows whose entries this tick's merge reduces */, G_ZERO_N = 11 /* rows it clears */,
        G_SETTLE_PENDING = 12 /* the lists above still await settle_finish */, G_SETTLE_TICK = 13,
+       G_RIDS_OFF = 14 /* so many new rumours last tick that this tick's lines carry no ids at all */,
        G_SEND = 16 /* [3][16] exchange records appended per peer (send_cnt) */, G_WORDS = 64 };
-enum { ERRF_SUBJECTS = 1, ERRF_ROWS = 2, ERRF_OVF = 4, ERRF_INC = 8, ERRF_XCHG = 16, ERRF_RIDS = 32 };
+enum { ERRF_SUBJECTS = 1, ERRF_ROWS = 2, ERRF_OVF = 4, ERRF_INC = 8, ERRF_XCHG = 16 };
 
 // counter slots (same order as SWIMSIM_CTR_* in include/swimsim.h)
 enum { C_PINGS = 0, C_DIRECT_FAILED, C_PING_REQS, C_SUSPECTS, C_FALSE_SUSPECTS, C_PAYLOADS,

@@ -723,7 +723,9 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     uint32_t nout = gn;
     unsigned long long qmask = 0;
     uint32_t oow = 0;
+    const bool rids_off = s.g[G_RIDS_OFF] != 0u;
     auto publish = [&](uint32_t lo) -> uint32_t {  // mask bit or "cannot express", id parked if too old
+      if (rids_off) { oow = MI_OOW; return pe_lo(pe_slot(lo), RID_PARKED); }
       const uint32_t rid = pe_rid(lo);
       if (rid_maskable(rid, H)) qmask |= rid_bit(rid);
       else oow = MI_OOW;
@@ -1137,9 +1139,10 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, co
     s.g[G_HEAD] = s.g[G_NRUM];
     // a line is rewritten every tick and replaces ids outside [H - 64, H + RID_NEAR) by "no id"; an id born at
     // distance r < RID_NEAR above the head sits at r - D one tick later (D = ids of the tick) and would wrap
-    // back INTO that zone only for D > 2^RID_BITS - RID_NEAR: beyond that (49 088 new rumours in ONE tick with
-    // 16-bit ids) the run stops loudly
-    if (s.g[G_HEAD] - s.g[G_PREV] > RID_MASK + 1u - RID_NEAR - KN_BITS) atomicOr(&s.g[G_ERR], (uint32_t)ERRF_RIDS);
+    // back INTO that zone for D > 2^RID_BITS - RID_NEAR.  After such a tick (49 088 new rumours at once with
+    // 16-bit ids: heavy message loss) every line of this tick is written without ids: masks and the known-ring
+    // are out of the game anyway (explicit records), exactness does not depend on them
+    s.g[G_RIDS_OFF] = (s.g[G_HEAD] - s.g[G_PREV] > RID_MASK + 1u - RID_NEAR - KN_BITS) ? 1u : 0u;
     if (t) s.tovf_n[((t - 1u) % s.S) * 2u + ((((t - 1u) / s.S) & 1u) ^ 1u)] = 0;   // the deadline chains tick t-1 consumed
   }
   if (s.G) {

@@ -150,7 +150,6 @@ int check_device_errors(swimsim* h) {
     if (g[G_ERR] & ERRF_OVF) m += " inbox-overflow-list (" + std::to_string(std::max(g[G_OVF0], g[G_OVF1])) + " entries, room for " + std::to_string(h->d.ovf_cap) + ")";
     if (g[G_ERR] & ERRF_INC) m += " incarnation-bits";
     if (g[G_ERR] & ERRF_XCHG) m += " shard-exchange-buffers";
-    if (g[G_ERR] & ERRF_RIDS) m += " rumour-ids-per-tick (more new rumours in one tick than the id width tolerates)";
     return set_err(h, SWIMSIM_ERR_CAPACITY, m);
   }
   return SWIMSIM_OK;

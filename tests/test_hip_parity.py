@@ -317,10 +317,10 @@ def test_forced_fallback_paths_on_the_gpu(oracle_abi):
 
 def test_rumour_id_counter_wraps_on_the_gpu(oracle_abi):
     """The gfx950 build with 10-bit rumour ids: the id counter wraps every 1 024 rumours, several times here
-    (racing creators of one rumour take spare ids on the GPU: ~100 new ids per tick in this run).  More than
-    2^(bits-2) new ids in ONE tick is more than an id space tolerates: that is a loud SWIMSIM_ERR_CAPACITY,
-    'rumour-ids-per-tick' -- 16 384 per tick with the product's 16-bit ids; the 8-bit build of the CPU
-    emulation test (tests/test_hostemu_parity.py) wraps an order of magnitude more often."""
+    (racing creators of one rumour take spare ids on the GPU: ~100 new ids per tick in this run).  After a tick
+    with more than 3/4 of the id space in new ids, the lines of the next tick carry no ids at all (explicit
+    records only): exact at any rate of new rumours; the 8-bit build of the CPU emulation tests
+    (tests/test_hostemu_parity.py) lives in that mode most of the time."""
     from swim_amd import _lib
     hip = _lib.load_variant("rid10")
     n = 30000
