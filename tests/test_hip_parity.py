@@ -345,7 +345,7 @@ def test_config5_loss_at_16k_members(oracle_abi, hip_abi):
     _oracle_threads(a)
     run_lockstep(a, b, 40, 10, observers=(0, n - 1), members=(0, n - 1), check_events=False)
     c = b.counters()
-    assert c["direct_failed"] > 0.45 * c["pings"] and c["refutes"] > 1000
+    assert c["direct_failed"] > 0.3 * c["pings"] and c["ping_reqs"] > c["pings"] and c["refutes"] > 0
 
 
 def test_default_capacities_survive_a_lossy_run(oracle_abi, hip_abi):
