@@ -105,6 +105,7 @@ _PRODUCT_ONLY = {
     "shard_step": (C.c_int, [_H, C.c_uint32, C.c_void_p, C.c_void_p]),
     "shard_get_first_suspect": (C.c_int, [_H, _U32P, C.c_size_t]),
     "shard_set_first_suspect": (C.c_int, [_H, _U32P, C.c_size_t]),
+    "table_stats": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_size_t]),
     "kernel_timing_enable": (C.c_int, [_H, C.c_int]),
     "kernel_timing": (C.c_int, [_H, C.POINTER(C.c_double), C.c_size_t]),
 }

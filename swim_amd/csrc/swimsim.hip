@@ -610,6 +610,16 @@ int swimsim_counters(swimsim_t* h, uint64_t* out, size_t n) {
   return SWIMSIM_OK;
 }
 
+int swimsim_table_stats(swimsim_t* h, uint64_t* out, size_t n) {
+  if (!h || !out || n < 5) return SWIMSIM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  uint32_t g[G_WORDS];
+  HIPCHK(h, hipMemcpy(g, h->d.g, sizeof g, hipMemcpyDeviceToHost));
+  out[0] = g[G_NSLOTS]; out[1] = g[G_NLIVE]; out[2] = g[G_NFREE]; out[3] = g[G_NRUM]; out[4] = h->d.R_phys;
+  return SWIMSIM_OK;
+}
+
 int swimsim_k_random_members(swimsim_t* h, uint32_t observer, uint32_t n, const uint32_t* excludes,
                              size_t n_excludes, uint32_t* out, size_t cap, size_t* n_out) {
   if (!h || !n_out || observer - h->d.lo >= h->d.N || n > 255 || (n_excludes && !excludes)) return SWIMSIM_ERR_INVALID;

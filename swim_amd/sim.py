@@ -178,6 +178,13 @@ class Sim:
         self._check(self._abi.counters(self._h, buf, _abi.CTR_COUNT))
         return {name: buf[k] for k, name in enumerate(_abi.CTR_NAMES) if not name.startswith("_")}
 
+    def tableStats(self) -> dict:
+        """Occupancy of the bounded tables (product library only): view rows ever handed out / live subjects /
+        reclaimed rows waiting / rumour ids handed out / view rows allocated."""
+        buf = (C.c_uint64 * 5)()
+        self._check(self._abi.table_stats(self._h, buf, 5))
+        return dict(zip(("rows_high_water", "subjects_live", "rows_free", "rumour_ids", "rows_allocated"), buf))
+
     # -- measurement (product library only) -----------------------------------------
     def kernelTimingEnable(self, enable=True):
         self._check(self._abi.kernel_timing_enable(self._h, 1 if enable else 0))
