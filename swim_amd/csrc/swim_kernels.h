@@ -969,7 +969,17 @@ __global__ void xlat_kernel(DevState s, PeerCounts r_counts) {
     const uint2 e = reinterpret_cast<const uint2*>(s.r_recv + (size_t)peer * (DICT_RECS + s.r_cap))[p];   // {subject, key}
     if (e.x != NONE32) {
       const uint32_t slot = get_slot(s, e.x);
-      out = make_uint2(pe_lo(slot, find_rid(s, slot, e.y)), e.y);
+      // a dictionary changes by a few entries per tick: keep last tick's translation of this position while it
+      // still names the same rumour (find_rid would take a fresh id on every call for a rumour whose cache way
+      // a newer rumour about the subject has taken over -- an id burst per tick that switches the masks off)
+      const uint2 prev = s.xl[(size_t)peer * DICT_ENTRIES + p];
+      const uint32_t prid = pe_rid(prev.x);
+      const uint2 pr = s.rum[prid & RID_MASK];
+      if (prev.x != NONE32 && prev.y == e.y && pe_slot(prev.x) == slot && prid != RID_PARKED && pr.x == slot && pr.y == e.y &&
+          ((s.g[G_NRUM] - prid) & RID_MASK) < RID_FAR)
+        out = prev;
+      else
+        out = make_uint2(pe_lo(slot, find_rid(s, slot, e.y)), e.y);
     }
   }
   s.xl[(size_t)peer * DICT_ENTRIES + p] = out;
