@@ -64,6 +64,7 @@ data SimConfig = SimConfig
   , simGcTicks        :: Word32   -- settling horizon (`removeDeadNodes`, src/Core.hs:65-67): 0 = off, maxBound = auto
   , simDevice         :: Int32
   , simTargetScheme   :: Word32   -- 0 = kRandomMembers (the reference), 1 = robust round-robin (src/Core.hs:232 FIXME)
+  , simJoinPull       :: Word32   -- 1 = a member that comes up merges a join host's member map (`joinHosts`, src/Types.hs:47)
   }
 
 data SwimsimT
@@ -93,7 +94,7 @@ foreign import ccall "wrapper" mkExchange :: ExchangeFn -> IO (FunPtr ExchangeFn
 foreign import ccall safe   "swimsim_shard_step"    c_shard_step    :: Ptr SwimsimT -> Word32 -> FunPtr ExchangeFn -> Ptr () -> IO CInt
 
 defaultSimConfig :: Config -> SimConfig
-defaultSimConfig c = SimConfig c 128 1 0 0 0 0 0 0 0
+defaultSimConfig c = SimConfig c 128 1 0 0 0 0 0 0 0 0
 
 memberNameOf :: Word32 -> String
 memberNameOf i = 'm' : show i
@@ -114,6 +115,7 @@ configureSim SimConfig{..} =
     pokeByteOff p swimsimConfig_gc_ticks           simGcTicks
     pokeByteOff p swimsimConfig_device             simDevice
     pokeByteOff p swimsimConfig_target_scheme      simTargetScheme
+    pokeByteOff p swimsimConfig_join_pull          simJoinPull
     -- the failure text comes back through OUR buffer: the library's per-thread text could belong to another
     -- OS thread by the time a second `safe` call reads it
     rc <- c_create p ph perr 512

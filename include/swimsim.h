@@ -110,7 +110,20 @@ typedef struct swimsim_config {
   uint32_t target_scheme;      /* SWIMSIM_TARGETS_RANDOM (the reference: kRandomMembers,
                                   src/Core.hs:239) or SWIMSIM_TARGETS_ROBUST (the FIXME at
                                   src/Core.hs:232 "move from random to robust scheme")   */
+  uint32_t join_pull;          /* 1: a member that comes (back) up pulls the member map of a join host
+                                  (`joinHosts`, src/Types.hs:47, src/Util.hs:46; the commented-out
+                                  PushPullMsg, src/Types.hs:165,177) -- see below.  0: it keeps the map
+                                  it had and learns the rest from gossip                       */
 } swimsim_config_t;
+
+/* Join-time state pull (join_pull = 1).  When member m comes up in tick t its join host
+ * is the first of the 8 draws mulhi(H(t, m, JOIN<<24 | a, 0), N), a = 0..7, that is not m, was up before this
+ * tick and has no scheduled change in this tick (so that the result does not depend on the order in which the
+ * tick's changes are applied); none => no pull.  For every subject s != m that has a view row, m's entry becomes
+ * max(own entry, the host's entry) -- the host itself counts as Alive at its own incarnation --, with
+ * lastChange = t and a suspicion deadline t + suspicion_ticks for a pulled Suspect.  A pulled entry is a view
+ * change like any other (counters, digest), but is not gossiped on and raises no event.  Not available on
+ * sharded handles (the host may live on another shard). */
 
 #define SWIMSIM_GC_AUTO 0xFFFFFFFFu
 

@@ -38,7 +38,7 @@
 #define INC_MAX 0x3FFFFFu   /* incarnation must fit 22 bits (key = inc<<2|state)   */
 
 enum { P_SELECT = 1, P_PROXY = 2, P_L_PING = 3, P_L_ACK = 4, P_L_REQ = 5,
-       P_L_FWD = 6, P_L_BACK = 7, P_L_RELAY = 8 };
+       P_L_FWD = 6, P_L_BACK = 7, P_L_RELAY = 8, P_JOIN = 9 };
 
 enum { TAG_SELF = 0x53454c46u, TAG_VIEW = 0x56494557u, TAG_PB = 0x50425546u,
        TAG_TIMER = 0x54494d52u, TAG_FD = 0x46444554u, TAG_EV = 0x45564e54u,
@@ -654,8 +654,37 @@ static int fault_cmp(const void* a, const void* b) {
   return x->order < y->order ? -1 : x->order > y->order;
 }
 
+/* Join-time state pull (include/swimsim.h; `joinHosts`, src/Types.hs:47): member m, just up,
+ * merges the member map of a join host -- a member that was up before this tick and has no change scheduled
+ * in it (faults[0..nf) are the tick's changes). */
+static void join_pull(swimoracle_t* o, uint32_t t, uint32_t m, size_t nf) {
+  uint32_t tk = tick_key(o->cfg.seed, t), h = NONE32;
+  for (uint32_t a = 0; a < SEL_ATTEMPTS && h == NONE32; a++) {
+    uint32_t c = (uint32_t)(((uint64_t)hash_h(tk, m, ((uint32_t)P_JOIN << 24) | a, 0) * o->N) >> 32);
+    int busy = (c == m) || !o->up[c];
+    for (size_t x = 0; x < nf && !busy; x++) busy = o->faults[x].member == c;
+    if (!busy) h = c;
+  }
+  if (h == NONE32) return;
+  for (uint32_t sl = 0; sl < o->nslots; sl++) {
+    if (o->free_at[sl] != NONE32) continue;
+    uint32_t s = o->subject_of[sl];
+    if (s == m) continue;
+    uint32_t kh = s == h ? key_make(o->self_inc[h], SWIMSIM_ALIVE) : view_get(o, h, s).key;
+    oentry_t cur = view_get(o, m, s);
+    if (kh <= cur.key) continue;
+    oentry_t* e = view_ref(o, m, s);
+    o->counters[SWIMSIM_CTR_EVDIGEST] += h4(TAG_EV, ((uint64_t)t << 32) | m, s, kh) - h4(TAG_EV, ((uint64_t)t << 32) | m, s, cur.key);
+    o->counters[SWIMSIM_CTR_CHANGES]++;
+    e->key = kh; e->since1 = t + 1;
+    o->last_change[s] = t;
+    if (key_state(kh) == SWIMSIM_SUSPECT) timer_push(o, m, s, t + o->S);
+  }
+}
+
 static void apply_faults(swimoracle_t* o, uint32_t t) {
-  size_t k = 0;
+  size_t k = 0, nf = 0;
+  while (nf < o->nfaults && o->faults[nf].tick <= t) nf++;
   while (k < o->nfaults && o->faults[k].tick <= t) {
     ofault_t f = o->faults[k++];
     uint32_t m = f.member;
@@ -673,6 +702,7 @@ static void apply_faults(swimoracle_t* o, uint32_t t) {
       o->last_change[m] = t;
       event_add(&o->ctx[0], t, m, m, key_make(ni, SWIMSIM_ALIVE), SWIMSIM_CAUSE_JOIN);
       o->first_suspect[m] = NONE32;
+      if (o->cfg.join_pull) join_pull(o, t, m, nf);
     }
   }
   if (k) { memmove(o->faults, o->faults + k, (o->nfaults - k) * sizeof *o->faults); o->nfaults -= k; }
@@ -933,6 +963,7 @@ static int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, char*
   if (c->n_shards == 0) c->n_shards = 1;
   if (c->n_shards != 1 || c->shard_index != 0) { snprintf(err, errn, "oracle: sharding is driven from outside (n_shards must be 1)"); return SWIMSIM_ERR_INVALID; }
   if (c->target_scheme > SWIMSIM_TARGETS_ROBUST) { snprintf(err, errn, "unknown target_scheme"); return SWIMSIM_ERR_INVALID; }
+  if (c->join_pull > 1) { snprintf(err, errn, "join_pull must be 0 or 1"); return SWIMSIM_ERR_INVALID; }
   return SWIMSIM_OK;
 }
 

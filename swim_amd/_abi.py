@@ -40,7 +40,7 @@ class Config(C.Structure):
         ("gc_ticks", C.c_uint32), ("event_cap", C.c_uint32), ("event_mask", C.c_uint32),
         ("inbox_cap", C.c_uint32),
         ("device", C.c_int32), ("shard_index", C.c_uint32), ("n_shards", C.c_uint32),
-        ("target_scheme", C.c_uint32),
+        ("target_scheme", C.c_uint32), ("join_pull", C.c_uint32),
     ]
 
 

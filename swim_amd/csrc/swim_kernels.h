@@ -590,6 +590,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
         if ((e.x & 3u) != ST_SUSPECT || !s.slot_used[r]) continue;
         const uint32_t dl = e.y - 1 + s.S;
         if (dl <= t) { if (woke || dl == t) examine(r, (e.x & ~3u) | ST_DEAD, 1u, false, 0u); }
+        else if (woke && dl % s.S == row_now) tput(r + 1);     // a pulled Suspect (since = t): this tick's own cell
         else if (woke) {
           const size_t ix = (size_t)(dl % s.S) * s.N + li;
           const uint4 cell = s.trow[ix];
@@ -1091,15 +1092,15 @@ __global__ __launch_bounds__(BLOCK) void settle_flush_kernel(DevState s) { settl
 // scheduled for t (host-sorted by member within the tick: one thread applies all changes of one member in
 // order, members in parallel), then the snapshot of the rumour-id counter that fixes the tick's window head H
 // (no ids are allocated between here and merge_kernel), then the rows eligible for settling at the end of t.
-__global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, const FaultRec* faults, uint32_t nfaults) {
+__global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, uint32_t tk, const FaultRec* faults, uint32_t nfaults) {
   __shared__ unsigned long long evd_sh;
-  __shared__ unsigned dropped_sh, nset;
+  __shared__ unsigned dropped_sh, nset, changes_sh;
   settle_finish(s);
-  if (threadIdx.x == 0) { evd_sh = 0; dropped_sh = 0; nset = 0; }
+  if (threadIdx.x == 0) { evd_sh = 0; dropped_sh = 0; nset = 0; changes_sh = 0; }
   __syncthreads();
   for (uint32_t k0 = threadIdx.x; k0 < nfaults; k0 += blockDim.x) {
     if (k0 && faults[k0 - 1].member == faults[k0].member) continue;      // not the first change of its member
-    unsigned long long evd = 0; unsigned dropped = 0;
+    unsigned long long evd = 0; unsigned dropped = 0, pulled = 0;
     for (uint32_t k = k0; k < nfaults && faults[k].member == faults[k0].member; ++k) {
       const uint32_t mbr = faults[k].member, up = faults[k].up;
       uint32_t mi = s.minfo[mbr];
@@ -1132,6 +1133,37 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, co
       set_mi(s, mbr, (mi & ~(MI_PBN | MI_OOW)) | (1u << MI_PBN_SHIFT) | MI_UP);
       s.inmask[ml] = 0;
       s.hot[ml] = make_uint2(ni, hot.y | 1u);                // merge_kernel fires the deadlines it slept through
+      if (s.join_pull) {
+        // join-time state pull (`joinHosts`, src/Types.hs:47; include/swimsim.h): merge the member map of the
+        // first drawn member that was up before this tick and has no change scheduled in it (the tick's changes
+        // are sorted by member: binary search) -- its cells are not written by anybody in this kernel
+        uint32_t host = NONE32;
+        const uint32_t mk = mix32(tk ^ mbr);
+        for (uint32_t a = 0; a < SEL_ATTEMPTS && host == NONE32; ++a) {
+          const uint32_t c = __umulhi(hash_mk(mk, ((uint32_t)P_JOIN << 24) | a, 0), s.NT);
+          if (c == mbr || !mi_up(s.minfo[c])) continue;
+          uint32_t lo = 0, hi = nfaults;
+          while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (faults[mid].member < c) lo = mid + 1; else hi = mid; }
+          if (lo < nfaults && faults[lo].member == c) continue;
+          host = c;
+        }
+        if (host != NONE32) {
+          const uint32_t nrows = min(s.g[G_NSLOTS], s.R_phys), hl = host - s.lo;
+          for (uint32_t r = 0; r < nrows; ++r) {
+            if (!s.slot_used[r]) continue;
+            const uint32_t subject = s.subject_of[r];
+            if (subject == mbr) continue;
+            const uint32_t sb = s.slot_base[r], vh = s.V[vidx(s, hl, r)].x;
+            const uint32_t kh = subject == host ? ((s.hot[hl].x << 2) | ST_ALIVE) : (vh ? vh : sb);
+            const uint32_t vm = s.V[vidx(s, ml, r)].x, curk = vm ? vm : sb;
+            if (kh <= curk) continue;
+            s.V[vidx(s, ml, r)] = make_uint2(kh, t + 1);       // its deadline, if Suspect: the cells are rebuilt by merge_kernel
+            if (s.G) s.slot_last[r] = t;
+            evd += h4(TAG_EV, ((uint64_t)t << 32) | mbr, subject, kh) - h4(TAG_EV, ((uint64_t)t << 32) | mbr, subject, curk);
+            pulled++;
+          }
+        }
+      }
       if (s.event_mask & (1u << 4)) {
         uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
         if (pos < s.event_cap) s.events[pos] = make_uint4(t, mbr, mbr, (akey << 8) | 4u);
@@ -1140,11 +1172,13 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, co
     }
     if (evd) atomicAdd(&evd_sh, evd);
     if (dropped) atomicAdd(&dropped_sh, dropped);
+    if (pulled) atomicAdd(&changes_sh, pulled);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     if (evd_sh) s.blk[(size_t)s.nblocks * C_COUNT + C_EVDIGEST] += evd_sh;
     if (dropped_sh) s.blk[(size_t)s.nblocks * C_COUNT + C_EVENTS_DROPPED] += dropped_sh;
+    if (changes_sh) s.blk[(size_t)s.nblocks * C_COUNT + C_CHANGES] += changes_sh;
     s.g[G_PREV] = s.g[G_HEAD];
     s.g[G_HEAD] = s.g[G_NRUM];
     // a line is rewritten every tick and replaces ids outside [H - 64, H + RID_NEAR) by "no id"; an id born at

@@ -134,6 +134,8 @@ int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, std::string*
   if (c->n_shards > 16 || c->shard_index >= c->n_shards) { *err = "n_shards must be <= 16 and shard_index < n_shards"; return SWIMSIM_ERR_INVALID; }
   if (c->n_members % c->n_shards) { *err = "n_members must be a multiple of n_shards"; return SWIMSIM_ERR_INVALID; }
   if (c->target_scheme > SWIMSIM_TARGETS_ROBUST) { *err = "unknown target_scheme"; return SWIMSIM_ERR_INVALID; }
+  if (c->join_pull > 1) { *err = "join_pull must be 0 or 1"; return SWIMSIM_ERR_INVALID; }
+  if (c->n_shards > 1 && c->join_pull) { *err = "join_pull is not available on sharded handles (the join host may live on another shard)"; return SWIMSIM_ERR_INVALID; }
   if (c->n_shards > 1 && c->gc_ticks) { *err = "settling (gc_ticks) is not available on sharded handles yet"; return SWIMSIM_ERR_INVALID; }
   if (c->n_shards > 1 && c->target_scheme != SWIMSIM_TARGETS_RANDOM) { *err = "the robust target scheme is not available on sharded handles yet"; return SWIMSIM_ERR_INVALID; }
   if (c->n_shards > 1 && c->n_members > (1u << 27)) { *err = "sharded clusters: n_members must be <= 2^27"; return SWIMSIM_ERR_INVALID; }
@@ -284,6 +286,7 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   const uint32_t NT = c.n_members, N = NT / c.n_shards;   // N = members owned by this handle
   d.N = N; d.NT = NT; d.lo = c.shard_index * N; d.n_shards = c.n_shards; d.shard = c.shard_index;
   d.scheme = c.target_scheme;
+  d.join_pull = c.join_pull;
   d.P = (uint32_t)c.probes_per_tick; d.K = (uint32_t)c.indirect_k; d.S = c.suspicion_ticks;
   d.L = c.retransmit_mult * ceil_log2((uint64_t)NT + 1);
   {
@@ -444,8 +447,8 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
     hipEvent_t* ev = h->timing ? &h->ev_pool[(size_t)k * 3] : nullptr;
     const size_t f0 = fpos;
     while (fpos < fend && h->faults[fpos].tick <= t) ++fpos;
-    hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, h->d_faults + f0, (uint32_t)(fpos - f0));
     const uint32_t tk = tick_key(h->cfg.seed, t);
+    hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, (uint32_t)(fpos - f0));
     const uint32_t pk = std::max(h->d.P, h->d.K);   // registers follow the probe / proxy arrays: four sizes
     if (pk <= 4) launch_tick<4>(h, t, tk, ev);
     else if (pk <= 8) launch_tick<8>(h, t, tk, ev);
@@ -710,9 +713,9 @@ int swimsim_shard_phase1(swimsim_t* h, uint32_t* counts) {
   if (rc) return rc;
   if (h->timing && !h->tick_ev[0]) for (int k = 0; k < 3; ++k) HIPCHK(h, hipEventCreate(&h->tick_ev[k]));
   const uint32_t t = (uint32_t)h->tick;
-  hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, h->d_faults, (uint32_t)fend);
-  h->faults.erase(h->faults.begin(), h->faults.begin() + (long)fend);
   const uint32_t tk = tick_key(h->cfg.seed, t);
+  hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults, (uint32_t)fend);
+  h->faults.erase(h->faults.begin(), h->faults.begin() + (long)fend);
   if (h->timing) (void)hipEventRecord(h->tick_ev[0], h->stream);
   const uint32_t pk = std::max(h->d.P, h->d.K);
   if (pk <= 4) hipLaunchKernelGGL((probe_kernel<4>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, Offsets{});

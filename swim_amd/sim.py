@@ -42,6 +42,7 @@ def _to_c_config(sc: SimConfig, shard_index: int = 0, n_shards: int = 1) -> _abi
     c.shard_index = shard_index
     c.n_shards = n_shards
     c.target_scheme = sc.targetScheme
+    c.join_pull = sc.joinPull
     return c
 
 

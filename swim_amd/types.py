@@ -60,6 +60,7 @@ class SimConfig:
     inboxCap: int = 0
     device: int = 0
     targetScheme: int = 0         # 0 = kRandomMembers (reference), 1 = robust round-robin (src/Core.hs:232)
+    joinPull: int = 0             # 1 = a member that comes up pulls a join host's member map (joinHosts, src/Types.hs:47)
 
 
 def memberName(member_id: int) -> str:

@@ -260,7 +260,8 @@ def test_saturated_million_members_window_vs_oracle(oracle_abi, hip_abi):
 @pytest.mark.parametrize("block", range(3))
 def test_random_configurations_on_the_gpu(oracle_abi, hip_abi, block):
     """Seeded randomised sweep (the generator of tests/test_random_sweep.py, sizes up to 65 536): sizes,
-    probe counts, loss, crashes and rejoins, both target schemes, 1-8 shards, tiny inboxes, settling."""
+    probe counts, loss, crashes and rejoins (with and without the join-time pull), both target schemes, 1-8
+    shards, tiny inboxes, settling."""
     import random
     from swim_amd import _abi
     from swim_amd.shard import LocalFabric, ShardedSim
@@ -277,7 +278,8 @@ def test_random_configurations_on_the_gpu(oracle_abi, hip_abi, block):
         seed = rng.randrange(1, 1 << 30)
         sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, eventMask=0x1F if n <= 4096 else 0,
                        suspicionTicks=rng.choice([3, 6, 12]), retransmitMult=rng.choice([1, 3]), maxSubjects=min(n, 4096),
-                       targetScheme=scheme, inboxCap=rng.choice([0, 0, 1, 2]) if n <= 4096 else 0, gcTicks=gc)
+                       targetScheme=scheme, inboxCap=rng.choice([0, 0, 1, 2]) if n <= 4096 else 0, gcTicks=gc,
+                       joinPull=1 if shards == 1 and seed % 2 else 0)
         a = Sim.create(oracle_abi, sc)
         _oracle_threads(a)
         b = Sim.create(hip_abi, sc) if shards == 1 else ShardedSim(hip_abi, sc, LocalFabric(shards), device="cuda:0")
@@ -386,3 +388,28 @@ def test_settling_parity_and_bounded_rows(oracle_abi, hip_abi):
     for o in live:
         assert len(s.members(o)) < 400                               # the removed ones are gone from the map
     s.close()
+
+
+def test_join_pull_many_joins_at_64k(oracle_abi, hip_abi):
+    """join_pull at a size where begin_kernel's block has real work: 2 000 members down, 1 200 of them
+    back in three ticks (several hundred joins per tick, each merging a host's whole member map), settling on."""
+    from swim_amd import _abi
+    n = 65536
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=77, lossPpm=2000, suspicionTicks=8, maxSubjects=4096,
+                   gcTicks=_abi.GC_AUTO, joinPull=1)
+    a = Sim.create(oracle_abi, sc)
+    _oracle_threads(a)
+    b = Sim.create(hip_abi, sc)
+    for k in range(2000):
+        m = (k * 31 + 7) % n
+        for s in (a, b):
+            s.scheduleFault(2 + k % 5, m, False)
+            if k < 1200:
+                s.scheduleFault(30 + k % 3, m, True)
+    for _t in range(8):
+        a.step(10); b.step(10)
+        assert a.counters() == b.counters()
+        assert a.digest() == b.digest()
+    for o in ((7 % n), (31 + 7) % n, 5):
+        assert a.members(o) == b.members(o)
+    a.close(); b.close()

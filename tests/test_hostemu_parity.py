@@ -148,3 +148,22 @@ def test_rumour_id_counter_wraps(oracle_abi):
     a, b = make_pair(oracle_abi, emu, sc, crashes, faults)
     run_lockstep(a, b, 140, 10, observers=(0, 1, n - 1), members=(0, 1, n - 1))
     assert b.counters()["changes"] > 256 * 300                      # thousands of ids: many wraps
+
+
+@pytest.mark.parametrize("gc", [0, 1])
+def test_join_pull_parity_with_churn(oracle_abi, emu_abi, gc):
+    """join_pull: members that come back merge a host's member map in their join tick (begin_kernel) --
+    several joins in one tick, hosts that are skipped because they change in the same tick, pulled Suspect
+    entries whose deadline the joiner then keeps itself, with and without settling."""
+    from swim_amd import _abi
+    n = 300
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=21, lossPpm=30000, eventMask=0x1F, suspicionTicks=6,
+                   retransmitMult=2, maxSubjects=200 if gc else 300, gcTicks=_abi.GC_AUTO if gc else 0, joinPull=1)
+    crashes = [(2 + 3 * k, (11 * k + 5) % n) for k in range(60)]
+    faults = [(t + 4 + (k % 6) * 5, m, True) for k, (t, m) in enumerate(crashes) if k % 2 == 0]
+    faults += [(50, m, False) for m in range(100, 140)] + [(58, m, True) for m in range(100, 140)]   # 40 joins in one tick
+    faults += [(58, m, False) for m in range(140, 170)]                                              # 30 busy non-hosts
+    a, b = make_pair(oracle_abi, emu_abi, sc, crashes, faults)
+    run_lockstep(a, b, 260, 1 if not gc else 4, observers=(0, 100, 139, n - 1), members=(0, 100, 139, n - 1))
+    c = b.counters()
+    assert c["timers_fired"] > 0 and (not gc or c["settled"] > 20)

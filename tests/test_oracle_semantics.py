@@ -268,3 +268,41 @@ def test_settling_does_not_change_what_the_protocol_decides(oracle_abi):
 def test_gc_ticks_below_the_safe_horizon_are_refused(oracle_abi):
     err, s = Sim.configure(oracle_abi, _gc_config(64, 5))
     assert s is None and "gc_ticks" in err
+
+
+def test_join_pull_merges_a_hosts_member_map(oracle_abi):
+    """join_pull (include/swimsim.h "Join-time state pull"; `joinHosts`, src/Types.hs:47): a member that comes
+    back up learns in its join tick what a live host knows -- without it, it learns the same facts only rumour
+    by rumour, and facts whose rumours have already died down only through its own failed probes."""
+    n = 64
+    dead = [5, 9, 21, 33]
+
+    def run(pull):
+        sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=8, eventMask=0x1F, suspicionTicks=5, joinPull=pull)
+        s = Sim.create(oracle_abi, sc)
+        s.crash(40, 1)                                  # down before it can hear of anything
+        for k, m in enumerate(dead):
+            s.crash(m, 3 + k)
+        s.scheduleFault(60, 40, True)                   # long after the four rumours have died down
+        s.step(60)                                      # ticks 0..59
+        before = s.counters()["changes"]
+        s.step(1)                                       # tick 60: the join
+        view = {m.memberName: (int(m.memberAlive), m.memberIncarnation) for m in s.members(40)}
+        got = (view, s.counters()["changes"] - before)
+        s.step(40)
+        late = {m.memberName: int(m.memberAlive) for m in s.members(40)}
+        s.close()
+        return got, late
+
+    (v1, d1), late1 = run(1)
+    (v0, d0), late0 = run(0)
+    assert all(v1.get("m%d" % m) == (2, 0) for m in dead), v1       # Dead@0 for all four, at the join tick
+    assert d1 >= 4
+    assert not any(("m%d" % m) in v0 for m in dead)                   # without the pull: nothing at the join tick;
+    assert late0                                                      # it finds out later by its own failed probes
+    assert all(late1.get("m%d" % m) == 2 for m in dead)
+
+
+def test_join_pull_is_refused_where_it_is_not_defined(oracle_abi):
+    with pytest.raises(Exception):
+        Sim.create(oracle_abi, SimConfig(cfg=Config(numToGossip=3), nMembers=64, seed=1, joinPull=2))
