@@ -397,6 +397,12 @@ __device__ inline uint32_t park_rid(uint32_t lo, uint32_t H) {
 //   digest; then the piggyback queue `disseminate` leaves as a FIXME (src/Core.hs:136-138; D5) is rebuilt.
 // Delivered rumours arrive as masks: new = (pushed | pulled) & ~known is the whole filter, and the
 // lanes of a wave walk their new bits in the same order, so their view / timer accesses coalesce.
+#ifndef PSTAT                   // tests/hostemu -DSWIM_PATH_STATS counts how often a site runs per lane / per wave
+#define PSTAT(...) ((void)0)
+#define PSITE(x) ((void)0)
+#else
+#define PSITE(x) (psite = (x))
+#endif
 #ifndef SWIM_GOSSIP_BATCH       // rumours whose loads are issued together in merge_kernel
 #define SWIM_GOSSIP_BATCH 4
 #endif
@@ -489,8 +495,10 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
   TimerCell tnew; tnew.lo = 0; tnew.hi = 0; tnew.n = 0;   // deadlines t + S: go to the row just consumed
 
   if (act) {
+    PSTAT(0);
     kn = s.pk[li].y & ~stale;
     if (pcount) {
+      PSTAT(1);
 #pragma unroll
       for (int h = 0; h < PB_SLOTS / 2; ++h) {
         const uint4 v = own_line[h];
@@ -507,12 +515,15 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
   };
   auto group_put = [&](uint32_t slot, uint32_t rid, uint32_t key, uint32_t subj) {
     uint32_t pos = 0;
+    PSTAT(2);
     for (uint32_t k = 0; k < gn; ++k) {
+      PSTAT(3);
       if (pe_slot(asm_[2 * k][tid]) == slot) { asm_[2 * k][tid] = pe_lo(slot, rid); asm_[2 * k + 1][tid] = key; return; }
       pos += gsubj[k][tid] < subj ? 1u : 0u;
     }
     if (pos >= (uint32_t)PB_SLOTS) return;                  // worse than the 8 kept (largest subjects drop)
     for (uint32_t k = min(gn, (uint32_t)PB_SLOTS - 1u); k > pos; --k) {
+      PSTAT(4);
       asm_[2 * k][tid] = asm_[2 * k - 2][tid]; asm_[2 * k + 1][tid] = asm_[2 * k - 1][tid]; gsubj[k][tid] = gsubj[k - 1][tid];
     }
     asm_[2 * pos][tid] = pe_lo(slot, rid); asm_[2 * pos + 1][tid] = key; gsubj[pos][tid] = subj;
@@ -535,6 +546,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     tnew.n++;
   };
   // `pre` = the caller already holds the view cell, the row's base and its subject (loaded in a batch, below)
+  int psite = 47; (void)psite;     // PSITE/PSTAT: path statistics of the host emulation, nothing in the product
   auto examine_with = [&](uint32_t slot, uint32_t key, uint32_t cause, bool hasrid, uint32_t rid_in, bool pre, uint2 e,
                           uint32_t sbase, uint32_t subject) {
     if (slot + 1 == my_slot1) {
@@ -543,9 +555,11 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
       return;
     }
     examined++;
+    PSTAT(5);
     if (!pre) e = s.V[vidx(s, li, slot)];
     const uint32_t curk = e.x ? e.x : (pre ? sbase : s.slot_base[slot]);   // untouched cell: the settled base
     if (key <= curk) return;                     // old incarnation / weaker state: ignore (:151)
+    PSTAT(6); PSTAT(psite);
     s.V[vidx(s, li, slot)] = make_uint2(key, t + 1);                    // memberLastChange = now (:176)
     if (s.G) s.slot_last[slot] = t;              // same value from every writer
     if (!pre) subject = s.subject_of[slot];
@@ -579,7 +593,9 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
   };
   if (act) {
     // phase 1: suspicion deadlines, evaluated on the start-of-tick view
+    PSITE(20);
     if (woke || (uint32_t)(due.w >> 16) == TR_FULL) {
+      PSTAT(7);
       // a member that just came back up (its cells may be stale, their chains gone) or a cell that says "look
       // everywhere": every view row is a candidate.  The member that came back also rebuilds its cells from
       // what it finds: deadlines still ahead go to the cell of their tick.
@@ -606,6 +622,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
         for (uint32_t k = 0; k < TR_PAY; ++k) {
           const uint32_t v = tc_get(cell, k);
           if (!v) break;
+          PSTAT(8);
           deadline(v - 1);
         }
         const uint32_t link = cell.w >> 16;
@@ -614,7 +631,9 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
       }
     }
     // phase 2: own probes that ended without any ack: Suspect at the viewed incarnation
+    PSITE(21);
     for (uint32_t f = 0; f < nfail; ++f) {
+      PSTAT(9);
       const uint32_t j = s.fail[(size_t)li * s.P + f];
       const uint32_t sl = (s.minfo[j] & MI_SLOT) - 1;
       const uint2 e = s.V[vidx(s, li, sl)];
@@ -635,6 +654,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     unsigned long long fresh = (pushed | pulled) & ~kn;
     kn |= fresh;
     while (fresh) {
+      PSTAT(10);
       uint32_t rid[GB]; uint2 r[GB]; uint2 e[GB]; uint32_t sb[GB], sj[GB];
       uint32_t n = 0;
 #pragma unroll
@@ -657,6 +677,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
 #pragma unroll
       for (int k = 0; k < GB; ++k) {
         if ((uint32_t)k >= n) continue;
+        PSTAT(11); PSITE(22 + k);
         // two rumours about one subject in a batch (Suspect and Dead arriving together): the later one looks at
         // the cell again (this thread's own store is visible to it)
         bool again = false;
@@ -671,7 +692,9 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
       // explicit records: the sources' 64-B lines (queues the masks could not carry in full)
       const uint32_t nin = cnt < s.inbox_cap ? cnt : s.inbox_cap;
       const uint32_t novf = cnt > s.inbox_cap ? min(s.g[G_OVF0 + (t & 1u)], s.ovf_cap) : 0u;
+      PSITE(30);
       for (uint32_t x = 0; x < nack + nin + novf; ++x) {
+        PSTAT(12);
         uint32_t srcw = NONE32;
         if (x < nack) srcw = s.ackfrom[(size_t)li * s.P + x];
         else if (x < nack + nin) srcw = s.inbox[(size_t)li * s.inbox_cap + (x - nack)];
@@ -680,6 +703,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
           if (o.x == li) srcw = o.y;
         }
         if (srcw == NONE32) continue;
+        PSTAT(13);
         const uint4* line = (srcw & SRC_FOREIGN) ? s.fl + (size_t)(srcw & (SRC_FOREIGN - 1u)) * 4
                                                  : line_ptr(s, srcw >> 31, srcw & 0x7FFFFFFFu);
         for (int h = 0; h < PB_SLOTS / 2; ++h) {
@@ -693,6 +717,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
               if (kn & rid_bit(rid)) continue;     // view already dominates it
               kn |= rid_bit(rid);
             }
+            PSTAT(14);
             examine(pe_slot(lo), pe_key(hi), 2u, true, rid);
           }
         }
@@ -705,6 +730,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
       uint32_t ni = refute + 1;
       if (ni > INC_MAX) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_INC); ni = INC_MAX; }
       self_inc = ni;
+      PSTAT(15);
       evd += h4(TAG_INC, ((uint64_t)t << 32) | i, ni, 0);
       refutes = 1;
       const uint32_t akey = (ni << 2) | ST_ALIVE;
@@ -744,6 +770,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
         for (int w = 0; w < 2; ++w) {
           const uint32_t lo = w ? v.z : v.x, hi = w ? v.w : v.y, tx = pe_tx(hi);
           if (tx > age && !((killmask >> (2 * h + w)) & 1u) && nout < (uint32_t)PB_SLOTS) {
+            PSTAT(16);
             asm_[2 * nout][tid] = publish(lo);
             asm_[2 * nout + 1][tid] = pe_hi(pe_key(hi), tx - age);
             nout++;
@@ -752,7 +779,9 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
       }
     }
     for (uint32_t k = nout; k < (uint32_t)PB_SLOTS; ++k) { asm_[2 * k][tid] = 0u; asm_[2 * k + 1][tid] = 0u; }
+    PSTAT(17, gn);
     if (nout) {
+      PSTAT(18);
       wflag = 1u | ((cur ^ 1u) << 1);              // the line itself is stored below, a whole wave at a time
       set_mi(s, i, (mi & ~MI_PB) | (nout << MI_PBN_SHIFT) | ((cur ^ 1u) << 20) | oow);
     } else if (pcount) {

@@ -172,7 +172,40 @@ void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, Args... args) {
     }, &ctx);
   }
 }
+// ---- path statistics (-DSWIM_PATH_STATS): how often each marked site of a kernel runs, per lane and per wave
+// (a wave executes a site max-over-its-lanes times): the divergence profile of DESIGN.md section 6
+constexpr int PSTAT_SITES = 48;
+struct PStat { std::vector<uint32_t> tab; uint32_t nthreads = 0; bool on = false; };
+inline PStat& pstat_state() { static PStat p; return p; }
+inline void pstat(int site, uint32_t n = 1) {
+  PStat& p = pstat_state();
+  if (!p.on) return;
+  const uint32_t g = bidx().x * bdim().x + tidx().x;
+  if (g >= p.nthreads) return;
+  p.tab[(size_t)site * p.nthreads + g] += n;
+}
 }  // namespace hostemu
+extern "C" __attribute__((used, visibility("default"))) void hostemu_pstat_begin(uint32_t nthreads) {
+  hostemu::PStat& p = hostemu::pstat_state();
+  p.nthreads = nthreads; p.tab.assign((size_t)hostemu::PSTAT_SITES * nthreads, 0u); p.on = true;
+}
+// out[site] = {sum over lanes, sum over waves of the max over lanes, waves with a non-zero lane}
+extern "C" __attribute__((used, visibility("default"))) void hostemu_pstat_end(uint64_t* out) {
+  hostemu::PStat& p = hostemu::pstat_state();
+  for (int s = 0; s < hostemu::PSTAT_SITES; ++s) {
+    uint64_t sum = 0, wsum = 0, wn = 0;
+    for (uint32_t w = 0; w < p.nthreads; w += 64) {
+      uint32_t mx = 0;
+      for (uint32_t l = w; l < w + 64 && l < p.nthreads; ++l) { const uint32_t v = p.tab[(size_t)s * p.nthreads + l]; sum += v; mx = v > mx ? v : mx; }
+      wsum += mx; wn += mx ? 1 : 0;
+    }
+    out[3 * s] = sum; out[3 * s + 1] = wsum; out[3 * s + 2] = wn;
+  }
+  p.on = false;
+}
+#ifdef SWIM_PATH_STATS
+#define PSTAT(...) hostemu::pstat(__VA_ARGS__)
+#endif
 
 #define threadIdx (hostemu::tidx())
 #define blockIdx (hostemu::bidx())
