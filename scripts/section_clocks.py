@@ -1,0 +1,50 @@
+"""Where the waves of probe_kernel / merge_kernel spend their time (MI355X): the -DSWIM_SECTION_CLOCKS build adds,
+per wave, the shader clocks between marks in the kernels to a table (swim_kernels.h SECT).  Time waiting for a
+load is charged to the section that first USES the value.  usage: section_clocks.py [libswimsim_sect.so]
+env: WARM, TICKS, MEMBERS, SCHEME=robust, GC=1, LOSS (ppm)"""
+import ctypes as C
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from swim_amd import Sim, workloads, _abi                      # noqa: E402
+
+MERGE = ["inputs", "own line -> oslot", "deadlines + failed probes", "delivered rumours (masks)", "explicit records + refute",
+         "queue rebuild", "state stores + counters", "barrier", "line store", "counter flush"]
+PROBE = ["target selection", "outcomes + pk gathers", "ping pushes", "acks", "indirect probes", "outputs + counters", "counter flush"]
+
+
+def main():
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "swim_amd", "csrc", "libswimsim_sect.so")
+    warm, ticks, n = int(os.environ.get("WARM", 150)), int(os.environ.get("TICKS", 100)), int(os.environ.get("MEMBERS", 1 << 20))
+    lib = C.CDLL(os.path.abspath(path))
+    abi = _abi.bind(lib, "swimsim_")
+    lib.swimsim_debug_sections.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    sc, crashes, _ = workloads.saturated(n, warm + ticks, loss_ppm=int(os.environ.get("LOSS", 0)))
+    sc.targetScheme = 1 if os.environ.get("SCHEME") == "robust" else 0
+    if os.environ.get("GC"):
+        sc.gcTicks = _abi.GC_AUTO
+    s = Sim.create(abi, sc)
+    workloads.apply_crashes(s, crashes)
+    s.step(warm)
+    out = (C.c_uint64 * 64)()
+    lib.swimsim_debug_sections(s._h, out)   # zero the table
+    s.kernelTimingEnable(True)
+    s.step(ticks)
+    kt = s.kernelTiming()
+    lib.swimsim_debug_sections(s._h, out)
+    res = {"members": n, "ticks": ticks, "probe_us": kt["probe_ms"] * 1e3 / kt["ticks"], "merge_us": kt["merge_ms"] * 1e3 / kt["ticks"]}
+    for name, base, labels in (("merge_kernel", 0, MERGE), ("probe_kernel", 32, PROBE)):
+        waves = out[base + 15]
+        tot = sum(out[base + k] for k in range(len(labels)))
+        rows = {lab: {"clocks_per_wave": round(out[base + k] / max(1, waves), 1), "share": round(out[base + k] / max(1, tot), 4)}
+                for k, lab in enumerate(labels)}
+        res[name] = {"waves": waves, "clocks_per_wave": round(tot / max(1, waves), 1), "sections": rows}
+    print(json.dumps(res, indent=1))
+    s.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -34,9 +34,47 @@ __device__ inline void ctr_add(BlockCounters* sh, int which, unsigned x) {
   if (x) atomicAdd(&sh->v[which], x);
 }
 
+// Block barrier that orders LDS traffic only.  __syncthreads() also waits until every global store and atomic the
+// wave has in flight is acknowledged (s_waitcnt vmcnt(0)): after a kernel's scattered stores that is thousands
+// of clocks per wave (profiles/r02u_sections.txt) for data nobody in the block reads.
+__device__ inline void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// the same between the lanes of one wave (LDS executes a wave's instructions in order)
+__device__ inline void lds_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+
+// Sum over the 64 lanes of a wave, returned to every lane.  ALL 64 lanes must be executing (call at wave-uniform
+// points).  Hand-written DPP prefix steps + one lane read: left to the compiler, a per-lane atomicAdd on one LDS
+// word becomes a scalar loop over the active lanes (~6 SALU instructions x 64 per counter -- most of the 2 300
+// scalar instructions a wave of merge_kernel used to execute, profiles/r02a_pmc_summary.txt).
+#define SWIM_DPP(v, ctrl, rows) ((unsigned)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rows, 0xf, false))
 __device__ inline unsigned wave_sum(unsigned x) {
-  for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
-  return x;
+  x += SWIM_DPP(x, 0x111, 0xf);        // row_shr:1
+  x += SWIM_DPP(x, 0x112, 0xf);        // row_shr:2
+  x += SWIM_DPP(x, 0x114, 0xf);        // row_shr:4
+  x += SWIM_DPP(x, 0x118, 0xf);        // row_shr:8   lane 15 of each row of 16 = the row's sum
+  x += SWIM_DPP(x, 0x142, 0xa);        // row_bcast:15 into rows 1 and 3
+  x += SWIM_DPP(x, 0x143, 0xc);        // row_bcast:31 into rows 2 and 3: lane 63 = the wave's sum
+  return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+__device__ inline unsigned long long wave_sum64(unsigned long long x) {
+#define SWIM_DPP64(ctrl, rows) x += (unsigned long long)SWIM_DPP((uint32_t)x, ctrl, rows) | ((unsigned long long)SWIM_DPP((uint32_t)(x >> 32), ctrl, rows) << 32)
+  SWIM_DPP64(0x111, 0xf); SWIM_DPP64(0x112, 0xf); SWIM_DPP64(0x114, 0xf); SWIM_DPP64(0x118, 0xf);
+  SWIM_DPP64(0x142, 0xa); SWIM_DPP64(0x143, 0xc);
+#undef SWIM_DPP64
+  return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, 63) |
+         ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), 63) << 32);
+}
+// a per-lane count into the block's counter: one LDS atomic per wave (wave-uniform call)
+__device__ inline void ctr_add_wave(BlockCounters* sh, int which, unsigned x) {
+  const unsigned tot = wave_sum(x);
+  if ((threadIdx.x & 63u) == 0u && tot) atomicAdd(&sh->v[which], tot);
 }
 __device__ inline unsigned wave_max(unsigned x) {            // lane 0 holds the result
   for (int o = 32; o > 0; o >>= 1) { const unsigned y = __shfl_down(x, o, 64); x = y > x ? y : x; }
@@ -44,10 +82,11 @@ __device__ inline unsigned wave_max(unsigned x) {            // lane 0 holds the
 }
 
 __device__ inline void ctr_flush(const DevState& s, BlockCounters* sh, uint32_t row) {
-  __syncthreads();
+  lds_barrier();
   if (threadIdx.x < C_COUNT) {
     unsigned long long x = threadIdx.x == C_EVDIGEST ? sh->evd : (unsigned long long)sh->v[threadIdx.x];
-    if (x) s.blk[(size_t)row * C_COUNT + threadIdx.x] += x;
+    // the row has one writer; an atomic without return so that the wave does not wait for the old value
+    if (x) atomicAdd(reinterpret_cast<unsigned long long*>(&s.blk[(size_t)row * C_COUNT + threadIdx.x]), x);
   }
 }
 
@@ -104,6 +143,17 @@ __device__ inline uint32_t get_slot(const DevState& s, uint32_t j) {
   return v - 1u;
 }
 
+// -DSWIM_SECTION_CLOCKS (measurement build, scripts/section_clocks.py): every wave adds the shader clocks it
+// spent between two marks to a table behind the counter rows; nothing of it is in the product build
+#ifdef SWIM_SECTION_CLOCKS
+#define SECT_BEGIN(base) unsigned long long sect_t_ = clock64(); SECT_ADD((base) + 15, 1ull)
+#define SECT_ADD(k, v) do { const unsigned long long b_ = __ballot(1); \
+    if ((threadIdx.x & 63u) == (uint32_t)(__ffsll(b_) - 1)) atomicAdd(reinterpret_cast<unsigned long long*>(&s.blk[((size_t)s.nblocks + 1) * C_COUNT + (blockIdx.x & 63u) * 64u + (k)]), (unsigned long long)(v)); } while (0)
+#define SECT(k) do { const unsigned long long n_ = clock64(); SECT_ADD(k, n_ - sect_t_); sect_t_ = clock64(); } while (0)
+#else
+#define SECT_BEGIN(base) ((void)0)
+#define SECT(k) ((void)0)
+#endif
 // ================================================================================================
 // probe kernel
 // ================================================================================================
@@ -137,7 +187,9 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
   const bool use_mask = H - Hprev <= MASK_SLACK;
   const unsigned long long stale = stale_positions(Hprev, H);   // ring positions nobody may trust this tick
   unsigned n_pings = 0;
+  unsigned payloads = 0, rumors = 0, dfail = 0, preqs = 0, susp = 0, fsusp = 0;
   unsigned long long ackacc = 0;                  // masks this member pulls in with its Acks
+  SECT_BEGIN(32);
   if (act) {
     const uint32_t mk = mix32(tk ^ i);
     const uint32_t mycnt = mi_pbn(mi);
@@ -168,8 +220,8 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
         }
       }
     }
+    SECT(32);                                       // target selection
     uint32_t nfail = 0, nack = 0;
-    unsigned payloads = 0, rumors = 0, dfail = 0, preqs = 0, susp = 0, fsusp = 0;
     // a delivery this shard cannot complete alone: the exchange routes it
     auto emit_raw = [&](uint32_t x, uint32_t y, unsigned long long m) {
       const uint32_t pos = atomicAdd(&ordn, 1u);
@@ -214,6 +266,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
       if (use_mask && ping_ok[p] && is_local(s, picks[p]) && (mymask || (ack_ok[p] && mi_pbn(pinfo[p]))))
         tk2[p] = s.pk[picks[p] - s.lo];
     }
+    SECT(33);                                       // outcomes + the targets' pk gathers issued
     // pass 3: the Pings' piggyback payloads: at most one atomicOr per target
     if (mycnt) {
       uint32_t pos[PMAX];
@@ -240,6 +293,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
           if (ping_ok[p] && is_local(s, picks[p])) push_commit(s, t, picks[p] - s.lo, mi_src(li, mi), pos[p]);
       }
     }
+    SECT(34);                                       // pushes
     if (robust) {
       // the Pings that reach ME this period: probe p of member q = i - o(t,p), if q is up, sees me Alive
       // and the Ping is not lost.  I merge q's queue: a gather instead of q's atomicOr.
@@ -273,6 +327,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
         payloads++; rumors += pj;
       }
     }
+    SECT(35);                                       // Acks
     // pass 5 (rare): probes without an ack -> k indirect probes -> maybe Suspect
     for (int p = 0; p < PMAX; ++p) {
       if ((uint32_t)p >= np) break;
@@ -313,20 +368,24 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
       if (upj) fsusp++;
       else atomicMin(&s.first_suspect[j], t);
     }
+    SECT(36);                                       // indirect probes
     s.probe_out[li] = (uint16_t)(n_pings | (nfail << 5) | (nack << 10));
-    ctr_add(&sh, C_PAYLOADS, payloads);
-    ctr_add(&sh, C_RUMORS_SEEN, rumors);
-    ctr_add(&sh, C_DIRECT_FAILED, dfail);
-    ctr_add(&sh, C_PING_REQS, preqs);
-    ctr_add(&sh, C_SUSPECTS, susp);
-    ctr_add(&sh, C_FALSE_SUSPECTS, fsusp);
   }
   if (li < s.N) s.ackmask[li] = ackacc;
-  // the two always-nonzero counters: wave-reduce first
-  unsigned wp = wave_sum(n_pings);
-  unsigned wa = wave_sum(act ? 1u : 0u);
-  if ((threadIdx.x & 63) == 0) { ctr_add(&sh, C_PINGS, wp); ctr_add(&sh, C_ACTIVE, wa); }
+  ctr_add_wave(&sh, C_PINGS, n_pings);
+  ctr_add_wave(&sh, C_ACTIVE, act ? 1u : 0u);
+  ctr_add_wave(&sh, C_PAYLOADS, payloads);
+  ctr_add_wave(&sh, C_RUMORS_SEEN, rumors);
+  // the rare ones: a wave-uniform test first
+  if (__ballot((dfail | susp) != 0u)) {
+    ctr_add_wave(&sh, C_DIRECT_FAILED, dfail);
+    ctr_add_wave(&sh, C_PING_REQS, preqs);
+    ctr_add_wave(&sh, C_SUSPECTS, susp);
+    ctr_add_wave(&sh, C_FALSE_SUSPECTS, fsusp);
+  }
+  SECT(37);                                         // outputs, counters
   ctr_flush(s, &sh, blockIdx.x);
+  SECT(38);
   if (s.n_shards > 1 && threadIdx.x == 0) s.ord_cnt[blockIdx.x] = ordn < s.ord_cap ? ordn : s.ord_cap;
 }
 
@@ -442,6 +501,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
   const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
   const uint32_t i = s.lo + li;                    // global id
   const uint32_t tid = threadIdx.x;
+  SECT_BEGIN(0);
   if (blockIdx.x == 0 && threadIdx.x == 0) s.g[G_OVF0 + ((t + 1) & 1u)] = 0;  // next tick's overflow list
   const uint32_t mi = li < s.N ? s.minfo[i] : 0u;
   const bool up = mi_up(mi);
@@ -454,7 +514,10 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
   unsigned long long pushed = 0, pulled = 0;
   uint2 hot0 = make_uint2(0u, 0u);
   uint4 due = make_uint4(0u, 0u, 0u, 0u);          // deadline row of this tick
-  const size_t trix = (size_t)(t % s.S) * s.N + li;
+  // this tick's deadline row: a wave-uniform base (scalar registers) indexed by li at both ends of the kernel --
+  // a 64-bit per-lane index held from the load to the final store was spilled to scratch, and its reload waited
+  // for every store the wave had in flight
+  uint4* const trow_now = s.trow + (size_t)(t % s.S) * s.N;
   if (up) {
     const uint32_t po = s.probe_out[li];
     nsent = po & 31u; nfail = (po >> 5) & 31u; nack = po >> 10;
@@ -467,7 +530,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
         if (v) { pulled |= v; s.ackslot[(size_t)li * s.P + p] = 0; }
       }
     hot0 = s.hot[li];
-    due = s.trow[trix];
+    due = trow_now[li];
   }
   const uint32_t pcount = mi_pbn(mi), cur = mi_buf(mi);
   const bool woke = (hot0.y & 1u) != 0;            // came back up: deadlines it slept through are still in trow
@@ -490,10 +553,11 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
   const uint4* own_line = reinterpret_cast<const uint4*>(s.pb + ((size_t)cur * s.N + (li < s.N ? li : 0u)) * PB_SLOTS);
   const uint32_t my_slot1 = mi & MI_SLOT;          // slot+1 of rumours about me
   uint32_t refute = NONE32;
-  unsigned changes = 0, timers_fired = 0, evdropped = 0, examined = 0;
+  unsigned changes = 0, timers_fired = 0, evdropped = 0, examined = 0, refutes = 0, pb_writes = 0;
   unsigned long long evd = 0, ha = 0;
   TimerCell tnew; tnew.lo = 0; tnew.hi = 0; tnew.n = 0;   // deadlines t + S: go to the row just consumed
 
+  SECT(0);                                          // inputs
   if (act) {
     PSTAT(0);
     kn = s.pk[li].y & ~stale;
@@ -591,6 +655,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     if (e.y - 1 + s.S <= t) examine(slot, (e.x & ~3u) | ST_DEAD, 1u, false, 0u);
     else if ((e.y - 1 + s.S) % s.S == row_now) tput(slot + 1);
   };
+  SECT(1);                                          // own line
   if (act) {
     // phase 1: suspicion deadlines, evaluated on the start-of-tick view
     PSITE(20);
@@ -649,6 +714,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
   // The loads are batched: a member's next GB positions are decoded together -- their rum[] entries in one
   // round of loads, then their view cells, row bases and subjects in a second one -- instead of three
   // dependent loads per rumour (the kernel waits on such chains most of its time, profiles/r02a_pmc_summary.txt).
+  SECT(2);                                          // deadlines, failed probes
   if (act) {
     constexpr int GB = SWIM_GOSSIP_BATCH;
     unsigned long long fresh = (pushed | pulled) & ~kn;
@@ -687,6 +753,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
       }
     }
   }
+  SECT(3);                                          // delivered rumours
   if (act) {
     if (cnt | nack) {
       // explicit records: the sources' 64-B lines (queues the masks could not carry in full)
@@ -725,7 +792,6 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     }
     // ---- refutation: bump own incarnation past the rumour's (src/Core.hs:155-166; D10); rumours at
     // an incarnation below my own are stale and ignored (:151)
-    unsigned refutes = 0;
     if (refute != NONE32 && refute >= self_inc) {
       uint32_t ni = refute + 1;
       if (ni > INC_MAX) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_INC); ni = INC_MAX; }
@@ -746,6 +812,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     // ---- rebuild the queue: [this tick's group, by subject][aged survivors, order kept], best 8 (D5),
     // assembled in LDS columns, then written as one 64-B line together with its mask.  Every period costs
     // a rumour at least one transmission (age >= 1), so old entries never tie with this tick's group.
+    SECT(4);                                        // explicit records, refutation
     const uint32_t age = nsent ? nsent : 1u;
     uint32_t nout = gn;
     unsigned long long qmask = 0;
@@ -787,24 +854,33 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     } else if (pcount) {
       set_mi(s, i, mi & ~MI_PB);
     }
+    SECT(5);                                        // queue rebuilt
     s.pk[li] = make_ulonglong2(nout ? qmask : 0ull, kn);
     if (pushed) s.inmask[li] = 0;
-    if (timer_due || tnew.n || woke) s.trow[trix] = tc_pack(tnew);   // consumed and refilled in one store
+    if (timer_due || tnew.n || woke) trow_now[li] = tc_pack(tnew);   // consumed and refilled in one store
     if (self_inc != hot0.x || woke) s.hot[li] = make_uint2(self_inc, hot0.y & ~1u);
     if (cnt) s.inbox_cnt[li] = 0;
-    ctr_add(&sh, C_CHANGES, changes);
-    ctr_add(&sh, C_PB_WRITES, (pcount || nout) ? 1u : 0u);
-    ctr_add(&sh, C_TIMERS_FIRED, timers_fired);
-    ctr_add(&sh, C_REFUTES, refutes);
-    ctr_add(&sh, C_EVENTS_DROPPED, evdropped);
-    ctr_add(&sh, C_EXAMINED, examined);
-    if (evd) atomicAdd(&sh.evd, evd);
+    pb_writes = (pcount || nout) ? 1u : 0u;
+  }
+  ctr_add_wave(&sh, C_CHANGES, changes);
+  ctr_add_wave(&sh, C_PB_WRITES, pb_writes);
+  ctr_add_wave(&sh, C_EXAMINED, examined);
+  {
+    const unsigned long long wevd = wave_sum64(evd);
+    if ((tid & 63u) == 0u && wevd) atomicAdd(&sh.evd, wevd);
+  }
+  if (__ballot((timers_fired | refutes | evdropped) != 0u)) {   // the rare ones: a wave-uniform test first
+    ctr_add_wave(&sh, C_TIMERS_FIRED, timers_fired);
+    ctr_add_wave(&sh, C_REFUTES, refutes);
+    ctr_add_wave(&sh, C_EVENTS_DROPPED, evdropped);
   }
   // ---- store the rebuilt lines.  L2 does not merge a lane's four 16-B pieces into one fabric write, so
   // the wave stores its 64 lines transposed: instruction k, lane l writes piece (l & 3) of the line of
   // member 16 k + (l >> 2): every instruction covers 1 KB of contiguous memory in full 128-B lines.
+  SECT(6);                                          // state stores, counters
   wfl[tid] = wflag;
-  __syncthreads();
+  lds_wave_sync();                                  // a wave stores its own 64 lines: nothing crosses waves here
+  SECT(7);                                          // barrier
   {
     const uint32_t wbase = tid & ~63u, lane = tid & 63u, q = lane & 3u;
 #pragma unroll
@@ -818,7 +894,9 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
       }
     }
   }
+  SECT(8);                                          // line store
   ctr_flush(s, &sh, blockIdx.x);
+  SECT(9);
 }
 
 // ================================================================================================

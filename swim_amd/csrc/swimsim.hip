@@ -345,7 +345,7 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   HK(hipHostMalloc(reinterpret_cast<void**>(&h->h_sync), G_WORDS * sizeof(uint32_t)));
   CK(dev_alloc(h, &d.ovf, (size_t)2 * d.ovf_cap, 0));
   CK(dev_alloc(h, &d.events, (size_t)d.event_cap, 0));
-  CK(dev_alloc(h, &d.blk, ((size_t)d.nblocks + 1) * C_COUNT, 0));
+  CK(dev_alloc(h, &d.blk, ((size_t)d.nblocks + 1) * C_COUNT + 4096, 0));   // + the section-clock table of the measurement build
   CK(dev_alloc(h, &h->d_scratch64, (size_t)1, 0));
   if (d.n_shards > 1) {
     // exchange buffers, sized from the expected traffic (2P deliveries per member, spread over the shards)
@@ -622,6 +622,20 @@ int swimsim_table_stats(swimsim_t* h, uint64_t* out, size_t n) {
   out[0] = g[G_NSLOTS]; out[1] = g[G_NLIVE]; out[2] = g[G_NFREE]; out[3] = g[G_NRUM]; out[4] = h->d.R_phys;
   return SWIMSIM_OK;
 }
+
+#ifdef SWIM_SECTION_CLOCKS
+// measurement build only (scripts/section_clocks.py): the 64 section-clock words (summed over their 64 copies), then zeroed
+int swimsim_debug_sections(swimsim_t* h, uint64_t* out) {
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  uint64_t* p = h->d.blk + ((size_t)h->d.nblocks + 1) * C_COUNT;
+  std::vector<uint64_t> tab(4096);
+  HIPCHK(h, hipMemcpy(tab.data(), p, tab.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemset(p, 0, tab.size() * sizeof(uint64_t)));
+  for (int k = 0; k < 64; ++k) { out[k] = 0; for (int c = 0; c < 64; ++c) out[k] += tab[(size_t)c * 64 + k]; }
+  return SWIMSIM_OK;
+}
+#endif
 
 int swimsim_k_random_members(swimsim_t* h, uint32_t observer, uint32_t n, const uint32_t* excludes,
                              size_t n_excludes, uint32_t* out, size_t cap, size_t* n_out) {

@@ -266,6 +266,46 @@ static inline unsigned long long __ballot(int pred) {
   return m;
 }
 
+// DPP / lane-read builtins the kernels use for wave reductions (swim_kernels.h wave_sum): gfx9 semantics of
+// v_mov_b32_dpp for row_shr:n (0x110 + n), row_bcast:15 (0x142), row_bcast:31 (0x143); a lane whose source is
+// invalid or whose row / bank is masked off keeps `old`
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  auto& s = hostemu::sched();
+  const uint32_t tid = hostemu::tidx().x;
+  s.exch[tid] = (uint32_t)src;
+  hostemu::wave_yield();
+  const uint32_t base = tid - tid % 64u, lane = tid % 64u, row = lane / 16u, inrow = lane % 16u;
+  int out = old;
+  if (((row_mask >> row) & 1) && ((bank_mask >> (inrow / 4u)) & 1)) {
+    int srcl = -1;
+    if (ctrl >= 0x111 && ctrl <= 0x11F) { const uint32_t n = (uint32_t)ctrl - 0x110u; if (inrow >= n) srcl = (int)(lane - n); }
+    else if (ctrl == 0x142) { if (row >= 1) srcl = (int)(row * 16u - 1u); }
+    else if (ctrl == 0x143) { if (row >= 2) srcl = 31; }
+    else abort();
+    if (srcl >= 0) out = (int)(uint32_t)s.exch[base + (uint32_t)srcl];
+    else if (bound_ctrl) out = 0;
+  }
+  hostemu::wave_yield();
+  s.exch[tid] = 0;
+  return out;
+}
+static inline int __builtin_amdgcn_readlane(int v, int lane) {
+  auto& s = hostemu::sched();
+  const uint32_t tid = hostemu::tidx().x;
+  s.exch[tid] = (uint32_t)v;
+  hostemu::wave_yield();
+  const int out = (int)(uint32_t)s.exch[tid - tid % 64u + (uint32_t)lane];
+  hostemu::wave_yield();
+  s.exch[tid] = 0;
+  return out;
+}
+// s_waitcnt: nothing is in flight here; s_barrier: the block barrier; wave_barrier: lanes are fibres, a yield
+// lets every lane of the wave reach this point first
+static inline void __builtin_amdgcn_s_waitcnt(int) {}
+#define __builtin_amdgcn_fence(...) ((void)0)
+static inline void __builtin_amdgcn_s_barrier() { hostemu::barrier(); }
+static inline void __builtin_amdgcn_wave_barrier() { hostemu::wave_yield(); }
+
 // ---- atomics (fibres never run concurrently: plain read-modify-write is atomic) ----------------------
 template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, int v) { unsigned o = *p; *p = o + (unsigned)v; return o; }
