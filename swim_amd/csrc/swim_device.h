@@ -98,6 +98,7 @@ struct DevState {
   unsigned long long* inmask;   // OR of the masks pushed to this member this tick (atomicOr by the pingers)
   unsigned long long* ackmask;  // OR of the masks this member pulled with its Acks (plain store by the prober)
   uint2* rum;              // [1 << RID_BITS] rumour id -> {slot, key}
+  uint4* ring;             // [64] this tick's ring, built by begin_kernel: position -> {slot, key, row base, subject}
   unsigned long long* rtab;// [R_max][RT_WAYS] (slot, key) -> rumour id: {key+1 : 32 | ready : 1 | rid : 16}
   // explicit delivery records "dst merges src's 64-B line": the exact fallback for queues with
   // entries outside the mask window, and for ticks that follow a burst of new rumour ids

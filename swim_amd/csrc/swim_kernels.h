@@ -462,11 +462,14 @@ __device__ inline uint32_t park_rid(uint32_t lo, uint32_t H) {
 #else
 #define PSITE(x) (psite = (x))
 #endif
+// Measured on MI355X (profiles/r02w_variants.txt): the kernel is bound by the instructions a wave executes, not
+// by occupancy (3, 4 and 5 waves per SIMD within 1 %; 5 spills) -- 4 waves leave 128 registers; a batch of 2
+// rumours beats 4 (fewer unrolled copies of the state rule executed by a wave whose lanes hold 1-2 new rumours)
 #ifndef SWIM_GOSSIP_BATCH       // rumours whose loads are issued together in merge_kernel
-#define SWIM_GOSSIP_BATCH 4
+#define SWIM_GOSSIP_BATCH 2
 #endif
 #ifndef SWIM_MERGE_WAVES
-#define SWIM_MERGE_WAVES 5
+#define SWIM_MERGE_WAVES 4
 #endif
 constexpr int ASM_STRIDE = BLOCK + 2;   // words per LDS column: keeps the transposed line store conflict-free
 
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
   __shared__ uint32_t gsubj[PB_SLOTS][ASM_STRIDE];      // subjects of this tick's group (its sort key)
   __shared__ uint32_t wfl[BLOCK];
   __shared__ uint32_t wmax[BLOCK / 64];
-  ctr_init(&sh);
+  __shared__ uint4 ring_sh[KN_BITS];                    // this tick's ring (begin_kernel): position -> {slot, key, base, subject}
   const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
   const uint32_t i = s.lo + li;                    // global id
   const uint32_t tid = threadIdx.x;
@@ -532,6 +535,8 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     hot0 = s.hot[li];
     due = trow_now[li];
   }
+  if (tid < KN_BITS) ring_sh[tid] = s.ring[tid];
+  ctr_init(&sh);                                   // its barrier also publishes the ring
   const uint32_t pcount = mi_pbn(mi), cur = mi_buf(mi);
   const bool woke = (hot0.y & 1u) != 0;            // came back up: deadlines it slept through are still in trow
   const bool timer_due = (due.x | due.y | due.z | due.w) != 0u;
@@ -558,16 +563,35 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
   TimerCell tnew; tnew.lo = 0; tnew.hi = 0; tnew.n = 0;   // deadlines t + S: go to the row just consumed
 
   SECT(0);                                          // inputs
+  // second round of loads, issued together: the known-ring, the own queue line and the view cells of the first
+  // DB deadlines of this tick's cell (the kernel spends its time waiting on such round trips, one after the
+  // other: profiles/r02u_section_clocks_before.txt)
+  constexpr int DB = 4;
+  uint32_t dsl[DB]; uint2 dcell[DB];
+#pragma unroll
+  for (int k = 0; k < DB; ++k) { dsl[k] = 0; dcell[k] = make_uint2(0u, 0u); }
+  const bool plain_due = timer_due && !woke && (uint32_t)(due.w >> 16) != TR_FULL;
   if (act) {
     PSTAT(0);
-    kn = s.pk[li].y & ~stale;
+    const unsigned long long known0 = s.pk[li].y;
+    uint4 ol[PB_SLOTS / 2];
     if (pcount) {
       PSTAT(1);
 #pragma unroll
-      for (int h = 0; h < PB_SLOTS / 2; ++h) {
-        const uint4 v = own_line[h];
-        oslot[h] = (pe_tx(v.y) ? pe_slot(v.x) : 0xFFFFu) | ((pe_tx(v.w) ? pe_slot(v.z) : 0xFFFFu) << 16);
+      for (int h = 0; h < PB_SLOTS / 2; ++h) ol[h] = own_line[h];
+    }
+    if (plain_due) {
+#pragma unroll
+      for (int k = 0; k < DB; ++k) {
+        dsl[k] = tc_get(due, k);
+        if (dsl[k]) dcell[k] = s.V[vidx(s, li, dsl[k] - 1)];
       }
+    }
+    kn = known0 & ~stale;
+    if (pcount) {
+#pragma unroll
+      for (int h = 0; h < PB_SLOTS / 2; ++h)
+        oslot[h] = (pe_tx(ol[h].y) ? pe_slot(ol[h].x) : 0xFFFFu) | ((pe_tx(ol[h].w) ? pe_slot(ol[h].z) : 0xFFFFu) << 16);
     }
   }
   auto kill_slot = [&](uint32_t slot) {
@@ -609,9 +633,11 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     tc_set(tnew, tnew.n, slot1);
     tnew.n++;
   };
-  // `pre` = the caller already holds the view cell, the row's base and its subject (loaded in a batch, below)
+  // `have`: what the caller already holds (loaded in a batch with its neighbours, below) -- the view cell, the
+  // row's base, its subject
+  enum { HAVE_CELL = 1, HAVE_BASE = 2, HAVE_SUBJ = 4, EX_LOAD = 0, EX_ALL = HAVE_CELL | HAVE_BASE | HAVE_SUBJ };
   int psite = 47; (void)psite;     // PSITE/PSTAT: path statistics of the host emulation, nothing in the product
-  auto examine_with = [&](uint32_t slot, uint32_t key, uint32_t cause, bool hasrid, uint32_t rid_in, bool pre, uint2 e,
+  auto examine_with = [&](uint32_t slot, uint32_t key, uint32_t cause, bool hasrid, uint32_t rid_in, int have, uint2 e,
                           uint32_t sbase, uint32_t subject) {
     if (slot + 1 == my_slot1) {
       // about self -> refute (src/Core.hs:155-166): remember the largest non-Alive incarnation
@@ -620,13 +646,13 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     }
     examined++;
     PSTAT(5);
-    if (!pre) e = s.V[vidx(s, li, slot)];
-    const uint32_t curk = e.x ? e.x : (pre ? sbase : s.slot_base[slot]);   // untouched cell: the settled base
+    if (!(have & HAVE_CELL)) e = s.V[vidx(s, li, slot)];
+    const uint32_t curk = e.x ? e.x : ((have & HAVE_BASE) ? sbase : s.slot_base[slot]);   // untouched cell: the settled base
     if (key <= curk) return;                     // old incarnation / weaker state: ignore (:151)
     PSTAT(6); PSTAT(psite);
     s.V[vidx(s, li, slot)] = make_uint2(key, t + 1);                    // memberLastChange = now (:176)
     if (s.G) s.slot_last[slot] = t;              // same value from every writer
-    if (!pre) subject = s.subject_of[slot];
+    if (!(have & HAVE_SUBJ)) subject = s.subject_of[slot];
     if (!ha) ha = mix64(mix64((uint64_t)TAG_EV) + (((uint64_t)t << 32) | i));
     const unsigned long long hx = mix64(ha + subject);                // h4(TAG_EV, a, subject, .) prefix
     evd += mix64(hx + key) - mix64(hx + curk);
@@ -643,16 +669,15 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     }
   };
   auto examine = [&](uint32_t slot, uint32_t key, uint32_t cause, bool hasrid, uint32_t rid_in) {
-    examine_with(slot, key, cause, hasrid, rid_in, false, make_uint2(0u, 0u), 0u, 0u);
+    examine_with(slot, key, cause, hasrid, rid_in, EX_LOAD, make_uint2(0u, 0u), 0u, 0u);
   };
   // one entry of this tick's deadline cell: Suspect since t' with t' + S <= t => Dead at the same incarnation
   // (D4); a deadline still ahead that belongs to this row goes back into the cell (a fixture of
   // swimsim_set_view); anything else (refuted, already Dead, reclaimed, superseded by a later suspicion with
   // its own cell) is dropped
-  auto deadline = [&](uint32_t slot) {
-    const uint2 e = s.V[vidx(s, li, slot)];
+  auto deadline = [&](uint32_t slot, uint2 e) {
     if ((e.x & 3u) != ST_SUSPECT) return;
-    if (e.y - 1 + s.S <= t) examine(slot, (e.x & ~3u) | ST_DEAD, 1u, false, 0u);
+    if (e.y - 1 + s.S <= t) examine_with(slot, (e.x & ~3u) | ST_DEAD, 1u, false, 0u, HAVE_CELL, e, 0u, 0u);
     else if ((e.y - 1 + s.S) % s.S == row_now) tput(slot + 1);
   };
   SECT(1);                                          // own line
@@ -682,13 +707,29 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
         }
       }
     } else if (timer_due) {
+      // a cell's view entries are loaded together (the first DB of this tick's cell already are); a slot that is
+      // twice in a cell (two suspicions of one subject accepted in one tick) is read again the second time: this
+      // thread may just have changed it
       uint4 cell = due;
-      for (;;) {
+      for (bool first = true;; first = false) {
+        uint2 ce[TR_PAY];
+#pragma unroll
+        for (int k = 0; k < (int)TR_PAY; ++k) {
+          const uint32_t v = tc_get(cell, k);
+          ce[k] = (first && k < DB) ? dcell[k < DB ? k : 0] : (v ? s.V[vidx(s, li, v - 1)] : make_uint2(0u, 0u));
+        }
         for (uint32_t k = 0; k < TR_PAY; ++k) {
           const uint32_t v = tc_get(cell, k);
           if (!v) break;
           PSTAT(8);
-          deadline(v - 1);
+          uint2 e = ce[0];
+          bool again = false;
+#pragma unroll
+          for (int j = 1; j < (int)TR_PAY; ++j) if (k == (uint32_t)j) e = ce[j];
+#pragma unroll
+          for (int j = 0; j < (int)TR_PAY - 1; ++j) again |= (uint32_t)j < k && tc_get(cell, j) == v;
+          if (again) e = s.V[vidx(s, li, v - 1)];
+          deadline(v - 1, e);
         }
         const uint32_t link = cell.w >> 16;
         if (!(link & TR_LINK) || link == TR_FULL) break;
@@ -711,9 +752,9 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
   // positions.  (Measured on MI355X, profiles/r02c_variants.txt: a wave-uniform walk over the UNION of the
   // lanes' positions coalesces the view rows but triples the iterations -- 237 us against 188 us; one
   // candidate loop shared by all sources with the bookkeeping parked in LDS -- 258 us.)
-  // The loads are batched: a member's next GB positions are decoded together -- their rum[] entries in one
-  // round of loads, then their view cells, row bases and subjects in a second one -- instead of three
-  // dependent loads per rumour (the kernel waits on such chains most of its time, profiles/r02a_pmc_summary.txt).
+  // The loads are batched: a member's next GB positions are decoded together -- what each position stands for
+  // comes from the block's copy of the tick's ring in LDS, so the only round trip is the batch's view cells
+  // (the kernel waits on such chains most of its time, profiles/r02a_pmc_summary.txt).
   SECT(2);                                          // deadlines, failed probes
   if (act) {
     constexpr int GB = SWIM_GOSSIP_BATCH;
@@ -721,25 +762,22 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     kn |= fresh;
     while (fresh) {
       PSTAT(10);
-      uint32_t rid[GB]; uint2 r[GB]; uint2 e[GB]; uint32_t sb[GB], sj[GB];
+      uint32_t rid[GB]; uint4 r[GB]; uint2 e[GB];
       uint32_t n = 0;
 #pragma unroll
       for (int k = 0; k < GB; ++k) {
-        rid[k] = 0; r[k] = make_uint2(0u, 0u); e[k] = make_uint2(0u, 0u); sb[k] = 0; sj[k] = 0;
+        rid[k] = 0; r[k] = make_uint4(0u, 0u, 0u, 0u); e[k] = make_uint2(0u, 0u);
         if (fresh) {
           const uint32_t p = (uint32_t)__ffsll((unsigned long long)fresh) - 1u;
           fresh &= fresh - 1ull;
           rid[k] = rid_at(p, H) & RID_MASK;
+          r[k] = ring_sh[p];                       // {slot, key, base, subject} of the id at position p
           n = (uint32_t)k + 1u;
         }
       }
 #pragma unroll
-      for (int k = 0; k < GB; ++k) if ((uint32_t)k < n) r[k] = s.rum[rid[k]];
-#pragma unroll
       for (int k = 0; k < GB; ++k)
-        if ((uint32_t)k < n && r[k].x + 1 != my_slot1) {
-          e[k] = s.V[vidx(s, li, r[k].x)]; sb[k] = s.slot_base[r[k].x]; sj[k] = s.subject_of[r[k].x];
-        }
+        if ((uint32_t)k < n && r[k].x + 1 != my_slot1) e[k] = s.V[vidx(s, li, r[k].x)];
 #pragma unroll
       for (int k = 0; k < GB; ++k) {
         if ((uint32_t)k >= n) continue;
@@ -749,7 +787,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
         bool again = false;
 #pragma unroll
         for (int j = 0; j < GB; ++j) again |= (j < k) && (r[j].x == r[k].x);
-        examine_with(r[k].x, r[k].y, 2u, true, rid[k], !again, e[k], sb[k], sj[k]);
+        examine_with(r[k].x, r[k].y, 2u, true, rid[k], again ? EX_LOAD : EX_ALL, e[k], r[k].z, r[k].w);
       }
     }
   }
@@ -773,20 +811,41 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
         PSTAT(13);
         const uint4* line = (srcw & SRC_FOREIGN) ? s.fl + (size_t)(srcw & (SRC_FOREIGN - 1u)) * 4
                                                  : line_ptr(s, srcw >> 31, srcw & 0x7FFFFFFFu);
-        for (int h = 0; h < PB_SLOTS / 2; ++h) {
-          const uint4 v = line[h];
+        uint4 ln[PB_SLOTS / 2];
 #pragma unroll
-          for (int w = 0; w < 2; ++w) {
-            const uint32_t lo = w ? v.z : v.x, hi = w ? v.w : v.y;
-            if (!pe_tx(hi)) continue;
-            const uint32_t rid = pe_rid(lo);
-            if (rid_in_ring(rid, H)) {
-              if (kn & rid_bit(rid)) continue;     // view already dominates it
-              kn |= rid_bit(rid);
-            }
-            PSTAT(14);
-            examine(pe_slot(lo), pe_key(hi), 2u, true, rid);
+        for (int h = 0; h < PB_SLOTS / 2; ++h) ln[h] = line[h];
+        // first the entries the state rule has to look at (alive, not dominated according to the ring), their
+        // view cells and row bases in ONE round of loads; then the rule, entry by entry.  (One dependent gather
+        // per entry made this loop 60 % of a tick under message loss, profiles/r02u_section_clocks_before.txt.)
+        uint32_t need = 0;
+        uint2 ce[PB_SLOTS]; uint32_t cb[PB_SLOTS];
+#pragma unroll
+        for (int q = 0; q < PB_SLOTS; ++q) {
+          const uint4 v = ln[q >> 1];
+          const uint32_t lo = (q & 1) ? v.z : v.x, hi = (q & 1) ? v.w : v.y;
+          ce[q] = make_uint2(0u, 0u); cb[q] = 0u;
+          bool want = pe_tx(hi) != 0u;
+          const uint32_t rid = pe_rid(lo);
+          if (want && rid_in_ring(rid, H)) {
+            if (kn & rid_bit(rid)) want = false;   // view already dominates it
+            else kn |= rid_bit(rid);
           }
+          if (want) {
+            need |= 1u << q;
+            const uint32_t slot = pe_slot(lo);
+            if (slot + 1 != my_slot1) { ce[q] = s.V[vidx(s, li, slot)]; cb[q] = s.slot_base[slot]; }
+          }
+        }
+        while (need) {
+          const uint32_t q = (uint32_t)__ffs(need) - 1u;
+          need &= need - 1u;
+          uint32_t lo = ln[0].x, hi = ln[0].y, sb = cb[0];
+          uint2 e = ce[0];
+#pragma unroll
+          for (int j = 1; j < PB_SLOTS; ++j)
+            if (q == (uint32_t)j) { lo = (j & 1) ? ln[j >> 1].z : ln[j >> 1].x; hi = (j & 1) ? ln[j >> 1].w : ln[j >> 1].y; sb = cb[j]; e = ce[j]; }
+          PSTAT(14);
+          examine_with(pe_slot(lo), pe_key(hi), 2u, true, pe_rid(lo), HAVE_CELL | HAVE_BASE, e, sb, 0u);   // slots of a line are distinct
         }
       }
     }
@@ -1295,6 +1354,14 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
     // are out of the game anyway (explicit records), exactness does not depend on them
     s.g[G_RIDS_OFF] = (s.g[G_HEAD] - s.g[G_PREV] > RID_MASK + 1u - RID_NEAR - KN_BITS) ? 1u : 0u;
     if (t) s.tovf_n[((t - 1u) % s.S) * 2u + ((((t - 1u) / s.S) & 1u) ^ 1u)] = 0;   // the deadline chains tick t-1 consumed
+  }
+  __syncthreads();
+  if (threadIdx.x < KN_BITS) {
+    // this tick's ring: what each mask / known-ring position stands for, with its row's base and subject, so
+    // that merge_kernel resolves a delivered bit from LDS instead of three dependent gathers
+    const uint2 r = s.rum[rid_at(threadIdx.x, s.g[G_HEAD]) & RID_MASK];
+    const uint32_t row = r.x < s.R_phys ? r.x : 0u;           // a position no id has owned yet: never looked at
+    s.ring[threadIdx.x] = make_uint4(r.x, r.y, s.slot_base[row], s.subject_of[row]);
   }
   if (s.G) {
     // rows whose subject nobody has changed its mind about for G ticks (counting this one, checked again by

@@ -319,6 +319,7 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   CK(dev_alloc(h, &d.inmask, (size_t)N, 0));
   CK(dev_alloc(h, &d.ackmask, (size_t)N, 0));
   CK(dev_alloc(h, &d.rum, (size_t)1 << RID_BITS, 0));
+  CK(dev_alloc(h, &d.ring, KN_BITS, 0));
   CK(dev_alloc(h, &d.rtab, (size_t)d.R_phys * RT_WAYS, 0));
   CK(dev_alloc(h, &d.subject_of, (size_t)d.R_phys, 0));
   CK(dev_alloc(h, &d.fail, (size_t)N * (d.P ? d.P : 1), 0));

@@ -97,7 +97,10 @@ struct Sched {
   std::vector<Fibre> f;
   uint32_t nthreads = 0, cur = 0;
   void (*entry)(void*) = nullptr; void* arg = nullptr;
-  uint64_t exch[1024];                                      // cross-lane exchange (shfl / ballot)
+  uint64_t exch[2][1024];                                   // cross-lane exchange (shfl / ballot / dpp), two alternating
+  uint8_t par[1024];                                        // buffers: one yield per operation is enough (a lane still
+                                                            // reading buffer A cannot be overtaken by a write to A: the
+                                                            // writer would have to pass the next operation's yield first)
 };
 inline Sched& sched() { static Sched s; return s; }
 inline dim3& tidx() { static dim3 v; return v; }
@@ -132,6 +135,7 @@ inline void run_block(uint32_t nthreads, void (*entry)(void*), void* arg) {
     for (size_t k = old; k < nthreads; ++k) s.f[k].stack = malloc(STACK_BYTES);
   }
   s.nthreads = nthreads; s.entry = entry; s.arg = arg;
+  memset(s.par, 0, sizeof s.par);
   for (uint32_t k = 0; k < nthreads; ++k) {
     getcontext(&s.f[k].ctx);
     s.f[k].ctx.uc_stack.ss_sp = s.f[k].stack;
@@ -230,12 +234,11 @@ static inline T __shfl_down(T x, int delta, int width = 64) {
   auto& s = hostemu::sched();
   const uint32_t tid = hostemu::tidx().x;
   uint64_t v = 0; memcpy(&v, &x, sizeof(T) < 8 ? sizeof(T) : 8);
-  s.exch[tid] = v;
+  uint64_t* xb = s.exch[s.par[tid] ^= 1];
+  xb[tid] = v;
   hostemu::wave_yield();
   const uint32_t lane = tid % (uint32_t)width, src = lane + (uint32_t)delta < (uint32_t)width ? tid + (uint32_t)delta : tid;
-  uint64_t r = src < s.nthreads ? s.exch[src] : v;
-  hostemu::wave_yield();
-  s.exch[tid] = 0;
+  uint64_t r = src < s.nthreads ? xb[src] : v;
   T out; memcpy(&out, &r, sizeof(T) < 8 ? sizeof(T) : 8);
   return out;
 }
@@ -244,25 +247,23 @@ static inline T __shfl(T x, int srcLane, int width = 64) {
   auto& s = hostemu::sched();
   const uint32_t tid = hostemu::tidx().x;
   uint64_t v = 0; memcpy(&v, &x, sizeof(T) < 8 ? sizeof(T) : 8);
-  s.exch[tid] = v;
+  uint64_t* xb = s.exch[s.par[tid] ^= 1];
+  xb[tid] = v;
   hostemu::wave_yield();
   const uint32_t base = tid - tid % (uint32_t)width, src = base + ((uint32_t)srcLane % (uint32_t)width);
-  uint64_t r = src < s.nthreads ? s.exch[src] : v;
-  hostemu::wave_yield();
-  s.exch[tid] = 0;
+  uint64_t r = src < s.nthreads ? xb[src] : v;
   T out; memcpy(&out, &r, sizeof(T) < 8 ? sizeof(T) : 8);
   return out;
 }
 static inline unsigned long long __ballot(int pred) {
   auto& s = hostemu::sched();
   const uint32_t tid = hostemu::tidx().x;
-  s.exch[tid] = pred ? 1u : 0u;
+  uint64_t* xb = s.exch[s.par[tid] ^= 1];
+  xb[tid] = pred ? 1u : 0u;
   hostemu::wave_yield();
   const uint32_t base = tid - tid % 64u;
   unsigned long long m = 0;
-  for (uint32_t l = 0; l < 64u && base + l < s.nthreads; ++l) if (s.exch[base + l]) m |= 1ull << l;
-  hostemu::wave_yield();
-  s.exch[tid] = 0;
+  for (uint32_t l = 0; l < 64u && base + l < s.nthreads; ++l) if (xb[base + l]) m |= 1ull << l;
   return m;
 }
 
@@ -272,7 +273,8 @@ static inline unsigned long long __ballot(int pred) {
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
   auto& s = hostemu::sched();
   const uint32_t tid = hostemu::tidx().x;
-  s.exch[tid] = (uint32_t)src;
+  uint64_t* xb = s.exch[s.par[tid] ^= 1];
+  xb[tid] = (uint32_t)src;
   hostemu::wave_yield();
   const uint32_t base = tid - tid % 64u, lane = tid % 64u, row = lane / 16u, inrow = lane % 16u;
   int out = old;
@@ -282,22 +284,18 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
     else if (ctrl == 0x142) { if (row >= 1) srcl = (int)(row * 16u - 1u); }
     else if (ctrl == 0x143) { if (row >= 2) srcl = 31; }
     else abort();
-    if (srcl >= 0) out = (int)(uint32_t)s.exch[base + (uint32_t)srcl];
+    if (srcl >= 0) out = (int)(uint32_t)xb[base + (uint32_t)srcl];
     else if (bound_ctrl) out = 0;
   }
-  hostemu::wave_yield();
-  s.exch[tid] = 0;
   return out;
 }
 static inline int __builtin_amdgcn_readlane(int v, int lane) {
   auto& s = hostemu::sched();
   const uint32_t tid = hostemu::tidx().x;
-  s.exch[tid] = (uint32_t)v;
+  uint64_t* xb = s.exch[s.par[tid] ^= 1];
+  xb[tid] = (uint32_t)v;
   hostemu::wave_yield();
-  const int out = (int)(uint32_t)s.exch[tid - tid % 64u + (uint32_t)lane];
-  hostemu::wave_yield();
-  s.exch[tid] = 0;
-  return out;
+  return (int)(uint32_t)xb[tid - tid % 64u + (uint32_t)lane];
 }
 // s_waitcnt: nothing is in flight here; s_barrier: the block barrier; wave_barrier: lanes are fibres, a yield
 // lets every lane of the wave reach this point first
