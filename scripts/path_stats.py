@@ -1,6 +1,6 @@
 """Divergence profile of merge_kernel: the product's kernels in the host emulation with
 -DSWIM_PATH_STATS count, for every marked site, how often it runs per lane and per wave (a wave executes a site
-max-over-its-lanes times).  usage: python scripts/path_stats.py [members] [ticks measured]"""
+max-over-its-lanes times).  usage: python scripts/path_stats.py [members] [ticks measured]   env: LOSS (ppm), GC=1"""
 import ctypes as C
 import os
 import sys
@@ -22,7 +22,11 @@ def main():
     ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     abi = hostemu_binding.load_variant("pstat", ["SWIM_PATH_STATS"])
     lib = C.CDLL(os.path.join(hostemu_binding.EMU, "_build", "libswimsim_hostemu_pstat.so"))
-    sc, crashes, _ = workloads.saturated(n, 400, seed=1, t0=0)
+    loss = int(os.environ.get("LOSS", 0))
+    sc, crashes, _ = workloads.saturated(n, 400, seed=1, t0=0, loss_ppm=loss)
+    if os.environ.get("GC"):
+        from swim_amd import _abi
+        sc.gcTicks = _abi.GC_AUTO
     s = Sim.create(abi, sc)
     for t, m in crashes:
         s.crash(m, t)

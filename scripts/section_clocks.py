@@ -10,8 +10,9 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from swim_amd import Sim, workloads, _abi                      # noqa: E402
 
-MERGE = ["inputs", "own line -> oslot", "deadlines + failed probes", "delivered rumours (masks)", "explicit records + refute",
-         "queue rebuild", "state stores + counters", "barrier", "line store", "counter flush"]
+MERGE = ["inputs", "known-ring + own line + first deadline cells", "failed probes", "delivered rumours (masks)",
+         "explicit records + refute", "queue rebuild", "state stores + counters", "wave sync", "line store", "counter flush",
+         "deadlines"]
 PROBE = ["target selection", "outcomes + pk gathers", "ping pushes", "acks", "indirect probes", "outputs + counters", "counter flush"]
 
 
@@ -42,6 +43,9 @@ def main():
         rows = {lab: {"clocks_per_wave": round(out[base + k] / max(1, waves), 1), "share": round(out[base + k] / max(1, tot), 4)}
                 for k, lab in enumerate(labels)}
         res[name] = {"waves": waves, "clocks_per_wave": round(tot / max(1, waves), 1), "sections": rows}
+    res["events_per_tick"] = {"full row scans (lanes)": out[16] / ticks, "deadline chain cells followed": out[17] / ticks,
+                              "explicit record lines read": out[18] / ticks, "deadline pool exhausted (lanes)": out[19] / ticks
+                              }
     print(json.dumps(res, indent=1))
     s.close()
 

@@ -98,6 +98,8 @@ struct DevState {
   unsigned long long* inmask;   // OR of the masks pushed to this member this tick (atomicOr by the pingers)
   unsigned long long* ackmask;  // OR of the masks this member pulled with its Acks (plain store by the prober)
   uint2* rum;              // [1 << RID_BITS] rumour id -> {slot, key}
+  ulonglong4* kw;          // [N] wide known-ring (explicit-record path; above), positions beyond KW_BITS unused
+  uint32_t* kw_head;       // [N] head the member's kw was written at
   uint4* ring;             // [64] this tick's ring, built by begin_kernel: position -> {slot, key, row base, subject}
   unsigned long long* rtab;// [R_max][RT_WAYS] (slot, key) -> rumour id: {key+1 : 32 | ready : 1 | rid : 16}
   // explicit delivery records "dst merges src's 64-B line": the exact fallback for queues with
@@ -238,8 +240,11 @@ __host__ __device__ inline uint32_t pe_hi(uint32_t key, uint32_t tx) { return ke
 constexpr uint32_t KN_BITS = 64, MASK_WIN = SWIM_MASK_WIN, MASK_SLACK = SWIM_MASK_SLACK, RID_BITS = SWIM_RID_BITS,
                    RID_MASK = (1u << RID_BITS) - 1u, RID_FAR = 1u << (RID_BITS - 1), RID_NEAR = 1u << (RID_BITS - 2),
                    RID_PARKED = RID_MASK;   // "no id": never handed out, never in a window (an entry too old for the ring)
+// the wide known-ring of the explicit-record path (kw, below): ids stay in queue lines for KW_BITS ids behind the head
+constexpr uint32_t KW_BITS = RID_NEAR < 256u ? RID_NEAR : 256u;
 static_assert(MASK_WIN + MASK_SLACK <= KN_BITS, "mask positions must be unambiguous");
-static_assert(RID_BITS <= 16 && KN_BITS + RID_NEAR < RID_FAR + 1 && KN_BITS <= RID_NEAR, "rumour ids: window < near range < parking distance");
+static_assert(RID_BITS <= 16 && KW_BITS + RID_NEAR < RID_FAR + 1 && KN_BITS <= KW_BITS && KW_BITS <= RID_NEAR && (KW_BITS & 63u) == 0u,
+              "rumour ids: window < near range < parking distance");
 constexpr int RT_WAYS = 8;
 constexpr unsigned long long RT_READY = 1ull << 16;
 
@@ -257,6 +262,41 @@ __device__ inline unsigned long long stale_positions(uint32_t prev, uint32_t hea
   const uint32_t sh = prev & 63u;
   return (run << sh) | (sh ? (run >> (64u - sh)) : 0ull);
 }
+// ---- the wide known-ring (explicit-record path only) -------------------------------------------
+// Under message loss queue lines travel as explicit records and a rumour is received ~50 times in its life; the
+// 64-position ring forgets it after 64 newer ids (4-6 ticks at 1 % loss and a million members), after which every
+// reception costs a scattered view-cell gather -- 48 per member-tick, the bound of that regime.  kw[member] keeps
+// "my view dominates the rumour with id r" for the last KW_BITS ids (position r mod KW_BITS), kw_head[member] the
+// head it was written at: positions of the ids [kw_head, H) are forgotten when it is read (they stood for ids that
+// have left the window).  Loaded and stored only by members that have explicit records this tick.
+struct Ring256 { unsigned long long w[4]; };
+__device__ inline bool rid_in_wide(uint32_t rid, uint32_t H) { return rid != RID_PARKED && ((H - 1u - rid) & RID_MASK) < KW_BITS; }
+__device__ inline unsigned long long low_bits(int n) { return n <= 0 ? 0ull : n >= 64 ? ~0ull : (1ull << n) - 1ull; }
+// forget the circular position range [a, a + len) of a KW_BITS-position ring
+__device__ inline void r256_forget(Ring256& r, uint32_t a, uint32_t len) {
+  a &= KW_BITS - 1u;
+#pragma unroll
+  for (int k = 0; k < (int)(KW_BITS / 64u); ++k) {
+    if (len >= KW_BITS) { r.w[k] = 0ull; continue; }
+    const int off = (int)(((uint32_t)(64 * k) - a) & (KW_BITS - 1u));   // distance of the word's first position from a
+    unsigned long long m = low_bits((int)len - off);
+    if (off > (int)KW_BITS - 64) m |= low_bits((int)len + (int)KW_BITS - off) & ~low_bits((int)KW_BITS - off);
+    r.w[k] &= ~m;
+  }
+}
+__device__ inline bool r256_test(const Ring256& r, uint32_t rid) {
+  const uint32_t q = rid & (KW_BITS - 1u);
+  unsigned long long w = r.w[0];
+#pragma unroll
+  for (int k = 1; k < (int)(KW_BITS / 64u); ++k) if ((q >> 6) == (uint32_t)k) w = r.w[k];
+  return (w >> (q & 63u)) & 1ull;
+}
+__device__ inline void r256_or(Ring256& r, uint32_t word, unsigned long long m) {
+#pragma unroll
+  for (int k = 0; k < (int)(KW_BITS / 64u); ++k) if (word == (uint32_t)k) r.w[k] |= m;
+}
+__device__ inline void r256_set(Ring256& r, uint32_t rid) { r256_or(r, (rid & (KW_BITS - 1u)) >> 6, 1ull << (rid & 63u)); }
+
 // can an entry with this id be expressed in a mask built at head H?
 __device__ inline bool rid_maskable(uint32_t rid, uint32_t H) {
   return rid != RID_PARKED && ((rid - (H - MASK_WIN)) & RID_MASK) < MASK_WIN + MASK_SLACK;
@@ -304,9 +344,11 @@ __device__ inline bool view_alive(const DevState& s, uint32_t li, uint32_t mc) {
 
 // ---- suspicion deadlines (trow) ---------------------------------------------------------------
 // One 16-byte cell per (deadline mod S, member): halfwords 0..6 = slot+1 of up to 7 deadlines, packed from 0;
-// halfword 7 = link: 0 none, TR_LINK | idx = the chain continues in overflow cell idx of the row's pool
-// (tovf; a member that accepts more than 7 suspicions in one tick -- heavy message loss), TR_FULL = "look at
-// every view row" (pool exhausted: exact, slow).  Pools alternate by cycle parity (t / S) & 1: tick t consumes
+// halfword 7 = link: 0 none, TR_FULL = "look at every view row" (pool exhausted: exact, slow), otherwise
+// TR_LINK | high bits: the chain continues in overflow cell idx = (hw7 & 0x7FFF) << 16 | hw6 of the row's pool
+// (tovf; a member that accepts more than 7 suspicions in one tick -- heavy message loss) and the cell holds
+// 6 deadlines (a 15-bit index ran out at 1 % loss and a million members: 48 000 members per tick fell back to
+// the full scan, profiles/r02y_batching_variants_and_lossy_events.txt).  Pools alternate by cycle parity (t / S) & 1: tick t consumes
 // the chains written at t - S from pool parity^1 while it writes the chains for t + S into pool parity.
 constexpr uint32_t TR_PAY = 7, TR_FULL = 0xFFFFu, TR_LINK = 0x8000u;
 struct TimerCell { unsigned long long lo, hi; uint32_t n; };
@@ -316,12 +358,19 @@ __device__ inline void tc_set(TimerCell& c, uint32_t pos, uint32_t v) {       //
   else c.hi |= (unsigned long long)v << (16u * (pos - 4u));
 }
 // without a pool (fixtures, cells rebuilt after a downtime): the 8th deadline turns the cell into "look everywhere"
+__device__ inline bool tc_linked(uint32_t w3) { const uint32_t l = w3 >> 16; return (l & TR_LINK) != 0u && l != TR_FULL; }
+__device__ inline uint32_t tc_link_idx(uint32_t w3) { return (((w3 >> 16) & (TR_LINK - 1u)) << 16) | (w3 & 0xFFFFu); }
+__device__ inline uint32_t tc_cap(const TimerCell& c) { return tc_linked((uint32_t)(c.hi >> 32)) ? TR_PAY - 1u : TR_PAY; }
+__device__ inline void tc_set_link(TimerCell& c, uint32_t idx) {     // on a cleared cell
+  c.hi = ((unsigned long long)(TR_LINK | (idx >> 16)) << 48) | ((unsigned long long)(idx & 0xFFFFu) << 32);
+}
 __device__ inline void tc_put_simple(TimerCell& c, uint32_t slot1) {
-  if (c.n < TR_PAY) tc_set(c, c.n, slot1);
+  if (c.n < tc_cap(c)) tc_set(c, c.n, slot1);
   else c.hi |= (unsigned long long)TR_FULL << 48;
   c.n++;
 }
 __device__ inline uint32_t tc_get(const uint4& v, uint32_t k) {
+  if (k == TR_PAY - 1u && tc_linked(v.w)) return 0u;                  // that halfword is part of the link
   const uint32_t w = k < 2u ? v.x : k < 4u ? v.y : k < 6u ? v.z : v.w;
   return (k & 1u) ? (w >> 16) : (w & 0xFFFFu);
 }

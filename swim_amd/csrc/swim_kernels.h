@@ -150,9 +150,11 @@ __device__ inline uint32_t get_slot(const DevState& s, uint32_t j) {
 #define SECT_ADD(k, v) do { const unsigned long long b_ = __ballot(1); \
     if ((threadIdx.x & 63u) == (uint32_t)(__ffsll(b_) - 1)) atomicAdd(reinterpret_cast<unsigned long long*>(&s.blk[((size_t)s.nblocks + 1) * C_COUNT + (blockIdx.x & 63u) * 64u + (k)]), (unsigned long long)(v)); } while (0)
 #define SECT(k) do { const unsigned long long n_ = clock64(); SECT_ADD(k, n_ - sect_t_); sect_t_ = clock64(); } while (0)
+#define SECT_COUNT(k) atomicAdd(reinterpret_cast<unsigned long long*>(&s.blk[((size_t)s.nblocks + 1) * C_COUNT + (blockIdx.x & 63u) * 64u + (k)]), 1ull)
 #else
 #define SECT_BEGIN(base) ((void)0)
 #define SECT(k) ((void)0)
+#define SECT_COUNT(k) ((void)0)
 #endif
 // ================================================================================================
 // probe kernel
@@ -439,11 +441,11 @@ __device__ inline uint32_t find_rid(const DevState& s, uint32_t slot, uint32_t k
   return rid;
 }
 
-// a rumour id that fell out of the known-ring window is replaced by RID_PARKED ("no id") at the next rewrite of
+// a rumour id that fell out of the (wide) known-ring window is replaced by RID_PARKED ("no id") at the next rewrite of
 // the line, so that a long-lived entry can never alias into a later window
 __device__ inline uint32_t park_rid(uint32_t lo, uint32_t H) {
-  const uint32_t above = (pe_rid(lo) - (H - KN_BITS)) & RID_MASK;     // distance above the window bottom
-  return (pe_rid(lo) != RID_PARKED && above < KN_BITS + RID_NEAR) ? lo : pe_lo(pe_slot(lo), RID_PARKED);
+  const uint32_t above = (pe_rid(lo) - (H - KW_BITS)) & RID_MASK;     // distance above the window bottom
+  return (pe_rid(lo) != RID_PARKED && above < KW_BITS + RID_NEAR) ? lo : pe_lo(pe_slot(lo), RID_PARKED);
 }
 
 
@@ -621,14 +623,14 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
   // a deadline t + S for this tick's cell; the 8th spills the cell into the row's overflow pool and links it
   const uint32_t row_now = t % s.S, par_now = (t / s.S) & 1u;
   auto tput = [&](uint32_t slot1) {
-    if (tnew.n == TR_PAY) {
+    if (tnew.n >= tc_cap(tnew)) {
       if (((uint32_t)(tnew.hi >> 48)) == TR_FULL) return;            // already "look everywhere"
       const uint32_t idx = atomicAdd(&s.tovf_n[row_now * 2u + par_now], 1u);
       if (idx < s.tovf_cap) {
         s.tovf[((size_t)row_now * 2u + par_now) * s.tovf_cap + idx] = tc_pack(tnew);
         tc_clear(tnew);
-        tnew.hi = (unsigned long long)(TR_LINK | idx) << 48;
-      } else { tnew.hi |= (unsigned long long)TR_FULL << 48; return; }
+        tc_set_link(tnew, idx);
+      } else { SECT_COUNT(19); tnew.hi |= (unsigned long long)TR_FULL << 48; return; }
     }
     tc_set(tnew, tnew.n, slot1);
     tnew.n++;
@@ -685,7 +687,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
     // phase 1: suspicion deadlines, evaluated on the start-of-tick view
     PSITE(20);
     if (woke || (uint32_t)(due.w >> 16) == TR_FULL) {
-      PSTAT(7);
+      PSTAT(7); SECT_COUNT(16);
       // a member that just came back up (its cells may be stale, their chains gone) or a cell that says "look
       // everywhere": every view row is a candidate.  The member that came back also rebuilds its cells from
       // what it finds: deadlines still ahead go to the cell of their tick.
@@ -707,35 +709,30 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
         }
       }
     } else if (timer_due) {
-      // a cell's view entries are loaded together (the first DB of this tick's cell already are); a slot that is
-      // twice in a cell (two suspicions of one subject accepted in one tick) is read again the second time: this
-      // thread may just have changed it
+      // the first DB view cells of this tick's cell were loaded above; a slot that is twice in the cell (two
+      // suspicions of one subject accepted in one tick) is read again the second time: this thread may just have
+      // changed it.  (Loading whole cells and whole explicit-record lines in batches was measured and dropped:
+      // 155 us against 141 us without loss, 2.23 against 2.28 ms at 1 % loss, profiles/r02y_*.txt.)
       uint4 cell = due;
       for (bool first = true;; first = false) {
-        uint2 ce[TR_PAY];
-#pragma unroll
-        for (int k = 0; k < (int)TR_PAY; ++k) {
-          const uint32_t v = tc_get(cell, k);
-          ce[k] = (first && k < DB) ? dcell[k < DB ? k : 0] : (v ? s.V[vidx(s, li, v - 1)] : make_uint2(0u, 0u));
-        }
         for (uint32_t k = 0; k < TR_PAY; ++k) {
           const uint32_t v = tc_get(cell, k);
           if (!v) break;
-          PSTAT(8);
-          uint2 e = ce[0];
-          bool again = false;
+          bool have = first && k < (uint32_t)DB;
+          uint2 e = dcell[0];
 #pragma unroll
-          for (int j = 1; j < (int)TR_PAY; ++j) if (k == (uint32_t)j) e = ce[j];
+          for (int j = 1; j < DB; ++j) if (k == (uint32_t)j) e = dcell[j];
 #pragma unroll
-          for (int j = 0; j < (int)TR_PAY - 1; ++j) again |= (uint32_t)j < k && tc_get(cell, j) == v;
-          if (again) e = s.V[vidx(s, li, v - 1)];
+          for (int j = 0; j < DB - 1; ++j) have &= !((uint32_t)j < k && dsl[j] == v);
+          if (!have) e = s.V[vidx(s, li, v - 1)];
           deadline(v - 1, e);
         }
-        const uint32_t link = cell.w >> 16;
-        if (!(link & TR_LINK) || link == TR_FULL) break;
-        cell = s.tovf[((size_t)row_now * 2u + (par_now ^ 1u)) * s.tovf_cap + (link & (TR_LINK - 1u))];
+        if (!tc_linked(cell.w)) break;
+        SECT_COUNT(17);
+        cell = s.tovf[((size_t)row_now * 2u + (par_now ^ 1u)) * s.tovf_cap + tc_link_idx(cell.w)];
       }
     }
+    SECT(10);                                       // deadlines
     // phase 2: own probes that ended without any ack: Suspect at the viewed incarnation
     PSITE(21);
     for (uint32_t f = 0; f < nfail; ++f) {
@@ -798,6 +795,18 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
       const uint32_t nin = cnt < s.inbox_cap ? cnt : s.inbox_cap;
       const uint32_t novf = cnt > s.inbox_cap ? min(s.g[G_OVF0 + (t & 1u)], s.ovf_cap) : 0u;
       PSITE(30);
+      // the wide known-ring (swim_device.h): what I learned since it was written is forgotten position-wise, what the
+      // 64-position ring knows is copied in (its ids own one or two of the wide ring's words)
+      Ring256 kw;
+      const uint32_t kwh0 = s.kw_head[li];
+      {
+        const ulonglong4 v = s.kw[li];
+        kw.w[0] = v.x; kw.w[1] = v.y; kw.w[2] = v.z; kw.w[3] = v.w;
+        r256_forget(kw, kwh0, H - kwh0);
+        const unsigned long long young = low_bits((int)(H & 63u));   // positions of the ids in H's own block of 64
+        r256_or(kw, (H >> 6) & (KW_BITS / 64u - 1u), kn & young);
+        r256_or(kw, ((H >> 6) - 1u) & (KW_BITS / 64u - 1u), kn & ~young);
+      }
       for (uint32_t x = 0; x < nack + nin + novf; ++x) {
         PSTAT(12);
         uint32_t srcw = NONE32;
@@ -808,46 +817,27 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
           if (o.x == li) srcw = o.y;
         }
         if (srcw == NONE32) continue;
-        PSTAT(13);
+        PSTAT(13); SECT_COUNT(18);
         const uint4* line = (srcw & SRC_FOREIGN) ? s.fl + (size_t)(srcw & (SRC_FOREIGN - 1u)) * 4
                                                  : line_ptr(s, srcw >> 31, srcw & 0x7FFFFFFFu);
-        uint4 ln[PB_SLOTS / 2];
+        for (int h = 0; h < PB_SLOTS / 2; ++h) {
+          const uint4 v = line[h];
 #pragma unroll
-        for (int h = 0; h < PB_SLOTS / 2; ++h) ln[h] = line[h];
-        // first the entries the state rule has to look at (alive, not dominated according to the ring), their
-        // view cells and row bases in ONE round of loads; then the rule, entry by entry.  (One dependent gather
-        // per entry made this loop 60 % of a tick under message loss, profiles/r02u_section_clocks_before.txt.)
-        uint32_t need = 0;
-        uint2 ce[PB_SLOTS]; uint32_t cb[PB_SLOTS];
-#pragma unroll
-        for (int q = 0; q < PB_SLOTS; ++q) {
-          const uint4 v = ln[q >> 1];
-          const uint32_t lo = (q & 1) ? v.z : v.x, hi = (q & 1) ? v.w : v.y;
-          ce[q] = make_uint2(0u, 0u); cb[q] = 0u;
-          bool want = pe_tx(hi) != 0u;
-          const uint32_t rid = pe_rid(lo);
-          if (want && rid_in_ring(rid, H)) {
-            if (kn & rid_bit(rid)) want = false;   // view already dominates it
-            else kn |= rid_bit(rid);
+          for (int w = 0; w < 2; ++w) {
+            const uint32_t lo = w ? v.z : v.x, hi = w ? v.w : v.y;
+            if (!pe_tx(hi)) continue;
+            const uint32_t rid = pe_rid(lo);
+            if (rid_in_wide(rid, H)) {
+              if (r256_test(kw, rid)) continue;    // view already dominates it
+              r256_set(kw, rid);
+              if (rid_in_ring(rid, H)) kn |= rid_bit(rid);
+            }
+            examine(pe_slot(lo), pe_key(hi), 2u, true, rid);
           }
-          if (want) {
-            need |= 1u << q;
-            const uint32_t slot = pe_slot(lo);
-            if (slot + 1 != my_slot1) { ce[q] = s.V[vidx(s, li, slot)]; cb[q] = s.slot_base[slot]; }
-          }
-        }
-        while (need) {
-          const uint32_t q = (uint32_t)__ffs(need) - 1u;
-          need &= need - 1u;
-          uint32_t lo = ln[0].x, hi = ln[0].y, sb = cb[0];
-          uint2 e = ce[0];
-#pragma unroll
-          for (int j = 1; j < PB_SLOTS; ++j)
-            if (q == (uint32_t)j) { lo = (j & 1) ? ln[j >> 1].z : ln[j >> 1].x; hi = (j & 1) ? ln[j >> 1].w : ln[j >> 1].y; sb = cb[j]; e = ce[j]; }
-          PSTAT(14);
-          examine_with(pe_slot(lo), pe_key(hi), 2u, true, pe_rid(lo), HAVE_CELL | HAVE_BASE, e, sb, 0u);   // slots of a line are distinct
         }
       }
+      s.kw[li] = make_ulonglong4(kw.w[0], kw.w[1], kw.w[2], kw.w[3]);
+      if (kwh0 != H) s.kw_head[li] = H;
     }
     // ---- refutation: bump own incarnation past the rumour's (src/Core.hs:155-166; D10); rumours at
     // an incarnation below my own are stale and ignored (:151)
@@ -1352,7 +1342,7 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
     // back INTO that zone for D > 2^RID_BITS - RID_NEAR.  After such a tick (49 088 new rumours at once with
     // 16-bit ids: heavy message loss) every line of this tick is written without ids: masks and the known-ring
     // are out of the game anyway (explicit records), exactness does not depend on them
-    s.g[G_RIDS_OFF] = (s.g[G_HEAD] - s.g[G_PREV] > RID_MASK + 1u - RID_NEAR - KN_BITS) ? 1u : 0u;
+    s.g[G_RIDS_OFF] = (s.g[G_HEAD] - s.g[G_PREV] > RID_MASK + 1u - RID_NEAR - KW_BITS) ? 1u : 0u;
     if (t) s.tovf_n[((t - 1u) % s.S) * 2u + ((((t - 1u) / s.S) & 1u) ^ 1u)] = 0;   // the deadline chains tick t-1 consumed
   }
   __syncthreads();

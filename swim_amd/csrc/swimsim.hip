@@ -320,11 +320,15 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   CK(dev_alloc(h, &d.ackmask, (size_t)N, 0));
   CK(dev_alloc(h, &d.rum, (size_t)1 << RID_BITS, 0));
   CK(dev_alloc(h, &d.ring, KN_BITS, 0));
+  CK(dev_alloc(h, &d.kw, N, 0));
+  CK(dev_alloc(h, &d.kw_head, N, 0));
   CK(dev_alloc(h, &d.rtab, (size_t)d.R_phys * RT_WAYS, 0));
   CK(dev_alloc(h, &d.subject_of, (size_t)d.R_phys, 0));
   CK(dev_alloc(h, &d.fail, (size_t)N * (d.P ? d.P : 1), 0));
   CK(dev_alloc(h, &d.trow, (size_t)N * d.S, 0));
-  d.tovf_cap = std::min<uint32_t>(0x7FFEu, std::max<uint32_t>(1024u, N / 4));
+  // overflow cells per (deadline row, cycle parity): members that accept more than 7 suspicions in one tick --
+  // a few per mille of the members without loss, one in three at 1 % loss and a million members
+  d.tovf_cap = std::max<uint32_t>(1024u, c.loss_ppm ? N / 2 : N / 16);
   CK(dev_alloc(h, &d.tovf, (size_t)d.S * 2 * d.tovf_cap, 0));
   CK(dev_alloc(h, &d.tovf_n, (size_t)d.S * 2, 0));
   CK(dev_alloc(h, &d.V, (size_t)(VTILE ? (N + VTILE - 1) / VTILE * VTILE : N) * d.R_phys, 0));

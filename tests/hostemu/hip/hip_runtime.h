@@ -39,9 +39,11 @@ struct uint2 { uint32_t x, y; };
 struct uint3 { uint32_t x, y, z; };
 struct alignas(16) uint4 { uint32_t x, y, z, w; };
 struct alignas(16) ulonglong2 { unsigned long long x, y; };
+struct alignas(32) ulonglong4 { unsigned long long x, y, z, w; };
 static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 static inline ulonglong2 make_ulonglong2(unsigned long long x, unsigned long long y) { return ulonglong2{x, y}; }
+static inline ulonglong4 make_ulonglong4(unsigned long long x, unsigned long long y, unsigned long long z, unsigned long long w) { return ulonglong4{x, y, z, w}; }
 struct dim3 {
   uint32_t x, y, z;
   dim3(uint32_t x_ = 1, uint32_t y_ = 1, uint32_t z_ = 1) : x(x_), y(y_), z(z_) {}

@@ -151,6 +151,25 @@ def test_rumour_id_counter_wraps(oracle_abi):
 
 
 @pytest.mark.parametrize("gc", [0, 1])
+def test_wide_known_ring_under_loss_with_wrapping_ids(oracle_abi, gc):
+    """10-bit rumour ids (the wide known-ring is a quarter of the id space) under 10 % message loss: deliveries
+    travel as explicit records, members remember up to 256 ids back, the id counter wraps several times,
+    members sleep through hundreds of ids and come back with a ring written long ago."""
+    from swim_amd import _abi
+    from tests import hostemu_binding
+    emu = hostemu_binding.load_variant("rid10", ["SWIM_RID_BITS=10"])
+    n = 700
+    crashes = workloads.hashed_crashes(n, 6, 1, 7, 3, 120)
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=6, lossPpm=100000, eventMask=0x1F, suspicionTicks=7,
+                   maxSubjects=700, gcTicks=_abi.GC_AUTO if gc else 0)
+    faults = [(t + 30, m, True) for (t, m) in crashes[:40]]
+    faults += [(20 + k, 300 + k, False) for k in range(20)] + [(75 + k, 300 + k, True) for k in range(20)]
+    a, b = make_pair(oracle_abi, emu, sc, crashes, faults)
+    run_lockstep(a, b, 150, 10, observers=(0, 1, 305, n - 1), members=(0, 1, 305, n - 1))
+    assert b.tableStats()["rumour_ids"] > 3 * 1024                   # the id counter wrapped at least three times
+
+
+@pytest.mark.parametrize("gc", [0, 1])
 def test_join_pull_parity_with_churn(oracle_abi, emu_abi, gc):
     """join_pull: members that come back merge a host's member map in their join tick (begin_kernel) --
     several joins in one tick, hosts that are skipped because they change in the same tick, pulled Suspect
