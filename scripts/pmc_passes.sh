@@ -4,7 +4,8 @@
 # Usage: pmc_passes.sh <outdir>
 R=${GRAFT_REPO_ROOT:-$PWD}; OUT=$1
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp WARM=${WARM:-150} TICKS=${TICKS:-40}
-run() { n=$1; shift; timeout 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -o p -- python $R/scripts/quick_time.py > $OUT/$n.log 2>&1; }
+# PASSES="p1 p2 p4" limits the passes (default: all)
+run() { n=$1; shift; [[ -n "$PASSES" && " $PASSES " != *" $n "* ]] && return; timeout 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -o p -- python $R/scripts/quick_time.py > $OUT/$n.log 2>&1; }
 run p1 FETCH_SIZE
 run p2 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 run p3 TCC_REQ_sum TCC_ATOMIC_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum

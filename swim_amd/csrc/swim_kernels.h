@@ -473,6 +473,9 @@ __device__ inline uint32_t park_rid(uint32_t lo, uint32_t H) {
 #ifndef SWIM_MERGE_WAVES
 #define SWIM_MERGE_WAVES 4
 #endif
+#ifndef SWIM_REC_LINE           // explicit records: 1 = a source's line in one round of loads, 0 = 16 bytes at a time
+#define SWIM_REC_LINE 1
+#endif
 constexpr int ASM_STRIDE = BLOCK + 2;   // words per LDS column: keeps the transposed line store conflict-free
 
 // Settling, the per-member part (swim_device.h; begin_kernel builds the lists, settle_finish commits):
@@ -820,6 +823,27 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
         PSTAT(13); SECT_COUNT(18);
         const uint4* line = (srcw & SRC_FOREIGN) ? s.fl + (size_t)(srcw & (SRC_FOREIGN - 1u)) * 4
                                                  : line_ptr(s, srcw >> 31, srcw & 0x7FFFFFFFu);
+#if SWIM_REC_LINE
+        // the whole line in one round of loads, then its entries one by one (a line is packed from the front)
+        uint4 ln[PB_SLOTS / 2];
+#pragma unroll
+        for (int h = 0; h < PB_SLOTS / 2; ++h) ln[h] = line[h];
+        for (uint32_t q = 0; q < (uint32_t)PB_SLOTS; ++q) {
+          uint32_t lo = ln[0].x, hi = ln[0].y;
+#pragma unroll
+          for (int j = 1; j < PB_SLOTS; ++j)
+            if (q == (uint32_t)j) { lo = (j & 1) ? ln[j >> 1].z : ln[j >> 1].x; hi = (j & 1) ? ln[j >> 1].w : ln[j >> 1].y; }
+          if (!pe_tx(hi)) break;
+          const uint32_t rid = pe_rid(lo);
+          if (rid_in_wide(rid, H)) {
+            if (r256_test(kw, rid)) continue;      // view already dominates it
+            r256_set(kw, rid);
+            if (rid_in_ring(rid, H)) kn |= rid_bit(rid);
+          }
+          PSTAT(14);
+          examine(pe_slot(lo), pe_key(hi), 2u, true, rid);
+        }
+#else
         for (int h = 0; h < PB_SLOTS / 2; ++h) {
           const uint4 v = line[h];
 #pragma unroll
@@ -832,9 +856,11 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
               r256_set(kw, rid);
               if (rid_in_ring(rid, H)) kn |= rid_bit(rid);
             }
+            PSTAT(14);
             examine(pe_slot(lo), pe_key(hi), 2u, true, rid);
           }
         }
+#endif
       }
       s.kw[li] = make_ulonglong4(kw.w[0], kw.w[1], kw.w[2], kw.w[3]);
       if (kwh0 != H) s.kw_head[li] = H;
