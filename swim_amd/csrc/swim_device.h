@@ -114,8 +114,10 @@ struct DevState {
                            //   look at in tick d (the FIXME at src/Core.hs:141; D4).  Every member reads and
                            //   rewrites row t mod S in tick t: coalesced, no per-member FIFO.
   uint4* tovf;             // [S][2][tovf_cap] overflow cells of the deadline rows (chains, two pools per row)
-  uint32_t* tovf_n;        // [S][2] cells handed out
-  uint32_t tovf_cap;
+  uint32_t* tovf_n;        // [S][2][tovf_nsub][16] cells handed out, one counter (on its own 64-B line) per sub-pool:
+                           // block b takes cells from sub-pool b mod tovf_nsub -- tens of thousands of members spill per
+                           // tick under message loss, and one counter serialises them (same-address atomics)
+  uint32_t tovf_cap, tovf_nsub, tovf_sub_cap;   // cells per (row, parity); sub-pools (power of two); cells per sub-pool
   uint2* V;                // [R_phys][N] {key = inc<<2|state, lastChange+1}; key 0 = default = slot_base[slot]
   // ---- settling (gc_ticks; include/swimsim.h): removeDeadNodes (src/Core.hs:65-67)
   uint32_t* slot_last;     // [R_phys] last tick any entry of the row changed / its subject announced itself

@@ -628,8 +628,10 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
   auto tput = [&](uint32_t slot1) {
     if (tnew.n >= tc_cap(tnew)) {
       if (((uint32_t)(tnew.hi >> 48)) == TR_FULL) return;            // already "look everywhere"
-      const uint32_t idx = atomicAdd(&s.tovf_n[row_now * 2u + par_now], 1u);
-      if (idx < s.tovf_cap) {
+      const uint32_t sub = blockIdx.x & (s.tovf_nsub - 1u);
+      const uint32_t got = atomicAdd(&s.tovf_n[((row_now * 2u + par_now) * s.tovf_nsub + sub) * 16u], 1u);
+      const uint32_t idx = sub * s.tovf_sub_cap + got;
+      if (got < s.tovf_sub_cap) {
         s.tovf[((size_t)row_now * 2u + par_now) * s.tovf_cap + idx] = tc_pack(tnew);
         tc_clear(tnew);
         tc_set_link(tnew, idx);
@@ -1363,14 +1365,16 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
     if (changes_sh) s.blk[(size_t)s.nblocks * C_COUNT + C_CHANGES] += changes_sh;
     s.g[G_PREV] = s.g[G_HEAD];
     s.g[G_HEAD] = s.g[G_NRUM];
-    // a line is rewritten every tick and replaces ids outside [H - 64, H + RID_NEAR) by "no id"; an id born at
+    // a line is rewritten every tick and replaces ids outside [H - KW_BITS, H + RID_NEAR) by "no id"; an id born at
     // distance r < RID_NEAR above the head sits at r - D one tick later (D = ids of the tick) and would wrap
-    // back INTO that zone for D > 2^RID_BITS - RID_NEAR.  After such a tick (49 088 new rumours at once with
+    // back INTO that zone for D > 2^RID_BITS - RID_NEAR - KW_BITS.  After such a tick (48 896 new rumours at once with
     // 16-bit ids: heavy message loss) every line of this tick is written without ids: masks and the known-ring
     // are out of the game anyway (explicit records), exactness does not depend on them
     s.g[G_RIDS_OFF] = (s.g[G_HEAD] - s.g[G_PREV] > RID_MASK + 1u - RID_NEAR - KW_BITS) ? 1u : 0u;
-    if (t) s.tovf_n[((t - 1u) % s.S) * 2u + ((((t - 1u) / s.S) & 1u) ^ 1u)] = 0;   // the deadline chains tick t-1 consumed
   }
+  if (t)                                                            // the deadline chains tick t-1 consumed
+    for (uint32_t k = threadIdx.x; k < s.tovf_nsub; k += blockDim.x)
+      s.tovf_n[((((t - 1u) % s.S) * 2u + ((((t - 1u) / s.S) & 1u) ^ 1u)) * s.tovf_nsub + k) * 16u] = 0;
   __syncthreads();
   if (threadIdx.x < KN_BITS) {
     // this tick's ring: what each mask / known-ring position stands for, with its row's base and subject, so

@@ -329,8 +329,12 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   // overflow cells per (deadline row, cycle parity): members that accept more than 7 suspicions in one tick --
   // a few per mille of the members without loss, one in three at 1 % loss and a million members
   d.tovf_cap = std::max<uint32_t>(1024u, c.loss_ppm ? N / 2 : N / 16);
+  d.tovf_nsub = 1;
+  while (d.tovf_nsub < 64u && d.tovf_nsub * 2u <= d.nblocks) d.tovf_nsub *= 2u;
+  d.tovf_sub_cap = d.tovf_cap / d.tovf_nsub;
+  d.tovf_cap = d.tovf_sub_cap * d.tovf_nsub;
   CK(dev_alloc(h, &d.tovf, (size_t)d.S * 2 * d.tovf_cap, 0));
-  CK(dev_alloc(h, &d.tovf_n, (size_t)d.S * 2, 0));
+  CK(dev_alloc(h, &d.tovf_n, (size_t)d.S * 2 * d.tovf_nsub * 16, 0));
   CK(dev_alloc(h, &d.V, (size_t)(VTILE ? (N + VTILE - 1) / VTILE * VTILE : N) * d.R_phys, 0));
   CK(dev_alloc(h, &d.slot_last, (size_t)d.R_phys, 0xFF));
   CK(dev_alloc(h, &d.slot_base, (size_t)d.R_phys, 0));
