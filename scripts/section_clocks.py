@@ -12,7 +12,7 @@ from swim_amd import Sim, workloads, _abi                      # noqa: E402
 
 MERGE = ["inputs", "known-ring + own line + first deadline cells", "failed probes", "delivered rumours (masks)",
          "explicit records + refute", "queue rebuild", "state stores + counters", "wave sync", "line store", "counter flush",
-         "deadlines"]
+         "deadlines", "records: source word", "records: line", "records: entries + state rule"]
 PROBE = ["target selection", "outcomes + pk gathers", "ping pushes", "acks", "indirect probes", "outputs + counters", "counter flush"]
 
 
@@ -44,7 +44,9 @@ def main():
                 for k, lab in enumerate(labels)}
         res[name] = {"waves": waves, "clocks_per_wave": round(tot / max(1, waves), 1), "sections": rows}
     res["events_per_tick"] = {"full row scans (lanes)": out[16] / ticks, "deadline chain cells followed": out[17] / ticks,
-                              "explicit record lines read": out[18] / ticks, "deadline pool exhausted (lanes)": out[19] / ticks
+                              "explicit record lines read": out[18] / ticks, "deadline pool exhausted (lanes)": out[19] / ticks,
+                              "state rule calls (lanes)": out[20] / ticks, "accepted changes (lanes)": out[21] / ticks,
+                              "deadline cells spilled (lanes)": out[22] / ticks
                               }
     print(json.dumps(res, indent=1))
     s.close()

@@ -150,7 +150,8 @@ __device__ inline uint32_t get_slot(const DevState& s, uint32_t j) {
 #define SECT_ADD(k, v) do { const unsigned long long b_ = __ballot(1); \
     if ((threadIdx.x & 63u) == (uint32_t)(__ffsll(b_) - 1)) atomicAdd(reinterpret_cast<unsigned long long*>(&s.blk[((size_t)s.nblocks + 1) * C_COUNT + (blockIdx.x & 63u) * 64u + (k)]), (unsigned long long)(v)); } while (0)
 #define SECT(k) do { const unsigned long long n_ = clock64(); SECT_ADD(k, n_ - sect_t_); sect_t_ = clock64(); } while (0)
-#define SECT_COUNT(k) atomicAdd(reinterpret_cast<unsigned long long*>(&s.blk[((size_t)s.nblocks + 1) * C_COUNT + (blockIdx.x & 63u) * 64u + (k)]), 1ull)
+#define SECT_COUNT(k) do { const unsigned long long b_ = __ballot(1); \
+    if ((threadIdx.x & 63u) == (uint32_t)(__ffsll(b_) - 1)) atomicAdd(reinterpret_cast<unsigned long long*>(&s.blk[((size_t)s.nblocks + 1) * C_COUNT + (blockIdx.x & 63u) * 64u + (k)]), (unsigned long long)__popcll(b_)); } while (0)
 #else
 #define SECT_BEGIN(base) ((void)0)
 #define SECT(k) ((void)0)
@@ -628,6 +629,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
   auto tput = [&](uint32_t slot1) {
     if (tnew.n >= tc_cap(tnew)) {
       if (((uint32_t)(tnew.hi >> 48)) == TR_FULL) return;            // already "look everywhere"
+      SECT_COUNT(22);
       const uint32_t sub = blockIdx.x & (s.tovf_nsub - 1u);
       const uint32_t got = atomicAdd(&s.tovf_n[((row_now * 2u + par_now) * s.tovf_nsub + sub) * 16u], 1u);
       const uint32_t idx = sub * s.tovf_sub_cap + got;
@@ -652,11 +654,11 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
       return;
     }
     examined++;
-    PSTAT(5);
+    PSTAT(5); SECT_COUNT(20);
     if (!(have & HAVE_CELL)) e = s.V[vidx(s, li, slot)];
     const uint32_t curk = e.x ? e.x : ((have & HAVE_BASE) ? sbase : s.slot_base[slot]);   // untouched cell: the settled base
     if (key <= curk) return;                     // old incarnation / weaker state: ignore (:151)
-    PSTAT(6); PSTAT(psite);
+    PSTAT(6); PSTAT(psite); SECT_COUNT(21);
     s.V[vidx(s, li, slot)] = make_uint2(key, t + 1);                    // memberLastChange = now (:176)
     if (s.G) s.slot_last[slot] = t;              // same value from every writer
     if (!(have & HAVE_SUBJ)) subject = s.subject_of[slot];
@@ -822,6 +824,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
           if (o.x == li) srcw = o.y;
         }
         if (srcw == NONE32) continue;
+        SECT(11);                                   // source word arrived
         PSTAT(13); SECT_COUNT(18);
         const uint4* line = (srcw & SRC_FOREIGN) ? s.fl + (size_t)(srcw & (SRC_FOREIGN - 1u)) * 4
                                                  : line_ptr(s, srcw >> 31, srcw & 0x7FFFFFFFu);
@@ -836,6 +839,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
           for (int j = 1; j < PB_SLOTS; ++j)
             if (q == (uint32_t)j) { lo = (j & 1) ? ln[j >> 1].z : ln[j >> 1].x; hi = (j & 1) ? ln[j >> 1].w : ln[j >> 1].y; }
           if (!pe_tx(hi)) break;
+          if (q == 0u) SECT(12);                    // line arrived
           const uint32_t rid = pe_rid(lo);
           if (rid_in_wide(rid, H)) {
             if (r256_test(kw, rid)) continue;      // view already dominates it
@@ -845,6 +849,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
           PSTAT(14);
           examine(pe_slot(lo), pe_key(hi), 2u, true, rid);
         }
+        SECT(13);                                   // its entries
 #else
         for (int h = 0; h < PB_SLOTS / 2; ++h) {
           const uint4 v = line[h];
