@@ -1,6 +1,6 @@
 """Quick per-kernel timing of the HIP tick at 1M members, saturated regime (not the bench contract).
 usage: quick_time.py [lib.so ...]   -- each library variant is timed with the library's own HIP events.
-env: WARM, TICKS, MEMBERS, REGIME (saturated|quiescent)"""
+env: WARM, TICKS, MEMBERS, REGIME (saturated|quiescent), SCHEME=robust, LOSS (ppm), GC=1"""
 import json, os, sys, time, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from swim_amd import Sim, workloads, _lib, _abi
@@ -10,7 +10,9 @@ libs = sys.argv[1:] or [_lib.LIB_PATH]
 for path in libs:
     abi = _abi.bind(C.CDLL(os.path.abspath(path)), "swimsim_")
     mk = workloads.saturated if REGIME == 'saturated' else workloads.quiescent
-    sc, crashes, _ = mk(N, WARM + TICKS)
+    sc, crashes, _ = mk(N, WARM + TICKS, loss_ppm=int(os.environ.get('LOSS', 0))) if REGIME == 'saturated' else mk(N, WARM + TICKS)
+    if os.environ.get('GC'):
+        sc.gcTicks = _abi.GC_AUTO
     sc.targetScheme = 1 if os.environ.get('SCHEME') == 'robust' else 0
     s = Sim.create(abi, sc); workloads.apply_crashes(s, crashes)
     s.step(WARM)

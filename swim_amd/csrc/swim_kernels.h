@@ -474,8 +474,8 @@ __device__ inline uint32_t park_rid(uint32_t lo, uint32_t H) {
 #ifndef SWIM_MERGE_WAVES
 #define SWIM_MERGE_WAVES 4
 #endif
-#ifndef SWIM_REC_LINE           // explicit records: 1 = a source's line in one round of loads, 0 = 16 bytes at a time
-#define SWIM_REC_LINE 1
+#ifndef SWIM_REC_LINE           // explicit records: 0 = 16 bytes at a time, 1 = a source's line in one round of loads, 2 = + its surviving entries' cells in one round
+#define SWIM_REC_LINE 2
 #endif
 constexpr int ASM_STRIDE = BLOCK + 2;   // words per LDS column: keeps the transposed line store conflict-free
 
@@ -814,21 +814,72 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
         r256_or(kw, (H >> 6) & (KW_BITS / 64u - 1u), kn & young);
         r256_or(kw, ((H >> 6) - 1u) & (KW_BITS / 64u - 1u), kn & ~young);
       }
+      auto source_word = [&](uint32_t x) -> uint32_t {
+        if (x < nack) return s.ackfrom[(size_t)li * s.P + x];
+        if (x < nack + nin) return s.inbox[(size_t)li * s.inbox_cap + (x - nack)];
+        if (x < nack + nin + novf) {
+          const uint2 o = s.ovf[(size_t)(t & 1u) * s.ovf_cap + (x - nack - nin)];
+          if (o.x == li) return o.y;
+        }
+        return NONE32;
+      };
+#if SWIM_REC_LINE == 2
+      uint32_t srcw_next = source_word(0u);        // one source ahead: its load travels with this source's line
+#endif
       for (uint32_t x = 0; x < nack + nin + novf; ++x) {
         PSTAT(12);
-        uint32_t srcw = NONE32;
-        if (x < nack) srcw = s.ackfrom[(size_t)li * s.P + x];
-        else if (x < nack + nin) srcw = s.inbox[(size_t)li * s.inbox_cap + (x - nack)];
-        else {
-          const uint2 o = s.ovf[(size_t)(t & 1u) * s.ovf_cap + (x - nack - nin)];
-          if (o.x == li) srcw = o.y;
-        }
+#if SWIM_REC_LINE == 2
+        const uint32_t srcw = srcw_next;
+        srcw_next = source_word(x + 1u);
+#else
+        const uint32_t srcw = source_word(x);
+#endif
         if (srcw == NONE32) continue;
         SECT(11);                                   // source word arrived
         PSTAT(13); SECT_COUNT(18);
         const uint4* line = (srcw & SRC_FOREIGN) ? s.fl + (size_t)(srcw & (SRC_FOREIGN - 1u)) * 4
                                                  : line_ptr(s, srcw >> 31, srcw & 0x7FFFFFFFu);
-#if SWIM_REC_LINE
+#if SWIM_REC_LINE == 2
+        // the whole line in one round of loads; its entries filtered by the rings (no memory); the view cells, row
+        // bases and subjects of the survivors in ONE round; then the rule on each (slots of a line are distinct).
+        // 1 % loss at a million members: 1.44 against 1.86 ms per tick; without loss no difference
+        // (profiles/r02i_*_rec_variants.txt).
+        uint4 ln[PB_SLOTS / 2];
+#pragma unroll
+        for (int h = 0; h < PB_SLOTS / 2; ++h) ln[h] = line[h];
+        uint32_t need = 0;
+        uint2 ce[PB_SLOTS]; uint32_t cb[PB_SLOTS], cs[PB_SLOTS];
+#pragma unroll
+        for (int q = 0; q < PB_SLOTS; ++q) {
+          const uint4 v = ln[q >> 1];
+          const uint32_t lo = (q & 1) ? v.z : v.x, hi = (q & 1) ? v.w : v.y;
+          ce[q] = make_uint2(0u, 0u); cb[q] = 0u; cs[q] = 0u;
+          bool want = pe_tx(hi) != 0u;
+          const uint32_t rid = pe_rid(lo);
+          if (want && rid_in_wide(rid, H)) {
+            if (r256_test(kw, rid)) want = false;  // view already dominates it
+            else { r256_set(kw, rid); if (rid_in_ring(rid, H)) kn |= rid_bit(rid); }
+          }
+          if (want) {
+            need |= 1u << q;
+            const uint32_t slot = pe_slot(lo);
+            if (slot + 1 != my_slot1) { ce[q] = s.V[vidx(s, li, slot)]; cb[q] = s.slot_base[slot]; cs[q] = s.subject_of[slot]; }
+          }
+        }
+        SECT(12);
+        while (need) {
+          const uint32_t q = (uint32_t)__ffs(need) - 1u;
+          need &= need - 1u;
+          uint32_t lo = ln[0].x, hi = ln[0].y, sb = cb[0], sj = cs[0];
+          uint2 e = ce[0];
+#pragma unroll
+          for (int j = 1; j < PB_SLOTS; ++j)
+            if (q == (uint32_t)j) { lo = (j & 1) ? ln[j >> 1].z : ln[j >> 1].x; hi = (j & 1) ? ln[j >> 1].w : ln[j >> 1].y; sb = cb[j]; sj = cs[j]; e = ce[j]; }
+          PSTAT(14);
+          examine_with(pe_slot(lo), pe_key(hi), 2u, true, pe_rid(lo), EX_ALL, e, sb, sj);
+        }
+        SECT(13);
+#elif SWIM_REC_LINE
         // the whole line in one round of loads, then its entries one by one (a line is packed from the front)
         uint4 ln[PB_SLOTS / 2];
 #pragma unroll
