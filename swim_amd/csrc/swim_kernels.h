@@ -474,9 +474,6 @@ __device__ inline uint32_t park_rid(uint32_t lo, uint32_t H) {
 #ifndef SWIM_MERGE_WAVES
 #define SWIM_MERGE_WAVES 4
 #endif
-#ifndef SWIM_REC_LINE           // explicit records: 0 = 16 bytes at a time, 1 = a source's line in one round of loads, 2 = + its surviving entries' cells in one round
-#define SWIM_REC_LINE 2
-#endif
 constexpr int ASM_STRIDE = BLOCK + 2;   // words per LDS column: keeps the transposed line store conflict-free
 
 // Settling, the per-member part (swim_device.h; begin_kernel builds the lists, settle_finish commits):
@@ -823,27 +820,21 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
         }
         return NONE32;
       };
-#if SWIM_REC_LINE == 2
       uint32_t srcw_next = source_word(0u);        // one source ahead: its load travels with this source's line
-#endif
       for (uint32_t x = 0; x < nack + nin + novf; ++x) {
         PSTAT(12);
-#if SWIM_REC_LINE == 2
         const uint32_t srcw = srcw_next;
         srcw_next = source_word(x + 1u);
-#else
-        const uint32_t srcw = source_word(x);
-#endif
         if (srcw == NONE32) continue;
         SECT(11);                                   // source word arrived
         PSTAT(13); SECT_COUNT(18);
         const uint4* line = (srcw & SRC_FOREIGN) ? s.fl + (size_t)(srcw & (SRC_FOREIGN - 1u)) * 4
                                                  : line_ptr(s, srcw >> 31, srcw & 0x7FFFFFFFu);
-#if SWIM_REC_LINE == 2
         // the whole line in one round of loads; its entries filtered by the rings (no memory); the view cells, row
         // bases and subjects of the survivors in ONE round; then the rule on each (slots of a line are distinct).
-        // 1 % loss at a million members: 1.44 against 1.86 ms per tick; without loss no difference
-        // (profiles/r02i_*_rec_variants.txt).
+        // Measured against the line read 16 bytes at a time with one dependent gather per entry: numToGossip = 10
+        // merge 319 -> 160 us; 1 % loss at a million members 1.86 -> 1.44 ms per tick; k = 3 without loss no
+        // difference (profiles/r02f_*, r02i_*_rec_variants.txt).
         uint4 ln[PB_SLOTS / 2];
 #pragma unroll
         for (int h = 0; h < PB_SLOTS / 2; ++h) ln[h] = line[h];
@@ -879,46 +870,6 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
           examine_with(pe_slot(lo), pe_key(hi), 2u, true, pe_rid(lo), EX_ALL, e, sb, sj);
         }
         SECT(13);
-#elif SWIM_REC_LINE
-        // the whole line in one round of loads, then its entries one by one (a line is packed from the front)
-        uint4 ln[PB_SLOTS / 2];
-#pragma unroll
-        for (int h = 0; h < PB_SLOTS / 2; ++h) ln[h] = line[h];
-        for (uint32_t q = 0; q < (uint32_t)PB_SLOTS; ++q) {
-          uint32_t lo = ln[0].x, hi = ln[0].y;
-#pragma unroll
-          for (int j = 1; j < PB_SLOTS; ++j)
-            if (q == (uint32_t)j) { lo = (j & 1) ? ln[j >> 1].z : ln[j >> 1].x; hi = (j & 1) ? ln[j >> 1].w : ln[j >> 1].y; }
-          if (!pe_tx(hi)) break;
-          if (q == 0u) SECT(12);                    // line arrived
-          const uint32_t rid = pe_rid(lo);
-          if (rid_in_wide(rid, H)) {
-            if (r256_test(kw, rid)) continue;      // view already dominates it
-            r256_set(kw, rid);
-            if (rid_in_ring(rid, H)) kn |= rid_bit(rid);
-          }
-          PSTAT(14);
-          examine(pe_slot(lo), pe_key(hi), 2u, true, rid);
-        }
-        SECT(13);                                   // its entries
-#else
-        for (int h = 0; h < PB_SLOTS / 2; ++h) {
-          const uint4 v = line[h];
-#pragma unroll
-          for (int w = 0; w < 2; ++w) {
-            const uint32_t lo = w ? v.z : v.x, hi = w ? v.w : v.y;
-            if (!pe_tx(hi)) continue;
-            const uint32_t rid = pe_rid(lo);
-            if (rid_in_wide(rid, H)) {
-              if (r256_test(kw, rid)) continue;    // view already dominates it
-              r256_set(kw, rid);
-              if (rid_in_ring(rid, H)) kn |= rid_bit(rid);
-            }
-            PSTAT(14);
-            examine(pe_slot(lo), pe_key(hi), 2u, true, rid);
-          }
-        }
-#endif
       }
       s.kw[li] = make_ulonglong4(kw.w[0], kw.w[1], kw.w[2], kw.w[3]);
       if (kwh0 != H) s.kw_head[li] = H;
