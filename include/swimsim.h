@@ -136,7 +136,9 @@ typedef struct swimsim_config {
  * as a population-wide tombstone (never picked, rumours at its incarnation ignored, an Alive at a
  * higher incarnation re-adds it); a settled Alive@i subject stays listed with since_tick = the settling
  * tick.  Nothing is settled while a member that is up still holds it Suspect.  The column is reusable
- * two ticks later.  G >= suspicion_ticks + L + 2 guarantees that no piggyback queue and no pending
+ * two ticks later.  A subject has a column from the first rumour anybody states about it -- a failed probe's
+ * suspicion, a delivered rumour, its OWN join announcement (a member that joins and goes down again before anybody
+ * hears of it leaves an empty column, which settles like any other: counter SETTLED, max_subjects).  G >= suspicion_ticks + L + 2 guarantees that no piggyback queue and no pending
  * timer of an up member refers to s any more.  Not available on sharded handles yet. */
 
 /* Target schemes for the direct probes of a period.

@@ -699,6 +699,10 @@ static void apply_faults(swimoracle_t* o, uint32_t t) {
       o->self_inc[m] = ni;
       o->counters[SWIMSIM_CTR_EVDIGEST] += h4(TAG_INC, ((uint64_t)t << 32) | m, ni, 0);
       cand_insert(&o->pb[m], m, key_make(ni, SWIMSIM_ALIVE), (uint8_t)o->L);
+      /* the announcement is a rumour about m: m has a view column from now on, whether or not anybody ever stores
+       * an entry in it (a member that goes down again before it is heard of: the column settles empty; counter 15,
+       * max_subjects and base_since see it) */
+      if (!view_ref(o, m, m)) return;
       o->last_change[m] = t;
       event_add(&o->ctx[0], t, m, m, key_make(ni, SWIMSIM_ALIVE), SWIMSIM_CAUSE_JOIN);
       o->first_suspect[m] = NONE32;

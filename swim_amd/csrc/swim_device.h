@@ -101,7 +101,7 @@ struct DevState {
   ulonglong4* kw;          // [N] wide known-ring (explicit-record path; above), positions beyond KW_BITS unused
   uint32_t* kw_head;       // [N] head the member's kw was written at
   uint4* ring;             // [64] this tick's ring, built by begin_kernel: position -> {slot, key, row base, subject}
-  unsigned long long* rtab;// [R_max][RT_WAYS] (slot, key) -> rumour id: {key+1 : 32 | ready : 1 | rid : 16}
+  unsigned long long* rtab;// [R_max][RT_WAYS] (slot, key) -> rumour id: {key+1 : 32 | allocation number >> RID_BITS : 15 | ready : 1 | rid : 16}
   // explicit delivery records "dst merges src's 64-B line": the exact fallback for queues with
   // entries outside the mask window, and for ticks that follow a burst of new rumour ids
   uint32_t* ackfrom;       // [N][P] sources whose Ack reached this member with such a payload
@@ -249,6 +249,9 @@ static_assert(RID_BITS <= 16 && KW_BITS + RID_NEAR < RID_FAR + 1 && KN_BITS <= K
               "rumour ids: window < near range < parking distance");
 constexpr int RT_WAYS = 8;
 constexpr unsigned long long RT_READY = 1ull << 16;
+// bits 17..31 of a way: the upper bits of the id counter when the id was handed out, so that the age of a cached id
+// is known beyond one turn of the id space (an id exactly 2^RID_BITS allocations old reads as brand-new otherwise)
+constexpr uint32_t RT_GEN_SHIFT = 17, RT_GEN_MASK = 0x7FFFu, RT_SPAN_MASK = (1u << (RID_BITS + 15)) - 1u;
 
 // ring / mask position arithmetic (H = head of the tick)
 __device__ inline bool rid_in_ring(uint32_t rid, uint32_t H) { return rid != RID_PARKED && ((H - 1u - rid) & RID_MASK) < KN_BITS; }

@@ -396,11 +396,11 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
 // merge kernel
 // ================================================================================================
 
-// a fresh rumour id (RID_PARKED is never handed out)
+// a fresh rumour id: its allocation number, whose low RID_BITS are the id (RID_PARKED is never handed out)
 __device__ inline uint32_t new_rid(const DevState& s) {
-  uint32_t rid;
-  do rid = atomicAdd(&s.g[G_NRUM], 1u) & RID_MASK; while (rid == RID_PARKED);
-  return rid;
+  uint32_t c;
+  do c = atomicAdd(&s.g[G_NRUM], 1u); while ((c & RID_MASK) == RID_PARKED);
+  return c;
 }
 
 // (slot, key) -> rumour id, created by whoever states the rumour first (own probe, own timer,
@@ -418,11 +418,14 @@ __device__ inline uint32_t find_rid(const DevState& s, uint32_t slot, uint32_t k
       if (e & RT_READY) {
         // a published id is reused only while it still names this rumour and is younger than half the id space:
         // the id counter wraps (RID_BITS), and an id that another rumour took over -- or one so old that it
-        // would read as an id just above the head -- would set a foreign bit in somebody's mask.  A stale entry
-        // is re-claimed like a free one.
+        // would read as an id just above the head -- would set a foreign bit in somebody's mask.  The age is
+        // taken from the allocation number kept with the id, not from the id: an id exactly one turn of the id
+        // space old is being handed out again in this very tick, rum[] may not show it yet, and its age modulo
+        // 2^RID_BITS reads as zero (found by a soak of the 8-bit build).  A stale entry is re-claimed like a free one.
         const uint32_t rid = (uint32_t)e & RID_MASK;
+        const uint32_t born = ((((uint32_t)e >> RT_GEN_SHIFT) & RT_GEN_MASK) << RID_BITS) | rid;
         const uint2 r = s.rum[rid];
-        if (r.x == slot && r.y == key && ((s.g[G_NRUM] - rid) & RID_MASK) < RID_FAR) return rid;
+        if (r.x == slot && r.y == key && ((s.g[G_NRUM] - born) & RT_SPAN_MASK) < RID_FAR) return rid;
       } else {
         e = atomicCAS(p, 0ull, 0ull);               // being published by another lane: re-read at device scope
         continue;
@@ -430,14 +433,14 @@ __device__ inline uint32_t find_rid(const DevState& s, uint32_t slot, uint32_t k
     } else if (ek > key + 1u) break;                // the way belongs to a newer rumour about this subject
     const unsigned long long seen = atomicCAS(p, e, claim);
     if (seen == e) {
-      const uint32_t rid = new_rid(s);
+      const uint32_t c = new_rid(s), rid = c & RID_MASK;
       s.rum[rid] = make_uint2(slot, key);           // read by other members from the next launch on
-      atomicExch(p, claim | RT_READY | rid);
+      atomicExch(p, claim | RT_READY | ((unsigned long long)((c >> RID_BITS) & RT_GEN_MASK) << RT_GEN_SHIFT) | rid);
       return rid;
     }
     e = seen;
   }
-  const uint32_t rid = new_rid(s);
+  const uint32_t rid = new_rid(s) & RID_MASK;
   s.rum[rid] = make_uint2(slot, key);
   return rid;
 }
