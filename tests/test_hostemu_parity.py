@@ -150,6 +150,52 @@ def test_rumour_id_counter_wraps(oracle_abi):
     assert b.counters()["changes"] > 256 * 300                      # thousands of ids: many wraps
 
 
+def test_a_join_nobody_hears_of_leaves_an_empty_row_that_settles(oracle_abi, emu_abi):
+    """A member comes up and goes down again in the same tick: its join announcement dies with its queue, nobody
+    ever stores an entry about it, yet the announcement gave it a view row (include/swimsim.h, settling).  The
+    row settles empty after G quiet ticks -- same `settled` count and digest on both sides (the oracle used to
+    allocate its columns lazily and missed this one)."""
+    from swim_amd import _abi
+    n = 96
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=5, eventMask=0x1F, suspicionTicks=4, retransmitMult=1,
+                   maxSubjects=32, gcTicks=_abi.GC_AUTO)
+    faults = [(12, 40, True), (12, 40, False), (30, 41, True), (30, 41, False)]     # up and down again within one tick
+    a, b = make_pair(oracle_abi, emu_abi, sc, [(2, 40), (2, 41)], faults)
+    run_lockstep(a, b, 120, 4, observers=(0, 40, 41, n - 1), members=(0, 40, 41))
+    assert b.counters()["settled"] >= 3                               # the two real subjects, and empty rows of rejoins
+
+
+@pytest.mark.parametrize("seed", [4, 8])
+def test_restated_rumour_one_turn_of_the_id_space_later(oracle_abi, seed):
+    """Regression (found by a soak of the 8-bit build): a member restates an old rumour -- a deadline it slept
+    through, a rejoin -- exactly when the id counter comes round to that rumour's cached id: the cached id's age
+    modulo the id space read as zero, the id was reused while another rumour was taking it over, and receivers
+    decoded the wrong rumour.  The cache now keeps the allocation number.  Both seeds diverged before the fix."""
+    import random
+    from tests import hostemu_binding
+    emu = hostemu_binding.load_variant("rid8", ["SWIM_RID_BITS=8"])
+    rng = random.Random(seed)
+    n, ticks = 600, 300
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=seed + 1, lossPpm=0, eventMask=0, suspicionTicks=4,
+                   retransmitMult=3, maxSubjects=n)
+    a = Sim.create(oracle_abi, sc)
+    b = Sim.create(emu, sc)
+    for _ in range(n // 4):
+        m, t = rng.randrange(n), rng.randrange(1, ticks)
+        for s in (a, b):
+            s.scheduleFault(t, m, False)
+        if rng.random() < 0.7:
+            t2 = t + rng.randrange(1, 150)
+            for s in (a, b):
+                s.scheduleFault(t2, m, True)
+    while a.tick < ticks:
+        a.step(10); b.step(10)
+        assert a.counters() == b.counters(), a.tick
+        assert a.digest() == b.digest(), a.tick
+    assert b.tableStats()["rumour_ids"] > 256                       # the id counter came round at least once
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("gc", [0, 1])
 def test_wide_known_ring_under_loss_with_wrapping_ids(oracle_abi, gc):
     """10-bit rumour ids (the wide known-ring is a quarter of the id space) under 10 % message loss: deliveries
