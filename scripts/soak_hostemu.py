@@ -1,0 +1,56 @@
+"""Randomised long-run soak of the product's kernels in the host emulation against the oracle (CPU only): random
+populations (130-3000), fan-outs, loss rates up to 20 %, settling, join pull, tiny inboxes, hundreds of crashes and
+rejoins over 200-800 ticks, on the normal build and the knob-shrunk ones (8- and 10-bit rumour ids, 4-id mask
+window).  Every 20 ticks: counters (the dropped-event count aside: implementation-defined once the ring overflows),
+state digest, events (while nothing was dropped), first-detection ticks at the end.
+usage: soak_hostemu.py <seed> <seconds>      -- prints one line per case; "DIVERGED" names the configuration."""
+import sys, random, time
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from swim_amd import Config, Sim, SimConfig, workloads, _abi
+from tests import hostemu_binding, oracle_binding
+orc = oracle_binding.load()
+variants = {"": hostemu_binding.load(), "rid10": hostemu_binding.load_variant("rid10", ["SWIM_RID_BITS=10"]),
+            "rid8": hostemu_binding.load_variant("rid8", ["SWIM_RID_BITS=8"]), "win4": hostemu_binding.load_variant("win4", ["SWIM_MASK_WIN=4", "SWIM_MASK_SLACK=2"])}
+seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+t_end = time.time() + float(sys.argv[2]) if len(sys.argv) > 2 else time.time() + 1200
+k = 0
+while time.time() < t_end:
+    rng = random.Random(seed0 * 100003 + k); k += 1
+    vname = rng.choice(list(variants))
+    n = rng.choice([130, 300, 700, 1500, 3000])
+    p = rng.choice([1, 3, 3, 5, 10])
+    loss = rng.choice([0, 20000, 50000, 100000, 200000])
+    gc = rng.random() < 0.6
+    jp = rng.random() < 0.5
+    S = rng.choice([4, 7, 12])
+    ticks = rng.choice([200, 400, 800])
+    sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=rng.randrange(1, 1 << 30), lossPpm=loss, eventMask=0x1F,
+                   suspicionTicks=S, retransmitMult=rng.choice([1, 2, 3]), maxSubjects=n, gcTicks=_abi.GC_AUTO if gc else 0,
+                   joinPull=1 if jp else 0, inboxCap=rng.choice([0, 0, 2]))
+    a = Sim.create(orc, sc); b = Sim.create(variants[vname], sc)
+    nf = rng.randrange(0, n // 4)
+    for _ in range(nf):
+        m, t = rng.randrange(n), rng.randrange(1, ticks)
+        for s in (a, b): s.scheduleFault(t, m, False)
+        if rng.random() < 0.7:
+            t2 = t + rng.randrange(1, 150)
+            for s in (a, b): s.scheduleFault(t2, m, True)
+    what = (vname, n, p, loss, gc, jp, S, ticks, sc.seed, nf)
+    ok = True
+    try:
+        for _ in range(ticks // 20):
+            a.step(20); b.step(20)
+            ca, cb = a.counters(), b.counters()
+            da, db = ca.pop("events_dropped"), cb.pop("events_dropped")
+            assert ca == cb, "counters %s" % {k2: (ca[k2], cb[k2]) for k2 in ca if ca[k2] != cb[k2]}
+            assert a.digest() == b.digest(), "digest"
+            ea, eb = a.drainEventsRaw(), b.drainEventsRaw()
+            if da == 0 and db == 0: assert ea == eb, "events"
+        assert a.firstDetection() == b.firstDetection(), "fd"
+    except AssertionError as e:
+        ok = False; print("DIVERGED", e, what, "tick", a.tick, flush=True)
+    except Exception as e:
+        ok = False; print("ERROR", repr(e)[:200], what, flush=True)
+    print("ok" if ok else "FAIL", what, b.tableStats() if ok else "", flush=True)
+    a.close(); b.close()
