@@ -139,7 +139,8 @@ typedef struct swimsim_config {
  * two ticks later.  A subject has a column from the first rumour anybody states about it -- a failed probe's
  * suspicion, a delivered rumour, its OWN join announcement (a member that joins and goes down again before anybody
  * hears of it leaves an empty column, which settles like any other: counter SETTLED, max_subjects).  G >= suspicion_ticks + L + 2 guarantees that no piggyback queue and no pending
- * timer of an up member refers to s any more.  Not available on sharded handles yet. */
+ * timer of an up member refers to s any more.  On sharded handles the decision needs every shard's word: a third,
+ * small exchange round per tick (swimsim_shard_settle_*, below). */
 
 /* Target schemes for the direct probes of a period.
  * RANDOM: numToGossip members drawn uniformly among those Alive in the prober's view (the reference).
@@ -149,8 +150,8 @@ typedef struct swimsim_config {
  *   section 9).  Every member is probed by exactly numToGossip members per period and every member
  *   probes every other one once per round: detection time is bounded, and since the pingers of a
  *   member are computable its Ping payloads are pulled instead of pushed (no atomics).  Targets that
- *   are not Alive in the prober's view are skipped, proxies stay uniformly random.  Not available on
- *   sharded handles yet. */
+ *   are not Alive in the prober's view are skipped, proxies stay uniformly random.  On sharded handles the
+ *   targets are the same and the payloads are pushed (the pinger may live on another shard). */
 enum { SWIMSIM_TARGETS_RANDOM = 0, SWIMSIM_TARGETS_ROBUST = 1 };
 
 typedef struct swimsim swimsim_t; /* opaque; owned by the library */
@@ -351,6 +352,16 @@ int swimsim_shard_phase3(swimsim_t* h, const uint32_t* p_counts_in, const uint32
 typedef int (*swimsim_exchange_fn)(void* ctx, int round, const uint32_t* counts_out /*[3*n_shards]*/,
                                    uint32_t* counts_in /*[3*n_shards]*/);
 int swimsim_shard_step(swimsim_t* h, uint32_t nticks, swimsim_exchange_fn xchg, void* ctx);
+/* Settling on a sharded cluster (gc_ticks > 0): a subject settles when it is quiet on EVERY shard, and every shard
+ * must commit the same base in the same tick.  After phase3 each shard holds a list of 8-byte records
+ * {subject | flags, largest entry among its up members} about its rows (kind 3: the SAME list for every peer, at
+ * send[p][0 .. counts[p]) of swimsim_shard_settle_buffers); round 3 delivers it to every peer's recv[me][..] like
+ * the other rounds, and swimsim_shard_settle_commit ends the tick.  swimsim_shard_step does it by itself and
+ * calls xchg(ctx, 3, counts_out, counts_in) with the kind-3 counts at index [p]. */
+#define SWIMSIM_SREC_BYTES 8u
+int swimsim_shard_settle_buffers(swimsim_t* h, void** send, void** recv, uint32_t* cap /* records per peer segment */);
+int swimsim_shard_settle_counts(swimsim_t* h, uint32_t* counts /*[n_shards] out*/);
+int swimsim_shard_settle_commit(swimsim_t* h, const uint32_t* counts_in /*[n_shards]*/);
 int swimsim_shard_get_first_suspect(swimsim_t* h, uint32_t* out, size_t n);
 int swimsim_shard_set_first_suspect(swimsim_t* h, const uint32_t* combined, size_t n);
 

@@ -103,6 +103,9 @@ _PRODUCT_ONLY = {
     "shard_phase2": (C.c_int, [_H, _U32P, _U32P]),
     "shard_phase3": (C.c_int, [_H, _U32P, _U32P]),
     "shard_step": (C.c_int, [_H, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "shard_settle_buffers": (C.c_int, [_H, _VPP, _VPP, _U32P]),
+    "shard_settle_counts": (C.c_int, [_H, _U32P]),
+    "shard_settle_commit": (C.c_int, [_H, _U32P]),
     "shard_get_first_suspect": (C.c_int, [_H, _U32P, C.c_size_t]),
     "shard_set_first_suspect": (C.c_int, [_H, _U32P, C.c_size_t]),
     "table_stats": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_size_t]),

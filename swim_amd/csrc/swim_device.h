@@ -31,6 +31,7 @@ enum { G_NSLOTS = 0 /* view rows ever handed out (high-water mark) */, G_ERR = 1
        G_SETTLE_N = 10 /* rows whose entries this tick's merge reduces */, G_ZERO_N = 11 /* rows it clears */,
        G_SETTLE_PENDING = 12 /* the lists above still await settle_finish */, G_SETTLE_TICK = 13,
        G_RIDS_OFF = 14 /* so many new rumours last tick that this tick's lines carry no ids at all */,
+       G_SETTLE_SEND = 15 /* sharded settling: records this shard publishes at the end of the tick (same list to every peer) */,
        G_SEND = 16 /* [3][16] exchange records appended per peer (send_cnt) */, G_WORDS = 64 };
 enum { ERRF_SUBJECTS = 1, ERRF_ROWS = 2, ERRF_OVF = 4, ERRF_INC = 8, ERRF_XCHG = 16 };
 
@@ -130,6 +131,8 @@ struct DevState {
   uint32_t* settle_key;
   uint32_t* settle_part;   // [R_phys][nblocks] merge_kernel's per-block maxima of the eligible rows (no atomics)
   uint32_t* zero_slots;    // [R_phys] rows settled at the end of the last tick: cleared by this tick's merge
+  uint32_t* slot_born;     // [R_phys] value of the id counter when the row was handed to its subject: a rumour id older than
+                           //   that names a rumour of the row's PREVIOUS subject (sharded settling: the tick's dictionary)
   uint64_t* pb;            // [2][N][PB_SLOTS] {lo: slot | rid<<16, hi: key | tx<<24}, sorted by priority
   uint32_t* first_suspect;
   uint32_t* crash_tick;
@@ -151,7 +154,14 @@ struct DevState {
   uint2* xl;               // [n_shards][64] a peer's dictionary in MY numbering {slot | rid<<16, key}
   uint4* fl;               // [n_shards * (x_cap + p_cap + r_cap)][4] "foreign lines": received entries my masks cannot carry
   unsigned long long* ackslot;  // [N][P] Ack payloads pulled from remote targets: one slot per probe, plain stores
+  // sharded settling: what every shard says about its rows at the end of a tick, all-gathered
+  uint2* s_send; uint2* s_recv;         // [n_shards][s_cap] {subject | SR_CAND / SR_VETO, largest entry among my up members}
+  uint32_t s_cap;
+  uint32_t* settle_acc;    // [NT] scratch of settle_commit_kernel (zero between launches)
 };
+// settle records: a shard lists a row as a CANDIDATE (quiet here for G ticks; y = the largest entry among its members
+// that are up) or as a VETO (an entry changed / the subject announced itself within the last G ticks)
+constexpr uint32_t SR_CAND = 1u << 30, SR_VETO = 1u << 31, SR_KEY = 0xFFFFFFu;
 constexpr uint32_t DICT_ENTRIES = 64;   // one dictionary entry per ring position ...
 constexpr uint32_t DICT_RECS = 32;      // ... = 32 sixteen-byte records at the head of every round-1 segment
 // Orders and round-1 records, 16 bytes: {x = dst | tag<<27, y = src | flags<<27, z/w = 64-bit mask}.

@@ -124,6 +124,7 @@ __device__ inline void ensure_slot(const DevState& s, uint32_t j) {
       s.subject_of[r] = j;
       s.slot_base[r] = s.base_key[j];
       s.slot_last[r] = NONE32;
+      s.slot_born[r] = s.g[G_NRUM];                 // any rumour id about j is allocated after this point
       s.slot_used[r] = 1;
       __threadfence();
       atomicXor(&s.minfo[j], MI_SLOT ^ (r + 1u));
@@ -200,6 +201,9 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
     uint32_t picks[PMAX], pinfo[PMAX];
     bool valid[PMAX];                               // probe index p is in use this period
     const bool robust = s.scheme == 1u;
+    // the robust scheme's Ping payloads are PULLED by the target (its pingers are computable) -- on one handle; on
+    // a sharded cluster the pinger may live elsewhere, and the payloads are pushed like the random scheme's
+    const bool pull = robust && s.n_shards == 1u;
     uint32_t np;                                    // probe indices in play
     if (!robust) {
       // ms <- kRandomMembers store (numToGossip cfg) []        (src/Core.hs:239)
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
         pos[p] = 0;
         if (ping_ok[p]) {
           payloads++; rumors += mycnt;
-          if (robust) continue;                      // the target pulls it (below): its pingers are computable
+          if (pull) continue;                        // the target pulls it (below): its pingers are computable
           if (is_local(s, picks[p])) {
             const uint32_t dl = picks[p] - s.lo;
             const unsigned long long m = mymask & ~(tk2[p].y & ~stale);   // only what the target does not know
@@ -290,14 +294,14 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
           }
         }
       }
-      if (expl && !robust) {
+      if (expl && !pull) {
 #pragma unroll
         for (int p = 0; p < PMAX; ++p)
           if (ping_ok[p] && is_local(s, picks[p])) push_commit(s, t, picks[p] - s.lo, mi_src(li, mi), pos[p]);
       }
     }
     SECT(34);                                       // pushes
-    if (robust) {
+    if (pull) {
       // the Pings that reach ME this period: probe p of member q = i - o(t,p), if q is up, sees me Alive
       // and the Ping is not lost.  I merge q's queue: a gather instead of q's atomicOr.
 #pragma unroll
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
     // for the target's queue (if its Ack arrived); the answer lands in my slot p without an atomic
 #pragma unroll
     for (int p = 0; p < PMAX; ++p) {
-      if (robust || !ping_ok[p] || is_local(s, picks[p])) continue;
+      if (pull || !ping_ok[p] || is_local(s, picks[p])) continue;
       const uint32_t fl = ((mymask && !(mi & MI_OOW)) ? OF_PAYLOAD : 0u) | (ack_ok[p] ? OF_WANTS_ACK : 0u);
       if (fl) emit_raw(picks[p] | ((uint32_t)(p + 1) << ID_BITS), i | (fl << ID_BITS), (fl & OF_PAYLOAD) ? mymask : 0ull);
     }
@@ -1234,7 +1238,7 @@ struct FaultRec { uint32_t member, up; };
 // settled while an up member holds the subject Suspect.  Runs at the start of begin_kernel, or on its own
 // before state is read (digest, views) -- whichever comes first.
 __device__ inline void settle_finish(const DevState& s) {
-  if (!s.G || !s.g[G_SETTLE_PENDING]) return;     // uniform
+  if (!s.G || s.n_shards > 1 || !s.g[G_SETTLE_PENDING]) return;     // uniform; shards: settle_publish / settle_commit
   __shared__ uint32_t nz_new, nfree;
   const uint32_t u = s.g[G_SETTLE_TICK], ns = s.g[G_SETTLE_N], nz = s.g[G_ZERO_N];
   if (threadIdx.x == 0) { nz_new = 0; nfree = s.g[G_NFREE]; }
@@ -1282,6 +1286,103 @@ __device__ inline void settle_finish(const DevState& s) {
 }
 __global__ __launch_bounds__(BLOCK) void settle_flush_kernel(DevState s) { settle_finish(s); }
 
+// Settling on a sharded cluster.  A subject settles when it is quiet on EVERY shard and the
+// largest entry among ALL up members is not Suspect, and every shard must commit the same base in the same
+// tick (the base is everybody's default).  So after merge_kernel of tick u each shard publishes what its rows
+// say -- one 8-byte record per row that is a candidate here (quiet for G ticks, with the largest entry among
+// my up members) or a veto (changed / announced within G ticks) --, the lists are all-gathered (exchange round
+// 3) and settle_commit_kernel takes the same decision everywhere.  Rows that hold nothing and are neither
+// (opened this tick for a peer's dictionary entry) say nothing.
+__global__ __launch_bounds__(BLOCK) void settle_publish_kernel(DevState s, uint32_t u) {
+  __shared__ uint32_t nrec, nfree;
+  __shared__ uint32_t red[BLOCK];
+  const uint32_t ns = s.g[G_SETTLE_N], nz = s.g[G_ZERO_N];
+  if (threadIdx.x == 0) { nrec = 0; nfree = s.g[G_NFREE]; }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < nz; k += blockDim.x) s.free_rows[nfree + k] = s.zero_slots[k];   // cleared by this tick's merge
+  for (uint32_t k = 0; k < ns; ++k) {
+    uint32_t m = 0;
+    for (uint32_t b = threadIdx.x; b < s.nblocks; b += blockDim.x) m = max(m, s.settle_part[(size_t)k * s.nblocks + b]);
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (uint32_t o = blockDim.x / 2; o > 0; o >>= 1) {
+      if (threadIdx.x < o) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + o]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) s.settle_key[k] = red[0];
+    __syncthreads();
+  }
+  auto emit = [&](uint32_t x, uint32_t y) {
+    const uint32_t pos = atomicAdd(&nrec, 1u);
+    if (pos >= s.s_cap) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG); return; }
+    for (uint32_t g = 0; g < s.n_shards; ++g) s.s_send[(size_t)g * s.s_cap + pos] = make_uint2(x, y);
+  };
+  for (uint32_t k = threadIdx.x; k < ns; k += blockDim.x) {
+    const uint32_t slot = s.settle_slots[k], last = s.slot_last[slot];
+    if (last != NONE32 && u - last < s.G) continue;          // somebody changed its mind during tick u: a veto below
+    emit(s.subject_of[slot] | SR_CAND, s.settle_key[k] & SR_KEY);
+  }
+  const uint32_t nrows = min(s.g[G_NSLOTS], s.R_phys);
+  for (uint32_t r = threadIdx.x; r < nrows; r += blockDim.x) {
+    if (!s.slot_used[r]) continue;
+    const uint32_t last = s.slot_last[r];
+    if (last != NONE32 && u - last < s.G) emit(s.subject_of[r] | SR_VETO, 0u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { s.g[G_NFREE] = nfree + nz; s.g[G_ZERO_N] = 0; s.g[G_SETTLE_SEND] = min(nrec, s.s_cap); }
+}
+
+// after round 3: every shard's list (mine in s_send, the peers' in s_recv).  One u32 per subject collects the
+// lists with atomicMax: a veto outranks everything, candidates combine to the largest entry; the thread that
+// takes the word back (atomicExch) commits the subject -- once per shard, the same decision everywhere.
+__global__ __launch_bounds__(BLOCK) void settle_commit_kernel(DevState s, uint32_t u, PeerCounts counts) {
+  __shared__ uint32_t nz_new;
+  if (threadIdx.x == 0) nz_new = 0;
+  auto list_of = [&](uint32_t p, uint32_t* n) -> const uint2* {
+    if (p == s.shard) { *n = s.g[G_SETTLE_SEND]; return s.s_send + (size_t)p * s.s_cap; }
+    *n = min(counts.v[p], s.s_cap);
+    return s.s_recv + (size_t)p * s.s_cap;
+  };
+  for (uint32_t p = 0; p < s.n_shards; ++p) {
+    uint32_t n; const uint2* l = list_of(p, &n);
+    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+      const uint2 r = l[k];
+      const uint32_t subject = r.x & ID_MASK;
+      if (subject < s.NT) atomicMax(&s.settle_acc[subject], (r.x & (SR_CAND | SR_VETO)) | (r.y & SR_KEY));
+    }
+  }
+  __syncthreads();
+  unsigned settled = 0, released = 0;
+  for (uint32_t p = 0; p < s.n_shards; ++p) {
+    uint32_t n; const uint2* l = list_of(p, &n);
+    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+      const uint32_t subject = l[k].x & ID_MASK;
+      if (subject >= s.NT) continue;
+      const uint32_t v = atomicExch(&s.settle_acc[subject], 0u);
+      if (!(v & SR_CAND) || (v & SR_VETO)) continue;          // taken by another thread / not quiet everywhere
+      const uint32_t kmax = v & SR_KEY;
+      if ((kmax & 3u) == ST_SUSPECT) continue;                 // a timer is still running somewhere
+      const uint32_t nb = max(s.base_key[subject], kmax);
+      s.base_key[subject] = nb;
+      s.base_since[subject] = u;
+      const uint32_t mi = s.minfo[subject], row1 = mi & MI_SLOT;
+      set_mi(s, subject, (mi & ~(MI_SLOT | MI_BASE)) | ((nb & 3u) << MI_BASE_SHIFT));
+      if (row1) {                                              // my row of the subject goes back
+        const uint32_t slot = row1 - 1u;
+        s.slot_used[slot] = 0;
+        for (int w = 0; w < RT_WAYS; ++w) s.rtab[(size_t)slot * RT_WAYS + w] = 0ull;
+        s.zero_slots[atomicAdd(&nz_new, 1u)] = slot;
+        released++;
+      }
+      if (is_local(s, subject)) settled++;                     // counted once per cluster: by the subject's owner
+    }
+  }
+  if (released) atomicAdd(&s.g[G_NLIVE], 0u - released);
+  if (settled) atomicAdd(reinterpret_cast<unsigned long long*>(&s.blk[(size_t)s.nblocks * C_COUNT + C_SETTLED]), (unsigned long long)settled);
+  __syncthreads();
+  if (threadIdx.x == 0) { s.g[G_ZERO_N] = nz_new; s.g[G_SETTLE_N] = 0; s.g[G_SETTLE_PENDING] = 0; }
+}
+
 // Start of tick t, one block: settling bookkeeping of the tick before, then the ground-truth changes
 // scheduled for t (host-sorted by member within the tick: one thread applies all changes of one member in
 // order, members in parallel), then the snapshot of the rumour-id counter that fixes the tick's window head H
@@ -1294,7 +1395,7 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
   __syncthreads();
   for (uint32_t k0 = threadIdx.x; k0 < nfaults; k0 += blockDim.x) {
     if (k0 && faults[k0 - 1].member == faults[k0].member) continue;      // not the first change of its member
-    unsigned long long evd = 0; unsigned dropped = 0, pulled = 0;
+    unsigned long long evd = 0; unsigned dropped = 0;
     for (uint32_t k = k0; k < nfaults && faults[k].member == faults[k0].member; ++k) {
       const uint32_t mbr = faults[k].member, up = faults[k].up;
       uint32_t mi = s.minfo[mbr];
@@ -1327,37 +1428,7 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
       set_mi(s, mbr, (mi & ~(MI_PBN | MI_OOW)) | (1u << MI_PBN_SHIFT) | MI_UP);
       s.inmask[ml] = 0;
       s.hot[ml] = make_uint2(ni, hot.y | 1u);                // merge_kernel fires the deadlines it slept through
-      if (s.join_pull) {
-        // join-time state pull (`joinHosts`, src/Types.hs:47; include/swimsim.h): merge the member map of the
-        // first drawn member that was up before this tick and has no change scheduled in it (the tick's changes
-        // are sorted by member: binary search) -- its cells are not written by anybody in this kernel
-        uint32_t host = NONE32;
-        const uint32_t mk = mix32(tk ^ mbr);
-        for (uint32_t a = 0; a < SEL_ATTEMPTS && host == NONE32; ++a) {
-          const uint32_t c = __umulhi(hash_mk(mk, ((uint32_t)P_JOIN << 24) | a, 0), s.NT);
-          if (c == mbr || !mi_up(s.minfo[c])) continue;
-          uint32_t lo = 0, hi = nfaults;
-          while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (faults[mid].member < c) lo = mid + 1; else hi = mid; }
-          if (lo < nfaults && faults[lo].member == c) continue;
-          host = c;
-        }
-        if (host != NONE32) {
-          const uint32_t nrows = min(s.g[G_NSLOTS], s.R_phys), hl = host - s.lo;
-          for (uint32_t r = 0; r < nrows; ++r) {
-            if (!s.slot_used[r]) continue;
-            const uint32_t subject = s.subject_of[r];
-            if (subject == mbr) continue;
-            const uint32_t sb = s.slot_base[r], vh = s.V[vidx(s, hl, r)].x;
-            const uint32_t kh = subject == host ? ((s.hot[hl].x << 2) | ST_ALIVE) : (vh ? vh : sb);
-            const uint32_t vm = s.V[vidx(s, ml, r)].x, curk = vm ? vm : sb;
-            if (kh <= curk) continue;
-            s.V[vidx(s, ml, r)] = make_uint2(kh, t + 1);       // its deadline, if Suspect: the cells are rebuilt by merge_kernel
-            if (s.G) s.slot_last[r] = t;
-            evd += h4(TAG_EV, ((uint64_t)t << 32) | mbr, subject, kh) - h4(TAG_EV, ((uint64_t)t << 32) | mbr, subject, curk);
-            pulled++;
-          }
-        }
-      }
+      if (s.join_pull) s.hot[ml].y |= 2u;                    // the state pull: second pass below
       if (s.event_mask & (1u << 4)) {
         uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
         if (pos < s.event_cap) s.events[pos] = make_uint4(t, mbr, mbr, (akey << 8) | 4u);
@@ -1366,9 +1437,54 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
     }
     if (evd) atomicAdd(&evd_sh, evd);
     if (dropped) atomicAdd(&dropped_sh, dropped);
-    if (pulled) atomicAdd(&changes_sh, pulled);
   }
   __syncthreads();
+  if (s.join_pull) {
+    // Join-time state pull (`joinHosts`, src/Types.hs:47; include/swimsim.h), behind the barrier: every row this
+    // tick's joins opened is complete, and nothing else in this kernel writes view cells.  A member that came up
+    // during the tick (whatever it did afterwards) merges the member map of the first drawn member that was up
+    // before this tick and has no change scheduled in it (the tick's changes are sorted by member: binary search).
+    for (uint32_t k0 = threadIdx.x; k0 < nfaults; k0 += blockDim.x) {
+      if (k0 && faults[k0 - 1].member == faults[k0].member) continue;
+      const uint32_t mbr = faults[k0].member;
+      if (!is_local(s, mbr)) continue;
+      const uint32_t ml = mbr - s.lo;
+      const uint2 hot = s.hot[ml];
+      if (!(hot.y & 2u)) continue;
+      s.hot[ml].y = hot.y & ~2u;
+      unsigned long long evd = 0; unsigned pulled = 0;
+      uint32_t host = NONE32;
+      const uint32_t mk = mix32(tk ^ mbr);
+      for (uint32_t a = 0; a < SEL_ATTEMPTS && host == NONE32; ++a) {
+        const uint32_t c = __umulhi(hash_mk(mk, ((uint32_t)P_JOIN << 24) | a, 0), s.NT);
+        if (c == mbr) continue;
+        uint32_t lo = 0, hi = nfaults;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (faults[mid].member < c) lo = mid + 1; else hi = mid; }
+        if (lo < nfaults && faults[lo].member == c) continue;
+        if (!mi_up(s.minfo[c])) continue;                        // no change this tick: its state before the tick
+        host = c;
+      }
+      if (host != NONE32) {
+        const uint32_t nrows = min(s.g[G_NSLOTS], s.R_phys), hl = host - s.lo;
+        for (uint32_t r = 0; r < nrows; ++r) {
+          if (!s.slot_used[r]) continue;
+          const uint32_t subject = s.subject_of[r];
+          if (subject == mbr) continue;
+          const uint32_t sb = s.slot_base[r], vh = s.V[vidx(s, hl, r)].x;
+          const uint32_t kh = subject == host ? ((s.hot[hl].x << 2) | ST_ALIVE) : (vh ? vh : sb);
+          const uint32_t vm = s.V[vidx(s, ml, r)].x, curk = vm ? vm : sb;
+          if (kh <= curk) continue;
+          s.V[vidx(s, ml, r)] = make_uint2(kh, t + 1);       // its deadline, if Suspect: the cells are rebuilt by merge_kernel
+          if (s.G) s.slot_last[r] = t;
+          evd += h4(TAG_EV, ((uint64_t)t << 32) | mbr, subject, kh) - h4(TAG_EV, ((uint64_t)t << 32) | mbr, subject, curk);
+          pulled++;
+        }
+      }
+      if (evd) atomicAdd(&evd_sh, evd);
+      if (pulled) atomicAdd(&changes_sh, pulled);
+    }
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
     if (evd_sh) s.blk[(size_t)s.nblocks * C_COUNT + C_EVDIGEST] += evd_sh;
     if (dropped_sh) s.blk[(size_t)s.nblocks * C_COUNT + C_EVENTS_DROPPED] += dropped_sh;
@@ -1415,7 +1531,14 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
     for (uint32_t p = 0; p < DICT_ENTRIES; ++p) {
       const uint32_t rid = rid_at(p, H);
       uint2 e = make_uint2(NONE32, 0u);
-      if (rid < H) { const uint2 r = s.rum[rid & RID_MASK]; e = make_uint2(s.subject_of[r.x], r.y); }   // else: no such id yet
+      if (rid < H) {                                   // else: no such id yet
+        const uint2 r = s.rum[rid & RID_MASK];
+        // with settling a row changes hands: an id handed out before the row went to its present subject names a
+        // rumour about the previous one (no queue holds it any more: G >= S + L + 2) -- not in the dictionary, or
+        // the peers would open rows for subjects nobody talks about
+        const bool live = !s.G || (r.x < s.R_phys && s.slot_used[r.x] && (int32_t)(rid - s.slot_born[r.x]) >= 0);
+        if (live) e = make_uint2(s.subject_of[r.x], r.y);
+      }
       for (uint32_t g = 0; g < s.n_shards; ++g)
         if (g != s.shard) reinterpret_cast<uint2*>(s.r_send + (size_t)g * rstride)[p] = e;
     }

@@ -136,8 +136,6 @@ int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, std::string*
   if (c->target_scheme > SWIMSIM_TARGETS_ROBUST) { *err = "unknown target_scheme"; return SWIMSIM_ERR_INVALID; }
   if (c->join_pull > 1) { *err = "join_pull must be 0 or 1"; return SWIMSIM_ERR_INVALID; }
   if (c->n_shards > 1 && c->join_pull) { *err = "join_pull is not available on sharded handles (the join host may live on another shard)"; return SWIMSIM_ERR_INVALID; }
-  if (c->n_shards > 1 && c->gc_ticks) { *err = "settling (gc_ticks) is not available on sharded handles yet"; return SWIMSIM_ERR_INVALID; }
-  if (c->n_shards > 1 && c->target_scheme != SWIMSIM_TARGETS_RANDOM) { *err = "the robust target scheme is not available on sharded handles yet"; return SWIMSIM_ERR_INVALID; }
   if (c->n_shards > 1 && c->n_members > (1u << 27)) { *err = "sharded clusters: n_members must be <= 2^27"; return SWIMSIM_ERR_INVALID; }
   return SWIMSIM_OK;
 }
@@ -345,6 +343,7 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   CK(dev_alloc(h, &d.settle_slots, (size_t)d.R_phys, 0));
   CK(dev_alloc(h, &d.settle_key, (size_t)d.R_phys, 0));
   CK(dev_alloc(h, &d.zero_slots, (size_t)d.R_phys, 0));
+  CK(dev_alloc(h, &d.slot_born, (size_t)d.R_phys, 0));
   CK(dev_alloc(h, &d.settle_part, d.G ? (size_t)d.R_phys * d.nblocks : 1, 0));
   CK(dev_alloc(h, &d.pb, (size_t)2 * N * PB_SLOTS, 0));
   CK(dev_alloc(h, &d.first_suspect, NT, 0xFF));
@@ -376,6 +375,12 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     CK(dev_alloc(h, &d.xl, (size_t)d.n_shards * DICT_ENTRIES, 0xFF));
     CK(dev_alloc(h, &d.fl, (size_t)d.n_shards * ((size_t)d.x_cap + d.p_cap + d.r_cap) * 4, 0));
     CK(dev_alloc(h, &d.ackslot, (size_t)N * std::max(1u, d.P), 0));
+    if (d.G) {                                   // settling: every shard's word about its rows, all-gathered per tick
+      d.s_cap = d.R_phys;
+      CK(dev_alloc(h, &d.s_send, (size_t)d.n_shards * d.s_cap, 0));
+      CK(dev_alloc(h, &d.s_recv, (size_t)d.n_shards * d.s_cap, 0));
+      CK(dev_alloc(h, &d.settle_acc, (size_t)NT, 0));
+    }
   }
   hipLaunchKernelGGL(init_members_kernel, dim3((NT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, d.minfo, d.mb, NT);
   HK(hipGetLastError());
@@ -741,10 +746,11 @@ int swimsim_shard_phase1(swimsim_t* h, uint32_t* counts) {
   h->faults.erase(h->faults.begin(), h->faults.begin() + (long)fend);
   if (h->timing) (void)hipEventRecord(h->tick_ev[0], h->stream);
   const uint32_t pk = std::max(h->d.P, h->d.K);
-  if (pk <= 4) hipLaunchKernelGGL((probe_kernel<4>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, Offsets{});
-  else if (pk <= 8) hipLaunchKernelGGL((probe_kernel<8>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, Offsets{});
-  else if (pk <= 12) hipLaunchKernelGGL((probe_kernel<12>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, Offsets{});
-  else hipLaunchKernelGGL((probe_kernel<16>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, Offsets{});
+  const Offsets off = robust_offsets(h, t);
+  if (pk <= 4) hipLaunchKernelGGL((probe_kernel<4>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, off);
+  else if (pk <= 8) hipLaunchKernelGGL((probe_kernel<8>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, off);
+  else if (pk <= 12) hipLaunchKernelGGL((probe_kernel<12>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, off);
+  else hipLaunchKernelGGL((probe_kernel<16>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, off);
   if (h->timing) (void)hipEventRecord(h->tick_ev[1], h->stream);
   hipLaunchKernelGGL(split_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
   rc = finish_phase(h, counts);
@@ -778,10 +784,38 @@ int swimsim_shard_phase3(swimsim_t* h, const uint32_t* p_counts_in, const uint32
   if (h->timing) (void)hipEventRecord(h->tick_ev[1], h->stream);
   hipLaunchKernelGGL(merge_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
   if (h->timing) (void)hipEventRecord(h->tick_ev[2], h->stream);
+  if (h->d.G) hipLaunchKernelGGL(settle_publish_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t);
   rc = finish_phase(h, nullptr);
   if (rc) return rc;
   if (h->timing) { float b = 0; HIPCHK(h, hipEventElapsedTime(&b, h->tick_ev[1], h->tick_ev[2])); h->merge_ms += b; h->timed_ticks++; }
   h->tick++;
+  h->shard_phase = h->d.G ? 3 : 0;                // settling: the tick ends with round 3 + swimsim_shard_settle_commit
+  return SWIMSIM_OK;
+}
+
+int swimsim_shard_settle_buffers(swimsim_t* h, void** send, void** recv, uint32_t* cap) {
+  if (!h || !send || !recv) return SWIMSIM_ERR_INVALID;
+  *send = h->d.s_send; *recv = h->d.s_recv;
+  if (cap) *cap = h->d.s_cap;
+  return SWIMSIM_OK;
+}
+
+int swimsim_shard_settle_counts(swimsim_t* h, uint32_t* counts) {
+  int rc = shard_check(h, 3);
+  if (rc) return rc;
+  if (!counts) return SWIMSIM_ERR_INVALID;
+  const uint32_t n = std::min(h->h_sync[G_SETTLE_SEND], h->d.s_cap);   // phase 3's copy of the globals
+  for (uint32_t p = 0; p < h->d.n_shards; ++p) counts[p] = p == h->d.shard ? 0u : n;
+  return SWIMSIM_OK;
+}
+
+int swimsim_shard_settle_commit(swimsim_t* h, const uint32_t* counts_in) {
+  int rc = shard_check(h, 3);
+  if (rc) return rc;
+  if (!counts_in) return SWIMSIM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(settle_commit_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, (uint32_t)(h->tick - 1), peer_counts(h, counts_in));
+  HIPCHK(h, hipGetLastError());
   h->shard_phase = 0;
   return SWIMSIM_OK;
 }
@@ -801,6 +835,15 @@ int swimsim_shard_step(swimsim_t* h, uint32_t nticks, swimsim_exchange_fn xchg, 
     if (xchg(ctx, 2, out.data(), in.data())) return set_err(h, SWIMSIM_ERR_STATE, "shard_step: the exchange callback failed in round 2");
     rc = swimsim_shard_phase3(h, in.data() + G, in.data() + 2 * G);
     if (rc) return rc;
+    if (h->d.G) {
+      std::fill(out.begin(), out.end(), 0u);
+      rc = swimsim_shard_settle_counts(h, out.data());
+      if (rc) return rc;
+      std::fill(in.begin(), in.end(), 0u);
+      if (xchg(ctx, 3, out.data(), in.data())) return set_err(h, SWIMSIM_ERR_STATE, "shard_step: the exchange callback failed in round 3");
+      rc = swimsim_shard_settle_commit(h, in.data());
+      if (rc) return rc;
+    }
   }
   return SWIMSIM_OK;
 }

@@ -26,7 +26,7 @@ from .sim import Sim, SwimError
 from .types import SimConfig
 
 _M64 = (1 << 64) - 1
-REC_BYTES = (16, 16, 72)         # record kinds: round-1 records (+dictionary), mask payloads, explicit payloads
+REC_BYTES = (16, 16, 72, 8)      # record kinds: round-1 records (+dictionary), mask payloads, explicit payloads, settle records
 
 
 def _wrap(ptr: int, nbytes: int, device):
@@ -58,6 +58,13 @@ class _Shard:
         self.sim._check(a.shard_buffers(h, sp, rp))
         self.send = [_wrap(sp[k], G * caps[k] * REC_BYTES[k], device).view(G, caps[k] * REC_BYTES[k]) for k in range(3)]
         self.recv = [_wrap(rp[k], G * caps[k] * REC_BYTES[k], device).view(G, caps[k] * REC_BYTES[k]) for k in range(3)]
+        self.settling = self.sim.resolved.gc_ticks != 0
+        if self.settling:                        # kind 3: what every shard says about its rows (round 3)
+            s3, r3, c3 = C.c_void_p(), C.c_void_p(), C.c_uint32()
+            self.sim._check(a.shard_settle_buffers(h, C.byref(s3), C.byref(r3), C.byref(c3)))
+            nb = c3.value * REC_BYTES[3]
+            self.send.append(_wrap(s3.value, G * nb, device).view(G, nb))
+            self.recv.append(_wrap(r3.value, G * nb, device).view(G, nb))
 
     def phase1(self):
         G = self.n_shards
@@ -74,6 +81,14 @@ class _Shard:
     def phase3(self, p_in: Sequence[int], x_in: Sequence[int]):
         G = self.n_shards
         self.sim._check(self.sim._abi.shard_phase3(self.sim._h, (C.c_uint32 * G)(*p_in), (C.c_uint32 * G)(*x_in)))
+
+    def settle_counts(self):
+        c = (C.c_uint32 * self.n_shards)()
+        self.sim._check(self.sim._abi.shard_settle_counts(self.sim._h, c))
+        return list(c)
+
+    def settle_commit(self, s_in: Sequence[int]):
+        self.sim._check(self.sim._abi.shard_settle_commit(self.sim._h, (C.c_uint32 * self.n_shards)(*s_in)))
 
 
 class LocalFabric:
@@ -266,15 +281,16 @@ class ShardedSim:
         def xchg(_ctx, rnd, c_out, c_in):
             try:
                 t0 = time.perf_counter()
-                acc[0 if rnd == 1 else 2] += t0 - state["t"]          # the phase that just ended
-                kinds = (0,) if rnd == 1 else (1, 2)
-                counts = [[[c_out[k * G + p] for p in range(G)] for k in kinds]]
+                acc[{1: 0, 2: 2, 3: 4}[rnd]] += t0 - state["t"]       # the phase that just ended
+                kinds = {1: (0,), 2: (1, 2), 3: (3,)}[rnd]
+                at = (lambda k: 0) if rnd == 3 else (lambda k: k * G)     # round 3: the kind-3 counts sit at [p]
+                counts = [[[c_out[at(k) + p] for p in range(G)] for k in kinds]]
                 got = f.exchange([sh], kinds, counts)[0]
                 for j, k in enumerate(kinds):
                     for p in range(G):
-                        c_in[k * G + p] = got[j][p]
+                        c_in[at(k) + p] = got[j][p]
                 state["t"] = time.perf_counter()
-                acc[1 if rnd == 1 else 3] += state["t"] - t0
+                acc[{1: 1, 2: 3, 3: 4}[rnd]] += state["t"] - t0
                 return 0
             except Exception:                                       # noqa: BLE001 -- must not unwind through C
                 import traceback
@@ -305,6 +321,10 @@ class ShardedSim:
             t4 = time.perf_counter()
             for k, s in enumerate(sh):
                 s.phase3(px_in[k][0], px_in[k][1])
+            if sh[0].settling:                                                      # round 3: settle records
+                s_in = f.exchange(sh, (3,), [[s.settle_counts()] for s in sh])
+                for k, s in enumerate(sh):
+                    s.settle_commit(s_in[k][0])
             t5 = time.perf_counter()
             for j, d in enumerate((t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
                 acc[j] += d

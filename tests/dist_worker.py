@@ -1,6 +1,7 @@
 """Worker for tests/test_shard_dist.py: one process = one shard (torch.distributed, gloo on CPU).
 Every rank drives its shard through the host emulation of the product kernels; rank 0 also runs the
-oracle and compares every observable.  usage: dist_worker.py <n_members> <p> <loss_ppm> <seed> <ticks>"""
+oracle and compares every observable.  usage: dist_worker.py <n_members> <p> <loss_ppm> <seed> <ticks> [gc]
+(gc = 1: settling on, suspicion 5 ticks, retransmit x1, and the member that went down comes back twice)"""
 import os
 import sys
 
@@ -10,14 +11,17 @@ sys.path.insert(0, ROOT)
 
 def main():
     n, p, loss, seed, ticks = (int(x) for x in sys.argv[1:6])
+    gc = len(sys.argv) > 6 and int(sys.argv[6]) != 0
     import torch.distributed as dist
     dist.init_process_group("gloo")
     rank = dist.get_rank()
-    from swim_amd import Config, Sim, SimConfig
+    from swim_amd import Config, Sim, SimConfig, _abi
     from swim_amd.shard import DistFabric, ShardedSim
     from tests import hostemu_binding, oracle_binding
     sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, eventMask=0x1F,
                    suspicionTicks=6, maxSubjects=min(n, 1024))
+    if gc:
+        sc.suspicionTicks, sc.retransmitMult, sc.gcTicks = 5, 1, _abi.GC_AUTO
     if os.environ.get("SWIM_DIST_DEVICE", "cpu") == "cuda":
         # all ranks share GPU 0 (RCCL refuses two ranks on one device): the real HIP library, device
         # buffers wrapped zero-copy, records staged through host memory over gloo
@@ -34,6 +38,10 @@ def main():
         s.crash(n // 2, 5)
         s.crash(3, 7)
         s.scheduleFault(30, n // 2, True)
+        if gc:
+            s.crash(n - 2, 33)
+            s.scheduleFault(70, n - 2, True)
+            s.crash(n // 2, 75)
     done = 0
     while done < ticks:
         k = min(5, ticks - done)
@@ -47,6 +55,8 @@ def main():
     fd = sh.firstDetection()
     if rank == 0:
         assert fd == ref.firstDetection()
+        if gc:
+            assert got[0]["settled"] >= 3, got[0]
         print("DIST-OK world=%d digest=%016x" % (dist.get_world_size(), got[1]))
     sh.close()
     dist.destroy_process_group()

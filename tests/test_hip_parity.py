@@ -153,6 +153,61 @@ def test_sharded_cluster_on_one_gpu(oracle_abi, hip_abi, n, shards, loss, seed):
     b.close()
 
 
+def test_sharded_settling_on_one_gpu(oracle_abi, hip_abi):
+    """gc_ticks on a sharded cluster (round 3: every shard's word about its rows; the same base committed by every
+    shard in the same tick): rows are reclaimed and reused per shard, members come back after their subject
+    was removed.  Several handles on this GPU; every observable against the (unsharded) oracle."""
+    from swim_amd import _abi
+    from swim_amd.shard import LocalFabric, ShardedSim
+    n, shards = 8192, 4
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=21, lossPpm=5000, eventMask=0x1F, suspicionTicks=5,
+                   retransmitMult=1, maxSubjects=400, gcTicks=_abi.GC_AUTO)
+    crashes = [(3 + 2 * k, (977 * k + 11) % n) for k in range(120)]
+    faults = [(t + 9 + (k % 5) * 14, m, True) for k, (t, m) in enumerate(crashes) if k % 3 == 0]
+    faults += [(t + 2, (m + 1) % n, False) for (t, m) in crashes[::7]]
+    faults += [(t + 12, (m + 1) % n, True) for (t, m) in crashes[::7]]
+    a = Sim.create(oracle_abi, sc)
+    _oracle_threads(a)
+    b = ShardedSim(hip_abi, sc, LocalFabric(shards), device="cuda:0")
+    for s in (a, b):
+        workloads.apply_crashes(s, crashes)
+        for (t, m, up) in faults:
+            s.scheduleFault(t, m, up)
+    done = 0
+    while done < 360:
+        a.step(12); b.step(12); done += 12
+        assert a.counters() == b.counters(), "counters differ after %d ticks" % done
+        assert a.digest() == b.digest(), "digest differs after %d ticks" % done
+        assert a.drainEventsRaw() == b.drainEventsRaw()
+        for o in (0, n - 1, crashes[0][1]):
+            assert a.members(o) == b.members(o)
+    assert a.firstDetection() == b.firstDetection()
+    assert b.counters()["settled"] > 100
+    b.close()
+
+
+@pytest.mark.parametrize("n,shards,p,loss,seed", [(4096, 4, 3, 0, 1), (3000, 3, 10, 50000, 2)])
+def test_sharded_robust_scheme_on_one_gpu(oracle_abi, hip_abi, n, shards, p, loss, seed):
+    """The robust target scheme on a sharded cluster (same targets, payloads pushed to the target's owner)."""
+    from swim_amd.shard import LocalFabric, ShardedSim
+    sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, targetScheme=1, eventMask=0x1F,
+                   suspicionTicks=7, maxSubjects=min(n, 2048))
+    crashes = workloads.hashed_crashes(n, seed, 1, 128, 3, 33)
+    a = Sim.create(oracle_abi, sc)
+    b = ShardedSim(hip_abi, sc, LocalFabric(shards), device="cuda:0")
+    for s in (a, b):
+        workloads.apply_crashes(s, crashes)
+        s.scheduleFault(45, crashes[0][1], True)
+    done = 0
+    while done < 70:
+        a.step(10); b.step(10); done += 10
+        assert a.counters() == b.counters(), "counters differ after %d ticks" % done
+        assert a.digest() == b.digest(), "digest differs after %d ticks" % done
+        assert a.drainEventsRaw() == b.drainEventsRaw()
+    assert a.firstDetection() == b.firstDetection()
+    b.close()
+
+
 def test_one_process_per_shard_on_one_gpu():
     """Two processes, one shard each, both on GPU 0, torch.distributed (gloo, records staged through
     host memory because RCCL refuses two ranks on one device): the DistFabric host code with the real

@@ -1,12 +1,12 @@
 """Randomised parity sweep: the product's kernels (host emulation) against the oracle over random sizes,
 probe counts, loss rates, fault schedules (crashes and rejoins, with and without the join-time pull), both
-target schemes, 1-8 shards and tiny inbox capacities -- every observable, every 10 ticks.  Seeded, so a failure reproduces; a longer run of the
+target schemes, 1-8 shards (also with the robust scheme and with settling), tiny inbox capacities -- every observable, every 10 ticks.  Seeded, so a failure reproduces; a longer run of the
 same generator (430 configurations) was clean when this was written."""
 import random
 
 import pytest
 
-from swim_amd import Config, Sim, SimConfig
+from swim_amd import Config, Sim, SimConfig, _abi
 from swim_amd.shard import LocalFabric, ShardedSim
 
 
@@ -21,12 +21,13 @@ def test_random_configurations(oracle_abi, block):
         loss = rng.choice([0, 0, 0, 10000, 100000, 300000])
         scheme = rng.choice([0, 0, 1])
         shards = 1
-        if scheme == 0 and n >= 64 and rng.random() < 0.4:
+        if n >= 64 and rng.random() < 0.4:
             shards = rng.choice([g for g in (2, 3, 4, 8) if n % g == 0] or [1])
         seed = rng.randrange(1, 1 << 30)
+        gc = _abi.GC_AUTO if rng.random() < 0.4 else 0
         sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, eventMask=0x1F,
-                       suspicionTicks=rng.choice([3, 6, 12]), maxSubjects=min(n, 1024),
-                       targetScheme=scheme, inboxCap=rng.choice([0, 0, 1, 2]),
+                       suspicionTicks=rng.choice([3, 6, 12]), retransmitMult=rng.choice([1, 1, 3]), maxSubjects=min(n, 1024),
+                       targetScheme=scheme, inboxCap=rng.choice([0, 0, 1, 2]), gcTicks=gc,
                        joinPull=1 if shards == 1 and seed % 2 else 0)
         a = Sim.create(oracle_abi, sc)
         b = Sim.create(emu, sc) if shards == 1 else ShardedSim(emu, sc, LocalFabric(shards))
@@ -38,8 +39,8 @@ def test_random_configurations(oracle_abi, block):
                 t2 = t + rng.randrange(1, 30)
                 for s in (a, b):
                     s.scheduleFault(t2, m, True)
-        what = (n, p, loss, scheme, shards, seed)
-        for _t in range(rng.choice([3, 6])):
+        what = (n, p, loss, scheme, shards, gc, seed)
+        for _t in range(rng.choice([3, 6, 10])):
             a.step(10); b.step(10)
             assert a.counters() == b.counters(), ("counters", what)
             assert a.digest() == b.digest(), ("digest", what)

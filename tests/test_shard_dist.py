@@ -25,3 +25,8 @@ def run_world(world, args, port):
 @pytest.mark.parametrize("world,n,p,loss,seed,port", [(2, 128, 3, 0, 1, 29611), (2, 256, 3, 100000, 2, 29612), (4, 256, 2, 50000, 3, 29613)])
 def test_one_process_per_shard_gloo(world, n, p, loss, seed, port):
     run_world(world, (n, p, loss, seed, 45), port)
+
+
+def test_one_process_per_shard_gloo_with_settling():
+    """gc_ticks on: the third exchange round (settle records) through swimsim_shard_step's callback."""
+    run_world(2, (192, 3, 20000, 7, 130, 1), 29614)

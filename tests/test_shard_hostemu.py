@@ -77,3 +77,44 @@ def test_sharded_with_tiny_mask_window(oracle_abi):
         s.scheduleFault(40, crashes[0][1], True)
     lockstep(a, b, 60, 5, observers=(0, n - 1), members=(0, n - 1))
     b.close()
+
+
+@pytest.mark.parametrize("shards,loss", [(2, 20000), (4, 0), (8, 50000)])
+def test_sharded_settling_with_churn(oracle_abi, emu_abi, shards, loss):
+    """gc_ticks on a sharded cluster: a subject settles only when it is quiet on every shard, every shard commits
+    the same base in the same tick (round 3), rows are reclaimed and reused per shard, members come back after
+    their subject was removed -- every observable equals the (unsharded) oracle's after every block of ticks."""
+    from swim_amd import _abi
+    n = 320
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=12 + shards, lossPpm=loss, eventMask=0x1F, suspicionTicks=5,
+                   retransmitMult=1, maxSubjects=60, gcTicks=_abi.GC_AUTO)
+    crashes = [(3 + 4 * k, (7 * k + 11) % n) for k in range(70)]
+    faults = [(t + 9 + (k % 5) * 14, m, True) for k, (t, m) in enumerate(crashes) if k % 3 == 0]
+    faults += [(t + 2, (m + 1) % n, False) for (t, m) in crashes[::7]]            # neighbours that sleep through deadlines
+    faults += [(t + 12, (m + 1) % n, True) for (t, m) in crashes[::7]]
+    a = Sim.create(oracle_abi, sc)
+    b = ShardedSim(emu_abi, sc, LocalFabric(shards))
+    for s in (a, b):
+        workloads.apply_crashes(s, crashes)
+        for (t, m, up) in faults:
+            s.scheduleFault(t, m, up)
+    lockstep(a, b, 420, 7, observers=(0, 12, n - 1), members=(0, 12, n - 1))
+    c = b.counters()
+    assert c["settled"] > 60 and c["timers_fired"] > 0
+    b.close()
+
+
+@pytest.mark.parametrize("n,shards,p,loss,seed", [(256, 4, 3, 0, 1), (300, 3, 2, 100000, 2), (512, 8, 10, 30000, 3)])
+def test_sharded_robust_target_scheme(oracle_abi, emu_abi, n, shards, p, loss, seed):
+    """The robust (round-robin) target scheme on a sharded cluster: same targets, payloads pushed to the
+    target's owner instead of pulled -- bit-identical to the unsharded oracle."""
+    sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, targetScheme=1, eventMask=0x1F,
+                   suspicionTicks=7, maxSubjects=min(n, 512))
+    crashes = workloads.hashed_crashes(n, seed, 1, 16, 3, 33)
+    a = Sim.create(oracle_abi, sc)
+    b = ShardedSim(emu_abi, sc, LocalFabric(shards))
+    for s in (a, b):
+        workloads.apply_crashes(s, crashes)
+        s.scheduleFault(45, crashes[0][1], True)
+    lockstep(a, b, 70, 5, observers=(0, n - 1, crashes[0][1]), members=(0, n - 1, crashes[0][1]))
+    b.close()
