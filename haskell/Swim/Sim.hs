@@ -87,6 +87,8 @@ foreign import ccall unsafe "swimsim_shard_info"    c_shard_info    :: Ptr Swims
 foreign import ccall unsafe "swimsim_shard_buffers" c_shard_buffers :: Ptr SwimsimT -> Ptr (Ptr ()) -> Ptr (Ptr ()) -> IO CInt
 -- settling on a sharded cluster: the kind-3 buffers of exchange round 3 (8-byte records, one list for every peer)
 foreign import ccall unsafe "swimsim_shard_settle_buffers" c_shard_settle_buffers :: Ptr SwimsimT -> Ptr (Ptr ()) -> Ptr (Ptr ()) -> Ptr Word32 -> IO CInt
+-- join_pull on a sharded cluster: the kind-4 buffers of exchange round 0 (16-byte records {joiner, subject, entry, -})
+foreign import ccall unsafe "swimsim_shard_join_buffers" c_shard_join_buffers :: Ptr SwimsimT -> Ptr (Ptr ()) -> Ptr (Ptr ()) -> Ptr Word32 -> IO CInt
 foreign import ccall safe   "swimsim_shard_phase1"  c_shard_phase1  :: Ptr SwimsimT -> Ptr Word32 -> IO CInt
 foreign import ccall safe   "swimsim_shard_phase2"  c_shard_phase2  :: Ptr SwimsimT -> Ptr Word32 -> Ptr Word32 -> IO CInt
 foreign import ccall safe   "swimsim_shard_phase3"  c_shard_phase3  :: Ptr SwimsimT -> Ptr Word32 -> Ptr Word32 -> IO CInt
@@ -272,8 +274,9 @@ decodeEnvelope bytes = BSU.unsafeUseAsCStringLen bytes $ \(src, len) ->
 -- is the embedder's all-to-all-v (MPI_Alltoallv, RCCL send/recv ..) over the buffers of
 -- swimsim_shard_buffers: `out` holds 3 * nShards record counts (kind-major) to deliver, the result the
 -- 3 * nShards counts that arrived.  With settling on (gcTicks) every tick ends with a round 3 over the buffers of
--- swimsim_shard_settle_buffers: the counts of that round sit at indices [0 .. nShards).  Every shard of the
--- cluster must make the same call.
+-- swimsim_shard_settle_buffers, and with joinPull a tick in which members come up starts with a round 0 over the
+-- buffers of swimsim_shard_join_buffers: the counts of those rounds sit at indices [0 .. nShards).  Every shard of
+-- the cluster must make the same call.
 stepShard :: Sim -> Word32 -> Int -> (Int -> [Word32] -> IO [Word32]) -> IO ()
 stepShard s nticks nShards exchange = withSim s $ \h -> do
   cb <- mkExchange $ \_ rnd pout pin -> do

@@ -359,9 +359,20 @@ int swimsim_shard_step(swimsim_t* h, uint32_t nticks, swimsim_exchange_fn xchg, 
  * the other rounds, and swimsim_shard_settle_commit ends the tick.  swimsim_shard_step does it by itself and
  * calls xchg(ctx, 3, counts_out, counts_in) with the kind-3 counts at index [p]. */
 #define SWIMSIM_SREC_BYTES 8u
+#define SWIMSIM_JREC_BYTES 16u
 int swimsim_shard_settle_buffers(swimsim_t* h, void** send, void** recv, uint32_t* cap /* records per peer segment */);
 int swimsim_shard_settle_counts(swimsim_t* h, uint32_t* counts /*[n_shards] out*/);
 int swimsim_shard_settle_commit(swimsim_t* h, const uint32_t* counts_in /*[n_shards]*/);
+/* join_pull on a sharded cluster: a join host may live on another shard than the member that comes up, and the pull
+ * precedes the tick's probes.  swimsim_shard_phase0 applies the tick's faults; when members come up in this tick
+ * (the schedule is replicated: every shard gets the same answer) it sets *round_needed and the owners of the hosts
+ * have written 16-byte records {joiner, subject, the host's entry, -} (kind 4) into send[p][0 .. counts[p]) of
+ * swimsim_shard_join_buffers: round 0 delivers them, swimsim_shard_join_ingest reports the arrivals, phase1
+ * continues the tick.  A no-op when join_pull is off or the tick has no joins; swimsim_shard_step does all of it
+ * and calls xchg(ctx, 0, ..) with the kind-4 counts at index [p]. */
+int swimsim_shard_phase0(swimsim_t* h, uint32_t* counts /*[n_shards] out*/, int* round_needed);
+int swimsim_shard_join_buffers(swimsim_t* h, void** send, void** recv, uint32_t* cap);
+int swimsim_shard_join_ingest(swimsim_t* h, const uint32_t* counts_in /*[n_shards]*/);
 int swimsim_shard_get_first_suspect(swimsim_t* h, uint32_t* out, size_t n);
 int swimsim_shard_set_first_suspect(swimsim_t* h, const uint32_t* combined, size_t n);
 

@@ -32,7 +32,9 @@ enum { G_NSLOTS = 0 /* view rows ever handed out (high-water mark) */, G_ERR = 1
        G_SETTLE_PENDING = 12 /* the lists above still await settle_finish */, G_SETTLE_TICK = 13,
        G_RIDS_OFF = 14 /* so many new rumours last tick that this tick's lines carry no ids at all */,
        G_SETTLE_SEND = 15 /* sharded settling: records this shard publishes at the end of the tick (same list to every peer) */,
-       G_SEND = 16 /* [3][16] exchange records appended per peer (send_cnt) */, G_WORDS = 64 };
+       G_SEND = 16 /* [3][16] exchange records appended per peer (send_cnt) */,
+       G_NJOINED = 64 /* members that came up in this tick (begin_kernel part A) */,
+       G_JSEND = 65 /* [16] join-pull records appended per peer (exchange round 0) */, G_WORDS = 96 };
 enum { ERRF_SUBJECTS = 1, ERRF_ROWS = 2, ERRF_OVF = 4, ERRF_INC = 8, ERRF_XCHG = 16 };
 
 // counter slots (same order as SWIMSIM_CTR_* in include/swimsim.h)
@@ -158,6 +160,9 @@ struct DevState {
   uint2* s_send; uint2* s_recv;         // [n_shards][s_cap] {subject | SR_CAND / SR_VETO, largest entry among my up members}
   uint32_t s_cap;
   uint32_t* settle_acc;    // [NT] scratch of settle_commit_kernel (zero between launches)
+  // join-time pulls whose host lives on another shard (round 0): {joiner, subject, the host's entry, -}
+  uint4* j_send; uint4* j_recv;         // [n_shards][j_cap]
+  uint32_t j_cap;
 };
 // settle records: a shard lists a row as a CANDIDATE (quiet here for G ticks; y = the largest entry among its members
 // that are up) or as a VETO (an entry changed / the subject announced itself within the last G ticks)

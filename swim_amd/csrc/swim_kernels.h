@@ -1383,19 +1383,59 @@ __global__ __launch_bounds__(BLOCK) void settle_commit_kernel(DevState s, uint32
   if (threadIdx.x == 0) { s.g[G_ZERO_N] = nz_new; s.g[G_SETTLE_N] = 0; s.g[G_SETTLE_PENDING] = 0; }
 }
 
-// Start of tick t, one block: settling bookkeeping of the tick before, then the ground-truth changes
-// scheduled for t (host-sorted by member within the tick: one thread applies all changes of one member in
-// order, members in parallel), then the snapshot of the rumour-id counter that fixes the tick's window head H
-// (no ids are allocated between here and merge_kernel), then the rows eligible for settling at the end of t.
-__global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, uint32_t tk, const FaultRec* faults, uint32_t nfaults) {
+// the join host of member m in the tick whose changes are `faults` (sorted by member): the first of 8 draws that is
+// not m, has no change scheduled in this tick and was up before it (include/swimsim.h, "Join-time state pull").
+// A pure function of replicated data (hashes, the schedule, ground truth): every shard finds the same host.
+__device__ inline uint32_t join_host(const DevState& s, uint32_t tk, uint32_t m, const FaultRec* faults, uint32_t nfaults) {
+  const uint32_t mk = mix32(tk ^ m);
+  for (uint32_t a = 0; a < SEL_ATTEMPTS; ++a) {
+    const uint32_t c = __umulhi(hash_mk(mk, ((uint32_t)P_JOIN << 24) | a, 0), s.NT);
+    if (c == m) continue;
+    uint32_t lo = 0, hi = nfaults;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (faults[mid].member < c) lo = mid + 1; else hi = mid; }
+    if (lo < nfaults && faults[lo].member == c) continue;
+    if (!mi_up(s.minfo[c])) continue;                          // no change this tick: its state before the tick
+    return c;
+  }
+  return NONE32;
+}
+
+// one pulled entry: joiner ml's cell of `slot` becomes kh if that is news to it
+__device__ inline void pull_entry(const DevState& s, uint32_t t, uint32_t mbr, uint32_t slot, uint32_t subject, uint32_t kh,
+                                  unsigned long long* evd, unsigned* pulled) {
+  const size_t ix = vidx(s, mbr - s.lo, slot);
+  const uint32_t vm = s.V[ix].x, curk = vm ? vm : s.slot_base[slot];
+  if (kh <= curk) return;
+  s.V[ix] = make_uint2(kh, t + 1);                             // its deadline, if Suspect: the cells are rebuilt by merge_kernel
+  if (s.G) s.slot_last[slot] = t;
+  *evd += h4(TAG_EV, ((uint64_t)t << 32) | mbr, subject, kh) - h4(TAG_EV, ((uint64_t)t << 32) | mbr, subject, curk);
+  (*pulled)++;
+}
+
+// Start of tick t, one block, in two parts (bit 0 / bit 1 of `part`; one launch does both unless a sharded
+// cluster has join-time pulls to exchange in between):
+//   A  settling bookkeeping of the tick before, then the ground-truth changes scheduled for t (host-sorted by member
+//      within the tick: one thread applies all changes of one member in order, members in parallel); the members that
+//      came up are listed in `joined` (every shard lists the same ones: ground truth is replicated);
+//   B  the joiners' state pulls -- from hosts on this shard directly, from hosts elsewhere as the records their owners
+//      sent (pull_send_kernel, exchange round 0) --, then the snapshot of the rumour-id counter that fixes the tick's
+//      window head H (no ids are allocated between here and merge_kernel), the tick's ring and dictionary, the rows
+//      eligible for settling at the end of t.
+__global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, uint32_t tk, const FaultRec* faults, uint32_t nfaults,
+                                                      uint32_t* joined, uint32_t part, PeerCounts jc) {
   __shared__ unsigned long long evd_sh;
   __shared__ unsigned dropped_sh, nset, changes_sh;
-  settle_finish(s);
-  if (threadIdx.x == 0) { evd_sh = 0; dropped_sh = 0; nset = 0; changes_sh = 0; }
+  if (part & 1u) settle_finish(s);
+  if (threadIdx.x == 0) {
+    evd_sh = 0; dropped_sh = 0; nset = 0; changes_sh = 0;
+    if (part & 1u) { s.g[G_NJOINED] = 0; for (int g = 0; g < MAX_SHARDS; ++g) s.g[G_JSEND + g] = 0; }
+  }
   __syncthreads();
+  if (part & 1u)
   for (uint32_t k0 = threadIdx.x; k0 < nfaults; k0 += blockDim.x) {
     if (k0 && faults[k0 - 1].member == faults[k0].member) continue;      // not the first change of its member
     unsigned long long evd = 0; unsigned dropped = 0;
+    bool came_up = false;
     for (uint32_t k = k0; k < nfaults && faults[k].member == faults[k0].member; ++k) {
       const uint32_t mbr = faults[k].member, up = faults[k].up;
       uint32_t mi = s.minfo[mbr];
@@ -1408,6 +1448,7 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
         else set_mi(s, mbr, mi & ~MI_UP);
         continue;
       }
+      came_up = true;
       if (!is_local(s, mbr)) { set_mi(s, mbr, mi | MI_UP); continue; }   // its owner does the rest
       // (re)join: new incarnation, announce Alive: the queue holds exactly that rumour
       const uint32_t ml = mbr - s.lo;
@@ -1428,57 +1469,56 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
       set_mi(s, mbr, (mi & ~(MI_PBN | MI_OOW)) | (1u << MI_PBN_SHIFT) | MI_UP);
       s.inmask[ml] = 0;
       s.hot[ml] = make_uint2(ni, hot.y | 1u);                // merge_kernel fires the deadlines it slept through
-      if (s.join_pull) s.hot[ml].y |= 2u;                    // the state pull: second pass below
       if (s.event_mask & (1u << 4)) {
         uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
         if (pos < s.event_cap) s.events[pos] = make_uint4(t, mbr, mbr, (akey << 8) | 4u);
         else dropped++;
       }
     }
+    if (came_up && s.join_pull) joined[atomicAdd(&s.g[G_NJOINED], 1u)] = faults[k0].member;   // whatever it did afterwards
     if (evd) atomicAdd(&evd_sh, evd);
     if (dropped) atomicAdd(&dropped_sh, dropped);
   }
   __syncthreads();
+  if (part == 1u) {                                 // the rest follows the exchange of the pulls (part 2)
+    if (threadIdx.x == 0) {
+      if (evd_sh) s.blk[(size_t)s.nblocks * C_COUNT + C_EVDIGEST] += evd_sh;
+      if (dropped_sh) s.blk[(size_t)s.nblocks * C_COUNT + C_EVENTS_DROPPED] += dropped_sh;
+    }
+    return;
+  }
   if (s.join_pull) {
     // Join-time state pull (`joinHosts`, src/Types.hs:47; include/swimsim.h), behind the barrier: every row this
     // tick's joins opened is complete, and nothing else in this kernel writes view cells.  A member that came up
-    // during the tick (whatever it did afterwards) merges the member map of the first drawn member that was up
-    // before this tick and has no change scheduled in it (the tick's changes are sorted by member: binary search).
-    for (uint32_t k0 = threadIdx.x; k0 < nfaults; k0 += blockDim.x) {
-      if (k0 && faults[k0 - 1].member == faults[k0].member) continue;
-      const uint32_t mbr = faults[k0].member;
-      if (!is_local(s, mbr)) continue;
-      const uint32_t ml = mbr - s.lo;
-      const uint2 hot = s.hot[ml];
-      if (!(hot.y & 2u)) continue;
-      s.hot[ml].y = hot.y & ~2u;
-      unsigned long long evd = 0; unsigned pulled = 0;
-      uint32_t host = NONE32;
-      const uint32_t mk = mix32(tk ^ mbr);
-      for (uint32_t a = 0; a < SEL_ATTEMPTS && host == NONE32; ++a) {
-        const uint32_t c = __umulhi(hash_mk(mk, ((uint32_t)P_JOIN << 24) | a, 0), s.NT);
-        if (c == mbr) continue;
-        uint32_t lo = 0, hi = nfaults;
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (faults[mid].member < c) lo = mid + 1; else hi = mid; }
-        if (lo < nfaults && faults[lo].member == c) continue;
-        if (!mi_up(s.minfo[c])) continue;                        // no change this tick: its state before the tick
-        host = c;
+    // during the tick merges its host's member map: (i) hosts on other shards sent theirs as records {joiner,
+    // subject, entry} (rows are opened for subjects this shard has not heard of); (ii) hosts on this shard are read.
+    for (uint32_t p = 0; p < s.n_shards; ++p) {
+      const uint32_t n = s.n_shards > 1 && p != s.shard ? min(jc.v[p], s.j_cap) : 0u;
+      for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+        const uint4 r = s.j_recv[(size_t)p * s.j_cap + k];
+        if (!is_local(s, r.x) || r.y >= s.NT) continue;
+        unsigned long long evd = 0; unsigned pulled = 0;
+        pull_entry(s, t, r.x, get_slot(s, r.y), r.y, r.z, &evd, &pulled);
+        if (evd) atomicAdd(&evd_sh, evd);
+        if (pulled) atomicAdd(&changes_sh, pulled);
       }
-      if (host != NONE32) {
-        const uint32_t nrows = min(s.g[G_NSLOTS], s.R_phys), hl = host - s.lo;
-        for (uint32_t r = 0; r < nrows; ++r) {
-          if (!s.slot_used[r]) continue;
-          const uint32_t subject = s.subject_of[r];
-          if (subject == mbr) continue;
-          const uint32_t sb = s.slot_base[r], vh = s.V[vidx(s, hl, r)].x;
-          const uint32_t kh = subject == host ? ((s.hot[hl].x << 2) | ST_ALIVE) : (vh ? vh : sb);
-          const uint32_t vm = s.V[vidx(s, ml, r)].x, curk = vm ? vm : sb;
-          if (kh <= curk) continue;
-          s.V[vidx(s, ml, r)] = make_uint2(kh, t + 1);       // its deadline, if Suspect: the cells are rebuilt by merge_kernel
-          if (s.G) s.slot_last[r] = t;
-          evd += h4(TAG_EV, ((uint64_t)t << 32) | mbr, subject, kh) - h4(TAG_EV, ((uint64_t)t << 32) | mbr, subject, curk);
-          pulled++;
-        }
+    }
+    __syncthreads();
+    const uint32_t nj = s.g[G_NJOINED];
+    for (uint32_t k = threadIdx.x; k < nj; k += blockDim.x) {
+      const uint32_t mbr = joined[k];
+      if (!is_local(s, mbr)) continue;
+      const uint32_t host = join_host(s, tk, mbr, faults, nfaults);
+      if (host == NONE32 || !is_local(s, host)) continue;
+      unsigned long long evd = 0; unsigned pulled = 0;
+      const uint32_t nrows = min(s.g[G_NSLOTS], s.R_phys), hl = host - s.lo;
+      for (uint32_t r = 0; r < nrows; ++r) {
+        if (!s.slot_used[r]) continue;
+        const uint32_t subject = s.subject_of[r];
+        if (subject == mbr) continue;
+        const uint32_t vh = s.V[vidx(s, hl, r)].x;
+        const uint32_t kh = subject == host ? ((s.hot[hl].x << 2) | ST_ALIVE) : vh;   // an untouched cell is the base: no news
+        if (kh) pull_entry(s, t, mbr, r, subject, kh, &evd, &pulled);
       }
       if (evd) atomicAdd(&evd_sh, evd);
       if (pulled) atomicAdd(&changes_sh, pulled);
@@ -1541,6 +1581,31 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
       }
       for (uint32_t g = 0; g < s.n_shards; ++g)
         if (g != s.shard) reinterpret_cast<uint2*>(s.r_send + (size_t)g * rstride)[p] = e;
+    }
+  }
+}
+
+// Sharded clusters with join_pull: between the two parts of begin_kernel the owner of a join host sends what the host
+// knows to the joiner's owner -- one record {joiner, subject, entry} per entry that differs from the base (the host
+// itself as Alive at its own incarnation) -- exchange round 0.  One thread per member that came up this tick.
+__global__ __launch_bounds__(BLOCK) void pull_send_kernel(DevState s, uint32_t tk, const FaultRec* faults, uint32_t nfaults,
+                                                           const uint32_t* joined) {
+  const uint32_t nj = s.g[G_NJOINED];
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nj; k += gridDim.x * blockDim.x) {
+    const uint32_t mbr = joined[k];
+    if (is_local(s, mbr)) continue;
+    const uint32_t host = join_host(s, tk, mbr, faults, nfaults);
+    if (host == NONE32 || !is_local(s, host)) continue;
+    const uint32_t peer = owner_of(s, mbr), nrows = min(s.g[G_NSLOTS], s.R_phys), hl = host - s.lo;
+    for (uint32_t r = 0; r < nrows; ++r) {
+      if (!s.slot_used[r]) continue;
+      const uint32_t subject = s.subject_of[r];
+      if (subject == mbr) continue;
+      const uint32_t kh = subject == host ? ((s.hot[hl].x << 2) | ST_ALIVE) : s.V[vidx(s, hl, r)].x;
+      if (!kh) continue;
+      const uint32_t pos = atomicAdd(&s.g[G_JSEND + peer], 1u);
+      if (pos < s.j_cap) s.j_send[(size_t)peer * s.j_cap + pos] = make_uint4(mbr, subject, kh, 0u);
+      else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG);
     }
   }
 }

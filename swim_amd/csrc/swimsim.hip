@@ -39,6 +39,7 @@ struct swimsim {
   std::vector<Fault> faults;      // sorted by (tick, order)
   uint32_t fault_order = 0;
   FaultRec* d_faults = nullptr; size_t d_faults_cap = 0;
+  uint32_t* d_joined = nullptr;                // members that came up in the tick being applied (as many as fault records)
   unsigned long long* d_scratch64 = nullptr;   // digest accumulator
   uint32_t* d_sel = nullptr;                   // [0..255] picks, [256] count, [257..] excludes
   size_t d_sel_cap = 0;
@@ -51,6 +52,9 @@ struct swimsim {
   std::string err;
   // sharded stepping (swimsim_shard_*): which phase of the current tick comes next, the tick's fault slice
   int shard_phase = 0;
+  bool begun = false;                          // swimsim_shard_phase0 applied this tick's faults already (part A of begin_kernel)
+  size_t begun_fend = 0;
+  uint32_t j_in[MAX_SHARDS] = {};              // join-pull records received in round 0
   uint32_t* h_sync = nullptr;                  // pinned host copy of the globals (flags + send counts)
   hipEvent_t tick_ev[3] = {nullptr, nullptr, nullptr};
 };
@@ -135,7 +139,6 @@ int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, std::string*
   if (c->n_members % c->n_shards) { *err = "n_members must be a multiple of n_shards"; return SWIMSIM_ERR_INVALID; }
   if (c->target_scheme > SWIMSIM_TARGETS_ROBUST) { *err = "unknown target_scheme"; return SWIMSIM_ERR_INVALID; }
   if (c->join_pull > 1) { *err = "join_pull must be 0 or 1"; return SWIMSIM_ERR_INVALID; }
-  if (c->n_shards > 1 && c->join_pull) { *err = "join_pull is not available on sharded handles (the join host may live on another shard)"; return SWIMSIM_ERR_INVALID; }
   if (c->n_shards > 1 && c->n_members > (1u << 27)) { *err = "sharded clusters: n_members must be <= 2^27"; return SWIMSIM_ERR_INVALID; }
   return SWIMSIM_OK;
 }
@@ -253,6 +256,7 @@ void swimsim_destroy(swimsim_t* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->d_faults) (void)hipFree(h->d_faults);
+  if (h->d_joined) (void)hipFree(h->d_joined);
   if (h->d_sel) (void)hipFree(h->d_sel);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->tick_ev) if (e) (void)hipEventDestroy(e);
@@ -381,6 +385,11 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
       CK(dev_alloc(h, &d.s_recv, (size_t)d.n_shards * d.s_cap, 0));
       CK(dev_alloc(h, &d.settle_acc, (size_t)NT, 0));
     }
+    if (d.join_pull) {                           // join-time pulls from hosts on other shards (round 0): a mass restart
+      d.j_cap = std::max<uint32_t>(1u << 16, 16u * d.R_phys);   // of J members costs J x (entries a host holds) records
+      CK(dev_alloc(h, &d.j_send, (size_t)d.n_shards * d.j_cap, 0));
+      CK(dev_alloc(h, &d.j_recv, (size_t)d.n_shards * d.j_cap, 0));
+    }
   }
   hipLaunchKernelGGL(init_members_kernel, dim3((NT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, d.minfo, d.mb, NT);
   HK(hipGetLastError());
@@ -429,9 +438,11 @@ static int upload_faults(swimsim* h, uint32_t nticks, size_t* fend_out) {
     if (fend > h->d_faults_cap) {
       HIPCHK(h, hipStreamSynchronize(h->stream));
       if (h->d_faults) HIPCHK(h, hipFree(h->d_faults));
-      h->d_faults = nullptr; h->d_faults_cap = 0;
+      if (h->d_joined) HIPCHK(h, hipFree(h->d_joined));
+      h->d_faults = nullptr; h->d_joined = nullptr; h->d_faults_cap = 0;
       const size_t cap = std::max<size_t>(1024, fend * 2);
       HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->d_faults), cap * sizeof(FaultRec)));
+      HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->d_joined), cap * sizeof(uint32_t)));
       h->d_faults_cap = cap;
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));   // previous call's begin kernels are done with the buffer
@@ -462,7 +473,8 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
     const size_t f0 = fpos;
     while (fpos < fend && h->faults[fpos].tick <= t) ++fpos;
     const uint32_t tk = tick_key(h->cfg.seed, t);
-    hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, (uint32_t)(fpos - f0));
+    hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, (uint32_t)(fpos - f0),
+                       h->d_joined, 3u, PeerCounts{});
     const uint32_t pk = std::max(h->d.P, h->d.K);   // registers follow the probe / proxy arrays: four sizes
     if (pk <= 4) launch_tick<4>(h, t, tk, ev);
     else if (pk <= 8) launch_tick<8>(h, t, tk, ev);
@@ -731,18 +743,71 @@ static PeerCounts peer_counts(const swimsim* h, const uint32_t* in) {
   return pc;
 }
 
+/* join_pull on a sharded cluster: the start of the tick in two parts around exchange round 0 (kind 4).  phase0
+ * applies the tick's faults; if members come up in this tick (every shard sees the same schedule, so every shard
+ * gets the same answer) *round_needed = 1, the owners of their join hosts have written what the hosts know as
+ * 16-byte records into send[p][0 .. counts[p]) of swimsim_shard_join_buffers, the caller delivers them like any
+ * other round and reports the arrivals with swimsim_shard_join_ingest; then phase1.  Without joins in the tick
+ * phase0 does nothing.  Optional (a no-op) when join_pull is off. */
+int swimsim_shard_phase0(swimsim_t* h, uint32_t* counts, int* round_needed) {
+  int rc = shard_check(h, 0);
+  if (rc) return rc;
+  if (!counts || !round_needed) return SWIMSIM_ERR_INVALID;
+  const uint32_t G = h->d.n_shards;
+  for (uint32_t p = 0; p < G; ++p) counts[p] = 0;
+  *round_needed = 0;
+  if (!h->d.join_pull || h->begun) return SWIMSIM_OK;
+  bool joins = false;
+  for (const Fault& f : h->faults) { if (f.tick > h->tick) break; joins |= f.up != 0; }
+  if (!joins) return SWIMSIM_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  size_t fend = 0;
+  rc = upload_faults(h, 1, &fend);
+  if (rc) return rc;
+  const uint32_t t = (uint32_t)h->tick;
+  const uint32_t tk = tick_key(h->cfg.seed, t);
+  hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults, (uint32_t)fend, h->d_joined, 1u, PeerCounts{});
+  hipLaunchKernelGGL(pull_send_kernel, dim3(std::min<uint32_t>(64u, (uint32_t)(fend + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, h->stream,
+                     h->d, tk, h->d_faults, (uint32_t)fend, h->d_joined);
+  rc = finish_phase(h, nullptr);
+  if (rc) return rc;
+  for (uint32_t p = 0; p < G; ++p) counts[p] = p == h->d.shard ? 0u : std::min(h->h_sync[G_JSEND + p], h->d.j_cap);
+  h->begun = true; h->begun_fend = fend;
+  *round_needed = 1;
+  return SWIMSIM_OK;
+}
+
+int swimsim_shard_join_buffers(swimsim_t* h, void** send, void** recv, uint32_t* cap) {
+  if (!h || !send || !recv) return SWIMSIM_ERR_INVALID;
+  *send = h->d.j_send; *recv = h->d.j_recv;
+  if (cap) *cap = h->d.j_cap;
+  return SWIMSIM_OK;
+}
+
+int swimsim_shard_join_ingest(swimsim_t* h, const uint32_t* counts_in) {
+  int rc = shard_check(h, 0);
+  if (rc) return rc;
+  if (!counts_in || !h->begun) return set_err(h, SWIMSIM_ERR_STATE, "join_ingest follows a swimsim_shard_phase0 that asked for round 0");
+  for (uint32_t p = 0; p < h->d.n_shards; ++p) h->j_in[p] = counts_in[p];
+  return SWIMSIM_OK;
+}
+
 int swimsim_shard_phase1(swimsim_t* h, uint32_t* counts) {
   int rc = shard_check(h, 0);
   if (rc) return rc;
   if (!counts) return SWIMSIM_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
-  size_t fend = 0;
-  rc = upload_faults(h, 1, &fend);
-  if (rc) return rc;
+  size_t fend = h->begun_fend;
+  if (!h->begun) { rc = upload_faults(h, 1, &fend); if (rc) return rc; }
   if (h->timing && !h->tick_ev[0]) for (int k = 0; k < 3; ++k) HIPCHK(h, hipEventCreate(&h->tick_ev[k]));
   const uint32_t t = (uint32_t)h->tick;
   const uint32_t tk = tick_key(h->cfg.seed, t);
-  hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults, (uint32_t)fend);
+  // one launch does the whole start of the tick, unless swimsim_shard_phase0 ran its first part already (join-time
+  // pulls to exchange in between)
+  hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults, (uint32_t)fend,
+                     h->d_joined, h->begun ? 2u : 3u, peer_counts(h, h->j_in));
+  h->begun = false;
+  std::fill(h->j_in, h->j_in + MAX_SHARDS, 0u);
   h->faults.erase(h->faults.begin(), h->faults.begin() + (long)fend);
   if (h->timing) (void)hipEventRecord(h->tick_ev[0], h->stream);
   const uint32_t pk = std::max(h->d.P, h->d.K);
@@ -825,7 +890,18 @@ int swimsim_shard_step(swimsim_t* h, uint32_t nticks, swimsim_exchange_fn xchg, 
   const uint32_t G = h->d.n_shards;
   std::vector<uint32_t> out(3 * MAX_SHARDS), in(3 * MAX_SHARDS);
   for (uint32_t k = 0; k < nticks; ++k) {
-    int rc = swimsim_shard_phase1(h, out.data());
+    int rc, need = 0;
+    if (h->d.join_pull) {
+      rc = swimsim_shard_phase0(h, out.data(), &need);
+      if (rc) return rc;
+      if (need) {
+        std::fill(in.begin(), in.end(), 0u);
+        if (xchg(ctx, 0, out.data(), in.data())) return set_err(h, SWIMSIM_ERR_STATE, "shard_step: the exchange callback failed in round 0");
+        rc = swimsim_shard_join_ingest(h, in.data());
+        if (rc) return rc;
+      }
+    }
+    rc = swimsim_shard_phase1(h, out.data());
     if (rc) return rc;
     std::fill(in.begin(), in.end(), 0u);
     if (xchg(ctx, 1, out.data(), in.data())) return set_err(h, SWIMSIM_ERR_STATE, "shard_step: the exchange callback failed in round 1");

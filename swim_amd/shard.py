@@ -26,7 +26,7 @@ from .sim import Sim, SwimError
 from .types import SimConfig
 
 _M64 = (1 << 64) - 1
-REC_BYTES = (16, 16, 72, 8)      # record kinds: round-1 records (+dictionary), mask payloads, explicit payloads, settle records
+REC_BYTES = (16, 16, 72, 8, 16)  # record kinds: round-1 records (+dictionary), mask payloads, explicit payloads, settle records, join pulls
 
 
 def _wrap(ptr: int, nbytes: int, device):
@@ -59,12 +59,25 @@ class _Shard:
         self.send = [_wrap(sp[k], G * caps[k] * REC_BYTES[k], device).view(G, caps[k] * REC_BYTES[k]) for k in range(3)]
         self.recv = [_wrap(rp[k], G * caps[k] * REC_BYTES[k], device).view(G, caps[k] * REC_BYTES[k]) for k in range(3)]
         self.settling = self.sim.resolved.gc_ticks != 0
-        if self.settling:                        # kind 3: what every shard says about its rows (round 3)
-            s3, r3, c3 = C.c_void_p(), C.c_void_p(), C.c_uint32()
-            self.sim._check(a.shard_settle_buffers(h, C.byref(s3), C.byref(r3), C.byref(c3)))
-            nb = c3.value * REC_BYTES[3]
-            self.send.append(_wrap(s3.value, G * nb, device).view(G, nb))
-            self.recv.append(_wrap(r3.value, G * nb, device).view(G, nb))
+        self.join_pull = self.sim.resolved.join_pull != 0
+        # kind 3: what every shard says about its rows (round 3, settling); kind 4: join-time pulls (round 0)
+        for kind, on, fn in ((3, self.settling, a.shard_settle_buffers), (4, self.join_pull, a.shard_join_buffers)):
+            if not on:
+                self.send.append(None); self.recv.append(None)
+                continue
+            sp_, rp_, cp_ = C.c_void_p(), C.c_void_p(), C.c_uint32()
+            self.sim._check(fn(h, C.byref(sp_), C.byref(rp_), C.byref(cp_)))
+            nb = cp_.value * REC_BYTES[kind]
+            self.send.append(_wrap(sp_.value, G * nb, device).view(G, nb))
+            self.recv.append(_wrap(rp_.value, G * nb, device).view(G, nb))
+
+    def phase0(self):
+        c, need = (C.c_uint32 * self.n_shards)(), C.c_int()
+        self.sim._check(self.sim._abi.shard_phase0(self.sim._h, c, C.byref(need)))
+        return list(c), bool(need.value)
+
+    def join_ingest(self, j_in: Sequence[int]):
+        self.sim._check(self.sim._abi.shard_join_ingest(self.sim._h, (C.c_uint32 * self.n_shards)(*j_in)))
 
     def phase1(self):
         G = self.n_shards
@@ -188,8 +201,8 @@ class DistFabric:
         if not hasattr(self, "_stage"):
             torch = self.torch
             dev = "cpu" if host else self.device
-            mk = lambda: [torch.empty(tuple(b.shape), dtype=torch.uint8, device=dev,
-                                      pin_memory=(host and self.on_gpu)) for b in sh.send]
+            mk = lambda: [None if b is None else torch.empty(tuple(b.shape), dtype=torch.uint8, device=dev,
+                                                             pin_memory=(host and self.on_gpu)) for b in sh.send]
             self._stage = (mk(), mk())
         return self._stage
 
@@ -281,16 +294,16 @@ class ShardedSim:
         def xchg(_ctx, rnd, c_out, c_in):
             try:
                 t0 = time.perf_counter()
-                acc[{1: 0, 2: 2, 3: 4}[rnd]] += t0 - state["t"]       # the phase that just ended
-                kinds = {1: (0,), 2: (1, 2), 3: (3,)}[rnd]
-                at = (lambda k: 0) if rnd == 3 else (lambda k: k * G)     # round 3: the kind-3 counts sit at [p]
+                acc[{0: 0, 1: 0, 2: 2, 3: 4}[rnd]] += t0 - state["t"]  # the phase that just ended
+                kinds = {0: (4,), 1: (0,), 2: (1, 2), 3: (3,)}[rnd]
+                at = (lambda k: 0) if rnd in (0, 3) else (lambda k: k * G)   # rounds 0 and 3: one kind, its counts at [p]
                 counts = [[[c_out[at(k) + p] for p in range(G)] for k in kinds]]
                 got = f.exchange([sh], kinds, counts)[0]
                 for j, k in enumerate(kinds):
                     for p in range(G):
                         c_in[at(k) + p] = got[j][p]
                 state["t"] = time.perf_counter()
-                acc[{1: 1, 2: 3, 3: 4}[rnd]] += state["t"] - t0
+                acc[{0: 1, 1: 1, 2: 3, 3: 4}[rnd]] += state["t"] - t0
                 return 0
             except Exception:                                       # noqa: BLE001 -- must not unwind through C
                 import traceback
@@ -311,6 +324,12 @@ class ShardedSim:
         acc = self.phase_seconds
         for _ in range(nticks):
             t0 = time.perf_counter()
+            if sh[0].join_pull:                                                     # round 0: join-time pulls
+                c0 = [s.phase0() for s in sh]
+                if c0[0][1]:
+                    j_in = f.exchange(sh, (4,), [[c[0]] for c in c0])
+                    for k, s in enumerate(sh):
+                        s.join_ingest(j_in[k][0])
             c1 = [s.phase1() for s in sh]
             t1 = time.perf_counter()
             r_in = f.exchange(sh, (0,), [[c[0]] for c in c1])                       # round 1

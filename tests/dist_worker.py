@@ -1,7 +1,7 @@
 """Worker for tests/test_shard_dist.py: one process = one shard (torch.distributed, gloo on CPU).
 Every rank drives its shard through the host emulation of the product kernels; rank 0 also runs the
-oracle and compares every observable.  usage: dist_worker.py <n_members> <p> <loss_ppm> <seed> <ticks> [gc]
-(gc = 1: settling on, suspicion 5 ticks, retransmit x1, and the member that went down comes back twice)"""
+oracle and compares every observable.  usage: dist_worker.py <n_members> <p> <loss_ppm> <seed> <ticks> [mode]
+(mode bit 0: settling on, suspicion 5 ticks, retransmit x1, and the member that went down comes back twice)"""
 import os
 import sys
 
@@ -11,7 +11,8 @@ sys.path.insert(0, ROOT)
 
 def main():
     n, p, loss, seed, ticks = (int(x) for x in sys.argv[1:6])
-    gc = len(sys.argv) > 6 and int(sys.argv[6]) != 0
+    mode = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    gc, pull = bool(mode & 1), bool(mode & 2)       # 1: settling, 2: join-time pull (round 0)
     import torch.distributed as dist
     dist.init_process_group("gloo")
     rank = dist.get_rank()
@@ -22,6 +23,8 @@ def main():
                    suspicionTicks=6, maxSubjects=min(n, 1024))
     if gc:
         sc.suspicionTicks, sc.retransmitMult, sc.gcTicks = 5, 1, _abi.GC_AUTO
+    if pull:
+        sc.joinPull = 1
     if os.environ.get("SWIM_DIST_DEVICE", "cpu") == "cuda":
         # all ranks share GPU 0 (RCCL refuses two ranks on one device): the real HIP library, device
         # buffers wrapped zero-copy, records staged through host memory over gloo
@@ -38,6 +41,10 @@ def main():
         s.crash(n // 2, 5)
         s.crash(3, 7)
         s.scheduleFault(30, n // 2, True)
+        if pull:
+            for m in range(10, 22):
+                s.crash(m, 12)
+                s.scheduleFault(26, m, True)                 # twelve joins in one tick, hosts on either shard
         if gc:
             s.crash(n - 2, 33)
             s.scheduleFault(70, n - 2, True)

@@ -208,6 +208,34 @@ def test_sharded_robust_scheme_on_one_gpu(oracle_abi, hip_abi, n, shards, p, los
     b.close()
 
 
+def test_sharded_join_pull_on_one_gpu(oracle_abi, hip_abi):
+    """join_pull on a sharded cluster (round 0: the owner of a join host sends what the host knows ahead of the tick's
+    probes), with settling: 400 joins in one tick at 16 384 members in 4 shards, every observable against the oracle."""
+    from swim_amd import _abi
+    from swim_amd.shard import LocalFabric, ShardedSim
+    n, shards = 16384, 4
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=31, lossPpm=10000, eventMask=0, suspicionTicks=6,
+                   retransmitMult=1, maxSubjects=2000, gcTicks=_abi.GC_AUTO, joinPull=1)
+    crashes = [(2 + k // 8, (2731 * k + 5) % n) for k in range(400)]
+    faults = [(70, m, True) for (_, m) in crashes] + [(40 + (k % 9), m, True) for k, (_, m) in enumerate(crashes[::5])]
+    a = Sim.create(oracle_abi, sc)
+    _oracle_threads(a)
+    b = ShardedSim(hip_abi, sc, LocalFabric(shards), device="cuda:0")
+    for s in (a, b):
+        workloads.apply_crashes(s, crashes)
+        for (t, m, up) in faults:
+            s.scheduleFault(t, m, up)
+    done = 0
+    while done < 140:
+        a.step(10); b.step(10); done += 10
+        assert a.counters() == b.counters(), "counters differ after %d ticks" % done
+        assert a.digest() == b.digest(), "digest differs after %d ticks" % done
+        for o in (0, crashes[0][1], n - 1):
+            assert a.members(o) == b.members(o)
+    assert a.firstDetection() == b.firstDetection()
+    b.close()
+
+
 def test_one_process_per_shard_on_one_gpu():
     """Two processes, one shard each, both on GPU 0, torch.distributed (gloo, records staged through
     host memory because RCCL refuses two ranks on one device): the DistFabric host code with the real

@@ -30,3 +30,8 @@ def test_one_process_per_shard_gloo(world, n, p, loss, seed, port):
 def test_one_process_per_shard_gloo_with_settling():
     """gc_ticks on: the third exchange round (settle records) through swimsim_shard_step's callback."""
     run_world(2, (192, 3, 20000, 7, 130, 1), 29614)
+
+
+def test_one_process_per_shard_gloo_with_join_pull_and_settling():
+    """join_pull (round 0: the hosts' entries travel to the joiners' owners ahead of the probes) + settling."""
+    run_world(2, (192, 3, 20000, 8, 130, 3), 29615)

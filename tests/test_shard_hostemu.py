@@ -118,3 +118,28 @@ def test_sharded_robust_target_scheme(oracle_abi, emu_abi, n, shards, p, loss, s
         s.scheduleFault(45, crashes[0][1], True)
     lockstep(a, b, 70, 5, observers=(0, n - 1, crashes[0][1]), members=(0, n - 1, crashes[0][1]))
     b.close()
+
+
+@pytest.mark.parametrize("shards,gc", [(2, False), (4, True), (3, True)])
+def test_sharded_join_pull_with_churn(oracle_abi, emu_abi, shards, gc):
+    """join_pull on a sharded cluster: the join host of a member that comes up usually lives on another shard -- its
+    owner sends what the host knows ahead of the tick's probes (round 0).  Several joins in one tick, hosts skipped
+    because they change in the same tick, pulled Suspect entries, rows opened by a pull, with and without settling."""
+    from swim_amd import _abi
+    n = 300
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=21 + shards, lossPpm=30000, eventMask=0x1F, suspicionTicks=6,
+                   retransmitMult=2, maxSubjects=200 if gc else 300, gcTicks=_abi.GC_AUTO if gc else 0, joinPull=1)
+    crashes = [(2 + 3 * k, (11 * k + 5) % n) for k in range(60)]
+    faults = [(t + 4 + (k % 6) * 5, m, True) for k, (t, m) in enumerate(crashes) if k % 2 == 0]
+    faults += [(50, m, False) for m in range(100, 140)] + [(58, m, True) for m in range(100, 140)]   # 40 joins in one tick
+    faults += [(58, m, False) for m in range(140, 170)]                                              # 30 busy non-hosts
+    a = Sim.create(oracle_abi, sc)
+    b = ShardedSim(emu_abi, sc, LocalFabric(shards))
+    for s in (a, b):
+        workloads.apply_crashes(s, crashes)
+        for (t, m, up) in faults:
+            s.scheduleFault(t, m, up)
+    lockstep(a, b, 260, 1 if not gc else 4, observers=(0, 100, 139, n - 1), members=(0, 100, 139, n - 1))
+    c = b.counters()
+    assert c["timers_fired"] > 0 and (not gc or c["settled"] > 20)
+    b.close()
