@@ -1,5 +1,5 @@
 """Randomised long-run soak of the product's kernels in the host emulation against the oracle (CPU only): random
-populations (130-3000), fan-outs, loss rates up to 20 %, settling, join pull, tiny inboxes, hundreds of crashes and
+populations (130-3000) on 1-8 shards, both target schemes, fan-outs, loss rates up to 20 %, settling, join pull, tiny inboxes, hundreds of crashes and
 rejoins over 200-800 ticks, on the normal build and the knob-shrunk ones (8- and 10-bit rumour ids, 4-id mask
 window).  Every 20 ticks: counters (the dropped-event count aside: implementation-defined once the ring overflows),
 state digest, events (while nothing was dropped), first-detection ticks at the end.
@@ -8,6 +8,7 @@ import sys, random, time
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from swim_amd import Config, Sim, SimConfig, workloads, _abi
+from swim_amd.shard import LocalFabric, ShardedSim
 from tests import hostemu_binding, oracle_binding
 orc = oracle_binding.load()
 variants = {"": hostemu_binding.load(), "rid10": hostemu_binding.load_variant("rid10", ["SWIM_RID_BITS=10"]),
@@ -19,6 +20,9 @@ while time.time() < t_end:
     rng = random.Random(seed0 * 100003 + k); k += 1
     vname = rng.choice(list(variants))
     n = rng.choice([130, 300, 700, 1500, 3000])
+    shards = rng.choice([1, 1, 2, 3, 4, 8])                      # sharded clusters take every option of the plain handle
+    n -= n % shards
+    scheme = 1 if rng.random() < 0.25 else 0
     p = rng.choice([1, 3, 3, 5, 10])
     loss = rng.choice([0, 20000, 50000, 100000, 200000])
     gc = rng.random() < 0.6
@@ -27,8 +31,11 @@ while time.time() < t_end:
     ticks = rng.choice([200, 400, 800])
     sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=rng.randrange(1, 1 << 30), lossPpm=loss, eventMask=0x1F,
                    suspicionTicks=S, retransmitMult=rng.choice([1, 2, 3]), maxSubjects=n, gcTicks=_abi.GC_AUTO if gc else 0,
-                   joinPull=1 if jp else 0, inboxCap=rng.choice([0, 0, 2]))
-    a = Sim.create(orc, sc); b = Sim.create(variants[vname], sc)
+                   joinPull=1 if jp else 0, inboxCap=rng.choice([0, 0, 2]), targetScheme=scheme)
+    a = Sim.create(orc, sc)
+    rm = shards > 1 and rng.random() < 0.5                       # replicated queue masks (read from the environment at create)
+    os.environ["SWIMSIM_SHARD_REPLICATED_MASKS"] = "1" if rm else "0"
+    b = Sim.create(variants[vname], sc) if shards == 1 else ShardedSim(variants[vname], sc, LocalFabric(shards))
     nf = rng.randrange(0, n // 4)
     for _ in range(nf):
         m, t = rng.randrange(n), rng.randrange(1, ticks)
@@ -36,7 +43,7 @@ while time.time() < t_end:
         if rng.random() < 0.7:
             t2 = t + rng.randrange(1, 150)
             for s in (a, b): s.scheduleFault(t2, m, True)
-    what = (vname, n, p, loss, gc, jp, S, ticks, sc.seed, nf)
+    what = (vname, n, p, loss, gc, jp, S, ticks, sc.seed, nf, shards, scheme, rm)
     ok = True
     try:
         for _ in range(ticks // 20):
@@ -52,5 +59,5 @@ while time.time() < t_end:
         ok = False; print("DIVERGED", e, what, "tick", a.tick, flush=True)
     except Exception as e:
         ok = False; print("ERROR", repr(e)[:200], what, flush=True)
-    print("ok" if ok else "FAIL", what, b.tableStats() if ok else "", flush=True)
+    print("ok" if ok else "FAIL", what, b.tableStats() if ok and shards == 1 else "", flush=True)
     a.close(); b.close()

@@ -107,6 +107,7 @@ _PRODUCT_ONLY = {
     "shard_settle_counts": (C.c_int, [_H, _U32P]),
     "shard_settle_commit": (C.c_int, [_H, _U32P]),
     "shard_phase0": (C.c_int, [_H, _U32P, C.POINTER(C.c_int)]),
+    "shard_gather_buffers": (C.c_int, [_H, _VPP, _VPP, _U32P]),
     "shard_join_buffers": (C.c_int, [_H, _VPP, _VPP, _U32P]),
     "shard_join_ingest": (C.c_int, [_H, _U32P]),
     "shard_get_first_suspect": (C.c_int, [_H, _U32P, C.c_size_t]),

@@ -34,7 +34,8 @@ enum { G_NSLOTS = 0 /* view rows ever handed out (high-water mark) */, G_ERR = 1
        G_SETTLE_SEND = 15 /* sharded settling: records this shard publishes at the end of the tick (same list to every peer) */,
        G_SEND = 16 /* [3][16] exchange records appended per peer (send_cnt) */,
        G_NJOINED = 64 /* members that came up in this tick (begin_kernel part A) */,
-       G_JSEND = 65 /* [16] join-pull records appended per peer (exchange round 0) */, G_WORDS = 96 };
+       G_JSEND = 65 /* [16] join-pull records appended per peer (exchange round 0) */,
+       G_FLDYN = 81 /* foreign lines handed out by remote_kernel this tick */, G_WORDS = 96 };
 enum { ERRF_SUBJECTS = 1, ERRF_ROWS = 2, ERRF_OVF = 4, ERRF_INC = 8, ERRF_XCHG = 16 };
 
 // counter slots (same order as SWIMSIM_CTR_* in include/swimsim.h)
@@ -163,7 +164,16 @@ struct DevState {
   // join-time pulls whose host lives on another shard (round 0): {joiner, subject, the host's entry, -}
   uint4* j_send; uint4* j_recv;         // [n_shards][j_cap]
   uint32_t j_cap;
+  // replicated queue masks (rm = 1; DESIGN.md section 7, "replicated masks"): every shard holds every member's
+  // start-of-tick queue mask and a byte about its queue (global index; the own slice is written by probe_kernel, the
+  // others arrive by all-gather), so that the direct probes between shards need no records
+  uint32_t rm;
+  unsigned long long* mask_all;  // [NT] queue mask over the OWNER's dictionary of the tick
+  uint8_t* q_all;                // [NT] bits 0-3 queue length, 4 = the mask cannot express the queue (MI_OOW), 5 = the member
+                                 //   handles its direct probes of remote targets by records this tick (Q_EXC)
+  uint32_t fl_dyn_base, fl_dyn_cap;   // region of `fl` for foreign lines that belong to no record (remote_kernel)
 };
+constexpr uint32_t Q_PBN = 0xFu, Q_OOW = 1u << 4, Q_EXC = 1u << 5;
 // settle records: a shard lists a row as a CANDIDATE (quiet here for G ticks; y = the largest entry among its members
 // that are up) or as a VETO (an entry changed / the subject announced itself within the last G ticks)
 constexpr uint32_t SR_CAND = 1u << 30, SR_VETO = 1u << 31, SR_KEY = 0xFFFFFFu;
@@ -405,8 +415,9 @@ template <int MAXN>
 __device__ inline uint32_t select_members(const DevState& s, uint32_t mk, uint32_t i, uint32_t n,
                                           uint32_t purpose, uint32_t hi_idx, const uint32_t* excl,
                                           uint32_t nexcl, uint32_t (&out)[MAXN],
-                                          uint32_t (&info)[MAXN], bool use_mask = false) {
+                                          uint32_t (&info)[MAXN], bool use_mask = false, bool* all_first = nullptr) {
   uint32_t np = 0;
+  bool first_only = true;          // every pick so far was the first draw of its index
   const uint32_t N = s.NT;
   // Issue the first-attempt gathers of all picks together (independent loads); eligibility is
   // then decided pick by pick in order, exactly as the sequential definition does.
@@ -444,9 +455,10 @@ __device__ inline uint32_t select_members(const DevState& s, uint32_t mk, uint32
       } else {
         c = __umulhi(hash_mk(mk, base | a, 0), N);
       }
-      if (eligible(c, have, mh)) { found = true; break; }
+      if (eligible(c, have, mh)) { found = true; first_only &= a == 0u; break; }
     }
     if (!found) {
+      first_only = false;
       uint32_t cs = (c + 1 == N) ? 0 : c + 1;
       for (uint32_t d = 0; d < N; ++d) {
         c = cs + d; if (c >= N) c -= N;
@@ -457,6 +469,7 @@ __device__ inline uint32_t select_members(const DevState& s, uint32_t mk, uint32
     for (int e = 0; e < MAXN; ++e) if ((uint32_t)e == np) { out[e] = c; info[e] = mc; }
     ++np;
   }
+  if (all_first) *all_first = first_only && np == n;
   return np;
 }
 

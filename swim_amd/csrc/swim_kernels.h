@@ -193,6 +193,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
   unsigned n_pings = 0;
   unsigned payloads = 0, rumors = 0, dfail = 0, preqs = 0, susp = 0, fsusp = 0;
   unsigned long long ackacc = 0;                  // masks this member pulls in with its Acks
+  unsigned long long pubmask = 0; uint32_t pubq = 0;   // replicated masks (sharded, s.rm): what the peers learn about my queue
   SECT_BEGIN(32);
   if (act) {
     const uint32_t mk = mix32(tk ^ i);
@@ -205,9 +206,15 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
     // a sharded cluster the pinger may live elsewhere, and the payloads are pushed like the random scheme's
     const bool pull = robust && s.n_shards == 1u;
     uint32_t np;                                    // probe indices in play
+    // replicated masks: a prober whose targets are simply its first draws, with a queue its mask expresses in full,
+    // leaves its direct probes of REMOTE targets to remote_kernel on both sides (no records); anybody else says so
+    // in its queue byte (Q_EXC) and sends records as before
+    bool clean = false;
     if (!robust) {
       // ms <- kRandomMembers store (numToGossip cfg) []        (src/Core.hs:239)
-      np = select_members<PMAX>(s, mk, i, s.P, P_SELECT, 0, nullptr, 0, picks, pinfo, use_mask);
+      bool all_first = false;
+      np = select_members<PMAX>(s, mk, i, s.P, P_SELECT, 0, nullptr, 0, picks, pinfo, use_mask, &all_first);
+      clean = s.rm && use_mask && !(mi & MI_OOW) && all_first;
       n_pings = np;
 #pragma unroll
       for (int p = 0; p < PMAX; ++p) valid[p] = (uint32_t)p < np;
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
     // for the target's queue (if its Ack arrived); the answer lands in my slot p without an atomic
 #pragma unroll
     for (int p = 0; p < PMAX; ++p) {
-      if (pull || !ping_ok[p] || is_local(s, picks[p])) continue;
+      if (pull || clean || !ping_ok[p] || is_local(s, picks[p])) continue;
       const uint32_t fl = ((mymask && !(mi & MI_OOW)) ? OF_PAYLOAD : 0u) | (ack_ok[p] ? OF_WANTS_ACK : 0u);
       if (fl) emit_raw(picks[p] | ((uint32_t)(p + 1) << ID_BITS), i | (fl << ID_BITS), (fl & OF_PAYLOAD) ? mymask : 0ull);
     }
@@ -377,8 +384,11 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
     }
     SECT(36);                                       // indirect probes
     s.probe_out[li] = (uint16_t)(n_pings | (nfail << 5) | (nack << 10));
+    pubmask = mymask;
+    pubq = mycnt | (((mi & MI_OOW) || !use_mask) ? Q_OOW : 0u) | (clean ? 0u : Q_EXC);   // a tick without masks: no queue travels as one
   }
   if (li < s.N) s.ackmask[li] = ackacc;
+  if (s.rm && li < s.N) { s.mask_all[i] = pubmask; s.q_all[i] = (uint8_t)pubq; }
   ctr_add_wave(&sh, C_PINGS, n_pings);
   ctr_add_wave(&sh, C_ACTIVE, act ? 1u : 0u);
   ctr_add_wave(&sh, C_PAYLOADS, payloads);
@@ -447,6 +457,18 @@ __device__ inline uint32_t find_rid(const DevState& s, uint32_t slot, uint32_t k
   const uint32_t rid = new_rid(s) & RID_MASK;
   s.rum[rid] = make_uint2(slot, key);
   return rid;
+}
+
+// An id handed out DURING a tick (xlat_kernel / ingest_kernel of a sharded cluster: rumours a peer knows and this shard
+// does not) is read in the same tick, through foreign lines, against rings whose head is the START of the tick: it
+// must not lie a whole turn of the id space minus the ring ahead of that head, or it reads as an OLD id inside the
+// ring (found by a soak of the 10-bit build: 3 000 members, 20 % loss, two shards -- deliveries filtered as "known";
+// the product's 16-bit ids reach that point at ~65 000 new rumours per shard and tick: heavy loss at a million
+// members).  Past that point entries travel without an id (exact: every filter is skipped).  Called AFTER the id was
+// obtained: the counter read here is beyond it.
+__device__ inline uint32_t young_rid(const DevState& s, uint32_t rid, uint32_t H) {
+  const uint32_t now = atomicOr(&s.g[G_NRUM], 0u);
+  return (now - H <= RID_MASK + 1u - KW_BITS) ? rid : RID_PARKED;
 }
 
 // a rumour id that fell out of the (wide) known-ring window is replaced by RID_PARKED ("no id") at the next rewrite of
@@ -809,6 +831,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
       // the wide known-ring (swim_device.h): what I learned since it was written is forgotten position-wise, what the
       // 64-position ring knows is copied in (its ids own one or two of the wide ring's words)
       Ring256 kw;
+      const bool ids_untrusted = s.g[G_RIDS_OFF] != 0u;
       const uint32_t kwh0 = s.kw_head[li];
       {
         const ulonglong4 v = s.kw[li];
@@ -854,7 +877,11 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState
           ce[q] = make_uint2(0u, 0u); cb[q] = 0u; cs[q] = 0u;
           bool want = pe_tx(hi) != 0u;
           const uint32_t rid = pe_rid(lo);
-          if (want && rid_in_wide(rid, H)) {
+          // after a tick with more new ids than the width tolerates (G_RIDS_OFF) the lines written in that tick hold
+          // ids that may be a whole turn of the id space apart -- two rumours under one id, or an id that reads as
+          // one of this tick's window: no id of a line is trusted in this tick (found by a soak of the 8-bit build:
+          // 3 000 members at 20 % loss allocate 660 ids in the first tick)
+          if (want && !ids_untrusted && rid_in_wide(rid, H)) {
             if (r256_test(kw, rid)) want = false;  // view already dominates it
             else { r256_set(kw, rid); if (rid_in_ring(rid, H)) kn |= rid_bit(rid); }
           }
@@ -1178,10 +1205,99 @@ __global__ void xlat_kernel(DevState s, PeerCounts r_counts) {
           ((s.g[G_NRUM] - prid) & RID_MASK) < RID_FAR)
         out = prev;
       else
-        out = make_uint2(pe_lo(slot, find_rid(s, slot, e.y)), e.y);
+        out = make_uint2(pe_lo(slot, young_rid(s, find_rid(s, slot, e.y), s.g[G_HEAD])), e.y);
     }
   }
   s.xl[(size_t)peer * DICT_ENTRIES + p] = out;
+}
+
+// Replicated masks (s.rm).  After round 1 every shard holds every member's start-of-tick queue
+// mask (over its owner's dictionary) and queue byte.  The direct probes between shards of "clean" probers -- targets
+// = first draws, queue fully expressed by its mask -- then need no records at all: both ends recompute the probe
+// from the hashes (pure functions of seed, tick, prober, probe index) and replicated ground truth.
+//   part (a), one thread per LOCAL member i: the Acks of its remote targets -- i pulls the target's replicated mask;
+//   part (b), one thread per REMOTE member g: the Pings of g that hit my members -- the target's shard delivers g's
+//     replicated mask itself; and where my member's queue cannot travel as a mask, its Ack goes out as the explicit
+//     record serve_kernel would have written.
+// Masks are translated through the owner's dictionary (xl, xlat_kernel) like any mask record; entries my masks
+// cannot carry this tick become foreign lines (fl) read through an explicit record.
+__device__ inline void rm_deliver(const DevState& s, uint32_t t, bool use_mask, uint32_t H, unsigned long long stale, const uint2* xls,
+                                  unsigned long long m, uint32_t dst_li, unsigned long long* pulled /* non-null: dst pulls it itself */) {
+  unsigned long long bits = 0; uint32_t nf = 0;
+  uint32_t tmp[2 * PB_SLOTS];
+  translate_mask(xls, m, use_mask, H, &bits, tmp, &nf);
+  if (pulled) *pulled |= bits;
+  else if (bits) {
+    const unsigned long long mm = bits & ~(s.pk[dst_li].y & ~stale);
+    if (mm) atomicOr(&s.inmask[dst_li], mm);
+  }
+  if (nf) {
+    const uint32_t k = atomicAdd(&s.g[G_FLDYN], 1u);
+    if (k >= s.fl_dyn_cap) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG); return; }
+    uint32_t* fl = reinterpret_cast<uint32_t*>(s.fl + ((size_t)s.fl_dyn_base + k) * 4);
+    for (uint32_t e = 0; e < (uint32_t)PB_SLOTS; ++e) { fl[2 * e] = e < nf ? tmp[2 * e] : 0u; fl[2 * e + 1] = e < nf ? tmp[2 * e + 1] : 0u; }
+    __threadfence();
+    push(s, t, dst_li, SRC_FOREIGN | (s.fl_dyn_base + k));
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void remote_kernel(DevState s, uint32_t t, uint32_t tk) {
+  __shared__ BlockCounters sh;
+  __shared__ uint2 xls[MAX_SHARDS * DICT_ENTRIES];
+  ctr_init(&sh);
+  for (uint32_t k = threadIdx.x; k < s.n_shards * DICT_ENTRIES; k += BLOCK) xls[k] = s.xl[k];
+  __syncthreads();
+  const uint32_t Hprev = s.g[G_PREV], H = s.g[G_HEAD];
+  const bool use_mask = H - Hprev <= MASK_SLACK;
+  const unsigned long long stale = stale_positions(Hprev, H);
+  unsigned payloads = 0, rumors = 0;
+  {                                                 // (a tick without masks HERE: my probers are all exceptions, my
+    const uint32_t NR = s.NT - s.N;                 //  members' queues travel as explicit records, what arrives becomes foreign lines)
+    for (uint32_t x = blockIdx.x * BLOCK + threadIdx.x; x < s.N + NR; x += gridDim.x * BLOCK) {
+      if (x < s.N) {
+        // ---- (a) my member i = lo + x: Acks of its remote targets
+        const uint32_t i = s.lo + x;
+        if (!(s.mb[i] & MB_UP) || (s.q_all[i] & Q_EXC)) continue;
+        const uint32_t mk = mix32(tk ^ i);
+        unsigned long long acc = 0;
+        for (uint32_t p = 0; p < s.P; ++p) {
+          const uint32_t c = __umulhi(hash_mk(mk, ((uint32_t)P_SELECT << 24) | (p << 8), 0), s.NT);
+          if (is_local(s, c) || !(s.mb[c] & MB_UP)) continue;
+          if (lost(s, tk, P_L_PING, i, c, p) || lost(s, tk, P_L_ACK, c, i, p)) continue;
+          const uint32_t qc = s.q_all[c], pj = qc & Q_PBN;
+          if (!pj) continue;
+          payloads++; rumors += pj;
+          if (!(qc & Q_OOW)) rm_deliver(s, t, use_mask, H, stale, xls + owner_of(s, c) * DICT_ENTRIES, s.mask_all[c], x, &acc);
+          // else: the target's owner sends the queue as an explicit record (part (b) over there)
+        }
+        if (acc) s.ackmask[x] |= acc;               // probe_kernel stored it; this thread is its only writer now
+      } else {
+        // ---- (b) a remote member g: its Pings that reach my members
+        const uint32_t r = x - s.N, g = r < s.lo ? r : r + s.N;
+        if (!(s.mb[g] & MB_UP)) continue;
+        const uint32_t qg = s.q_all[g];
+        if (qg & Q_EXC) continue;
+        const uint32_t mk = mix32(tk ^ g);
+        for (uint32_t p = 0; p < s.P; ++p) {
+          const uint32_t c = __umulhi(hash_mk(mk, ((uint32_t)P_SELECT << 24) | (p << 8), 0), s.NT);
+          if (!is_local(s, c)) continue;
+          const uint32_t mc = s.minfo[c];
+          if (!mi_up(mc) || lost(s, tk, P_L_PING, g, c, p)) continue;
+          if (qg & Q_PBN) rm_deliver(s, t, use_mask, H, stale, xls + owner_of(s, g) * DICT_ENTRIES, s.mask_all[g], c - s.lo, nullptr);
+          if (((mc & MI_OOW) || !use_mask) && mi_pbn(mc) && !lost(s, tk, P_L_ACK, c, g, p)) {
+            // my member's queue cannot travel as a mask: its Ack's payload as an explicit record into g's slot p
+            const uint32_t peer = owner_of(s, g);
+            const uint32_t pos = atomicAdd(&s.send_cnt[2 * MAX_SHARDS + peer], 1u);
+            if (pos < s.x_cap) write_xrec(s, s.x_send + ((size_t)peer * s.x_cap + pos) * XREC_WORDS, g | ((p + 1u) << ID_BITS), c - s.lo, mc);
+            else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG);
+          }
+        }
+      }
+    }
+  }
+  ctr_add(&sh, C_PAYLOADS, payloads);
+  ctr_add(&sh, C_RUMORS_SEEN, rumors);
+  ctr_flush(s, &sh, blockIdx.x);
 }
 
 // after round 2: payload records for my members, as masks over the sender's dictionary or as explicit ids
@@ -1217,7 +1333,7 @@ __global__ __launch_bounds__(BLOCK) void ingest_kernel(DevState s, uint32_t t, P
       for (uint32_t e = 0; e < ne; ++e) {
         const uint32_t subject = rec[2 + 2 * e], key = rec[3 + 2 * e];
         const uint32_t slot = get_slot(s, subject);
-        const uint32_t rid = find_rid(s, slot, key);
+        const uint32_t rid = young_rid(s, find_rid(s, slot, key), H);
         if (use_mask && rid_in_ring(rid, H)) bits |= rid_bit(rid);     // an id of an earlier tick
         else { fl[2 * nf] = pe_lo(slot, rid); fl[2 * nf + 1] = pe_hi(key, 1u); nf++; }
       }
@@ -1566,6 +1682,7 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
   if (s.n_shards > 1 && threadIdx.x == 0) {
     const uint32_t H = s.g[G_NRUM];
     for (int k = 0; k < 3 * MAX_SHARDS; ++k) s.send_cnt[k] = 0;
+    s.g[G_FLDYN] = 0;
     // this tick's dictionary for the peers: ring position -> {subject, key} of the id that owns it
     const size_t rstride = DICT_RECS + s.r_cap;
     for (uint32_t p = 0; p < DICT_ENTRIES; ++p) {

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -377,7 +378,17 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     CK(dev_alloc(h, &d.x_send, (size_t)d.n_shards * d.x_cap * XREC_WORDS, 0));
     CK(dev_alloc(h, &d.x_recv, (size_t)d.n_shards * d.x_cap * XREC_WORDS, 0));
     CK(dev_alloc(h, &d.xl, (size_t)d.n_shards * DICT_ENTRIES, 0xFF));
-    CK(dev_alloc(h, &d.fl, (size_t)d.n_shards * ((size_t)d.x_cap + d.p_cap + d.r_cap) * 4, 0));
+    // SWIMSIM_SHARD_REPLICATED_MASKS=1: the direct probes between shards through all-gathered queue masks instead of
+    // records (off by default until it has been timed on the GPU)
+    const char* rm_env = std::getenv("SWIMSIM_SHARD_REPLICATED_MASKS");
+    d.rm = (rm_env && rm_env[0] == '1') ? 1u : 0u;
+    d.fl_dyn_base = (uint32_t)std::min<size_t>((size_t)d.n_shards * ((size_t)d.x_cap + d.p_cap + d.r_cap), (size_t)1 << 29);
+    d.fl_dyn_cap = d.rm ? std::max<uint32_t>(4096u, N / 4) : 0u;
+    CK(dev_alloc(h, &d.fl, ((size_t)d.n_shards * ((size_t)d.x_cap + d.p_cap + d.r_cap) + d.fl_dyn_cap) * 4, 0));
+    if (d.rm) {
+      CK(dev_alloc(h, &d.mask_all, (size_t)NT, 0));
+      CK(dev_alloc(h, &d.q_all, ((size_t)NT + 15) & ~(size_t)15, 0));
+    }
     CK(dev_alloc(h, &d.ackslot, (size_t)N * std::max(1u, d.P), 0));
     if (d.G) {                                   // settling: every shard's word about its rows, all-gathered per tick
       d.s_cap = d.R_phys;
@@ -832,6 +843,7 @@ int swimsim_shard_phase2(swimsim_t* h, const uint32_t* r_counts_in, uint32_t* co
   HIPCHK(h, hipSetDevice(h->device));
   const PeerCounts rc_in = peer_counts(h, r_counts_in);
   hipLaunchKernelGGL(xlat_kernel, dim3(h->d.n_shards), dim3(DICT_ENTRIES), 0, h->stream, h->d, rc_in);
+  if (h->d.rm) hipLaunchKernelGGL(remote_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, (uint32_t)h->tick, tick_key(h->cfg.seed, (uint32_t)h->tick));
   hipLaunchKernelGGL(serve_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, (uint32_t)h->tick, rc_in);
   rc = finish_phase(h, counts);
   if (rc) return rc;
@@ -855,6 +867,14 @@ int swimsim_shard_phase3(swimsim_t* h, const uint32_t* p_counts_in, const uint32
   if (h->timing) { float b = 0; HIPCHK(h, hipEventElapsedTime(&b, h->tick_ev[1], h->tick_ev[2])); h->merge_ms += b; h->timed_ticks++; }
   h->tick++;
   h->shard_phase = h->d.G ? 3 : 0;                // settling: the tick ends with round 3 + swimsim_shard_settle_commit
+  return SWIMSIM_OK;
+}
+
+int swimsim_shard_gather_buffers(swimsim_t* h, void** send /*[2]*/, void** recv /*[2]*/, uint32_t* n_local) {
+  if (!h || !send || !recv) return SWIMSIM_ERR_INVALID;
+  if (n_local) *n_local = h->d.rm ? h->d.N : 0u;
+  send[0] = h->d.rm ? (void*)(h->d.mask_all + h->d.lo) : nullptr; send[1] = h->d.rm ? (void*)(h->d.q_all + h->d.lo) : nullptr;
+  recv[0] = h->d.mask_all; recv[1] = h->d.q_all;
   return SWIMSIM_OK;
 }
 
@@ -903,6 +923,11 @@ int swimsim_shard_step(swimsim_t* h, uint32_t nticks, swimsim_exchange_fn xchg, 
     }
     rc = swimsim_shard_phase1(h, out.data());
     if (rc) return rc;
+    if (h->d.rm) {                                  // the all-gather of queue masks and queue bytes: N records to every peer
+      std::vector<uint32_t> go(3 * MAX_SHARDS, 0u), gi(3 * MAX_SHARDS, 0u);
+      for (uint32_t p = 0; p < G; ++p) if (p != h->d.shard) { go[p] = h->d.N; go[G + p] = h->d.N; }
+      if (xchg(ctx, 4, go.data(), gi.data())) return set_err(h, SWIMSIM_ERR_STATE, "shard_step: the exchange callback failed in round 4");
+    }
     std::fill(in.begin(), in.end(), 0u);
     if (xchg(ctx, 1, out.data(), in.data())) return set_err(h, SWIMSIM_ERR_STATE, "shard_step: the exchange callback failed in round 1");
     rc = swimsim_shard_phase2(h, in.data(), out.data());

@@ -26,7 +26,8 @@ from .sim import Sim, SwimError
 from .types import SimConfig
 
 _M64 = (1 << 64) - 1
-REC_BYTES = (16, 16, 72, 8, 16)  # record kinds: round-1 records (+dictionary), mask payloads, explicit payloads, settle records, join pulls
+REC_BYTES = (16, 16, 72, 8, 16, 8, 1)   # record kinds: round-1 records (+dictionary), mask payloads, explicit payloads, settle
+                                        # records, join pulls, replicated queue masks, replicated queue bytes (all-gathered)
 
 
 def _wrap(ptr: int, nbytes: int, device):
@@ -70,6 +71,19 @@ class _Shard:
             nb = cp_.value * REC_BYTES[kind]
             self.send.append(_wrap(sp_.value, G * nb, device).view(G, nb))
             self.recv.append(_wrap(rp_.value, G * nb, device).view(G, nb))
+
+        # kinds 5 / 6: the replicated queue masks / bytes (all-gather after phase 1): the send "segments" of all
+        # peers are one and the same slice, the receive segments are the peers' slices of the whole table
+        gs, gr, gn = (C.c_void_p * 2)(), (C.c_void_p * 2)(), C.c_uint32()
+        self.sim._check(a.shard_gather_buffers(h, gs, gr, C.byref(gn)))
+        self.replicated = gn.value != 0
+        for k in (0, 1):
+            if not self.replicated:
+                self.send.append(None); self.recv.append(None)
+                continue
+            nb = gn.value * REC_BYTES[5 + k]
+            self.send.append(_wrap(gs[k], nb, device).view(1, nb).expand(G, nb))
+            self.recv.append(_wrap(gr[k], G * nb, device).view(G, nb))
 
     def phase0(self):
         c, need = (C.c_uint32 * self.n_shards)(), C.c_int()
@@ -212,14 +226,19 @@ class DistFabric:
         sh, nk = shards[0], len(kinds)
         host = self.transport == "host"
         grp = self._cpu_group() if (host and self.on_gpu) else None
-        flat = [counts[0][j][p] for p in range(G) for j in range(nk)]          # peer-major for all_to_all
-        cs = torch.tensor(flat, dtype=torch.int64, device="cpu" if host else self.device)
-        cr = torch.empty_like(cs)
-        dist.all_to_all_single(cr, cs, group=grp)
-        got = [int(v) for v in cr.tolist()]
-        recv = [[got[p * nk + j] for p in range(G)] for j in range(nk)]
+        gather = kinds == (5, 6)                   # the all-gather of the replicated tables: every count is n_local
+        if gather:
+            recv = [[0 if p == me else sh.n_local for p in range(G)] for _ in kinds]
+        else:
+            flat = [counts[0][j][p] for p in range(G) for j in range(nk)]      # peer-major for all_to_all
+            cs = torch.tensor(flat, dtype=torch.int64, device="cpu" if host else self.device)
+            cr = torch.empty_like(cs)
+            dist.all_to_all_single(cr, cs, group=grp)
+            got = [int(v) for v in cr.tolist()]
+            recv = [[got[p * nk + j] for p in range(G)] for j in range(nk)]
         ops, landing = [], []
         stage = self._staging(sh, host)
+        staged = set()
         for p in range(G):
             if p == me:
                 continue
@@ -227,8 +246,11 @@ class DistFabric:
                 n_out, n_in = counts[0][j][p], recv[j][p]
                 if n_out:
                     nb = n_out * REC_BYTES[kind]
-                    out = stage[0][kind][p, :nb]
-                    out.copy_(sh.send[kind][p, :nb])
+                    row = 0 if gather else p           # the same slice goes to every peer: staged once
+                    out = stage[0][kind][row, :nb]
+                    if (kind, row) not in staged:
+                        out.copy_(sh.send[kind][row, :nb])
+                        staged.add((kind, row))
                     ops.append(dist.P2POp(dist.isend, out, p, group=grp))
                 if n_in:
                     tmp = stage[1][kind][p, : n_in * REC_BYTES[kind]]
@@ -294,16 +316,17 @@ class ShardedSim:
         def xchg(_ctx, rnd, c_out, c_in):
             try:
                 t0 = time.perf_counter()
-                acc[{0: 0, 1: 0, 2: 2, 3: 4}[rnd]] += t0 - state["t"]  # the phase that just ended
-                kinds = {0: (4,), 1: (0,), 2: (1, 2), 3: (3,)}[rnd]
-                at = (lambda k: 0) if rnd in (0, 3) else (lambda k: k * G)   # rounds 0 and 3: one kind, its counts at [p]
+                acc[{0: 0, 1: 0, 2: 2, 3: 4, 4: 0}[rnd]] += t0 - state["t"]  # the phase that just ended
+                kinds = {0: (4,), 1: (0,), 2: (1, 2), 3: (3,), 4: (5, 6)}[rnd]
+                # rounds 0 and 3: one kind, its counts at [p]; round 4: kinds 5 and 6 at [p] and [G + p]
+                at = (lambda k: 0) if rnd in (0, 3) else ((lambda k: (k - 5) * G) if rnd == 4 else (lambda k: k * G))
                 counts = [[[c_out[at(k) + p] for p in range(G)] for k in kinds]]
                 got = f.exchange([sh], kinds, counts)[0]
                 for j, k in enumerate(kinds):
                     for p in range(G):
                         c_in[at(k) + p] = got[j][p]
                 state["t"] = time.perf_counter()
-                acc[{0: 1, 1: 1, 2: 3, 3: 4}[rnd]] += state["t"] - t0
+                acc[{0: 1, 1: 1, 2: 3, 3: 4, 4: 1}[rnd]] += state["t"] - t0
                 return 0
             except Exception:                                       # noqa: BLE001 -- must not unwind through C
                 import traceback
@@ -332,6 +355,9 @@ class ShardedSim:
                         s.join_ingest(j_in[k][0])
             c1 = [s.phase1() for s in sh]
             t1 = time.perf_counter()
+            if sh[0].replicated:                                                    # round 4: all-gather of the queue masks
+                full = lambda s: [0 if p == s.index else s.n_local for p in range(self.n_shards)]
+                f.exchange(sh, (5, 6), [[full(s), full(s)] for s in sh])
             r_in = f.exchange(sh, (0,), [[c[0]] for c in c1])                       # round 1
             t2 = time.perf_counter()
             c2 = [s.phase2(r_in[k][0]) for k, s in enumerate(sh)]

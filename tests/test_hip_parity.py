@@ -236,6 +236,14 @@ def test_sharded_join_pull_on_one_gpu(oracle_abi, hip_abi):
     b.close()
 
 
+@pytest.mark.parametrize("n,shards,loss,seed", [(4096, 4, 0, 1), (65536, 8, 20000, 3)])
+def test_replicated_masks_on_one_gpu(oracle_abi, hip_abi, monkeypatch, n, shards, loss, seed):
+    """SWIMSIM_SHARD_REPLICATED_MASKS=1 (off by default until timed): the direct probes between shards through
+    all-gathered queue masks -- no records for clean probers (remote_kernel) -- must give the same run."""
+    monkeypatch.setenv("SWIMSIM_SHARD_REPLICATED_MASKS", "1")
+    test_sharded_cluster_on_one_gpu(oracle_abi, hip_abi, n, shards, loss, seed)
+
+
 def test_one_process_per_shard_on_one_gpu():
     """Two processes, one shard each, both on GPU 0, torch.distributed (gloo, records staged through
     host memory because RCCL refuses two ranks on one device): the DistFabric host code with the real

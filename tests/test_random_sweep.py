@@ -2,6 +2,7 @@
 probe counts, loss rates, fault schedules (crashes and rejoins, with and without the join-time pull), both
 target schemes, 1-8 shards (also with the robust scheme, settling and the join-time pull), tiny inbox capacities -- every observable, every 10 ticks.  Seeded, so a failure reproduces; a longer run of the
 same generator (430 configurations) was clean when this was written."""
+import os
 import random
 
 import pytest
@@ -30,7 +31,12 @@ def test_random_configurations(oracle_abi, block):
                        targetScheme=scheme, inboxCap=rng.choice([0, 0, 1, 2]), gcTicks=gc,
                        joinPull=seed % 2)
         a = Sim.create(oracle_abi, sc)
-        b = Sim.create(emu, sc) if shards == 1 else ShardedSim(emu, sc, LocalFabric(shards))
+        rm = shards > 1 and rng.random() < 0.5       # replicated queue masks instead of probe records (read at create)
+        os.environ["SWIMSIM_SHARD_REPLICATED_MASKS"] = "1" if rm else "0"
+        try:
+            b = Sim.create(emu, sc) if shards == 1 else ShardedSim(emu, sc, LocalFabric(shards))
+        finally:
+            del os.environ["SWIMSIM_SHARD_REPLICATED_MASKS"]
         for _f in range(rng.randrange(0, max(1, n // 8) + 1)):
             m, t = rng.randrange(n), rng.randrange(1, 40)
             for s in (a, b):
@@ -39,7 +45,7 @@ def test_random_configurations(oracle_abi, block):
                 t2 = t + rng.randrange(1, 30)
                 for s in (a, b):
                     s.scheduleFault(t2, m, True)
-        what = (n, p, loss, scheme, shards, gc, seed)
+        what = (n, p, loss, scheme, shards, gc, rm, seed)
         for _t in range(rng.choice([3, 6, 10])):
             a.step(10); b.step(10)
             assert a.counters() == b.counters(), ("counters", what)

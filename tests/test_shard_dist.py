@@ -10,11 +10,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_world(world, args, port):
+def run_world(world, args, port, **extra_env):
     from tests import hostemu_binding, oracle_binding
     hostemu_binding.build()
     oracle_binding.build()
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1", **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py")] + [str(a) for a in args]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
@@ -35,3 +35,10 @@ def test_one_process_per_shard_gloo_with_settling():
 def test_one_process_per_shard_gloo_with_join_pull_and_settling():
     """join_pull (round 0: the hosts' entries travel to the joiners' owners ahead of the probes) + settling."""
     run_world(2, (192, 3, 20000, 8, 130, 3), 29615)
+
+
+def test_one_process_per_shard_gloo_with_replicated_masks():
+    """SWIMSIM_SHARD_REPLICATED_MASKS=1: the all-gather of queue masks (round 4) through swimsim_shard_step's callback,
+    with loss, settling and the join-time pull on top."""
+    run_world(4, (256, 3, 50000, 9, 60, 0), 29616, SWIMSIM_SHARD_REPLICATED_MASKS="1")
+    run_world(2, (192, 3, 20000, 8, 130, 3), 29617, SWIMSIM_SHARD_REPLICATED_MASKS="1")

@@ -143,3 +143,30 @@ def test_sharded_join_pull_with_churn(oracle_abi, emu_abi, shards, gc):
     c = b.counters()
     assert c["timers_fired"] > 0 and (not gc or c["settled"] > 20)
     b.close()
+
+
+@pytest.fixture
+def replicated_masks(monkeypatch):
+    """SWIMSIM_SHARD_REPLICATED_MASKS=1 (read at create): the direct probes between shards through all-gathered queue
+    masks, no records for clean probers."""
+    monkeypatch.setenv("SWIMSIM_SHARD_REPLICATED_MASKS", "1")
+
+
+@pytest.mark.parametrize("n,shards,p,loss,seed", [
+    (128, 2, 3, 0, 1), (256, 4, 3, 0, 2), (192, 3, 2, 50000, 3), (512, 8, 3, 200000, 4), (64, 2, 10, 300000, 5),
+])
+def test_replicated_masks_match_oracle(oracle_abi, emu_abi, replicated_masks, n, shards, p, loss, seed):
+    test_sharded_matches_oracle(oracle_abi, emu_abi, n, shards, p, loss, seed)
+
+
+def test_replicated_masks_saturated_queues(oracle_abi, emu_abi, replicated_masks):
+    test_sharded_saturated_queues(oracle_abi, emu_abi)
+
+
+def test_replicated_masks_with_tiny_mask_window(oracle_abi, replicated_masks):
+    test_sharded_with_tiny_mask_window(oracle_abi)
+
+
+def test_replicated_masks_with_settling_and_join_pull(oracle_abi, emu_abi, replicated_masks):
+    test_sharded_settling_with_churn(oracle_abi, emu_abi, 4, 20000)
+    test_sharded_join_pull_with_churn(oracle_abi, emu_abi, 3, True)
