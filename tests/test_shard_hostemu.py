@@ -79,8 +79,8 @@ def test_sharded_with_tiny_mask_window(oracle_abi):
     b.close()
 
 
-@pytest.mark.parametrize("shards,loss", [(2, 20000), (4, 0), (8, 50000)])
-def test_sharded_settling_with_churn(oracle_abi, emu_abi, shards, loss):
+@pytest.mark.parametrize("shards,loss,ticks", [(2, 20000, 420), (4, 0, 300), (8, 50000, 140)])
+def test_sharded_settling_with_churn(oracle_abi, emu_abi, shards, loss, ticks):
     """gc_ticks on a sharded cluster: a subject settles only when it is quiet on every shard, every shard commits
     the same base in the same tick (round 3), rows are reclaimed and reused per shard, members come back after
     their subject was removed -- every observable equals the (unsharded) oracle's after every block of ticks."""
@@ -98,9 +98,9 @@ def test_sharded_settling_with_churn(oracle_abi, emu_abi, shards, loss):
         workloads.apply_crashes(s, crashes)
         for (t, m, up) in faults:
             s.scheduleFault(t, m, up)
-    lockstep(a, b, 420, 7, observers=(0, 12, n - 1), members=(0, 12, n - 1))
+    lockstep(a, b, ticks, 7, observers=(0, 12, n - 1), members=(0, 12, n - 1))
     c = b.counters()
-    assert c["settled"] > 60 and c["timers_fired"] > 0
+    assert c["settled"] > (60 if ticks >= 420 else 10) and c["timers_fired"] > 0
     b.close()
 
 
@@ -168,5 +168,5 @@ def test_replicated_masks_with_tiny_mask_window(oracle_abi, replicated_masks):
 
 
 def test_replicated_masks_with_settling_and_join_pull(oracle_abi, emu_abi, replicated_masks):
-    test_sharded_settling_with_churn(oracle_abi, emu_abi, 4, 20000)
+    test_sharded_settling_with_churn(oracle_abi, emu_abi, 2, 20000, 210)
     test_sharded_join_pull_with_churn(oracle_abi, emu_abi, 3, True)
