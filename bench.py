@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--num-to-gossip", type=int, default=3, help="P = k (the reference's default config has 10)")
     ap.add_argument("--gc", action="store_true", help="settling on (gc_ticks = auto): view rows are reclaimed")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle replay (baseline + verification)")
+    ap.add_argument("--replicated-masks", action="store_true",
+                    help="multi-GPU: the direct probes between shards through all-gathered queue masks instead of records "
+                         "(DESIGN.md section 7; off by default until timed on hardware)")
     args = ap.parse_args()
 
     import torch
@@ -150,13 +153,16 @@ def main():
     if args.gc:
         sc.gcTicks = _abi.GC_AUTO
     exchange = "none (one shard)"
+    if args.replicated_masks:
+        os.environ["SWIMSIM_SHARD_REPLICATED_MASKS"] = "1"      # read by swimsim_create
     if world == 1:
         sim = Sim.create(_lib.load(), sc)
     else:
         from swim_amd.shard import DistFabric, ShardedSim
         fabric = DistFabric("cuda:%d" % local_rank, transport="host" if share_gpu else "auto")
         sim = ShardedSim(_lib.load(), sc, fabric, device="cuda:%d" % local_rank)
-        exchange = "torch.distributed p2p, transport=%s%s" % (fabric.transport, (" [" + fabric.note + "]") if fabric.note else "")
+        exchange = "torch.distributed p2p, transport=%s%s%s" % (fabric.transport, (" [" + fabric.note + "]") if fabric.note else "",
+                                                                 ", replicated queue masks" if args.replicated_masks else "")
     workloads.apply_crashes(sim, crashes)
 
     def barrier():

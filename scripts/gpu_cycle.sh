@@ -1,7 +1,7 @@
 #!/bin/bash
 # one GPU iteration: parity tests, bench lines, kernel-trace stats, PMC passes.
-# usage: gpu_cycle.sh <tag> [what...]   what = tests bench extra prof pmc (default: all)   -> gpurun_out/<tag>_*
-TAG=$1; shift; WHAT="${*:-tests bench extra prof pmc}"
+# usage: gpu_cycle.sh <tag> [what...]   what = tests bench extra shard prof pmc (default: all)   -> gpurun_out/<tag>_*
+TAG=$1; shift; WHAT="${*:-tests bench extra shard prof pmc}"
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out; mkdir -p $O
 cd $R
 has() { [[ " $WHAT " == *" $1 "* ]]; }
@@ -20,6 +20,10 @@ if has extra; then
   b saturated_p10 --steps 100 --warmup 20 --num-to-gossip 10 --no-cpu-baseline
   b loss1pct_gc --steps 200 --warmup 50 --loss-ppm 10000 --gc --no-cpu-baseline
   b loss30pct_16k --steps 200 --warmup 20 --members 16384 --loss-ppm 300000 --no-cpu-baseline
+fi
+if has shard; then
+  # one population as 1 / 2 / 4 / 8 handles on this GPU, record path against replicated queue masks
+  timeout 600 python scripts/shard_time.py 1 2 4 8 2>&1 | tee $O/${TAG}_shard_overhead_one_gpu.txt
 fi
 cd /tmp && export TMPDIR=/tmp
 if has prof; then

@@ -309,6 +309,9 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     const double l = c.loss_ppm / 1e6, pf = 1.0 - (1.0 - l) * (1.0 - l);
     const double lam = 2.0 * c.probes_per_tick + 4.0 * c.probes_per_tick * c.indirect_k * pf;
     if (lam > c.inbox_cap) d.ovf_cap = (uint32_t)std::min<double>(3.0e8, std::max<double>(d.ovf_cap, 2.0 * lam * N + 65536.0));
+    // heavy fan-in (P = K = 10 under 20 % loss: ~160 deliveries per member-tick, twice that once a tenth of the members is
+    // down and every probe of them escalates): room for a quarter of the expected deliveries beyond the inboxes
+    d.ovf_cap = (uint32_t)std::min<double>(3.0e8, std::max<double>(d.ovf_cap, 0.25 * lam * N));
   }
   d.ord_cap = 0; d.r_cap = d.p_cap = d.x_cap = 0;
   CK(dev_alloc(h, &d.minfo, NT, 0));
@@ -365,7 +368,12 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     // with headroom; overruns are loud (SWIMSIM_ERR_CAPACITY), never silent drops
     const double per_peer = (double)N * std::max(1u, d.P) / d.n_shards;
     const double lossf = 1.0 + 8.0 * c.loss_ppm / 1e6 * std::max(1u, d.K);
-    d.ord_cap = (uint32_t)std::min<double>(BLOCK * 64.0, BLOCK * (2.0 * std::max(1u, d.P) * lossf + 4.0));
+    // orders a probe block leaves: one per direct probe of a remote target, and up to four hops per proxy of every
+    // direct probe that fails (P x K x 4 x P[fail]); the old bound of 64 per member overflowed at P = K = 10 with 20 %
+    // loss (found by the sharded soak: a loud capacity error)
+    const double l_ = c.loss_ppm / 1e6, pfail = 1.0 - (1.0 - l_) * (1.0 - l_);
+    const double per_member = std::max(1u, d.P) * (1.0 + 4.0 * std::max(1u, d.K) * pfail);
+    d.ord_cap = (uint32_t)std::min<double>(BLOCK * 2048.0, BLOCK * (1.5 * per_member + 6.0 * std::sqrt(per_member) + 4.0));
     d.r_cap = (uint32_t)(per_peer * 1.5 * lossf) + 4096;
     d.p_cap = (uint32_t)(per_peer * 3.0 * lossf) + 4096;
     d.x_cap = d.p_cap;                           // a tick after a burst of rumour ids sends everything explicitly
