@@ -89,7 +89,7 @@ foreign import ccall unsafe "swimsim_shard_buffers" c_shard_buffers :: Ptr Swims
 foreign import ccall unsafe "swimsim_shard_settle_buffers" c_shard_settle_buffers :: Ptr SwimsimT -> Ptr (Ptr ()) -> Ptr (Ptr ()) -> Ptr Word32 -> IO CInt
 -- join_pull on a sharded cluster: the kind-4 buffers of exchange round 0 (16-byte records {joiner, subject, entry, -})
 foreign import ccall unsafe "swimsim_shard_join_buffers" c_shard_join_buffers :: Ptr SwimsimT -> Ptr (Ptr ()) -> Ptr (Ptr ()) -> Ptr Word32 -> IO CInt
--- replicated queue masks (SWIMSIM_SHARD_REPLICATED_MASKS=1): the two all-gathered tables of exchange round 4
+-- replicated queue masks (SWIMSIM_SHARD_REPLICATED_MASKS=1): the two tables all-gathered with exchange round 1
 foreign import ccall unsafe "swimsim_shard_gather_buffers" c_shard_gather_buffers :: Ptr SwimsimT -> Ptr (Ptr ()) -> Ptr (Ptr ()) -> Ptr Word32 -> IO CInt
 foreign import ccall safe   "swimsim_shard_phase1"  c_shard_phase1  :: Ptr SwimsimT -> Ptr Word32 -> IO CInt
 foreign import ccall safe   "swimsim_shard_phase2"  c_shard_phase2  :: Ptr SwimsimT -> Ptr Word32 -> Ptr Word32 -> IO CInt
@@ -278,9 +278,9 @@ decodeEnvelope bytes = BSU.unsafeUseAsCStringLen bytes $ \(src, len) ->
 -- 3 * nShards counts that arrived.  With settling on (gcTicks) every tick ends with a round 3 over the buffers of
 -- swimsim_shard_settle_buffers, and with joinPull a tick in which members come up starts with a round 0 over the
 -- buffers of swimsim_shard_join_buffers: the counts of those rounds sit at indices [0 .. nShards).  Every shard of
--- the cluster must make the same call.  With SWIMSIM_SHARD_REPLICATED_MASKS=1 in the environment a round 4 follows
--- phase 1: an all-gather of every shard's slice of the two tables of swimsim_shard_gather_buffers (counts of the
--- 8-byte kind at [0 .. nShards), of the 1-byte kind at [nShards .. 2 nShards)).
+-- the cluster must make the same call.  With SWIMSIM_SHARD_REPLICATED_MASKS=1 in the environment round 1 also
+-- all-gathers every shard's slice of the two tables of swimsim_shard_gather_buffers (counts of the 8-byte kind at
+-- [nShards .. 2 nShards), of the 1-byte kind at [2 nShards .. 3 nShards)).
 stepShard :: Sim -> Word32 -> Int -> (Int -> [Word32] -> IO [Word32]) -> IO ()
 stepShard s nticks nShards exchange = withSim s $ \h -> do
   cb <- mkExchange $ \_ rnd pout pin -> do

@@ -375,7 +375,8 @@ int swimsim_shard_phase0(swimsim_t* h, uint32_t* counts /*[n_shards] out*/, int*
  * shard's slice of two tables -- 8 bytes (kind 5) and 1 byte (kind 6) per member, n_local records each -- is
  * all-gathered: send[k] is this shard's slice (the SAME bytes go to every peer), recv[k] the whole table, peer p's
  * slice at recv[k] + p * n_local * record size.  The direct probes between shards then need no records (DESIGN.md
- * section 7).  swimsim_shard_step calls xchg(ctx, 4, ..) for it, kind 5 counts at [p], kind 6 at [n_shards + p].
+ * section 7).  It travels WITH round 1: in that mode swimsim_shard_step's xchg(ctx, 1, ..) finds the kind-5 counts at
+ * [n_shards + p] and the kind-6 counts at [2 n_shards + p] (n_local for every peer) next to the kind-0 counts at [p].
  * n_local = 0: the mode is off, there is nothing to gather. */
 #define SWIMSIM_GREC5_BYTES 8u
 #define SWIMSIM_GREC6_BYTES 1u

@@ -931,11 +931,11 @@ int swimsim_shard_step(swimsim_t* h, uint32_t nticks, swimsim_exchange_fn xchg, 
     }
     rc = swimsim_shard_phase1(h, out.data());
     if (rc) return rc;
-    if (h->d.rm) {                                  // the all-gather of queue masks and queue bytes: N records to every peer
-      std::vector<uint32_t> go(3 * MAX_SHARDS, 0u), gi(3 * MAX_SHARDS, 0u);
-      for (uint32_t p = 0; p < G; ++p) if (p != h->d.shard) { go[p] = h->d.N; go[G + p] = h->d.N; }
-      if (xchg(ctx, 4, go.data(), gi.data())) return set_err(h, SWIMSIM_ERR_STATE, "shard_step: the exchange callback failed in round 4");
-    }
+    if (h->d.rm)                                    // round 1 also all-gathers the queue masks (kind 5) and queue bytes
+      for (uint32_t p = 0; p < G; ++p) {            // (kind 6): N records to every peer, counted at [G + p] and [2G + p]
+        out[G + p] = p == h->d.shard ? 0u : h->d.N;
+        out[2 * G + p] = p == h->d.shard ? 0u : h->d.N;
+      }
     std::fill(in.begin(), in.end(), 0u);
     if (xchg(ctx, 1, out.data(), in.data())) return set_err(h, SWIMSIM_ERR_STATE, "shard_step: the exchange callback failed in round 1");
     rc = swimsim_shard_phase2(h, in.data(), out.data());

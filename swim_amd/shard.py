@@ -226,16 +226,17 @@ class DistFabric:
         sh, nk = shards[0], len(kinds)
         host = self.transport == "host"
         grp = self._cpu_group() if (host and self.on_gpu) else None
-        gather = kinds == (5, 6)                   # the all-gather of the replicated tables: every count is n_local
-        if gather:
-            recv = [[0 if p == me else sh.n_local for p in range(G)] for _ in kinds]
-        else:
-            flat = [counts[0][j][p] for p in range(G) for j in range(nk)]      # peer-major for all_to_all
+        # kinds 5 / 6 = the all-gather of the replicated tables: every count is n_local, nothing to ask the peers
+        vk = [j for j, k in enumerate(kinds) if k not in (5, 6)]
+        recv = [[0 if p == me else sh.n_local for p in range(G)] for _ in kinds]
+        if vk:
+            flat = [counts[0][j][p] for p in range(G) for j in vk]             # peer-major for all_to_all
             cs = torch.tensor(flat, dtype=torch.int64, device="cpu" if host else self.device)
             cr = torch.empty_like(cs)
             dist.all_to_all_single(cr, cs, group=grp)
             got = [int(v) for v in cr.tolist()]
-            recv = [[got[p * nk + j] for p in range(G)] for j in range(nk)]
+            for x, j in enumerate(vk):
+                recv[j] = [got[p * len(vk) + x] for p in range(G)]
         ops, landing = [], []
         stage = self._staging(sh, host)
         staged = set()
@@ -246,7 +247,7 @@ class DistFabric:
                 n_out, n_in = counts[0][j][p], recv[j][p]
                 if n_out:
                     nb = n_out * REC_BYTES[kind]
-                    row = 0 if gather else p           # the same slice goes to every peer: staged once
+                    row = 0 if kind in (5, 6) else p   # the same slice goes to every peer: staged once
                     out = stage[0][kind][row, :nb]
                     if (kind, row) not in staged:
                         out.copy_(sh.send[kind][row, :nb])
@@ -316,17 +317,17 @@ class ShardedSim:
         def xchg(_ctx, rnd, c_out, c_in):
             try:
                 t0 = time.perf_counter()
-                acc[{0: 0, 1: 0, 2: 2, 3: 4, 4: 0}[rnd]] += t0 - state["t"]  # the phase that just ended
-                kinds = {0: (4,), 1: (0,), 2: (1, 2), 3: (3,), 4: (5, 6)}[rnd]
-                # rounds 0 and 3: one kind, its counts at [p]; round 4: kinds 5 and 6 at [p] and [G + p]
-                at = (lambda k: 0) if rnd in (0, 3) else ((lambda k: (k - 5) * G) if rnd == 4 else (lambda k: k * G))
+                acc[{0: 0, 1: 0, 2: 2, 3: 4}[rnd]] += t0 - state["t"]  # the phase that just ended
+                kinds = {0: (4,), 1: (0, 5, 6) if sh.replicated else (0,), 2: (1, 2), 3: (3,)}[rnd]
+                # rounds 0 and 3: one kind, its counts at [p]; round 1 with replicated masks: kinds 5 and 6 at [G + p], [2G + p]
+                at = (lambda k: 0) if rnd in (0, 3) else (lambda k: (k - 4) * G if k >= 5 else k * G)
                 counts = [[[c_out[at(k) + p] for p in range(G)] for k in kinds]]
                 got = f.exchange([sh], kinds, counts)[0]
                 for j, k in enumerate(kinds):
                     for p in range(G):
                         c_in[at(k) + p] = got[j][p]
                 state["t"] = time.perf_counter()
-                acc[{0: 1, 1: 1, 2: 3, 3: 4, 4: 1}[rnd]] += state["t"] - t0
+                acc[{0: 1, 1: 1, 2: 3, 3: 4}[rnd]] += state["t"] - t0
                 return 0
             except Exception:                                       # noqa: BLE001 -- must not unwind through C
                 import traceback
@@ -355,10 +356,11 @@ class ShardedSim:
                         s.join_ingest(j_in[k][0])
             c1 = [s.phase1() for s in sh]
             t1 = time.perf_counter()
-            if sh[0].replicated:                                                    # round 4: all-gather of the queue masks
+            if sh[0].replicated:                                                    # round 1 + the all-gather of the queue masks
                 full = lambda s: [0 if p == s.index else s.n_local for p in range(self.n_shards)]
-                f.exchange(sh, (5, 6), [[full(s), full(s)] for s in sh])
-            r_in = f.exchange(sh, (0,), [[c[0]] for c in c1])                       # round 1
+                r_in = f.exchange(sh, (0, 5, 6), [[c[0], full(s), full(s)] for c, s in zip(c1, sh)])
+            else:
+                r_in = f.exchange(sh, (0,), [[c[0]] for c in c1])                   # round 1
             t2 = time.perf_counter()
             c2 = [s.phase2(r_in[k][0]) for k, s in enumerate(sh)]
             t3 = time.perf_counter()
