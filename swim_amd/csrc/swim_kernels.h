@@ -233,6 +233,10 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
           n_pings += valid[p] ? 1u : 0u;
         }
       }
+      // replicated masks: clean = no target of this period's rotation was skipped
+      clean = s.rm && use_mask && !(mi & MI_OOW);
+#pragma unroll
+      for (int p = 0; p < PMAX; ++p) if ((uint32_t)p < np && off.o[p] && !valid[p]) clean = false;
     }
     SECT(32);                                       // target selection
     uint32_t nfail = 0, nack = 0;
@@ -1241,7 +1245,18 @@ __device__ inline void rm_deliver(const DevState& s, uint32_t t, bool use_mask, 
   }
 }
 
-__global__ __launch_bounds__(BLOCK) void remote_kernel(DevState s, uint32_t t, uint32_t tk) {
+// probe p of member i in a clean period: its first draw (random scheme) or its rotation target (robust scheme; NONE32:
+// the rotation has no target at this index)
+__device__ inline uint32_t clean_target(const DevState& s, uint32_t mk, uint32_t i, uint32_t p, const Offsets& off) {
+  if (s.scheme == 1u) {
+    if (!off.o[p]) return NONE32;
+    const uint32_t c = i + off.o[p];
+    return c >= s.NT ? c - s.NT : c;
+  }
+  return __umulhi(hash_mk(mk, ((uint32_t)P_SELECT << 24) | (p << 8), 0), s.NT);
+}
+
+__global__ __launch_bounds__(BLOCK) void remote_kernel(DevState s, uint32_t t, uint32_t tk, Offsets off) {
   __shared__ BlockCounters sh;
   __shared__ uint2 xls[MAX_SHARDS * DICT_ENTRIES];
   ctr_init(&sh);
@@ -1261,8 +1276,8 @@ __global__ __launch_bounds__(BLOCK) void remote_kernel(DevState s, uint32_t t, u
         const uint32_t mk = mix32(tk ^ i);
         unsigned long long acc = 0;
         for (uint32_t p = 0; p < s.P; ++p) {
-          const uint32_t c = __umulhi(hash_mk(mk, ((uint32_t)P_SELECT << 24) | (p << 8), 0), s.NT);
-          if (is_local(s, c) || !(s.mb[c] & MB_UP)) continue;
+          const uint32_t c = clean_target(s, mk, i, p, off);
+          if (c == NONE32 || is_local(s, c) || !(s.mb[c] & MB_UP)) continue;
           if (lost(s, tk, P_L_PING, i, c, p) || lost(s, tk, P_L_ACK, c, i, p)) continue;
           const uint32_t qc = s.q_all[c], pj = qc & Q_PBN;
           if (!pj) continue;
@@ -1279,8 +1294,8 @@ __global__ __launch_bounds__(BLOCK) void remote_kernel(DevState s, uint32_t t, u
         if (qg & Q_EXC) continue;
         const uint32_t mk = mix32(tk ^ g);
         for (uint32_t p = 0; p < s.P; ++p) {
-          const uint32_t c = __umulhi(hash_mk(mk, ((uint32_t)P_SELECT << 24) | (p << 8), 0), s.NT);
-          if (!is_local(s, c)) continue;
+          const uint32_t c = clean_target(s, mk, g, p, off);
+          if (c == NONE32 || !is_local(s, c)) continue;
           const uint32_t mc = s.minfo[c];
           if (!mi_up(mc) || lost(s, tk, P_L_PING, g, c, p)) continue;
           if (qg & Q_PBN) rm_deliver(s, t, use_mask, H, stale, xls + owner_of(s, g) * DICT_ENTRIES, s.mask_all[g], c - s.lo, nullptr);

@@ -851,7 +851,7 @@ int swimsim_shard_phase2(swimsim_t* h, const uint32_t* r_counts_in, uint32_t* co
   HIPCHK(h, hipSetDevice(h->device));
   const PeerCounts rc_in = peer_counts(h, r_counts_in);
   hipLaunchKernelGGL(xlat_kernel, dim3(h->d.n_shards), dim3(DICT_ENTRIES), 0, h->stream, h->d, rc_in);
-  if (h->d.rm) hipLaunchKernelGGL(remote_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, (uint32_t)h->tick, tick_key(h->cfg.seed, (uint32_t)h->tick));
+  if (h->d.rm) hipLaunchKernelGGL(remote_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, (uint32_t)h->tick, tick_key(h->cfg.seed, (uint32_t)h->tick), robust_offsets(h, (uint32_t)h->tick));
   hipLaunchKernelGGL(serve_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, (uint32_t)h->tick, rc_in);
   rc = finish_phase(h, counts);
   if (rc) return rc;

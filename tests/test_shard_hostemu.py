@@ -170,3 +170,9 @@ def test_replicated_masks_with_tiny_mask_window(oracle_abi, replicated_masks):
 def test_replicated_masks_with_settling_and_join_pull(oracle_abi, emu_abi, replicated_masks):
     test_sharded_settling_with_churn(oracle_abi, emu_abi, 2, 20000, 210)
     test_sharded_join_pull_with_churn(oracle_abi, emu_abi, 3, True)
+
+
+def test_replicated_masks_with_the_robust_scheme(oracle_abi, emu_abi, replicated_masks):
+    """Clean = no target of the period's rotation skipped; both ends compute the rotation instead of the first draws."""
+    test_sharded_robust_target_scheme(oracle_abi, emu_abi, 256, 4, 3, 0, 1)
+    test_sharded_robust_target_scheme(oracle_abi, emu_abi, 300, 3, 2, 100000, 2)
