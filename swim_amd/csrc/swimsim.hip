@@ -310,8 +310,8 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     const double lam = 2.0 * c.probes_per_tick + 4.0 * c.probes_per_tick * c.indirect_k * pf;
     if (lam > c.inbox_cap) d.ovf_cap = (uint32_t)std::min<double>(3.0e8, std::max<double>(d.ovf_cap, 2.0 * lam * N + 65536.0));
     // heavy fan-in (P = K = 10 under 20 % loss: ~160 deliveries per member-tick, twice that once a tenth of the members is
-    // down and every probe of them escalates): room for a quarter of the expected deliveries beyond the inboxes
-    d.ovf_cap = (uint32_t)std::min<double>(3.0e8, std::max<double>(d.ovf_cap, 0.25 * lam * N));
+    // down and every probe of them escalates): room for half of the expected deliveries beyond the inboxes
+    d.ovf_cap = (uint32_t)std::min<double>(3.0e8, std::max<double>(d.ovf_cap, 0.5 * lam * N + 65536.0));
   }
   d.ord_cap = 0; d.r_cap = d.p_cap = d.x_cap = 0;
   CK(dev_alloc(h, &d.minfo, NT, 0));

@@ -79,7 +79,7 @@ def test_sharded_with_tiny_mask_window(oracle_abi):
     b.close()
 
 
-@pytest.mark.parametrize("shards,loss,ticks", [(2, 20000, 420), (4, 0, 300), (8, 50000, 140)])
+@pytest.mark.parametrize("shards,loss,ticks", [(2, 20000, 420), (4, 0, 200), (8, 50000, 140)])
 def test_sharded_settling_with_churn(oracle_abi, emu_abi, shards, loss, ticks):
     """gc_ticks on a sharded cluster: a subject settles only when it is quiet on every shard, every shard commits
     the same base in the same tick (round 3), rows are reclaimed and reused per shard, members come back after
@@ -120,7 +120,7 @@ def test_sharded_robust_target_scheme(oracle_abi, emu_abi, n, shards, p, loss, s
     b.close()
 
 
-@pytest.mark.parametrize("shards,gc", [(2, False), (4, True), (3, True)])
+@pytest.mark.parametrize("shards,gc", [(2, False), (4, True)])
 def test_sharded_join_pull_with_churn(oracle_abi, emu_abi, shards, gc):
     """join_pull on a sharded cluster: the join host of a member that comes up usually lives on another shard -- its
     owner sends what the host knows ahead of the tick's probes (round 0).  Several joins in one tick, hosts skipped
@@ -152,9 +152,7 @@ def replicated_masks(monkeypatch):
     monkeypatch.setenv("SWIMSIM_SHARD_REPLICATED_MASKS", "1")
 
 
-@pytest.mark.parametrize("n,shards,p,loss,seed", [
-    (128, 2, 3, 0, 1), (256, 4, 3, 0, 2), (192, 3, 2, 50000, 3), (512, 8, 3, 200000, 4), (64, 2, 10, 300000, 5),
-])
+@pytest.mark.parametrize("n,shards,p,loss,seed", [(256, 4, 3, 0, 2), (512, 8, 3, 200000, 4), (64, 2, 10, 300000, 5)])
 def test_replicated_masks_match_oracle(oracle_abi, emu_abi, replicated_masks, n, shards, p, loss, seed):
     test_sharded_matches_oracle(oracle_abi, emu_abi, n, shards, p, loss, seed)
 
