@@ -425,7 +425,8 @@ __device__ inline uint32_t new_rid(const DevState& s) {
 // refutation, join); everyone else learns the id from the piggyback entry that carries the rumour.
 // One way per (incarnation, state) combination, newer combinations evict older ones.  Duplicate ids
 // for one rumour are harmless (an id is only a filter key), so every failure path just takes a fresh id.
-__device__ inline uint32_t find_rid(const DevState& s, uint32_t slot, uint32_t key) {
+__device__ inline uint32_t find_rid(const DevState& s, uint32_t slot, uint32_t key, uint32_t* number = nullptr) {
+  // *number: the id's allocation number modulo 2^(RID_BITS + 15) (its age relative to a head: young_rid)
   const uint32_t way = ((key >> 2) * 3u + (key & 3u)) & (uint32_t)(RT_WAYS - 1);
   unsigned long long* p = s.rtab + (size_t)slot * RT_WAYS + way;
   const unsigned long long claim = (unsigned long long)(key + 1u) << 32;
@@ -443,7 +444,7 @@ __device__ inline uint32_t find_rid(const DevState& s, uint32_t slot, uint32_t k
         const uint32_t rid = (uint32_t)e & RID_MASK;
         const uint32_t born = ((((uint32_t)e >> RT_GEN_SHIFT) & RT_GEN_MASK) << RID_BITS) | rid;
         const uint2 r = s.rum[rid];
-        if (r.x == slot && r.y == key && ((s.g[G_NRUM] - born) & RT_SPAN_MASK) < RID_FAR) return rid;
+        if (r.x == slot && r.y == key && ((s.g[G_NRUM] - born) & RT_SPAN_MASK) < RID_FAR) { if (number) *number = born; return rid; }
       } else {
         e = atomicCAS(p, 0ull, 0ull);               // being published by another lane: re-read at device scope
         continue;
@@ -454,12 +455,14 @@ __device__ inline uint32_t find_rid(const DevState& s, uint32_t slot, uint32_t k
       const uint32_t c = new_rid(s), rid = c & RID_MASK;
       s.rum[rid] = make_uint2(slot, key);           // read by other members from the next launch on
       atomicExch(p, claim | RT_READY | ((unsigned long long)((c >> RID_BITS) & RT_GEN_MASK) << RT_GEN_SHIFT) | rid);
+      if (number) *number = c & RT_SPAN_MASK;
       return rid;
     }
     e = seen;
   }
-  const uint32_t rid = new_rid(s) & RID_MASK;
+  const uint32_t c2 = new_rid(s), rid = c2 & RID_MASK;
   s.rum[rid] = make_uint2(slot, key);
+  if (number) *number = c2 & RT_SPAN_MASK;
   return rid;
 }
 
@@ -468,11 +471,11 @@ __device__ inline uint32_t find_rid(const DevState& s, uint32_t slot, uint32_t k
 // must not lie a whole turn of the id space minus the ring ahead of that head, or it reads as an OLD id inside the
 // ring (found by a soak of the 10-bit build: 3 000 members, 20 % loss, two shards -- deliveries filtered as "known";
 // the product's 16-bit ids reach that point at ~65 000 new rumours per shard and tick: heavy loss at a million
-// members).  Past that point entries travel without an id (exact: every filter is skipped).  Called AFTER the id was
-// obtained: the counter read here is beyond it.
-__device__ inline uint32_t young_rid(const DevState& s, uint32_t rid, uint32_t H) {
-  const uint32_t now = atomicOr(&s.g[G_NRUM], 0u);
-  return (now - H <= RID_MASK + 1u - KW_BITS) ? rid : RID_PARKED;
+// members).  Past that point entries travel without an id (exact: every filter is skipped).  `number` = the id's
+// allocation number as find_rid reports it.
+__device__ inline uint32_t young_rid(uint32_t rid, uint32_t number, uint32_t H) {
+  const uint32_t ahead = (number - H) & RT_SPAN_MASK;           // an id older than the head reads as a huge distance
+  return (ahead <= RID_MASK + 1u - KW_BITS || ahead > RT_SPAN_MASK / 2u) ? rid : RID_PARKED;
 }
 
 // a rumour id that fell out of the (wide) known-ring window is replaced by RID_PARKED ("no id") at the next rewrite of
@@ -1209,7 +1212,11 @@ __global__ void xlat_kernel(DevState s, PeerCounts r_counts) {
           ((s.g[G_NRUM] - prid) & RID_MASK) < RID_FAR)
         out = prev;
       else
-        out = make_uint2(pe_lo(slot, young_rid(s, find_rid(s, slot, e.y), s.g[G_HEAD])), e.y);
+      {
+        uint32_t num = 0;
+        const uint32_t nrid = find_rid(s, slot, e.y, &num);
+        out = make_uint2(pe_lo(slot, young_rid(nrid, num, s.g[G_HEAD])), e.y);
+      }
     }
   }
   s.xl[(size_t)peer * DICT_ENTRIES + p] = out;
@@ -1348,7 +1355,8 @@ __global__ __launch_bounds__(BLOCK) void ingest_kernel(DevState s, uint32_t t, P
       for (uint32_t e = 0; e < ne; ++e) {
         const uint32_t subject = rec[2 + 2 * e], key = rec[3 + 2 * e];
         const uint32_t slot = get_slot(s, subject);
-        const uint32_t rid = young_rid(s, find_rid(s, slot, key), H);
+        uint32_t num = 0;
+        const uint32_t rid0 = find_rid(s, slot, key, &num), rid = young_rid(rid0, num, H);
         if (use_mask && rid_in_ring(rid, H)) bits |= rid_bit(rid);     // an id of an earlier tick
         else { fl[2 * nf] = pe_lo(slot, rid); fl[2 * nf + 1] = pe_hi(key, 1u); nf++; }
       }
