@@ -290,7 +290,8 @@ int swimsim_counters(swimsim_t* h, uint64_t* out, size_t n);
 /* Occupancy of the bounded tables (what SWIMSIM_ERR_CAPACITY guards), for long runs:
  * out[0] = view rows ever handed out (high-water mark; bounded under settling), out[1] = subjects that hold a
  * row now (max_subjects bounds it), out[2] = reclaimed rows waiting for reuse, out[3] = rumour ids handed out
- * so far (the id counter wraps, SWIM_RID_BITS), out[4] = view rows allocated.  n >= 5. */
+ * so far (the id counter wraps, SWIM_RID_BITS), out[4] = view rows allocated; with n >= 7 also out[5] = entries in the
+ * fuller of the two inbox overflow lists, out[6] = their capacity.  n >= 5. */
 int swimsim_table_stats(swimsim_t* h, uint64_t* out, size_t n);
 
 /* ---- unit-level hooks (what test/Spec.hs exercises directly) --------------- */

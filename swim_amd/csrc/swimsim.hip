@@ -665,6 +665,7 @@ int swimsim_table_stats(swimsim_t* h, uint64_t* out, size_t n) {
   uint32_t g[G_WORDS];
   HIPCHK(h, hipMemcpy(g, h->d.g, sizeof g, hipMemcpyDeviceToHost));
   out[0] = g[G_NSLOTS]; out[1] = g[G_NLIVE]; out[2] = g[G_NFREE]; out[3] = g[G_NRUM]; out[4] = h->d.R_phys;
+  if (n >= 7) { out[5] = std::max(g[G_OVF0], g[G_OVF1]); out[6] = h->d.ovf_cap; }   // inbox overflow list: entries in the fuller of the two, room
   return SWIMSIM_OK;
 }
 

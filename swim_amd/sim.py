@@ -181,10 +181,11 @@ class Sim:
 
     def tableStats(self) -> dict:
         """Occupancy of the bounded tables (product library only): view rows ever handed out / live subjects /
-        reclaimed rows waiting / rumour ids handed out / view rows allocated."""
-        buf = (C.c_uint64 * 5)()
-        self._check(self._abi.table_stats(self._h, buf, 5))
-        return dict(zip(("rows_high_water", "subjects_live", "rows_free", "rumour_ids", "rows_allocated"), buf))
+        reclaimed rows waiting / rumour ids handed out / view rows allocated / inbox overflow entries and room."""
+        buf = (C.c_uint64 * 7)()
+        self._check(self._abi.table_stats(self._h, buf, 7))
+        return dict(zip(("rows_high_water", "subjects_live", "rows_free", "rumour_ids", "rows_allocated", "inbox_overflow",
+                         "inbox_overflow_room"), buf))
 
     # -- measurement (product library only) -----------------------------------------
     def kernelTimingEnable(self, enable=True):
