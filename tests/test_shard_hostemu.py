@@ -174,3 +174,28 @@ def test_replicated_masks_with_the_robust_scheme(oracle_abi, emu_abi, replicated
     """Clean = no target of the period's rotation skipped; both ends compute the rotation instead of the first draws."""
     test_sharded_robust_target_scheme(oracle_abi, emu_abi, 256, 4, 3, 0, 1)
     test_sharded_robust_target_scheme(oracle_abi, emu_abi, 300, 3, 2, 100000, 2)
+
+
+def test_shard_phases_are_refused_out_of_order(emu_abi):
+    """The sharded entry points are a small state machine (phase0? -> phase1 -> phase2 -> phase3 [-> settle]); anything
+    out of order is SWIMSIM_ERR_STATE with a message, never a silent step."""
+    import ctypes as C
+    from swim_amd import _abi
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=128, seed=1, gcTicks=_abi.GC_AUTO, suspicionTicks=5, retransmitMult=1)
+    s = Sim.create(emu_abi, sc, shard_index=0, n_shards=2)
+    a, h = emu_abi, s._h
+    c3, c1 = (C.c_uint32 * 6)(), (C.c_uint32 * 2)()
+    assert a.step(h, 1) == _abi.ERR_STATE                                   # a shard is not stepped alone
+    assert a.shard_phase2(h, c1, c3) == _abi.ERR_STATE                      # before phase 1
+    assert a.shard_settle_commit(h, c1) == _abi.ERR_STATE                   # no tick to end yet
+    assert a.shard_phase1(h, c3) == _abi.OK
+    assert a.shard_phase1(h, c3) == _abi.ERR_STATE
+    assert b"order" in a.last_error(h)
+    assert a.shard_phase2(h, c1, c3) == _abi.OK and a.shard_phase3(h, c1, c1) == _abi.OK
+    assert a.shard_phase1(h, c3) == _abi.ERR_STATE                          # settling: the tick ends with round 3
+    assert a.shard_settle_counts(h, c1) == _abi.OK and a.shard_settle_commit(h, c1) == _abi.OK
+    assert a.shard_phase1(h, c3) == _abi.OK
+    s.close()
+    plain = Sim.create(emu_abi, SimConfig(cfg=Config(numToGossip=3), nMembers=64, seed=1))
+    assert emu_abi.shard_phase1(plain._h, c3) == _abi.ERR_STATE             # not a sharded handle
+    plain.close()
