@@ -393,7 +393,9 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     const char* rm_env = std::getenv("SWIMSIM_SHARD_REPLICATED_MASKS");
     d.rm = (rm_env && rm_env[0] == '1') ? 1u : 0u;
     d.fl_dyn_base = (uint32_t)std::min<size_t>((size_t)d.n_shards * ((size_t)d.x_cap + d.p_cap + d.r_cap), (size_t)1 << 29);
-    d.fl_dyn_cap = d.rm ? std::max<uint32_t>(4096u, N / 4) : 0u;
+    // foreign lines of remote_kernel: normally a handful per tick (a rumour's first tick abroad), but in a tick without
+    // masks HERE every payload that arrives becomes one: a Ping and an Ack per probe
+    d.fl_dyn_cap = d.rm ? 2u * N * std::max(1u, d.P) + 4096u : 0u;
     CK(dev_alloc(h, &d.fl, ((size_t)d.n_shards * ((size_t)d.x_cap + d.p_cap + d.r_cap) + d.fl_dyn_cap) * 4, 0));
     if (d.rm) {
       CK(dev_alloc(h, &d.mask_all, (size_t)NT, 0));
