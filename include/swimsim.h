@@ -372,6 +372,8 @@ int swimsim_shard_settle_commit(swimsim_t* h, const uint32_t* counts_in /*[n_sha
  * continues the tick.  A no-op when join_pull is off or the tick has no joins; swimsim_shard_step does all of it
  * and calls xchg(ctx, 0, ..) with the kind-4 counts at index [p]. */
 int swimsim_shard_phase0(swimsim_t* h, uint32_t* counts /*[n_shards] out*/, int* round_needed);
+int swimsim_shard_join_buffers(swimsim_t* h, void** send, void** recv, uint32_t* cap /* records per peer segment */);
+int swimsim_shard_join_ingest(swimsim_t* h, const uint32_t* counts_in /*[n_shards]*/);
 /* Replicated queue masks (environment SWIMSIM_SHARD_REPLICATED_MASKS=1 at create; off by default): after phase1 every
  * shard's slice of two tables -- 8 bytes (kind 5) and 1 byte (kind 6) per member, n_local records each -- is
  * all-gathered: send[k] is this shard's slice (the SAME bytes go to every peer), recv[k] the whole table, peer p's
@@ -382,8 +384,6 @@ int swimsim_shard_phase0(swimsim_t* h, uint32_t* counts /*[n_shards] out*/, int*
 #define SWIMSIM_GREC5_BYTES 8u
 #define SWIMSIM_GREC6_BYTES 1u
 int swimsim_shard_gather_buffers(swimsim_t* h, void** send /*[2]*/, void** recv /*[2]*/, uint32_t* n_local);
-int swimsim_shard_join_buffers(swimsim_t* h, void** send, void** recv, uint32_t* cap);
-int swimsim_shard_join_ingest(swimsim_t* h, const uint32_t* counts_in /*[n_shards]*/);
 int swimsim_shard_get_first_suspect(swimsim_t* h, uint32_t* out, size_t n);
 int swimsim_shard_set_first_suspect(swimsim_t* h, const uint32_t* combined, size_t n);
 

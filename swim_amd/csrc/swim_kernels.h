@@ -1643,7 +1643,7 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
       }
     }
     __syncthreads();
-    const uint32_t nj = s.g[G_NJOINED];
+    const uint32_t nj = atomicOr(&s.g[G_NJOINED], 0u);       // counted with atomics by other waves of this block: read where they landed
     for (uint32_t k = threadIdx.x; k < nj; k += blockDim.x) {
       const uint32_t mbr = joined[k];
       if (!is_local(s, mbr)) continue;
