@@ -1,7 +1,7 @@
 #!/bin/bash
 # one GPU iteration: parity tests, bench lines, kernel-trace stats, PMC passes.
-# usage: gpu_cycle.sh <tag> [what...]   what = tests bench extra shard prof pmc (default: all)   -> gpurun_out/<tag>_*
-TAG=$1; shift; WHAT="${*:-tests bench extra shard prof pmc}"
+# usage: gpu_cycle.sh <tag> [what...]   what = tests bench extra variants shard prof pmc (default: all)   -> gpurun_out/<tag>_*
+TAG=$1; shift; WHAT="${*:-tests bench extra variants shard prof pmc}"
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out; mkdir -p $O
 cd $R
 has() { [[ " $WHAT " == *" $1 "* ]]; }
@@ -20,6 +20,11 @@ if has extra; then
   b saturated_p10 --steps 100 --warmup 20 --num-to-gossip 10 --no-cpu-baseline
   b loss1pct_gc --steps 200 --warmup 50 --loss-ppm 10000 --gc --no-cpu-baseline
   b loss30pct_16k --steps 200 --warmup 20 --members 16384 --loss-ppm 300000 --no-cpu-baseline
+fi
+if has variants; then
+  # the tick kernels with the state by value (product) against by pointer (libswimsim_sptr.so: no scalar spills)
+  timeout 600 python scripts/quick_time.py swim_amd/csrc/libswimsim.so swim_amd/csrc/libswimsim_sptr.so 2>&1 | tee $O/${TAG}_variants_state_by_pointer.txt
+  LOSS=10000 GC=1 TICKS=60 WARM=60 timeout 600 python scripts/quick_time.py swim_amd/csrc/libswimsim.so swim_amd/csrc/libswimsim_sptr.so 2>&1 | tee -a $O/${TAG}_variants_state_by_pointer.txt
 fi
 if has shard; then
   # one population as 1 / 2 / 4 / 8 handles on this GPU, record path against replicated queue masks

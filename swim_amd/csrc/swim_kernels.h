@@ -158,6 +158,19 @@ __device__ inline uint32_t get_slot(const DevState& s, uint32_t j) {
 #define SECT(k) ((void)0)
 #define SECT_COUNT(k) ((void)0)
 #endif
+// -DSWIM_STATE_BY_POINTER (measurement knob, default off): the two tick kernels take the state through a pointer to a
+// device copy instead of by value.  By value, the compiler fetches every field a kernel uses at its entry (kernel
+// arguments are loaded there by construction) and parks what does not fit in scalar registers in vector lanes --
+// merge_kernel: 79 scalars parked, 922 lane reads at use sites (scripts/isa_histogram.py); through a pointer a
+// field is a scalar load where it is used, and the fields of cold branches are never touched on the hot path.
+#ifdef SWIM_STATE_BY_POINTER
+#define SWIM_STATE_PARAM const DevState* __restrict__ state_ptr
+#define SWIM_STATE_BIND const DevState& s = *state_ptr;
+#else
+#define SWIM_STATE_PARAM DevState s
+#define SWIM_STATE_BIND
+#endif
+
 // ================================================================================================
 // probe kernel
 // ================================================================================================
@@ -177,7 +190,8 @@ __device__ inline void deliver_local(const DevState& s, uint32_t t, bool use_mas
 #define SWIM_PROBE_WAVES 5
 #endif
 template <int PMAX>
-__global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3 : PMAX <= 12 ? 2 : 1) void probe_kernel(DevState s, uint32_t t, uint32_t tk, Offsets off) {
+__global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3 : PMAX <= 12 ? 2 : 1) void probe_kernel(SWIM_STATE_PARAM, uint32_t t, uint32_t tk, Offsets off) {
+  SWIM_STATE_BIND
   __shared__ BlockCounters sh;
   __shared__ uint32_t ordn;                        // deliveries left to the exchange (sharded runs)
   if (threadIdx.x == 0) ordn = 0;
@@ -533,7 +547,8 @@ __device__ inline void settle_pass(const DevState& s, uint32_t li, bool up, uint
     for (uint32_t k = 0; k < nz; ++k) s.V[vidx(s, li, s.zero_slots[k])] = make_uint2(0u, 0u);
 }
 
-__global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(DevState s, uint32_t t) {
+__global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STATE_PARAM, uint32_t t) {
+  SWIM_STATE_BIND
   __shared__ BlockCounters sh;
   __shared__ uint32_t asm_[PB_SLOTS * 2][ASM_STRIDE];   // the outgoing line is assembled here: [2 entry + word][thread]
   __shared__ uint32_t gsubj[PB_SLOTS][ASM_STRIDE];      // subjects of this tick's group (its sort key)

@@ -40,6 +40,7 @@ struct swimsim {
   std::vector<Fault> faults;      // sorted by (tick, order)
   uint32_t fault_order = 0;
   FaultRec* d_faults = nullptr; size_t d_faults_cap = 0;
+  DevState* d_state = nullptr;                 // device copy of d (SWIM_STATE_BY_POINTER builds)
   uint32_t* d_joined = nullptr;                // members that came up in the tick being applied (as many as fault records)
   unsigned long long* d_scratch64 = nullptr;   // digest accumulator
   uint32_t* d_sel = nullptr;                   // [0..255] picks, [256] count, [257..] excludes
@@ -59,6 +60,13 @@ struct swimsim {
   uint32_t* h_sync = nullptr;                  // pinned host copy of the globals (flags + send counts)
   hipEvent_t tick_ev[3] = {nullptr, nullptr, nullptr};
 };
+
+// the tick kernels' state argument: by value, or (-DSWIM_STATE_BY_POINTER, measurement knob) a pointer to a device copy
+#ifdef SWIM_STATE_BY_POINTER
+#define SWIM_STATE_ARG(h) ((const swim::DevState*)(h)->d_state)
+#else
+#define SWIM_STATE_ARG(h) (h)->d
+#endif
 
 namespace {
 
@@ -229,9 +237,9 @@ Offsets robust_offsets(const swimsim* h, uint32_t t) {
 template <int PMAX>
 void launch_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev) {
   if (ev) (void)hipEventRecord(ev[0], h->stream);
-  hipLaunchKernelGGL((probe_kernel<PMAX>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, robust_offsets(h, t));
+  hipLaunchKernelGGL((probe_kernel<PMAX>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, tk, robust_offsets(h, t));
   if (ev) (void)hipEventRecord(ev[1], h->stream);
-  hipLaunchKernelGGL(merge_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
+  hipLaunchKernelGGL(merge_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t);
   if (ev) (void)hipEventRecord(ev[2], h->stream);
 }
 
@@ -414,6 +422,8 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
       CK(dev_alloc(h, &d.j_recv, (size_t)d.n_shards * d.j_cap, 0));
     }
   }
+  CK(dev_alloc(h, &h->d_state, (size_t)1, 0));
+  HK(hipMemcpyAsync(h->d_state, &d, sizeof d, hipMemcpyHostToDevice, h->stream));   // behind the allocation's memset
   hipLaunchKernelGGL(init_members_kernel, dim3((NT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, d.minfo, d.mb, NT);
   HK(hipGetLastError());
   HK(hipStreamSynchronize(h->stream));
@@ -836,10 +846,10 @@ int swimsim_shard_phase1(swimsim_t* h, uint32_t* counts) {
   if (h->timing) (void)hipEventRecord(h->tick_ev[0], h->stream);
   const uint32_t pk = std::max(h->d.P, h->d.K);
   const Offsets off = robust_offsets(h, t);
-  if (pk <= 4) hipLaunchKernelGGL((probe_kernel<4>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, off);
-  else if (pk <= 8) hipLaunchKernelGGL((probe_kernel<8>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, off);
-  else if (pk <= 12) hipLaunchKernelGGL((probe_kernel<12>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, off);
-  else hipLaunchKernelGGL((probe_kernel<16>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk, off);
+  if (pk <= 4) hipLaunchKernelGGL((probe_kernel<4>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, tk, off);
+  else if (pk <= 8) hipLaunchKernelGGL((probe_kernel<8>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, tk, off);
+  else if (pk <= 12) hipLaunchKernelGGL((probe_kernel<12>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, tk, off);
+  else hipLaunchKernelGGL((probe_kernel<16>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, tk, off);
   if (h->timing) (void)hipEventRecord(h->tick_ev[1], h->stream);
   hipLaunchKernelGGL(split_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
   rc = finish_phase(h, counts);
@@ -872,7 +882,7 @@ int swimsim_shard_phase3(swimsim_t* h, const uint32_t* p_counts_in, const uint32
   const uint32_t t = (uint32_t)h->tick;
   hipLaunchKernelGGL(ingest_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, peer_counts(h, p_counts_in), peer_counts(h, x_counts_in));
   if (h->timing) (void)hipEventRecord(h->tick_ev[1], h->stream);
-  hipLaunchKernelGGL(merge_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
+  hipLaunchKernelGGL(merge_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t);
   if (h->timing) (void)hipEventRecord(h->tick_ev[2], h->stream);
   if (h->d.G) hipLaunchKernelGGL(settle_publish_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t);
   rc = finish_phase(h, nullptr);

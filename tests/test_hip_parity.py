@@ -408,6 +408,19 @@ def test_forced_fallback_paths_on_the_gpu(oracle_abi):
     run_lockstep(a, b, 70, 10, observers=(0, 1, n - 1), members=(0, 1, n - 1), check_events=False)
 
 
+def test_state_by_pointer_build_on_the_gpu(oracle_abi):
+    """The gfx950 build whose tick kernels take the state through a pointer to a device copy (-DSWIM_STATE_BY_POINTER:
+    no scalar spills, measurement knob of DESIGN.md 11.1d): the same sources must give the same run."""
+    from swim_amd import _lib
+    hip = _lib.load_variant("sptr")
+    n = 50000
+    crashes = workloads.hashed_crashes(n, 6, 1, 200, 3, 43)
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=6, lossPpm=10000, eventMask=0, suspicionTicks=6, maxSubjects=4096)
+    a, b = make_pair(oracle_abi, hip, sc, crashes, [(45, m, True) for (_, m) in crashes[:50]])
+    _oracle_threads(a)
+    run_lockstep(a, b, 70, 10, observers=(0, 1, n - 1), members=(0, 1, n - 1), check_events=False)
+
+
 def test_rumour_id_counter_wraps_on_the_gpu(oracle_abi):
     """The gfx950 build with 10-bit rumour ids: the id counter wraps every 1 024 rumours, several times here
     (racing creators of one rumour take spare ids on the GPU: ~100 new ids per tick in this run).  After a tick

@@ -254,3 +254,15 @@ def test_more_new_ids_in_one_tick_than_the_id_space(oracle_abi, variant, bits, s
         assert a.counters() == b.counters() and a.digest() == b.digest(), "tick %d" % a.tick
         assert a.drainEventsRaw() == b.drainEventsRaw()
     a.close(); b.close()
+
+
+def test_state_by_pointer_build_gives_the_same_run(oracle_abi):
+    """-DSWIM_STATE_BY_POINTER (measurement knob: the tick kernels take the state through a pointer to a device copy,
+    which removes their scalar spills): the same sources, the same run."""
+    from tests import hostemu_binding
+    emu = hostemu_binding.load_variant("sptr", ["SWIM_STATE_BY_POINTER"])
+    n = 600
+    crashes = workloads.hashed_crashes(n, 9, 1, 6, 3, 33)
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=9, lossPpm=30000, eventMask=0x1F, suspicionTicks=6, maxSubjects=600)
+    a, b = make_pair(oracle_abi, emu, sc, crashes, [(45, m, True) for (_, m) in crashes[:20]])
+    run_lockstep(a, b, 60, 5, observers=(0, 1, n - 1), members=(0, 1, n - 1))
