@@ -1,5 +1,5 @@
 """Static instruction mix of the gfx950 kernels (no GPU needed): hipcc -S of swimsim.hip, instructions of each kernel
-by class.  Static counts, not executed ones -- a map of what the code is made of (quarter-rate integer multiplies of the
+by class (environment DEFS="-DSWIM_STATE_BY_POINTER ..." compiles a variant).  Static counts, not executed ones -- a map of what the code is made of (quarter-rate integer multiplies of the
 hashes, lane moves of spilled scalars, waits) to read next to the section clocks.  usage: isa_histogram.py [kernel ...]"""
 import collections
 import os
@@ -20,7 +20,8 @@ CLASSES = [("int mul (quarter rate)", ("v_mul_lo", "v_mul_hi", "v_mad_u64", "v_m
 
 with tempfile.TemporaryDirectory() as tmp:
     asm = os.path.join(tmp, "swimsim.s")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-o", asm,
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", *os.environ.get("DEFS", "").split(),
+                           "--cuda-device-only", "-S", "-o", asm,
                            os.path.join(ROOT, "swim_amd", "csrc", "swimsim.hip")], stderr=subprocess.DEVNULL, cwd=tmp)
     txt = open(asm).read()
 parts = re.split(r"\n(_ZN4swim[^\n:]+):[^\n]*\n", txt)
