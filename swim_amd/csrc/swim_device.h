@@ -172,7 +172,20 @@ struct DevState {
   uint8_t* q_all;                // [NT] bits 0-3 queue length, 4 = the mask cannot express the queue (MI_OOW), 5 = the member
                                  //   handles its direct probes of remote targets by records this tick (Q_EXC)
   uint32_t fl_dyn_base, fl_dyn_cap;   // region of `fl` for foreign lines that belong to no record (remote_kernel)
+#ifdef SWIM_ABLATE
+  uint32_t dbg;            // measurement build (scripts/ablate.py): memory operations the tick kernels leave out
+#endif
 };
+// -DSWIM_ABLATE (libswimsim_abl.so, measurement only: results are WRONG by construction): a tick kernel skips the class
+// of memory operations named by a bit of DevState::dbg, so that its share of the launch time can be read off
+#ifdef SWIM_ABLATE
+#define ABL(bit) ((s.dbg & (uint32_t)(bit)) != 0u)
+#else
+#define ABL(bit) false
+#endif
+enum { ABL_PUSH_ATOMIC = 1, ABL_PK_GATHER = 2, ABL_MB_GATHER = 4, ABL_ACKMASK_STORE = 8, ABL_V_STORE = 16, ABL_V_LOAD = 32,
+       ABL_OWN_LINE = 64, ABL_LINE_STORE = 128, ABL_EVD = 256, ABL_FIND_RID = 512, ABL_GROUP = 1024, ABL_STATE_STORES = 2048,
+       ABL_INPUTS = 4096, ABL_DEADLINES = 8192, ABL_RUMOURS = 16384 };
 constexpr uint32_t Q_PBN = 0xFu, Q_OOW = 1u << 4, Q_EXC = 1u << 5;
 // settle records: a shard lists a row as a CANDIDATE (quiet here for G ticks; y = the largest entry among its members
 // that are up) or as a VETO (an entry changed / the subject announced itself within the last G ticks)
@@ -353,7 +366,7 @@ __device__ inline uint32_t probe_mi(const DevState& s, uint32_t c, bool use_mask
 #ifdef SWIM_NO_MB            // measurement knob: always gather the full word
   return s.minfo[c];
 #endif
-  const uint32_t b = s.mb[c];
+  const uint32_t b = ABL(ABL_MB_GATHER) ? (MB_UP | (8u << MB_PBN_SHIFT)) : s.mb[c];
   if ((b & (MB_ROW | MB_OOW)) || !use_mask) return s.minfo[c];
   return ((b & MB_UP) ? MI_UP : 0u) | (((b >> MB_PBN_SHIFT) & 0xFu) << MI_PBN_SHIFT) |
          ((b & MB_BASE_NA) ? ((uint32_t)ST_DEAD << MI_BASE_SHIFT) : 0u);

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
 #pragma unroll
     for (int p = 0; p < PMAX; ++p) {
       tk2[p] = make_ulonglong2(0ull, 0ull);
-      if (use_mask && ping_ok[p] && is_local(s, picks[p]) && (mymask || (ack_ok[p] && mi_pbn(pinfo[p]))))
+      if (use_mask && ping_ok[p] && is_local(s, picks[p]) && (mymask || (ack_ok[p] && mi_pbn(pinfo[p]))) && !ABL(ABL_PK_GATHER))
         tk2[p] = s.pk[picks[p] - s.lo];
     }
     SECT(33);                                       // outcomes + the targets' pk gathers issued
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
           if (is_local(s, picks[p])) {
             const uint32_t dl = picks[p] - s.lo;
             const unsigned long long m = mymask & ~(tk2[p].y & ~stale);   // only what the target does not know
-            if (m) atomicOr(&s.inmask[dl], m);
+            if (m && !ABL(ABL_PUSH_ATOMIC)) atomicOr(&s.inmask[dl], m);
             if (expl) pos[p] = atomicAdd(&s.inbox_cnt[dl], 1u);
           } else if (expl) {
             emit_order(picks[p], i);                 // my queue as an explicit payload record
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
     pubmask = mymask;
     pubq = mycnt | (((mi & MI_OOW) || !use_mask) ? Q_OOW : 0u) | (clean ? 0u : Q_EXC);   // a tick without masks: no queue travels as one
   }
-  if (li < s.N) s.ackmask[li] = ackacc;
+  if (li < s.N && !ABL(ABL_ACKMASK_STORE)) s.ackmask[li] = ackacc;
   if (s.rm && li < s.N) { s.mask_all[i] = pubmask; s.q_all[i] = (uint8_t)pubq; }
   ctr_add_wave(&sh, C_PINGS, n_pings);
   ctr_add_wave(&sh, C_ACTIVE, act ? 1u : 0u);
@@ -632,13 +632,13 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
     if (pcount) {
       PSTAT(1);
 #pragma unroll
-      for (int h = 0; h < PB_SLOTS / 2; ++h) ol[h] = own_line[h];
+      for (int h = 0; h < PB_SLOTS / 2; ++h) ol[h] = ABL(ABL_OWN_LINE) ? make_uint4(0u, 0u, 0u, 0u) : own_line[h];
     }
     if (plain_due) {
 #pragma unroll
       for (int k = 0; k < DB; ++k) {
         dsl[k] = tc_get(due, k);
-        if (dsl[k]) dcell[k] = s.V[vidx(s, li, dsl[k] - 1)];
+        if (dsl[k] && !ABL(ABL_V_LOAD)) dcell[k] = s.V[vidx(s, li, dsl[k] - 1)];
       }
     }
     kn = known0 & ~stale;
@@ -703,22 +703,24 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
     }
     examined++;
     PSTAT(5); SECT_COUNT(20);
-    if (!(have & HAVE_CELL)) e = s.V[vidx(s, li, slot)];
+    if (!(have & HAVE_CELL) && !ABL(ABL_V_LOAD)) e = s.V[vidx(s, li, slot)];
     const uint32_t curk = e.x ? e.x : ((have & HAVE_BASE) ? sbase : s.slot_base[slot]);   // untouched cell: the settled base
     if (key <= curk) return;                     // old incarnation / weaker state: ignore (:151)
     PSTAT(6); PSTAT(psite); SECT_COUNT(21);
-    s.V[vidx(s, li, slot)] = make_uint2(key, t + 1);                    // memberLastChange = now (:176)
+    if (!ABL(ABL_V_STORE)) s.V[vidx(s, li, slot)] = make_uint2(key, t + 1);                    // memberLastChange = now (:176)
     if (s.G) s.slot_last[slot] = t;              // same value from every writer
     if (!(have & HAVE_SUBJ)) subject = s.subject_of[slot];
     if (!ha) ha = mix64(mix64((uint64_t)TAG_EV) + (((uint64_t)t << 32) | i));
     const unsigned long long hx = mix64(ha + subject);                // h4(TAG_EV, a, subject, .) prefix
-    evd += mix64(hx + key) - mix64(hx + curk);
+    if (!ABL(ABL_EVD)) evd += mix64(hx + key) - mix64(hx + curk);
     changes += (e.y != t + 1) ? 1u : 0u;
     if (cause == 1u) timers_fired++;
     if ((key & 3u) == ST_SUSPECT) tput(slot + 1);                     // deadline t + S (D4)
-    const uint32_t rid = hasrid ? rid_in : find_rid(s, slot, key);
+    const uint32_t rid = (hasrid || ABL(ABL_FIND_RID)) ? rid_in : find_rid(s, slot, key);
+    if (!ABL(ABL_GROUP)) {
     kill_slot(slot);
     group_put(slot, rid, key, subject);          // `Just msg` -> Broadcast -> enqueue (D5)
+    }
     if (s.event_mask & (1u << cause)) {
       const uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
       if (pos < s.event_cap) s.events[pos] = make_uint4(t, i, subject, (key << 8) | cause);
@@ -779,8 +781,8 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
           for (int j = 1; j < DB; ++j) if (k == (uint32_t)j) e = dcell[j];
 #pragma unroll
           for (int j = 0; j < DB - 1; ++j) have &= !((uint32_t)j < k && dsl[j] == v);
-          if (!have) e = s.V[vidx(s, li, v - 1)];
-          deadline(v - 1, e);
+          if (!have && !ABL(ABL_V_LOAD)) e = s.V[vidx(s, li, v - 1)];
+          if (!ABL(ABL_DEADLINES)) deadline(v - 1, e);
         }
         if (!tc_linked(cell.w)) break;
         SECT_COUNT(17);
@@ -812,6 +814,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
     constexpr int GB = SWIM_GOSSIP_BATCH;
     unsigned long long fresh = (pushed | pulled) & ~kn;
     kn |= fresh;
+    if (ABL(ABL_RUMOURS)) fresh = 0;
     while (fresh) {
       PSTAT(10);
       uint32_t rid[GB]; uint4 r[GB]; uint2 e[GB];
@@ -829,7 +832,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
       }
 #pragma unroll
       for (int k = 0; k < GB; ++k)
-        if ((uint32_t)k < n && r[k].x + 1 != my_slot1) e[k] = s.V[vidx(s, li, r[k].x)];
+        if ((uint32_t)k < n && r[k].x + 1 != my_slot1 && !ABL(ABL_V_LOAD)) e[k] = s.V[vidx(s, li, r[k].x)];
 #pragma unroll
       for (int k = 0; k < GB; ++k) {
         if ((uint32_t)k >= n) continue;
@@ -972,7 +975,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
     if (pcount) {
 #pragma unroll
       for (int h = 0; h < PB_SLOTS / 2; ++h) {
-        const uint4 v = own_line[h];
+        const uint4 v = ABL(ABL_OWN_LINE) ? make_uint4(0u, 0u, 0u, 0u) : own_line[h];
 #pragma unroll
         for (int w = 0; w < 2; ++w) {
           const uint32_t lo = w ? v.z : v.x, hi = w ? v.w : v.y, tx = pe_tx(hi);
@@ -995,9 +998,11 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
       set_mi(s, i, mi & ~MI_PB);
     }
     SECT(5);                                        // queue rebuilt
+    if (!ABL(ABL_STATE_STORES)) {
     s.pk[li] = make_ulonglong2(nout ? qmask : 0ull, kn);
     if (pushed) s.inmask[li] = 0;
     if (timer_due || tnew.n || woke) trow_now[li] = tc_pack(tnew);   // consumed and refilled in one store
+    }
     if (self_inc != hot0.x || woke) s.hot[li] = make_uint2(self_inc, hot0.y & ~1u);
     if (cnt) s.inbox_cnt[li] = 0;
     pb_writes = (pcount || nout) ? 1u : 0u;
@@ -1027,7 +1032,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
     for (int k = 0; k < 4; ++k) {
       const uint32_t m = wbase + 16u * k + (lane >> 2);          // thread whose line this lane helps to store
       const uint32_t fl = wfl[m];
-      if (fl & 1u) {
+      if ((fl & 1u) && !ABL(ABL_LINE_STORE)) {
         const uint32_t gm = blockIdx.x * BLOCK + m;
         uint4* line = reinterpret_cast<uint4*>(s.pb + ((size_t)(fl >> 1) * s.N + gm) * PB_SLOTS);
         line[q] = make_uint4(asm_[4 * q][m], asm_[4 * q + 1][m], asm_[4 * q + 2][m], asm_[4 * q + 3][m]);

@@ -683,6 +683,11 @@ int swimsim_table_stats(swimsim_t* h, uint64_t* out, size_t n) {
   return SWIMSIM_OK;
 }
 
+#ifdef SWIM_ABLATE
+// measurement build only (scripts/ablate.py): which memory operations the tick kernels leave out from now on
+int swimsim_debug_ablate(swimsim_t* h, uint32_t mask) { h->d.dbg = mask; return SWIMSIM_OK; }
+#endif
+
 #ifdef SWIM_SECTION_CLOCKS
 // measurement build only (scripts/section_clocks.py): the 64 section-clock words (summed over their 64 copies), then zeroed
 int swimsim_debug_sections(swimsim_t* h, uint64_t* out) {
