@@ -18,13 +18,14 @@ if has extra; then
   b saturated_gc --steps 300 --warmup 150 --gc --no-cpu-baseline
   b saturated_robust --steps 300 --warmup 150 --scheme robust --no-cpu-baseline
   b saturated_p10 --steps 100 --warmup 20 --num-to-gossip 10 --no-cpu-baseline
-  b loss1pct_gc --steps 200 --warmup 50 --loss-ppm 10000 --gc --no-cpu-baseline
-  b loss30pct_16k --steps 200 --warmup 20 --members 16384 --loss-ppm 300000 --no-cpu-baseline
+  # the lossy lines carry the same-cluster CPU figure and the oracle check (shorter windows: the threaded oracle needs them)
+  b loss1pct_gc --steps 60 --warmup 20 --loss-ppm 10000 --gc
+  b loss30pct_16k --steps 200 --warmup 20 --members 16384 --loss-ppm 300000
+  b loss30pct_64k --steps 100 --warmup 20 --members 65536 --loss-ppm 300000
 fi
 if has variants; then
-  # the tick kernels with the state by value (product) against by pointer (libswimsim_sptr.so: no scalar spills)
-  timeout 600 python scripts/quick_time.py swim_amd/csrc/libswimsim.so swim_amd/csrc/libswimsim_sptr.so 2>&1 | tee $O/${TAG}_variants_state_by_pointer.txt
-  LOSS=10000 GC=1 TICKS=60 WARM=60 timeout 600 python scripts/quick_time.py swim_amd/csrc/libswimsim.so swim_amd/csrc/libswimsim_sptr.so 2>&1 | tee -a $O/${TAG}_variants_state_by_pointer.txt
+  # the tick kernels with the state by value (product) against by pointer (libswimsim_sptr.so): the same cluster, stepped in turn
+  timeout 600 python scripts/ab_time.py swim_amd/csrc/libswimsim.so swim_amd/csrc/libswimsim_sptr.so 2>&1 | tee $O/${TAG}_variants_state_by_pointer.txt
 fi
 if has shard; then
   # one population as 1 / 2 / 4 / 8 handles on this GPU, record path against replicated queue masks

@@ -35,7 +35,9 @@ enum { G_NSLOTS = 0 /* view rows ever handed out (high-water mark) */, G_ERR = 1
        G_SEND = 16 /* [3][16] exchange records appended per peer (send_cnt) */,
        G_NJOINED = 64 /* members that came up in this tick (begin_kernel part A) */,
        G_JSEND = 65 /* [16] join-pull records appended per peer (exchange round 0) */,
-       G_FLDYN = 81 /* foreign lines handed out by remote_kernel this tick */, G_WORDS = 96 };
+       G_FLDYN = 81 /* foreign lines handed out by remote_kernel this tick */,
+       G_TODO = 82 /* todo entries reserved by the records phase this tick */, G_ANYREC = 83 /* somebody wrote an explicit record this tick */,
+       G_WORDS = 96 };
 enum { ERRF_SUBJECTS = 1, ERRF_ROWS = 2, ERRF_OVF = 4, ERRF_INC = 8, ERRF_XCHG = 16 };
 
 // counter slots (same order as SWIMSIM_CTR_* in include/swimsim.h)
@@ -111,6 +113,12 @@ struct DevState {
   uint32_t* ackfrom;       // [N][P] sources whose Ack reached this member with such a payload
   uint32_t* inbox_cnt;     // explicit deliveries to this member this tick
   uint32_t* inbox;         // [N][inbox_cap] source ids (bit31 = source's pb buffer)
+  uint4* todo;             // [todo_cap] what the records phase of merge_kernel leaves for the rest of the kernel: the record entries that survived the rings,
+                           //   {slot | rid << 16, key, row base, subject}; a member's list starts at todo_off[member], its
+                           //   length replaces inbox_cnt[member]; kn_rec[member] = ring positions of the ids they carried
+  uint32_t* todo_off;
+  unsigned long long* kn_rec;
+  uint32_t todo_cap;
   uint2* hot;              // {storeIncarnation, flags: bit 0 = came back up, deadlines slept through not fired yet}
   uint32_t* subject_of;    // slot -> subject
   uint32_t* fail;          // [N][P] targets whose probe ended without ack
@@ -312,31 +320,34 @@ __device__ inline unsigned long long stale_positions(uint32_t prev, uint32_t hea
 // "my view dominates the rumour with id r" for the last KW_BITS ids (position r mod KW_BITS), kw_head[member] the
 // head it was written at: positions of the ids [kw_head, H) are forgotten when it is read (they stood for ids that
 // have left the window).  Loaded and stored only by members that have explicit records this tick.
-struct Ring256 { unsigned long long w[4]; };
+// four scalar words, not an array: an array member that is indexed inside helper loops stays in memory (the compiler kept
+// `w[4]` in scratch -- 40 bytes per lane and 53 scratch instructions in merge_kernel -- or moved it to LDS)
+struct Ring256 { unsigned long long w0, w1, w2, w3; };
+static_assert(KW_BITS == 256u || KW_BITS == 128u || KW_BITS == 64u, "the wide ring is one, two or four words");
 __device__ inline bool rid_in_wide(uint32_t rid, uint32_t H) { return rid != RID_PARKED && ((H - 1u - rid) & RID_MASK) < KW_BITS; }
 __device__ inline unsigned long long low_bits(int n) { return n <= 0 ? 0ull : n >= 64 ? ~0ull : (1ull << n) - 1ull; }
+// the positions of word k that the circular range [a, a + len) of a KW_BITS-position ring covers
+__device__ inline unsigned long long r256_range_word(uint32_t a, uint32_t len, int k) {
+  if (len >= KW_BITS) return ~0ull;
+  const int off = (int)(((uint32_t)(64 * k) - a) & (KW_BITS - 1u));   // distance of the word's first position from a
+  unsigned long long m = low_bits((int)len - off);
+  if (off > (int)KW_BITS - 64) m |= low_bits((int)len + (int)KW_BITS - off) & ~low_bits((int)KW_BITS - off);
+  return m;
+}
 // forget the circular position range [a, a + len) of a KW_BITS-position ring
 __device__ inline void r256_forget(Ring256& r, uint32_t a, uint32_t len) {
   a &= KW_BITS - 1u;
-#pragma unroll
-  for (int k = 0; k < (int)(KW_BITS / 64u); ++k) {
-    if (len >= KW_BITS) { r.w[k] = 0ull; continue; }
-    const int off = (int)(((uint32_t)(64 * k) - a) & (KW_BITS - 1u));   // distance of the word's first position from a
-    unsigned long long m = low_bits((int)len - off);
-    if (off > (int)KW_BITS - 64) m |= low_bits((int)len + (int)KW_BITS - off) & ~low_bits((int)KW_BITS - off);
-    r.w[k] &= ~m;
-  }
+  r.w0 &= ~r256_range_word(a, len, 0);
+  if (KW_BITS > 64u) r.w1 &= ~r256_range_word(a, len, 1);
+  if (KW_BITS > 128u) { r.w2 &= ~r256_range_word(a, len, 2); r.w3 &= ~r256_range_word(a, len, 3); }
 }
 __device__ inline bool r256_test(const Ring256& r, uint32_t rid) {
-  const uint32_t q = rid & (KW_BITS - 1u);
-  unsigned long long w = r.w[0];
-#pragma unroll
-  for (int k = 1; k < (int)(KW_BITS / 64u); ++k) if ((q >> 6) == (uint32_t)k) w = r.w[k];
+  const uint32_t q = rid & (KW_BITS - 1u), k = q >> 6;
+  const unsigned long long w = k == 0u ? r.w0 : k == 1u ? r.w1 : k == 2u ? r.w2 : r.w3;
   return (w >> (q & 63u)) & 1ull;
 }
 __device__ inline void r256_or(Ring256& r, uint32_t word, unsigned long long m) {
-#pragma unroll
-  for (int k = 0; k < (int)(KW_BITS / 64u); ++k) if (word == (uint32_t)k) r.w[k] |= m;
+  r.w0 |= word == 0u ? m : 0ull; r.w1 |= word == 1u ? m : 0ull; r.w2 |= word == 2u ? m : 0ull; r.w3 |= word == 3u ? m : 0ull;
 }
 __device__ inline void r256_set(Ring256& r, uint32_t rid) { r256_or(r, (rid & (KW_BITS - 1u)) >> 6, 1ull << (rid & 63u)); }
 

@@ -158,6 +158,12 @@ __device__ inline uint32_t get_slot(const DevState& s, uint32_t j) {
 #define SECT(k) ((void)0)
 #define SECT_COUNT(k) ((void)0)
 #endif
+#ifndef PSTAT                   // tests/hostemu -DSWIM_PATH_STATS counts how often a site runs per lane / per wave
+#define PSTAT(...) ((void)0)
+#define PSITE(x) ((void)0)
+#else
+#define PSITE(x) (psite = (x))
+#endif
 // -DSWIM_STATE_BY_POINTER (measurement knob, default off): the two tick kernels take the state through a pointer to a
 // device copy instead of by value.  By value, the compiler fetches every field a kernel uses at its entry (kernel
 // arguments are loaded there by construction) and parks what does not fit in scalar registers in vector lanes --
@@ -208,6 +214,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
   unsigned payloads = 0, rumors = 0, dfail = 0, preqs = 0, susp = 0, fsusp = 0;
   unsigned long long ackacc = 0;                  // masks this member pulls in with its Acks
   unsigned long long pubmask = 0; uint32_t pubq = 0;   // replicated masks (sharded, s.rm): what the peers learn about my queue
+  bool wrote_rec = false;                          // this member left an explicit record somewhere: the records phase of merge_kernel has work
   SECT_BEGIN(32);
   if (act) {
     const uint32_t mk = mix32(tk ^ i);
@@ -270,9 +277,10 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
       if (dst == i) {
         // pulled by myself: no atomics, a private word and (rarely) a private explicit list
         if (use_mask) ackacc |= src == i ? mymask : s.pk[src - s.lo].x;
-        if (!use_mask || (msrc & MI_OOW)) push(s, t, li, mi_src(src - s.lo, msrc));
+        if (!use_mask || (msrc & MI_OOW)) { push(s, t, li, mi_src(src - s.lo, msrc)); wrote_rec = true; }
       } else if (is_local(s, dst)) {
         deliver_local(s, t, use_mask, stale, dst - s.lo, src - s.lo, msrc, src == i ? mymask : (use_mask ? s.pk[src - s.lo].x : 0ull));
+        wrote_rec |= !use_mask || (msrc & MI_OOW);
       } else {
         emit_order(dst, src);
       }
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
             const uint32_t dl = picks[p] - s.lo;
             const unsigned long long m = mymask & ~(tk2[p].y & ~stale);   // only what the target does not know
             if (m && !ABL(ABL_PUSH_ATOMIC)) atomicOr(&s.inmask[dl], m);
-            if (expl) pos[p] = atomicAdd(&s.inbox_cnt[dl], 1u);
+            if (expl) { pos[p] = atomicAdd(&s.inbox_cnt[dl], 1u); wrote_rec = true; }
           } else if (expl) {
             emit_order(picks[p], i);                 // my queue as an explicit payload record
           }
@@ -336,7 +344,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
         const uint32_t mq = probe_mi(s, q, use_mask);
         if (!mi_up(mq) || !mi_pbn(mq) || !view_alive(s, q - s.lo, mi) || lost(s, tk, P_L_PING, q, i, p)) continue;
         if (use_mask) ackacc |= s.pk[q - s.lo].x;
-        if (!use_mask || (mq & MI_OOW)) push(s, t, li, mi_src(q - s.lo, mq));
+        if (!use_mask || (mq & MI_OOW)) { push(s, t, li, mi_src(q - s.lo, mq)); wrote_rec = true; }
       }
     }
     // remote targets: ONE record per probe carries my queue's mask (if it says everything) and the request
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
       const uint32_t pj = mi_pbn(pinfo[p]);
       if (pj) {
         ackacc |= tk2[p].x;
-        if (!use_mask || (pinfo[p] & MI_OOW)) { s.ackfrom[(size_t)li * s.P + nack] = mi_src(picks[p] - s.lo, pinfo[p]); nack++; }
+        if (!use_mask || (pinfo[p] & MI_OOW)) { s.ackfrom[(size_t)li * s.P + nack] = mi_src(picks[p] - s.lo, pinfo[p]); nack++; wrote_rec = true; }
         payloads++; rumors += pj;
       }
     }
@@ -406,6 +414,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
     pubq = mycnt | (((mi & MI_OOW) || !use_mask) ? Q_OOW : 0u) | (clean ? 0u : Q_EXC);   // a tick without masks: no queue travels as one
   }
   if (li < s.N && !ABL(ABL_ACKMASK_STORE)) s.ackmask[li] = ackacc;
+  if (__ballot(wrote_rec) && (threadIdx.x & 63u) == 0u) s.g[G_ANYREC] = 1u;   // one plain store per wave that wrote any
   if (s.rm && li < s.N) { s.mask_all[i] = pubmask; s.q_all[i] = (uint8_t)pubq; }
   ctr_add_wave(&sh, C_PINGS, n_pings);
   ctr_add_wave(&sh, C_ACTIVE, act ? 1u : 0u);
@@ -500,6 +509,136 @@ __device__ inline uint32_t park_rid(uint32_t lo, uint32_t H) {
 }
 
 
+// ================================================================================================
+// records phase (the start of merge_kernel in a tick with explicit records)
+// ================================================================================================
+// Explicit delivery records "dst merges src's 64-B line" (swim_device.h): the exact path behind the masks -- queues
+// with entries outside the mask window, every delivery of a tick that follows a burst of rumour ids (message loss),
+// payloads from other shards my masks cannot carry.  A member with records reads its sources' lines, filters the
+// entries through the wide known-ring (kw: "my view dominates rumour id r" for the last KW_BITS ids) and leaves the
+// survivors as a todo list for the rest of the kernel: {slot | rid << 16, key, row base, subject}, 16 bytes each, in
+// a region of `todo` reserved per wave (upper bound: 8 entries per source; one atomic per wave).  It follows
+// src/Core.hs:110-117 for messages that arrive as whole Envelopes.
+// Why a phase of its own, in front of everything else (measured, profiles/r03d_*, r03g_*, r03i_*): walked in the
+// middle of the kernel -- with the tick's group, deadlines and counters live, and its own batch of view cells, bases
+// and subjects in registers -- this path set the register allocation of the whole kernel: 128 VGPRs + 56 bytes of
+// scratch against 95 and none, although a lossless tick never enters it (merge 158 -> 147 us at a million members).
+// As a kernel of its own it costs 10 us per tick even when it leaves at once: every kernel boundary on this chip
+// writes the XCDs' L2s back and invalidates them (5-6 us gaps between the tick's kernels in the trace).  Here it
+// needs 62 registers with nothing else live, and the view cells are the todo loop's business, four at a time.
+// inclusive prefix sum over the lanes of a wave (the DPP steps of wave_sum leave it in every lane)
+__device__ inline unsigned wave_prefix_incl(unsigned x) {
+  x += SWIM_DPP(x, 0x111, 0xf); x += SWIM_DPP(x, 0x112, 0xf); x += SWIM_DPP(x, 0x114, 0xf); x += SWIM_DPP(x, 0x118, 0xf);
+  x += SWIM_DPP(x, 0x142, 0xa); x += SWIM_DPP(x, 0x143, 0xc);
+  return x;
+}
+__device__ __forceinline__ void records_phase(const DevState& s, uint32_t t, uint32_t li, uint32_t mi) {
+  const bool up = mi_up(mi);
+  uint32_t cnt = 0, nack = 0;
+  if (up) { cnt = s.inbox_cnt[li]; nack = s.probe_out[li] >> 10; }
+  const bool has = (cnt | nack) != 0u;
+  if (!__ballot(has)) return;
+#ifdef SWIM_REC_STATS
+  { const unsigned long long b = __ballot(has); if ((threadIdx.x & 63u) == 0u) { atomicAdd(&s.g[90], (uint32_t)__popcll(b)); atomicAdd(&s.g[91], 1u); } if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&s.g[92], 1u); }
+#endif
+  const uint32_t H = s.g[G_HEAD];
+  const uint32_t nin = cnt < s.inbox_cap ? cnt : s.inbox_cap;
+  const uint32_t novf = cnt > s.inbox_cap ? min(s.g[G_OVF0 + (t & 1u)], s.ovf_cap) : 0u;
+  // room for 8 survivors per source; the overflow list is shared: count my entries first
+  uint32_t mine_ovf = 0;
+  for (uint32_t x = 0; x < novf; ++x) mine_ovf += s.ovf[(size_t)(t & 1u) * s.ovf_cap + x].x == li ? 1u : 0u;
+  const uint32_t ub = has ? (nack + nin + mine_ovf) * (uint32_t)PB_SLOTS : 0u;
+  const uint32_t incl = wave_prefix_incl(ub);
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  uint32_t base = 0;
+  if ((threadIdx.x & 63u) == 0u) base = atomicAdd(&s.g[G_TODO], total);
+  base = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
+  if (base + total > s.todo_cap || base + total < base) {          // loud, never a silent drop
+    if ((threadIdx.x & 63u) == 0u) atomicOr(&s.g[G_ERR], (uint32_t)ERRF_OVF);
+    if (has) s.inbox_cnt[li] = 0;
+    return;
+  }
+  if (!has) return;
+  const uint32_t off = base + incl - ub;
+  uint4* out = s.todo + off;
+  uint32_t nout = 0;
+  const uint32_t my_slot1 = mi & MI_SLOT;
+  // my 64-position ring as merge_kernel will hold it when it comes to the records: last tick's new ids forgotten,
+  // this tick's mask deliveries learnt
+  unsigned long long kn = s.pk[li].y & ~stale_positions(s.g[G_PREV], H);
+  {
+    unsigned long long got = s.inmask[li] | s.ackmask[li];
+    if (s.n_shards > 1) for (uint32_t p = 0; p < s.P; ++p) got |= s.ackslot[(size_t)li * s.P + p];
+    kn |= got;
+  }
+  unsigned long long learnt = 0;                   // ring positions of the ids the records carry: merge_kernel ORs them in
+  // the wide known-ring (swim_device.h): what I learned since it was written is forgotten position-wise, what the
+  // 64-position ring knows is copied in (its ids own one or two of the wide ring's words)
+  Ring256 kw;
+  const bool ids_untrusted = s.g[G_RIDS_OFF] != 0u;
+  const uint32_t kwh0 = s.kw_head[li];
+  {
+    const ulonglong4 v = s.kw[li];
+    kw.w0 = v.x; kw.w1 = v.y; kw.w2 = v.z; kw.w3 = v.w;
+    r256_forget(kw, kwh0, H - kwh0);
+    const unsigned long long young = low_bits((int)(H & 63u));   // positions of the ids in H's own block of 64
+    r256_or(kw, (H >> 6) & (KW_BITS / 64u - 1u), kn & young);
+    r256_or(kw, ((H >> 6) - 1u) & (KW_BITS / 64u - 1u), kn & ~young);
+  }
+  auto source_word = [&](uint32_t x) -> uint32_t {
+    if (x < nack) return s.ackfrom[(size_t)li * s.P + x];
+    if (x < nack + nin) return s.inbox[(size_t)li * s.inbox_cap + (x - nack)];
+    if (x < nack + nin + novf) {
+      const uint2 o = s.ovf[(size_t)(t & 1u) * s.ovf_cap + (x - nack - nin)];
+      if (o.x == li) return o.y;
+    }
+    return NONE32;
+  };
+  uint32_t srcw_next = source_word(0u);            // one source ahead: its load travels with this source's line
+  for (uint32_t x = 0; x < nack + nin + novf; ++x) {
+    PSTAT(12);
+    const uint32_t srcw = srcw_next;
+    srcw_next = source_word(x + 1u);
+    if (srcw == NONE32) continue;
+    PSTAT(13);
+    const uint4* line = (srcw & SRC_FOREIGN) ? s.fl + (size_t)(srcw & (SRC_FOREIGN - 1u)) * 4
+                                             : line_ptr(s, srcw >> 31, srcw & 0x7FFFFFFFu);
+    // the whole line in one round of loads; its entries filtered by the rings (no memory); row base and subject of
+    // the survivors in one round (tiny tables); the view cells are merge_kernel's business
+    uint4 ln[PB_SLOTS / 2];
+#pragma unroll
+    for (int h = 0; h < PB_SLOTS / 2; ++h) ln[h] = line[h];
+#pragma unroll
+    for (int q = 0; q < PB_SLOTS; ++q) {
+      const uint4 v = ln[q >> 1];
+      const uint32_t lo = (q & 1) ? v.z : v.x, hi = (q & 1) ? v.w : v.y;
+      bool want = pe_tx(hi) != 0u;
+      const uint32_t rid = pe_rid(lo);
+      // after a tick with more new ids than the width tolerates (G_RIDS_OFF) the lines written in that tick hold
+      // ids that may be a whole turn of the id space apart -- two rumours under one id, or an id that reads as
+      // one of this tick's window: no id of a line is trusted in this tick (found by a soak of the 8-bit build:
+      // 3 000 members at 20 % loss allocate 660 ids in the first tick)
+      if (want && !ids_untrusted && rid_in_wide(rid, H)) {
+        if (r256_test(kw, rid)) want = false;      // view already dominates it
+        else { r256_set(kw, rid); if (rid_in_ring(rid, H)) learnt |= rid_bit(rid); }
+      }
+      if (want) {
+        const uint32_t slot = pe_slot(lo);
+        uint32_t sb = 0u, sj = 0u;
+        if (slot + 1 != my_slot1) { sb = s.slot_base[slot]; sj = s.subject_of[slot]; }
+        out[nout++] = make_uint4(lo, pe_key(hi), sb, sj);
+      }
+    }
+  }
+  s.kw[li] = make_ulonglong4(kw.w0, kw.w1, kw.w2, kw.w3);
+  if (kwh0 != H) s.kw_head[li] = H;
+  s.kn_rec[li] = learnt;
+  s.todo_off[li] = off;
+  s.inbox_cnt[li] = nout;                          // the todo loop: entries of my list (the end of the kernel clears the count)
+}
+
+
+
 // One thread = one member's end of tick:
 //   suspicion timers (the FIXME at src/Core.hs:141; D4), own probes that ended without an ack
 //   (src/Core.hs:253) and the rumours delivered this tick (src/Core.hs:110-117) go through the state
@@ -509,12 +648,6 @@ __device__ inline uint32_t park_rid(uint32_t lo, uint32_t H) {
 //   digest; then the piggyback queue `disseminate` leaves as a FIXME (src/Core.hs:136-138; D5) is rebuilt.
 // Delivered rumours arrive as masks: new = (pushed | pulled) & ~known is the whole filter, and the
 // lanes of a wave walk their new bits in the same order, so their view / timer accesses coalesce.
-#ifndef PSTAT                   // tests/hostemu -DSWIM_PATH_STATS counts how often a site runs per lane / per wave
-#define PSTAT(...) ((void)0)
-#define PSITE(x) ((void)0)
-#else
-#define PSITE(x) (psite = (x))
-#endif
 // Measured on MI355X (profiles/r02w_variants.txt): the kernel is bound by the instructions a wave executes, not
 // by occupancy (3, 4 and 5 waves per SIMD within 1 %; 5 spills) -- 4 waves leave 128 registers; a batch of 2
 // rumours beats 4 (fewer unrolled copies of the state rule executed by a wave whose lanes hold 1-2 new rumours)
@@ -522,7 +655,10 @@ __device__ inline uint32_t park_rid(uint32_t lo, uint32_t H) {
 #define SWIM_GOSSIP_BATCH 2
 #endif
 #ifndef SWIM_MERGE_WAVES
-#define SWIM_MERGE_WAVES 4
+#define SWIM_MERGE_WAVES 5
+#endif
+#ifndef SWIM_TODO_BATCH         // todo entries (explicit records' survivors) whose view cells merge_kernel loads together
+#define SWIM_TODO_BATCH 4
 #endif
 constexpr int ASM_STRIDE = BLOCK + 2;   // words per LDS column: keeps the transposed line store conflict-free
 
@@ -562,12 +698,13 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
   if (blockIdx.x == 0 && threadIdx.x == 0) s.g[G_OVF0 + ((t + 1) & 1u)] = 0;  // next tick's overflow list
   const uint32_t mi = li < s.N ? s.minfo[i] : 0u;
   const bool up = mi_up(mi);
+  if (s.g[G_ANYREC]) records_phase(s, t, li, mi);  // wave-uniform: somebody wrote an explicit record this tick
   const uint32_t H = s.g[G_HEAD];
   const unsigned long long stale = stale_positions(s.g[G_PREV], H);
   if (s.G) settle_pass(s, li, up, wmax);
 
   // ---- this member's inputs of the tick (coalesced)
-  uint32_t nsent = 0, nfail = 0, nack = 0, cnt = 0;
+  uint32_t nsent = 0, nfail = 0, cnt = 0;
   unsigned long long pushed = 0, pulled = 0;
   uint2 hot0 = make_uint2(0u, 0u);
   uint4 due = make_uint4(0u, 0u, 0u, 0u);          // deadline row of this tick
@@ -577,8 +714,8 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
   uint4* const trow_now = s.trow + (size_t)(t % s.S) * s.N;
   if (up) {
     const uint32_t po = s.probe_out[li];
-    nsent = po & 31u; nfail = (po >> 5) & 31u; nack = po >> 10;
-    cnt = s.inbox_cnt[li];
+    nsent = po & 31u; nfail = (po >> 5) & 31u;
+    cnt = s.inbox_cnt[li];                           // entries of my todo list (records phase)
     pushed = s.inmask[li];
     pulled = s.ackmask[li];
     if (s.n_shards > 1)                              // Ack payloads of remote targets: one slot per probe
@@ -594,7 +731,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
   const uint32_t pcount = mi_pbn(mi), cur = mi_buf(mi);
   const bool woke = (hot0.y & 1u) != 0;            // came back up: deadlines it slept through are still in trow
   const bool timer_due = (due.x | due.y | due.z | due.w) != 0u;
-  const bool act = up && ((pushed | pulled) != 0ull || (cnt | nack | nfail | pcount | (uint32_t)timer_due | (uint32_t)woke));
+  const bool act = up && ((pushed | pulled) != 0ull || (cnt | nfail | pcount | (uint32_t)timer_due | (uint32_t)woke));
   // idle this tick: only keep the ring valid (swim_device.h); nothing to write when no id was allocated
   if (up && !act && stale) { const ulonglong2 v = s.pk[li]; if (v.y & stale) s.pk[li] = make_ulonglong2(v.x, v.y & ~stale); }
 
@@ -842,96 +979,40 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
         bool again = false;
 #pragma unroll
         for (int j = 0; j < GB; ++j) again |= (j < k) && (r[j].x == r[k].x);
-        examine_with(r[k].x, r[k].y, 2u, true, rid[k], again ? EX_LOAD : EX_ALL, e[k], r[k].z, r[k].w);
+        examine_with(r[k].x, r[k].y, 2u, true, rid[k], again ? (HAVE_BASE | HAVE_SUBJ) : EX_ALL, e[k], r[k].z, r[k].w);
       }
     }
   }
   SECT(3);                                          // delivered rumours
   if (act) {
-    if (cnt | nack) {
-      // explicit records: the sources' 64-B lines (queues the masks could not carry in full)
-      const uint32_t nin = cnt < s.inbox_cap ? cnt : s.inbox_cap;
-      const uint32_t novf = cnt > s.inbox_cap ? min(s.g[G_OVF0 + (t & 1u)], s.ovf_cap) : 0u;
+    if (cnt) {
+      // explicit records (queues the masks could not carry in full): the records phase has read the sources' lines, filtered
+      // their entries through the rings and left the survivors as this member's todo list {slot | rid << 16, key, row
+      // base, subject} -- TB entries and their view cells per round of loads, then the rule on each
       PSITE(30);
-      // the wide known-ring (swim_device.h): what I learned since it was written is forgotten position-wise, what the
-      // 64-position ring knows is copied in (its ids own one or two of the wide ring's words)
-      Ring256 kw;
-      const bool ids_untrusted = s.g[G_RIDS_OFF] != 0u;
-      const uint32_t kwh0 = s.kw_head[li];
-      {
-        const ulonglong4 v = s.kw[li];
-        kw.w[0] = v.x; kw.w[1] = v.y; kw.w[2] = v.z; kw.w[3] = v.w;
-        r256_forget(kw, kwh0, H - kwh0);
-        const unsigned long long young = low_bits((int)(H & 63u));   // positions of the ids in H's own block of 64
-        r256_or(kw, (H >> 6) & (KW_BITS / 64u - 1u), kn & young);
-        r256_or(kw, ((H >> 6) - 1u) & (KW_BITS / 64u - 1u), kn & ~young);
-      }
-      auto source_word = [&](uint32_t x) -> uint32_t {
-        if (x < nack) return s.ackfrom[(size_t)li * s.P + x];
-        if (x < nack + nin) return s.inbox[(size_t)li * s.inbox_cap + (x - nack)];
-        if (x < nack + nin + novf) {
-          const uint2 o = s.ovf[(size_t)(t & 1u) * s.ovf_cap + (x - nack - nin)];
-          if (o.x == li) return o.y;
+      kn |= s.kn_rec[li];                          // ring positions of the ids the records carried
+      const uint4* td = s.todo + s.todo_off[li];
+      constexpr int TB = SWIM_TODO_BATCH;
+      for (uint32_t x0 = 0; x0 < cnt; x0 += TB) {
+        uint4 en[TB]; uint2 ce[TB];
+#pragma unroll
+        for (int k = 0; k < TB; ++k) { en[k] = make_uint4(0u, 0u, 0u, 0u); if (x0 + k < cnt) en[k] = td[x0 + k]; }
+#pragma unroll
+        for (int k = 0; k < TB; ++k) {
+          ce[k] = make_uint2(0u, 0u);
+          if (x0 + k < cnt && pe_slot(en[k].x) + 1 != my_slot1 && !ABL(ABL_V_LOAD)) ce[k] = s.V[vidx(s, li, pe_slot(en[k].x))];
         }
-        return NONE32;
-      };
-      uint32_t srcw_next = source_word(0u);        // one source ahead: its load travels with this source's line
-      for (uint32_t x = 0; x < nack + nin + novf; ++x) {
-        PSTAT(12);
-        const uint32_t srcw = srcw_next;
-        srcw_next = source_word(x + 1u);
-        if (srcw == NONE32) continue;
-        SECT(11);                                   // source word arrived
-        PSTAT(13); SECT_COUNT(18);
-        const uint4* line = (srcw & SRC_FOREIGN) ? s.fl + (size_t)(srcw & (SRC_FOREIGN - 1u)) * 4
-                                                 : line_ptr(s, srcw >> 31, srcw & 0x7FFFFFFFu);
-        // the whole line in one round of loads; its entries filtered by the rings (no memory); the view cells, row
-        // bases and subjects of the survivors in ONE round; then the rule on each (slots of a line are distinct).
-        // Measured against the line read 16 bytes at a time with one dependent gather per entry: numToGossip = 10
-        // merge 319 -> 160 us; 1 % loss at a million members 1.86 -> 1.44 ms per tick; k = 3 without loss no
-        // difference (profiles/r02f_*, r02i_*_rec_variants.txt).
-        uint4 ln[PB_SLOTS / 2];
+        for (uint32_t k = 0; k < (uint32_t)TB && x0 + k < cnt; ++k) {
+          uint4 e4 = en[0]; uint2 e = ce[0];
+          bool again = false;                      // an earlier entry of the batch is about the same subject: look again
 #pragma unroll
-        for (int h = 0; h < PB_SLOTS / 2; ++h) ln[h] = line[h];
-        uint32_t need = 0;
-        uint2 ce[PB_SLOTS]; uint32_t cb[PB_SLOTS], cs[PB_SLOTS];
+          for (int j = 1; j < TB; ++j) if (k == (uint32_t)j) { e4 = en[j]; e = ce[j]; }
 #pragma unroll
-        for (int q = 0; q < PB_SLOTS; ++q) {
-          const uint4 v = ln[q >> 1];
-          const uint32_t lo = (q & 1) ? v.z : v.x, hi = (q & 1) ? v.w : v.y;
-          ce[q] = make_uint2(0u, 0u); cb[q] = 0u; cs[q] = 0u;
-          bool want = pe_tx(hi) != 0u;
-          const uint32_t rid = pe_rid(lo);
-          // after a tick with more new ids than the width tolerates (G_RIDS_OFF) the lines written in that tick hold
-          // ids that may be a whole turn of the id space apart -- two rumours under one id, or an id that reads as
-          // one of this tick's window: no id of a line is trusted in this tick (found by a soak of the 8-bit build:
-          // 3 000 members at 20 % loss allocate 660 ids in the first tick)
-          if (want && !ids_untrusted && rid_in_wide(rid, H)) {
-            if (r256_test(kw, rid)) want = false;  // view already dominates it
-            else { r256_set(kw, rid); if (rid_in_ring(rid, H)) kn |= rid_bit(rid); }
-          }
-          if (want) {
-            need |= 1u << q;
-            const uint32_t slot = pe_slot(lo);
-            if (slot + 1 != my_slot1) { ce[q] = s.V[vidx(s, li, slot)]; cb[q] = s.slot_base[slot]; cs[q] = s.subject_of[slot]; }
-          }
-        }
-        SECT(12);
-        while (need) {
-          const uint32_t q = (uint32_t)__ffs(need) - 1u;
-          need &= need - 1u;
-          uint32_t lo = ln[0].x, hi = ln[0].y, sb = cb[0], sj = cs[0];
-          uint2 e = ce[0];
-#pragma unroll
-          for (int j = 1; j < PB_SLOTS; ++j)
-            if (q == (uint32_t)j) { lo = (j & 1) ? ln[j >> 1].z : ln[j >> 1].x; hi = (j & 1) ? ln[j >> 1].w : ln[j >> 1].y; sb = cb[j]; sj = cs[j]; e = ce[j]; }
+          for (int j = 0; j < TB - 1; ++j) again |= (uint32_t)j < k && pe_slot(en[j].x) == pe_slot(e4.x);
           PSTAT(14);
-          examine_with(pe_slot(lo), pe_key(hi), 2u, true, pe_rid(lo), EX_ALL, e, sb, sj);
+          examine_with(pe_slot(e4.x), e4.y, 2u, true, pe_rid(e4.x), again ? (HAVE_BASE | HAVE_SUBJ) : EX_ALL, e, e4.z, e4.w);
         }
-        SECT(13);
       }
-      s.kw[li] = make_ulonglong4(kw.w[0], kw.w[1], kw.w[2], kw.w[3]);
-      if (kwh0 != H) s.kw_head[li] = H;
     }
     // ---- refutation: bump own incarnation past the rumour's (src/Core.hs:155-166; D10); rumours at
     // an incarnation below my own are stale and ignored (:151)
@@ -1690,6 +1771,8 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
     if (changes_sh) s.blk[(size_t)s.nblocks * C_COUNT + C_CHANGES] += changes_sh;
     s.g[G_PREV] = s.g[G_HEAD];
     s.g[G_HEAD] = s.g[G_NRUM];
+    s.g[G_TODO] = 0;                                // the records phase's region counter
+    s.g[G_ANYREC] = s.n_shards > 1 ? 1u : 0u;       // set by whoever writes an explicit record (the exchange kernels may)
     // a line is rewritten every tick and replaces ids outside [H - KW_BITS, H + RID_NEAR) by "no id"; an id born at
     // distance r < RID_NEAR above the head sits at r - D one tick later (D = ids of the tick) and would wrap
     // back INTO that zone for D > 2^RID_BITS - RID_NEAR - KW_BITS.  After such a tick (48 896 new rumours at once with

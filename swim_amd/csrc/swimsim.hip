@@ -323,6 +323,13 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     // all deliveries of a tick beyond the 256-slot inboxes): room for every expected delivery
     d.ovf_cap = (uint32_t)std::min<double>(3.0e8, std::max<double>(d.ovf_cap, lam * N + 65536.0));
   }
+  {
+    // the records phase of merge_kernel reserves 8 todo entries per explicit-record source: room for the expected number of sources per
+    // member (every delivery, when the masks are off) with headroom; overruns are loud (SWIMSIM_ERR_CAPACITY)
+    const double l = c.loss_ppm / 1e6, pf = 1.0 - (1.0 - l) * (1.0 - l);
+    const double lam = 2.0 * c.probes_per_tick + 4.0 * c.probes_per_tick * c.indirect_k * pf;
+    d.todo_cap = (uint32_t)std::min<double>(2.0e9, (double)N * (1.25 * lam + 2.0) * PB_SLOTS + 65536.0);
+  }
   d.ord_cap = 0; d.r_cap = d.p_cap = d.x_cap = 0;
   CK(dev_alloc(h, &d.minfo, NT, 0));
   CK(dev_alloc(h, &d.mb, ((size_t)NT + 3) & ~(size_t)3, 0));
@@ -331,6 +338,9 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   CK(dev_alloc(h, &d.inbox_cnt, N, 0));
   CK(dev_alloc(h, &d.inbox, (size_t)N * d.inbox_cap, 0));
   CK(dev_alloc(h, &d.hot, N, 0));
+  CK(dev_alloc(h, &d.todo, (size_t)d.todo_cap, 0));
+  CK(dev_alloc(h, &d.todo_off, N, 0));
+  CK(dev_alloc(h, &d.kn_rec, N, 0));
   CK(dev_alloc(h, &d.pk, (size_t)N, 0));
   CK(dev_alloc(h, &d.inmask, (size_t)N, 0));
   CK(dev_alloc(h, &d.ackmask, (size_t)N, 0));
@@ -679,7 +689,10 @@ int swimsim_table_stats(swimsim_t* h, uint64_t* out, size_t n) {
   uint32_t g[G_WORDS];
   HIPCHK(h, hipMemcpy(g, h->d.g, sizeof g, hipMemcpyDeviceToHost));
   out[0] = g[G_NSLOTS]; out[1] = g[G_NLIVE]; out[2] = g[G_NFREE]; out[3] = g[G_NRUM]; out[4] = h->d.R_phys;
-  if (n >= 7) { out[5] = std::max(g[G_OVF0], g[G_OVF1]); out[6] = h->d.ovf_cap; }   // inbox overflow list: entries in the fuller of the two, room
+  if (n >= 7) { out[5] = std::max(g[G_OVF0], g[G_OVF1]); out[6] = h->d.ovf_cap; }
+#ifdef SWIM_REC_STATS
+  if (n >= 10) { out[7] = g[90]; out[8] = g[91]; out[9] = g[92]; }
+#endif   // inbox overflow list: entries in the fuller of the two, room
   return SWIMSIM_OK;
 }
 

@@ -517,3 +517,46 @@ def test_join_pull_many_joins_at_64k(oracle_abi, hip_abi):
     for o in ((7 % n), (31 + 7) % n, 5):
         assert a.members(o) == b.members(o)
     a.close(); b.close()
+
+
+def test_one_percent_loss_million_members_vs_oracle(oracle_abi, hip_abi):
+    """The only lossy regime with a throughput claim, oracle-checked at full size ("the lossy regime is not
+    oracle-checked at the benchmarked size"): 1 048 576 members, 1 % message loss, ~1 crash per tick, settling on --
+    explicit records for every delivery after the id bursts, the wide known-ring, deadline overflow pools with their
+    sub-pools (where both soak-found id-overflow bugs lived).  Digest, every counter and the first-detection ticks."""
+    from swim_amd import _abi
+    n = 1 << 20
+    sc, crashes, _ = workloads.saturated(n, 90, seed=1, t0=0, loss_ppm=10000)
+    sc.gcTicks = _abi.GC_AUTO
+    a, b = make_pair(oracle_abi, hip_abi, sc, crashes)
+    _oracle_threads(a)
+    for stop in (30, 60, 75):
+        a.step(stop - a.tick); b.step(stop - b.tick)
+        ca, cb = a.counters(), b.counters()
+        assert ca == cb, "counters differ at tick %d" % stop
+        assert a.digest() == b.digest(), "digest differs at tick %d" % stop
+    assert a.firstDetection() == b.firstDetection()
+    assert cb["false_suspects"] > 0 and cb["refutes"] > 0            # the loss really bites
+    for o in (0, 777777):
+        assert a.members(o) == b.members(o)
+
+
+def test_wire_datagram_of_a_hip_member_equals_the_oracle_members(oracle_abi, hip_abi):
+    """Rows f-2 / a18 under the driver's GPU run: what a simulated member puts on the wire in a period -- its control
+    message and its piggyback queue as one compound Envelope (src/Types.hs:96-119, swim_wire.cpp) -- serialised from
+    the HIP handle's state and from the oracle handle's must be the same bytes, and decode back to the same messages."""
+    from swim_amd import wire
+    from swim_amd.types import Ping, Ack, IndirectPing
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=4096, seed=11, lossPpm=20000, eventMask=0x1F, suspicionTicks=8)
+    crashes = [(2, 100), (3, 2000), (5, 3000)]
+    a, b = make_pair(oracle_abi, hip_abi, sc, crashes)
+    a.step(14); b.step(14)
+    seen = 0
+    for m in (0, 1, 99, 101, 1999, 2048, 4095):
+        for ctl in (Ping(seqNo=14, node="m%d" % m), Ack(seqNo=14, payload=[]), IndirectPing(seqNo=14, target=5, port=4000, node="m7")):
+            da, db = wire.datagram_of(a, m, ctl), wire.datagram_of(b, m, ctl)
+            assert da == db
+            err, msgs = wire.decode(db)
+            assert err is None and msgs[0] == ctl
+            seen += len(msgs) - 1
+    assert seen > 0                                                  # queues were not empty: rumours rode along
