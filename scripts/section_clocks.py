@@ -11,8 +11,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from swim_amd import Sim, workloads, _abi                      # noqa: E402
 
 MERGE = ["inputs", "known-ring + own line + first deadline cells", "failed probes", "delivered rumours (masks)",
-         "explicit records + refute", "queue rebuild", "state stores + counters", "wave sync", "line store", "counter flush",
-         "deadlines", "records: source word", "records: line", "records: entries + state rule"]
+         "todo list (records' survivors) + refute", "queue rebuild", "state stores + counters", "wave sync", "line store", "counter flush",
+         "deadlines", "records: counts, region, rings", "records: source word + line wait", "records: ring filter + survivor stores", "records: final stores (+ flag wait)"]
+RECORDS = ["counts, rings -> LDS, prefix", "pair -> member, source words, lines", "ring filter (LDS atomics)", "chunk barrier + layout",
+           "write-out", "serial pass + final stores"]
 PROBE = ["target selection", "outcomes + pk gathers", "ping pushes", "acks", "indirect probes", "outputs + counters", "counter flush"]
 
 
@@ -37,7 +39,7 @@ def main():
     kt = s.kernelTiming()
     lib.swimsim_debug_sections(s._h, out)
     res = {"members": n, "ticks": ticks, "probe_us": kt["probe_ms"] * 1e3 / kt["ticks"], "merge_us": kt["merge_ms"] * 1e3 / kt["ticks"]}
-    for name, base, labels in (("merge_kernel", 0, MERGE), ("probe_kernel", 32, PROBE)):
+    for name, base, labels in (("merge_kernel", 0, MERGE), ("probe_kernel", 32, PROBE), ("records_kernel", 48, RECORDS)):
         waves = out[base + 15]
         tot = sum(out[base + k] for k in range(len(labels)))
         rows = {lab: {"clocks_per_wave": round(out[base + k] / max(1, waves), 1), "share": round(out[base + k] / max(1, tot), 4)}

@@ -36,8 +36,12 @@ enum { G_NSLOTS = 0 /* view rows ever handed out (high-water mark) */, G_ERR = 1
        G_NJOINED = 64 /* members that came up in this tick (begin_kernel part A) */,
        G_JSEND = 65 /* [16] join-pull records appended per peer (exchange round 0) */,
        G_FLDYN = 81 /* foreign lines handed out by remote_kernel this tick */,
-       G_TODO = 82 /* todo entries reserved by the records phase this tick */, G_ANYREC = 83 /* somebody wrote an explicit record this tick */,
+       G_ANYREC = 83 /* somebody wrote an explicit record this tick */,
        G_WORDS = 96 };
+// the todo buffer (explicit records' survivors) is cut into TODO_REGIONS regions with a counter each, on 64-byte lines of
+// their own (todo_n[region * 16]): workgroup b reserves from region b mod TODO_REGIONS -- every wave of the grid bumping
+// ONE word was 12 % of merge_kernel's wave time at 1 % loss (same-address atomics serialise, profiles/r03t_*)
+constexpr uint32_t TODO_REGIONS = 64;
 enum { ERRF_SUBJECTS = 1, ERRF_ROWS = 2, ERRF_OVF = 4, ERRF_INC = 8, ERRF_XCHG = 16 };
 
 // counter slots (same order as SWIMSIM_CTR_* in include/swimsim.h)
@@ -113,12 +117,14 @@ struct DevState {
   uint32_t* ackfrom;       // [N][P] sources whose Ack reached this member with such a payload
   uint32_t* inbox_cnt;     // explicit deliveries to this member this tick
   uint32_t* inbox;         // [N][inbox_cap] source ids (bit31 = source's pb buffer)
-  uint4* todo;             // [todo_cap] what the records phase of merge_kernel leaves for the rest of the kernel: the record entries that survived the rings,
-                           //   {slot | rid << 16, key, row base, subject}; a member's list starts at todo_off[member], its
+  uint2* todo;             // [todo_cap] what the records phase of merge_kernel leaves for the rest of the kernel: the record entries that survived the rings,
+                           //   {slot | rid << 16, key}; a member's list is todo_seg[member], its total
                            //   length replaces inbox_cnt[member]; kn_rec[member] = ring positions of the ids they carried
-  uint32_t* todo_off;
+  uint4* todo_seg;         // [N] a member's list in two segments {start 0, length 0, start 1, length 1} (the flattened pass of
+                           //   records_kernel; what its serial pass adds: overflow-list sources, members with more sources than a chunk)
   unsigned long long* kn_rec;
-  uint32_t todo_cap;
+  uint32_t* todo_n;        // [TODO_REGIONS * 16] entries handed out per region this tick (begin_kernel zeroes them)
+  uint32_t todo_cap;       // entries per region
   uint2* hot;              // {storeIncarnation, flags: bit 0 = came back up, deadlines slept through not fired yet}
   uint32_t* subject_of;    // slot -> subject
   uint32_t* fail;          // [N][P] targets whose probe ended without ack

@@ -153,10 +153,14 @@ __device__ inline uint32_t get_slot(const DevState& s, uint32_t j) {
 #define SECT(k) do { const unsigned long long n_ = clock64(); SECT_ADD(k, n_ - sect_t_); sect_t_ = clock64(); } while (0)
 #define SECT_COUNT(k) do { const unsigned long long b_ = __ballot(1); \
     if ((threadIdx.x & 63u) == (uint32_t)(__ffsll(b_) - 1)) atomicAdd(reinterpret_cast<unsigned long long*>(&s.blk[((size_t)s.nblocks + 1) * C_COUNT + (blockIdx.x & 63u) * 64u + (k)]), (unsigned long long)__popcll(b_)); } while (0)
+#define SECT_PARAM , unsigned long long& sect_t_
+#define SECT_ARG , sect_t_
 #else
 #define SECT_BEGIN(base) ((void)0)
 #define SECT(k) ((void)0)
 #define SECT_COUNT(k) ((void)0)
+#define SECT_PARAM
+#define SECT_ARG
 #endif
 #ifndef PSTAT                   // tests/hostemu -DSWIM_PATH_STATS counts how often a site runs per lane / per wave
 #define PSTAT(...) ((void)0)
@@ -516,7 +520,7 @@ __device__ inline uint32_t park_rid(uint32_t lo, uint32_t H) {
 // with entries outside the mask window, every delivery of a tick that follows a burst of rumour ids (message loss),
 // payloads from other shards my masks cannot carry.  A member with records reads its sources' lines, filters the
 // entries through the wide known-ring (kw: "my view dominates rumour id r" for the last KW_BITS ids) and leaves the
-// survivors as a todo list for the rest of the kernel: {slot | rid << 16, key, row base, subject}, 16 bytes each, in
+// survivors as a todo list for the rest of the kernel: {slot | rid << 16, key}, 8 bytes each, in
 // a region of `todo` reserved per wave (upper bound: 8 entries per source; one atomic per wave).  It follows
 // src/Core.hs:110-117 for messages that arrive as whole Envelopes.
 // Why a phase of its own, in front of everything else (measured, profiles/r03d_*, r03g_*, r03i_*): walked in the
@@ -532,59 +536,35 @@ __device__ inline unsigned wave_prefix_incl(unsigned x) {
   x += SWIM_DPP(x, 0x142, 0xa); x += SWIM_DPP(x, 0x143, 0xc);
   return x;
 }
-__device__ __forceinline__ void records_phase(const DevState& s, uint32_t t, uint32_t li, uint32_t mi) {
-  const bool up = mi_up(mi);
-  uint32_t cnt = 0, nack = 0;
-  if (up) { cnt = s.inbox_cnt[li]; nack = s.probe_out[li] >> 10; }
-  const bool has = (cnt | nack) != 0u;
-  if (!__ballot(has)) return;
-#ifdef SWIM_REC_STATS
-  { const unsigned long long b = __ballot(has); if ((threadIdx.x & 63u) == 0u) { atomicAdd(&s.g[90], (uint32_t)__popcll(b)); atomicAdd(&s.g[91], 1u); } if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&s.g[92], 1u); }
-#endif
-  const uint32_t H = s.g[G_HEAD];
-  const uint32_t nin = cnt < s.inbox_cap ? cnt : s.inbox_cap;
-  const uint32_t novf = cnt > s.inbox_cap ? min(s.g[G_OVF0 + (t & 1u)], s.ovf_cap) : 0u;
-  // room for 8 survivors per source; the overflow list is shared: count my entries first
-  uint32_t mine_ovf = 0;
-  for (uint32_t x = 0; x < novf; ++x) mine_ovf += s.ovf[(size_t)(t & 1u) * s.ovf_cap + x].x == li ? 1u : 0u;
-  const uint32_t ub = has ? (nack + nin + mine_ovf) * (uint32_t)PB_SLOTS : 0u;
-  const uint32_t incl = wave_prefix_incl(ub);
-  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-  uint32_t base = 0;
-  if ((threadIdx.x & 63u) == 0u) base = atomicAdd(&s.g[G_TODO], total);
-  base = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
-  if (base + total > s.todo_cap || base + total < base) {          // loud, never a silent drop
-    if ((threadIdx.x & 63u) == 0u) atomicOr(&s.g[G_ERR], (uint32_t)ERRF_OVF);
-    if (has) s.inbox_cnt[li] = 0;
-    return;
-  }
-  if (!has) return;
-  const uint32_t off = base + incl - ub;
-  uint4* out = s.todo + off;
-  uint32_t nout = 0;
-  const uint32_t my_slot1 = mi & MI_SLOT;
-  // my 64-position ring as merge_kernel will hold it when it comes to the records: last tick's new ids forgotten,
-  // this tick's mask deliveries learnt
-  unsigned long long kn = s.pk[li].y & ~stale_positions(s.g[G_PREV], H);
-  {
-    unsigned long long got = s.inmask[li] | s.ackmask[li];
-    if (s.n_shards > 1) for (uint32_t p = 0; p < s.P; ++p) got |= s.ackslot[(size_t)li * s.P + p];
-    kn |= got;
-  }
-  unsigned long long learnt = 0;                   // ring positions of the ids the records carry: merge_kernel ORs them in
-  // the wide known-ring (swim_device.h): what I learned since it was written is forgotten position-wise, what the
-  // 64-position ring knows is copied in (its ids own one or two of the wide ring's words)
+// reserve n todo entries in the workgroup's region; NONE32 = no room (loud: ERRF_OVF)
+__device__ inline uint32_t todo_reserve(const DevState& s, uint32_t n) {
+  const uint32_t region = blockIdx.x & (TODO_REGIONS - 1u);
+  const uint32_t got = atomicAdd(&s.todo_n[region * 16u], n);
+  if (got + n > s.todo_cap || got + n < got) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_OVF); return NONE32; }
+  return region * s.todo_cap + got;
+}
+// the member's wide known-ring as the records meet it: what it learnt since it was written forgotten position-wise, what
+// the 64-position ring knows copied in (its ids own one or two of the wide ring's words)
+__device__ inline Ring256 load_wide_ring(const DevState& s, uint32_t li, uint32_t H, unsigned long long kn) {
   Ring256 kw;
-  const bool ids_untrusted = s.g[G_RIDS_OFF] != 0u;
   const uint32_t kwh0 = s.kw_head[li];
-  {
-    const ulonglong4 v = s.kw[li];
-    kw.w0 = v.x; kw.w1 = v.y; kw.w2 = v.z; kw.w3 = v.w;
-    r256_forget(kw, kwh0, H - kwh0);
-    const unsigned long long young = low_bits((int)(H & 63u));   // positions of the ids in H's own block of 64
-    r256_or(kw, (H >> 6) & (KW_BITS / 64u - 1u), kn & young);
-    r256_or(kw, ((H >> 6) - 1u) & (KW_BITS / 64u - 1u), kn & ~young);
-  }
+  const ulonglong4 v = s.kw[li];
+  kw.w0 = v.x; kw.w1 = v.y; kw.w2 = v.z; kw.w3 = v.w;
+  r256_forget(kw, kwh0, H - kwh0);
+  const unsigned long long young = low_bits((int)(H & 63u));   // positions of the ids in H's own block of 64
+  r256_or(kw, (H >> 6) & (KW_BITS / 64u - 1u), kn & young);
+  r256_or(kw, ((H >> 6) - 1u) & (KW_BITS / 64u - 1u), kn & ~young);
+  return kw;
+}
+// One member's sources walked by its own thread, survivors stored as they are found: the form for the exception (a
+// lossless tick with a few out-of-window queues: the start of merge_kernel) and for what records_kernel's flattened pass
+// leaves out (overflow-list sources, a member with more sources than a chunk).  first / count select the sources:
+// [first, first + count) of the sequence ackfrom[0..nack), inbox[0..nin), my entries of the overflow list.
+// Returns the number of survivors stored at out[0..).
+__device__ inline uint32_t records_serial(const DevState& s, uint32_t t, uint32_t li, uint32_t H, bool ids_untrusted, Ring256& kw,
+                                          unsigned long long& learnt, uint32_t nack, uint32_t nin, uint32_t novf, uint32_t first,
+                                          uint2* out SECT_PARAM) {
+  uint32_t nout = 0;
   auto source_word = [&](uint32_t x) -> uint32_t {
     if (x < nack) return s.ackfrom[(size_t)li * s.P + x];
     if (x < nack + nin) return s.inbox[(size_t)li * s.inbox_cap + (x - nack)];
@@ -594,8 +574,9 @@ __device__ __forceinline__ void records_phase(const DevState& s, uint32_t t, uin
     }
     return NONE32;
   };
-  uint32_t srcw_next = source_word(0u);            // one source ahead: its load travels with this source's line
-  for (uint32_t x = 0; x < nack + nin + novf; ++x) {
+  uint32_t srcw_next = source_word(first);         // one source ahead: its load travels with this source's line
+  SECT(11);                                         // records: counts, region, rings
+  for (uint32_t x = first; x < nack + nin + novf; ++x) {
     PSTAT(12);
     const uint32_t srcw = srcw_next;
     srcw_next = source_word(x + 1u);
@@ -603,11 +584,15 @@ __device__ __forceinline__ void records_phase(const DevState& s, uint32_t t, uin
     PSTAT(13);
     const uint4* line = (srcw & SRC_FOREIGN) ? s.fl + (size_t)(srcw & (SRC_FOREIGN - 1u)) * 4
                                              : line_ptr(s, srcw >> 31, srcw & 0x7FFFFFFFu);
-    // the whole line in one round of loads; its entries filtered by the rings (no memory); row base and subject of
-    // the survivors in one round (tiny tables); the view cells are merge_kernel's business
+    // the whole line in one round of loads; its entries filtered by the rings (no memory); the survivors stored as they
+    // are: row bases, subjects and view cells are the todo loop's business
     uint4 ln[PB_SLOTS / 2];
 #pragma unroll
     for (int h = 0; h < PB_SLOTS / 2; ++h) ln[h] = line[h];
+#ifdef SWIM_SECTION_CLOCKS
+    if (ln[0].x == 0xFFFFFFF1u && ln[3].w == 0xFFFFFFF3u) learnt |= 1ull;   // (measurement build: the mark below waits for the line)
+#endif
+    SECT(12);                                       // records: source word + line arrived
 #pragma unroll
     for (int q = 0; q < PB_SLOTS; ++q) {
       const uint4 v = ln[q >> 1];
@@ -622,22 +607,235 @@ __device__ __forceinline__ void records_phase(const DevState& s, uint32_t t, uin
         if (r256_test(kw, rid)) want = false;      // view already dominates it
         else { r256_set(kw, rid); if (rid_in_ring(rid, H)) learnt |= rid_bit(rid); }
       }
-      if (want) {
-        const uint32_t slot = pe_slot(lo);
-        uint32_t sb = 0u, sj = 0u;
-        if (slot + 1 != my_slot1) { sb = s.slot_base[slot]; sj = s.subject_of[slot]; }
-        out[nout++] = make_uint4(lo, pe_key(hi), sb, sj);
-      }
+      if (want) out[nout++] = make_uint2(lo, pe_key(hi));
     }
+    SECT(13);                                       // records: ring filter + survivors stored
   }
+  return nout;
+}
+
+__device__ __forceinline__ void records_phase(const DevState& s, uint32_t t, uint32_t li, uint32_t mi, unsigned long long got SECT_PARAM) {
+  const bool up = mi_up(mi);
+  uint32_t cnt = 0, nack = 0;
+  if (up) { cnt = s.inbox_cnt[li]; nack = s.probe_out[li] >> 10; }
+  const bool has = (cnt | nack) != 0u;
+  if (!__ballot(has)) return;
+#ifdef SWIM_REC_STATS
+  { const unsigned long long b = __ballot(has); if ((threadIdx.x & 63u) == 0u) { atomicAdd(&s.g[90], (uint32_t)__popcll(b)); atomicAdd(&s.g[91], 1u); } }
+#endif
+  const uint32_t H = s.g[G_HEAD];
+  const uint32_t nin = cnt < s.inbox_cap ? cnt : s.inbox_cap;
+  const uint32_t novf = cnt > s.inbox_cap ? min(s.g[G_OVF0 + (t & 1u)], s.ovf_cap) : 0u;
+  // room for 8 survivors per source; the overflow list is shared: count my entries first
+  uint32_t mine_ovf = 0;
+  for (uint32_t x = 0; x < novf; ++x) mine_ovf += s.ovf[(size_t)(t & 1u) * s.ovf_cap + x].x == li ? 1u : 0u;
+  const uint32_t ub = has ? (nack + nin + mine_ovf) * (uint32_t)PB_SLOTS : 0u;
+  const uint32_t incl = wave_prefix_incl(ub);
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  uint32_t base = 0;
+  if ((threadIdx.x & 63u) == 0u) base = todo_reserve(s, total);   // one atomic per wave
+  base = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
+  if (base == NONE32) { if (has) s.inbox_cnt[li] = 0; return; }    // loud (ERRF_OVF), never a silent drop
+  if (!has) return;
+  const uint32_t off = base + incl - ub;
+  // my 64-position ring as the rest of the kernel will hold it when it comes to the records: last tick's new ids
+  // forgotten, this tick's mask deliveries (got: pushed to me and pulled by me) learnt
+  const unsigned long long kn = (s.pk[li].y & ~stale_positions(s.g[G_PREV], H)) | got;
+  unsigned long long learnt = 0;                   // ring positions of the ids the records carry: ORed into the ring later
+  Ring256 kw = load_wide_ring(s, li, H, kn);
+  const uint32_t nout = records_serial(s, t, li, H, s.g[G_RIDS_OFF] != 0u, kw, learnt, nack, nin, novf, 0u, s.todo + off SECT_ARG);
   s.kw[li] = make_ulonglong4(kw.w0, kw.w1, kw.w2, kw.w3);
-  if (kwh0 != H) s.kw_head[li] = H;
+  s.kw_head[li] = H;
   s.kn_rec[li] = learnt;
-  s.todo_off[li] = off;
+  s.todo_seg[li] = make_uint4(off, nout, 0u, 0u);
   s.inbox_cnt[li] = nout;                          // the todo loop: entries of my list (the end of the kernel clears the count)
 }
 
-
+// ================================================================================================
+// records kernel (between probe_kernel and merge_kernel, for handles whose every tick has records: message loss, shards)
+// ================================================================================================
+// The same job as records_phase -- sources' lines -> ring filter -> todo lists -- when EVERY member has six or more
+// sources in every tick.  What the one-thread-per-member form costs there was measured (profiles/r03t_*, 1 % loss, a
+// million members: the phase is 54 % of merge_kernel's wave time): a wave walks max-over-its-lanes sources (13-14 rounds
+// for a mean of 6.7); every survivor is an 8-byte scattered store, and on gfx9 a wave that waits for its next load also
+// waits for every store it has in flight (one counter, in order); every wave of the grid bumps one counter.  Here:
+//   * a workgroup's (member, source) pairs are dealt to its 256 threads round-robin -- every lane loads a line in every
+//     round, ceil(pairs / 256) rounds;
+//   * the members' wide rings live in LDS for the pass (test and set = one LDS atomic: two lanes that meet the same new
+//     rumour in lines of one member keep one copy);
+//   * a chunk = the pairs of whole members, at most REC_UNROLL per thread: the lines stay in registers while the
+//     survivors are counted (LDS), the chunk's output is laid out member by member, reserved with one atomic and
+//     written in one burst -- no load waits behind a store;
+//   * overflow-list sources and a member with more sources than a chunk holds are walked by the member's own thread
+//     afterwards (records_serial) into a second segment of its list.
+// The order of a list's entries differs from the serial form's; nothing observable depends on it (the merge is
+// commutative; duplicates are looked at twice and accepted once).
+constexpr uint32_t REC_UNROLL = 2, REC_CHUNK = BLOCK * REC_UNROLL;   // pairs per thread / per workgroup in a chunk
+// exclusive prefix sum over the threads of the workgroup (every thread calls); *total = the sum
+__device__ inline uint32_t block_prefix_excl(uint32_t x, uint32_t* wsum /* LDS, BLOCK / 64 + 1 words */, uint32_t* total) {
+  const uint32_t incl = wave_prefix_incl(x);
+  __syncthreads();                                  // the previous use of wsum is over
+  if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  uint32_t before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < BLOCK / 64; ++w) { const uint32_t v = wsum[w]; all += v; before += (uint32_t)w < (threadIdx.x >> 6) ? v : 0u; }
+  *total = all;
+  return before + incl - x;
+}
+__global__ __launch_bounds__(BLOCK, 5) void records_kernel(DevState s, uint32_t t) {
+  if (!s.g[G_ANYREC]) return;                      // uniform: nobody wrote a record this tick
+  __shared__ unsigned long long kw_sh[4][BLOCK];   // the members' wide rings
+  __shared__ unsigned long long learnt_sh[BLOCK];
+  __shared__ uint32_t pref[BLOCK + 1];             // exclusive prefix of the members' dealt sources (acks + inbox)
+  __shared__ uint32_t nack_sh[BLOCK];
+  __shared__ uint32_t cntc[BLOCK], offc[BLOCK];    // a chunk's survivors per member, and where each member's run starts
+  __shared__ uint32_t wsum[BLOCK / 64 + 1];
+  __shared__ uint32_t chunk_base;
+  const uint32_t tid = threadIdx.x, li = blockIdx.x * BLOCK + tid, i = s.lo + li;
+  SECT_BEGIN(48);
+  const uint32_t mi = li < s.N ? s.minfo[i] : 0u;
+  const bool up = mi_up(mi);
+  uint32_t cnt = 0, nack = 0;
+  if (up) { cnt = s.inbox_cnt[li]; nack = s.probe_out[li] >> 10; }
+  const bool has = (cnt | nack) != 0u;
+  const uint32_t H = s.g[G_HEAD];
+  const bool ids_untrusted = s.g[G_RIDS_OFF] != 0u;
+  const uint32_t nin = cnt < s.inbox_cap ? cnt : s.inbox_cap;
+  const uint32_t novf = cnt > s.inbox_cap ? min(s.g[G_OVF0 + (t & 1u)], s.ovf_cap) : 0u;
+  const bool dealt = has && nack + nin <= REC_CHUNK;   // else: all of it in the serial pass
+  if (has) {
+    unsigned long long got = s.inmask[li] | s.ackmask[li];
+    if (s.n_shards > 1) for (uint32_t p = 0; p < s.P; ++p) got |= s.ackslot[(size_t)li * s.P + p];
+    const unsigned long long kn = (s.pk[li].y & ~stale_positions(s.g[G_PREV], H)) | got;
+    const Ring256 kw = load_wide_ring(s, li, H, kn);
+    kw_sh[0][tid] = kw.w0; kw_sh[1][tid] = kw.w1; kw_sh[2][tid] = kw.w2; kw_sh[3][tid] = kw.w3;
+  }
+  learnt_sh[tid] = 0ull; nack_sh[tid] = nack;
+  uint32_t T = 0;
+  const uint32_t myp = block_prefix_excl(dealt ? nack + nin : 0u, wsum, &T);
+  pref[tid] = myp;
+  if (tid == 0) pref[BLOCK] = T;
+  uint4 seg = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+  SECT(48);                                         // counts, rings -> LDS, prefix
+  for (uint32_t m0 = 0; m0 < (uint32_t)BLOCK && pref[m0] < T;) {       // uniform: chunks of whole members
+    uint32_t lo = m0 + 1u, hi = BLOCK;               // m1 = the largest member bound with at most REC_CHUNK pairs from m0 on
+    while (lo < hi) { const uint32_t mid = (lo + hi + 1u) >> 1; if (pref[mid] - pref[m0] <= REC_CHUNK) lo = mid; else hi = mid - 1u; }
+    const uint32_t m1 = lo, x0 = pref[m0], x1 = pref[m1];
+    cntc[tid] = 0;
+    __syncthreads();
+    // A chunk is at most REC_UNROLL pairs per thread: their source words, then their lines, travel together and the
+    // lines stay in registers until the survivors' places are known (the pass waits on memory, not on arithmetic).
+    uint32_t mm[REC_UNROLL], sw[REC_UNROLL], keep[REC_UNROLL], pos0[REC_UNROLL];
+    uint4 ln[REC_UNROLL][PB_SLOTS / 2];
+#pragma unroll
+    for (int u = 0; u < (int)REC_UNROLL; ++u) {
+      const uint32_t x = x0 + tid + (uint32_t)u * BLOCK;
+      mm[u] = NONE32; sw[u] = 0u; keep[u] = 0u; pos0[u] = 0u;
+      if (x < x1) {
+        uint32_t a = m0, b = m1;                     // the member whose pair x is: the last one with pref <= x
+        while (b - a > 1u) { const uint32_t mid = (a + b) >> 1; if (pref[mid] <= x) a = mid; else b = mid; }
+        const uint32_t k = x - pref[a], ml = blockIdx.x * BLOCK + a, na = nack_sh[a];
+        mm[u] = a;
+        sw[u] = k < na ? s.ackfrom[(size_t)ml * s.P + k] : s.inbox[(size_t)ml * s.inbox_cap + (k - na)];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < (int)REC_UNROLL; ++u) {
+#pragma unroll
+      for (int h = 0; h < PB_SLOTS / 2; ++h) ln[u][h] = make_uint4(0u, 0u, 0u, 0u);
+      if (mm[u] != NONE32) {
+        const uint4* line = (sw[u] & SRC_FOREIGN) ? s.fl + (size_t)(sw[u] & (SRC_FOREIGN - 1u)) * 4
+                                                   : line_ptr(s, sw[u] >> 31, sw[u] & 0x7FFFFFFFu);
+#pragma unroll
+        for (int h = 0; h < PB_SLOTS / 2; ++h) ln[u][h] = line[h];
+      }
+    }
+#ifdef SWIM_SECTION_CLOCKS
+    if (ln[0][0].x == 0xFFFFFFF1u && ln[REC_UNROLL - 1][3].w == 0xFFFFFFF3u) atomicOr(&learnt_sh[tid], 1ull);   // (the mark below waits for the lines)
+#endif
+    SECT(49);                                       // pair -> member search, source words, lines
+#pragma unroll
+    for (int u = 0; u < (int)REC_UNROLL; ++u) {
+      if (mm[u] == NONE32) continue;
+      const uint32_t m = mm[u];
+#pragma unroll
+      for (int q = 0; q < PB_SLOTS; ++q) {
+        const uint4 v = ln[u][q >> 1];
+        const uint32_t elo = (q & 1) ? v.z : v.x, ehi = (q & 1) ? v.w : v.y;
+        bool want = pe_tx(ehi) != 0u;
+        const uint32_t rid = pe_rid(elo);
+        if (want && !ids_untrusted && rid_in_wide(rid, H)) {       // (records_serial says why ids may be untrusted)
+          const uint32_t qq = rid & (KW_BITS - 1u);
+          const unsigned long long bit = 1ull << (qq & 63u);
+          unsigned long long* w = &kw_sh[qq >> 6][m];
+          if (*w & bit) want = false;                // view already dominates it
+          else if (atomicOr(w, bit) & bit) want = false;   // another lane met it first in another line of this member
+          else if (rid_in_ring(rid, H)) atomicOr(&learnt_sh[m], rid_bit(rid));
+        }
+        keep[u] |= want ? 1u << q : 0u;
+      }
+      if (keep[u]) pos0[u] = atomicAdd(&cntc[m], (uint32_t)__popc(keep[u]));   // this line's run inside its member's
+    }
+    SECT(50);                                       // ring filter (LDS atomics)
+    __syncthreads();                                  // every line of the chunk is counted
+    uint32_t total = 0;
+    const uint32_t myo = block_prefix_excl(cntc[tid], wsum, &total);
+    offc[tid] = myo;
+    if (tid == 0) chunk_base = total ? todo_reserve(s, total) : 0u;
+    __syncthreads();
+    SECT(51);                                       // chunk barrier, layout
+    const uint32_t cb = chunk_base;
+    if (cb != NONE32) {
+      // the survivors, member by member: a chunk's output is one compact run of the todo buffer (a few KB), written
+      // in one burst with no load behind it
+#pragma unroll
+      for (int u = 0; u < (int)REC_UNROLL; ++u) {
+        if (!keep[u]) continue;
+        uint2* out = s.todo + (size_t)cb + offc[mm[u]] + pos0[u];
+        uint32_t n = 0;
+#pragma unroll
+        for (int q = 0; q < PB_SLOTS; ++q) {
+          const uint4 v = ln[u][q >> 1];
+          if ((keep[u] >> q) & 1u) out[n++] = make_uint2((q & 1) ? v.z : v.x, pe_key((q & 1) ? v.w : v.y));
+        }
+      }
+      if (tid >= m0 && tid < m1 && dealt) seg = make_uint4(cb + myo, cntc[tid], 0u, 0u);
+    }
+    __syncthreads();
+    SECT(52);                                       // write-out
+    m0 = m1;
+  }
+  // what the deal left out: overflow-list sources, a member with more sources than a chunk -- by its own thread
+  if (has && (novf || !dealt)) {
+    uint32_t mine_ovf = 0;
+    for (uint32_t x = 0; x < novf; ++x) mine_ovf += s.ovf[(size_t)(t & 1u) * s.ovf_cap + x].x == li ? 1u : 0u;
+    const uint32_t nsrc = (dealt ? 0u : nack + nin) + mine_ovf;
+    const uint32_t base = nsrc ? todo_reserve(s, nsrc * (uint32_t)PB_SLOTS) : NONE32;
+    if (base != NONE32) {
+      Ring256 kw; kw.w0 = kw_sh[0][tid]; kw.w1 = kw_sh[1][tid]; kw.w2 = kw_sh[2][tid]; kw.w3 = kw_sh[3][tid];
+      unsigned long long learnt = learnt_sh[tid];
+      unsigned long long dummy_clock = 0; (void)dummy_clock;
+      const uint32_t n1 = records_serial(s, t, li, H, ids_untrusted, kw, learnt, nack, nin, novf, dealt ? nack + nin : 0u, s.todo + base
+#ifdef SWIM_SECTION_CLOCKS
+                                         , dummy_clock
+#endif
+                                         );
+      kw_sh[0][tid] = kw.w0; kw_sh[1][tid] = kw.w1; kw_sh[2][tid] = kw.w2; kw_sh[3][tid] = kw.w3;
+      learnt_sh[tid] = learnt;
+      seg.z = base; seg.w = n1;
+    }
+  }
+  if (has) {
+    s.kw[li] = make_ulonglong4(kw_sh[0][tid], kw_sh[1][tid], kw_sh[2][tid], kw_sh[3][tid]);
+    s.kw_head[li] = H;
+    s.kn_rec[li] = learnt_sh[tid];
+    s.todo_seg[li] = seg;
+    s.inbox_cnt[li] = seg.y + seg.w;                 // merge_kernel: entries of my list (it clears the count)
+  }
+  SECT(53);                                         // serial pass (overflow list, oversized members), final stores
+}
 
 // One thread = one member's end of tick:
 //   suspicion timers (the FIXME at src/Core.hs:141; D4), own probes that ended without an ack
@@ -654,8 +852,8 @@ __device__ __forceinline__ void records_phase(const DevState& s, uint32_t t, uin
 #ifndef SWIM_GOSSIP_BATCH       // rumours whose loads are issued together in merge_kernel
 #define SWIM_GOSSIP_BATCH 2
 #endif
-#ifndef SWIM_MERGE_WAVES
-#define SWIM_MERGE_WAVES 5
+#ifndef SWIM_MERGE_WAVES         // 4: 106 VGPRs, nothing spilled; 5 (96 VGPRs) spills the todo loop's batch -- same speed without
+#define SWIM_MERGE_WAVES 4       // records, slower with (profiles/r03s_*)
 #endif
 #ifndef SWIM_TODO_BATCH         // todo entries (explicit records' survivors) whose view cells merge_kernel loads together
 #define SWIM_TODO_BATCH 4
@@ -683,7 +881,7 @@ __device__ inline void settle_pass(const DevState& s, uint32_t li, bool up, uint
     for (uint32_t k = 0; k < nz; ++k) s.V[vidx(s, li, s.zero_slots[k])] = make_uint2(0u, 0u);
 }
 
-__global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STATE_PARAM, uint32_t t) {
+__global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STATE_PARAM, uint32_t t, uint32_t rec_inline) {
   SWIM_STATE_BIND
   __shared__ BlockCounters sh;
   __shared__ uint32_t asm_[PB_SLOTS * 2][ASM_STRIDE];   // the outgoing line is assembled here: [2 entry + word][thread]
@@ -698,10 +896,8 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
   if (blockIdx.x == 0 && threadIdx.x == 0) s.g[G_OVF0 + ((t + 1) & 1u)] = 0;  // next tick's overflow list
   const uint32_t mi = li < s.N ? s.minfo[i] : 0u;
   const bool up = mi_up(mi);
-  if (s.g[G_ANYREC]) records_phase(s, t, li, mi);  // wave-uniform: somebody wrote an explicit record this tick
   const uint32_t H = s.g[G_HEAD];
   const unsigned long long stale = stale_positions(s.g[G_PREV], H);
-  if (s.G) settle_pass(s, li, up, wmax);
 
   // ---- this member's inputs of the tick (coalesced)
   uint32_t nsent = 0, nfail = 0, cnt = 0;
@@ -715,7 +911,6 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
   if (up) {
     const uint32_t po = s.probe_out[li];
     nsent = po & 31u; nfail = (po >> 5) & 31u;
-    cnt = s.inbox_cnt[li];                           // entries of my todo list (records phase)
     pushed = s.inmask[li];
     pulled = s.ackmask[li];
     if (s.n_shards > 1)                              // Ack payloads of remote targets: one slot per probe
@@ -726,6 +921,12 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
     hot0 = s.hot[li];
     due = trow_now[li];
   }
+  // the records phase, behind the loads above (the wait for its flag -- a scalar load at the cold start of the kernel --
+  // used to stand in front of them: 7 500 clocks per wave in a tick without records, profiles/r03r_*)
+  if (rec_inline && s.g[G_ANYREC]) records_phase(s, t, li, mi, pushed | pulled SECT_ARG);   // wave-uniform: somebody wrote an explicit record this tick
+  SECT(14);                                         // records phase
+  if (up) cnt = s.inbox_cnt[li];                    // entries of my todo list
+  if (s.G) settle_pass(s, li, up, wmax);
   if (tid < KN_BITS) ring_sh[tid] = s.ring[tid];
   ctr_init(&sh);                                   // its barrier also publishes the ring
   const uint32_t pcount = mi_pbn(mi), cur = mi_buf(mi);
@@ -987,30 +1188,40 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
   if (act) {
     if (cnt) {
       // explicit records (queues the masks could not carry in full): the records phase has read the sources' lines, filtered
-      // their entries through the rings and left the survivors as this member's todo list {slot | rid << 16, key, row
-      // base, subject} -- TB entries and their view cells per round of loads, then the rule on each
+      // their entries through the rings and left the survivors as this member's todo list {slot | rid << 16, key} -- TB
+      // entries per round of loads, then their view cells, row bases and subjects in ONE round, then the rule on each
       PSITE(30);
       kn |= s.kn_rec[li];                          // ring positions of the ids the records carried
-      const uint4* td = s.todo + s.todo_off[li];
+      const uint4 sg = s.todo_seg[li];             // the list in two segments (records_kernel; one from the phase above)
+      auto td = [&](uint32_t x) -> uint2 { return s.todo[x < sg.y ? (size_t)sg.x + x : (size_t)sg.z + (x - sg.y)]; };
       constexpr int TB = SWIM_TODO_BATCH;
-      for (uint32_t x0 = 0; x0 < cnt; x0 += TB) {
-        uint4 en[TB]; uint2 ce[TB];
+      uint2 en[TB];
 #pragma unroll
-        for (int k = 0; k < TB; ++k) { en[k] = make_uint4(0u, 0u, 0u, 0u); if (x0 + k < cnt) en[k] = td[x0 + k]; }
+      for (int k = 0; k < TB; ++k) { en[k] = make_uint2(0u, 0u); if ((uint32_t)k < cnt) en[k] = td((uint32_t)k); }
+      for (uint32_t x0 = 0; x0 < cnt; x0 += TB) {
+        uint2 ce[TB]; uint32_t cb[TB], cs[TB];
+        uint2 cur_en[TB];
 #pragma unroll
         for (int k = 0; k < TB; ++k) {
-          ce[k] = make_uint2(0u, 0u);
-          if (x0 + k < cnt && pe_slot(en[k].x) + 1 != my_slot1 && !ABL(ABL_V_LOAD)) ce[k] = s.V[vidx(s, li, pe_slot(en[k].x))];
+          cur_en[k] = en[k];
+          ce[k] = make_uint2(0u, 0u); cb[k] = 0u; cs[k] = 0u;
+          const uint32_t slot = pe_slot(en[k].x);
+          if (x0 + k < cnt && slot + 1 != my_slot1) {
+            if (!ABL(ABL_V_LOAD)) ce[k] = s.V[vidx(s, li, slot)];
+            cb[k] = s.slot_base[slot]; cs[k] = s.subject_of[slot];
+          }
         }
+#pragma unroll
+        for (int k = 0; k < TB; ++k) { en[k] = make_uint2(0u, 0u); if (x0 + TB + k < cnt) en[k] = td(x0 + TB + k); }   // the next batch's entries travel meanwhile
         for (uint32_t k = 0; k < (uint32_t)TB && x0 + k < cnt; ++k) {
-          uint4 e4 = en[0]; uint2 e = ce[0];
+          uint2 e2 = cur_en[0], e = ce[0]; uint32_t sb = cb[0], sj = cs[0];
           bool again = false;                      // an earlier entry of the batch is about the same subject: look again
 #pragma unroll
-          for (int j = 1; j < TB; ++j) if (k == (uint32_t)j) { e4 = en[j]; e = ce[j]; }
+          for (int j = 1; j < TB; ++j) if (k == (uint32_t)j) { e2 = cur_en[j]; e = ce[j]; sb = cb[j]; sj = cs[j]; }
 #pragma unroll
-          for (int j = 0; j < TB - 1; ++j) again |= (uint32_t)j < k && pe_slot(en[j].x) == pe_slot(e4.x);
+          for (int j = 0; j < TB - 1; ++j) again |= (uint32_t)j < k && pe_slot(cur_en[j].x) == pe_slot(e2.x);
           PSTAT(14);
-          examine_with(pe_slot(e4.x), e4.y, 2u, true, pe_rid(e4.x), again ? (HAVE_BASE | HAVE_SUBJ) : EX_ALL, e, e4.z, e4.w);
+          examine_with(pe_slot(e2.x), e2.y, 2u, true, pe_rid(e2.x), again ? (HAVE_BASE | HAVE_SUBJ) : EX_ALL, e, sb, sj);
         }
       }
     }
@@ -1771,7 +1982,6 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
     if (changes_sh) s.blk[(size_t)s.nblocks * C_COUNT + C_CHANGES] += changes_sh;
     s.g[G_PREV] = s.g[G_HEAD];
     s.g[G_HEAD] = s.g[G_NRUM];
-    s.g[G_TODO] = 0;                                // the records phase's region counter
     s.g[G_ANYREC] = s.n_shards > 1 ? 1u : 0u;       // set by whoever writes an explicit record (the exchange kernels may)
     // a line is rewritten every tick and replaces ids outside [H - KW_BITS, H + RID_NEAR) by "no id"; an id born at
     // distance r < RID_NEAR above the head sits at r - D one tick later (D = ids of the tick) and would wrap
@@ -1780,6 +1990,7 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
     // are out of the game anyway (explicit records), exactness does not depend on them
     s.g[G_RIDS_OFF] = (s.g[G_HEAD] - s.g[G_PREV] > RID_MASK + 1u - RID_NEAR - KW_BITS) ? 1u : 0u;
   }
+  for (uint32_t k = threadIdx.x; k < TODO_REGIONS; k += blockDim.x) s.todo_n[k * 16u] = 0;   // the todo buffer's regions
   if (t)                                                            // the deadline chains tick t-1 consumed
     for (uint32_t k = threadIdx.x; k < s.tovf_nsub; k += blockDim.x)
       s.tovf_n[((((t - 1u) % s.S) * 2u + ((((t - 1u) / s.S) & 1u) ^ 1u)) * s.tovf_nsub + k) * 16u] = 0;

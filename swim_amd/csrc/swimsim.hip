@@ -234,12 +234,24 @@ Offsets robust_offsets(const swimsim* h, uint32_t t) {
   return off;
 }
 
+// Explicit records are read by records_kernel (its own launch: a kernel boundary costs ~10 us on this chip, profiles/r03i_*)
+// on handles whose every tick has them for every member -- message loss (after a burst of rumour ids no queue travels
+// as a mask), shards (the exchange kernels push records); a lossless handle meets them in a few ticks per hundred and
+// reads them in a phase at the start of merge_kernel instead.  Same result either way (tests run both on both).
+bool records_kernel_every_tick(const swimsim* h) {
+  const char* force = std::getenv("SWIMSIM_RECORDS_KERNEL");             // test / measurement knob: 0 = never, 1 = always
+  if (force && (force[0] == '0' || force[0] == '1')) return force[0] == '1';
+  return h->cfg.loss_ppm != 0 || h->d.n_shards > 1;
+}
+
 template <int PMAX>
 void launch_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev) {
   if (ev) (void)hipEventRecord(ev[0], h->stream);
   hipLaunchKernelGGL((probe_kernel<PMAX>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, tk, robust_offsets(h, t));
   if (ev) (void)hipEventRecord(ev[1], h->stream);
-  hipLaunchKernelGGL(merge_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t);
+  const bool rk = records_kernel_every_tick(h);
+  if (rk) hipLaunchKernelGGL(records_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
+  hipLaunchKernelGGL(merge_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, rk ? 0u : 1u);
   if (ev) (void)hipEventRecord(ev[2], h->stream);
 }
 
@@ -328,7 +340,9 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     // member (every delivery, when the masks are off) with headroom; overruns are loud (SWIMSIM_ERR_CAPACITY)
     const double l = c.loss_ppm / 1e6, pf = 1.0 - (1.0 - l) * (1.0 - l);
     const double lam = 2.0 * c.probes_per_tick + 4.0 * c.probes_per_tick * c.indirect_k * pf;
-    d.todo_cap = (uint32_t)std::min<double>(2.0e9, (double)N * (1.25 * lam + 2.0) * PB_SLOTS + 65536.0);
+    // (per region: a workgroup reserves from region b mod TODO_REGIONS; small clusters have fewer workgroups than regions)
+    const uint32_t nb = (N + BLOCK - 1) / BLOCK, share = std::min<uint32_t>(TODO_REGIONS, nb);
+    d.todo_cap = (uint32_t)std::min<double>(3.0e7, ((double)N * (1.25 * lam + 2.0) * PB_SLOTS) / share + 65536.0);
   }
   d.ord_cap = 0; d.r_cap = d.p_cap = d.x_cap = 0;
   CK(dev_alloc(h, &d.minfo, NT, 0));
@@ -338,8 +352,9 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   CK(dev_alloc(h, &d.inbox_cnt, N, 0));
   CK(dev_alloc(h, &d.inbox, (size_t)N * d.inbox_cap, 0));
   CK(dev_alloc(h, &d.hot, N, 0));
-  CK(dev_alloc(h, &d.todo, (size_t)d.todo_cap, 0));
-  CK(dev_alloc(h, &d.todo_off, N, 0));
+  CK(dev_alloc(h, &d.todo, (size_t)d.todo_cap * TODO_REGIONS, 0));
+  CK(dev_alloc(h, &d.todo_seg, N, 0));
+  CK(dev_alloc(h, &d.todo_n, (size_t)TODO_REGIONS * 16, 0));
   CK(dev_alloc(h, &d.kn_rec, N, 0));
   CK(dev_alloc(h, &d.pk, (size_t)N, 0));
   CK(dev_alloc(h, &d.inmask, (size_t)N, 0));
@@ -354,7 +369,10 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   CK(dev_alloc(h, &d.trow, (size_t)N * d.S, 0));
   // overflow cells per (deadline row, cycle parity): members that accept more than 7 suspicions in one tick --
   // a few per mille of the members without loss, one in three at 1 % loss and a million members
-  d.tovf_cap = std::max<uint32_t>(1024u, c.loss_ppm ? N / 2 : N / 16);
+  // (measured at 30 % loss, profiles/r03w_*: with N / 2 cells the pools ran dry, the cells said "look at every view row" and
+  // 89 % of merge_kernel's wave time went into those scans -- under heavy loss most members accept more than 7 suspicions
+  // in a tick, several chained cells each)
+  d.tovf_cap = std::max<uint32_t>(1024u, c.loss_ppm >= 50000u ? 4u * N : c.loss_ppm >= 20000u ? 2u * N : c.loss_ppm ? N / 2 : N / 16);
   d.tovf_nsub = 1;
   while (d.tovf_nsub < 64u && d.tovf_nsub * 2u <= d.nblocks) d.tovf_nsub *= 2u;
   d.tovf_sub_cap = d.tovf_cap / d.tovf_nsub;
@@ -900,7 +918,9 @@ int swimsim_shard_phase3(swimsim_t* h, const uint32_t* p_counts_in, const uint32
   const uint32_t t = (uint32_t)h->tick;
   hipLaunchKernelGGL(ingest_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, peer_counts(h, p_counts_in), peer_counts(h, x_counts_in));
   if (h->timing) (void)hipEventRecord(h->tick_ev[1], h->stream);
-  hipLaunchKernelGGL(merge_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t);
+  const bool rk = records_kernel_every_tick(h);
+  if (rk) hipLaunchKernelGGL(records_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
+  hipLaunchKernelGGL(merge_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, rk ? 0u : 1u);
   if (h->timing) (void)hipEventRecord(h->tick_ev[2], h->stream);
   if (h->d.G) hipLaunchKernelGGL(settle_publish_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t);
   rc = finish_phase(h, nullptr);
