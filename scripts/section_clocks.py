@@ -29,8 +29,17 @@ def main():
     sc.targetScheme = 1 if os.environ.get("SCHEME") == "robust" else 0
     if os.environ.get("GC"):
         sc.gcTicks = _abi.GC_AUTO
+    churn = int(os.environ.get("CHURN", 0))        # per mille of the members crash and come back (50 ticks later) per 100 ticks
+    if churn:
+        from swim_amd import Config, SimConfig
+        sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=9, maxSubjects=12000, gcTicks=_abi.GC_AUTO, eventMask=1)
+        crashes = []
     s = Sim.create(abi, sc)
     workloads.apply_crashes(s, crashes)
+    if churn:
+        T = warm + ticks + 60
+        for (t, m) in workloads.hashed_crashes(n, 9, churn * T // 100, 1000, 5, T - 60):
+            s.crash(m, t); s.scheduleFault(t + 50, m, True)
     s.step(warm)
     out = (C.c_uint64 * 64)()
     lib.swimsim_debug_sections(s._h, out)   # zero the table

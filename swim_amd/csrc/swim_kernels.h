@@ -1078,31 +1078,54 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
     else if ((e.y - 1 + s.S) % s.S == row_now) tput(slot + 1);
   };
   SECT(1);                                          // own line
-  if (act) {
-    // phase 1: suspicion deadlines, evaluated on the start-of-tick view
-    PSITE(20);
-    if (woke || (uint32_t)(due.w >> 16) == TR_FULL) {
-      PSTAT(7); SECT_COUNT(16);
-      // a member that just came back up (its cells may be stale, their chains gone) or a cell that says "look
-      // everywhere": every view row is a candidate.  The member that came back also rebuilds its cells from
-      // what it finds: deadlines still ahead go to the cell of their tick.
-      if (woke) for (uint32_t row = 0; row < s.S; ++row) s.trow[(size_t)row * s.N + li] = make_uint4(0u, 0u, 0u, 0u);
-      const uint32_t ns = min(s.g[G_NSLOTS], s.R_phys);
-      for (uint32_t r = 0; r < ns; ++r) {
-        const uint2 e = s.V[vidx(s, li, r)];
-        if ((e.x & 3u) != ST_SUSPECT || !s.slot_used[r]) continue;
-        const uint32_t dl = e.y - 1 + s.S;
-        if (dl <= t) { if (woke || dl == t) examine(r, (e.x & ~3u) | ST_DEAD, 1u, false, 0u); }
-        else if (woke && dl % s.S == row_now) tput(r + 1);     // a pulled Suspect (since = t): this tick's own cell
-        else if (woke) {
-          const size_t ix = (size_t)(dl % s.S) * s.N + li;
-          const uint4 cell = s.trow[ix];
-          TimerCell c2; c2.lo = cell.x | ((unsigned long long)cell.y << 32); c2.hi = cell.z | ((unsigned long long)cell.w << 32); c2.n = 0;
-          while (c2.n < TR_PAY && tc_get(cell, c2.n)) c2.n++;
-          tc_put_simple(c2, r + 1);
-          s.trow[ix] = tc_pack(c2);
+  // phase 1: suspicion deadlines, evaluated on the start-of-tick view
+  {
+    // A member that just came back up (its cells may be stale, their chains gone) or a cell that says "look
+    // everywhere": every view row is a candidate.  The member that came back also rebuilds its cells from what it
+    // finds: deadlines still ahead go to the cell of their tick.  The WAVE walks the rows for it, 64 at a time (one
+    // lane alone read them one after the other: thousands of dependent round trips per member that woke up, the
+    // whole launch waiting for the slowest wave -- 18 ms per tick with 25 rejoins per tick among 2 M members and
+    // 6 700 rows in use, profiles/r02o_*): each lane loads one row's cell of the member in turn, the Suspect cells
+    // found are handed to the member's own lane, which applies the rule.
+    const bool scan_me = act && (woke || (uint32_t)(due.w >> 16) == TR_FULL);
+    unsigned long long scanners = __ballot(scan_me);
+    if (scanners) {
+      PSITE(20);
+      if (scan_me) { PSTAT(7); SECT_COUNT(16); }
+      if (scan_me && woke) for (uint32_t row = 0; row < s.S; ++row) s.trow[(size_t)row * s.N + li] = make_uint4(0u, 0u, 0u, 0u);
+      const uint32_t ns = min(s.g[G_NSLOTS], s.R_phys), lane = tid & 63u;
+      for (; scanners; scanners &= scanners - 1ull) {
+        const int L = __ffsll((unsigned long long)scanners) - 1;
+        const uint32_t li_L = (uint32_t)__builtin_amdgcn_readlane((int)li, L);
+        for (uint32_t r0 = 0; r0 < ns; r0 += 64u) {
+          const uint32_t r = r0 + lane;
+          uint2 e = make_uint2(0u, 0u);
+          if (r < ns) e = s.V[vidx(s, li_L, r)];
+          unsigned long long hits = __ballot(r < ns && (e.x & 3u) == ST_SUSPECT && s.slot_used[r < ns ? r : 0u]);
+          for (; hits; hits &= hits - 1ull) {
+            const int src = __ffsll((unsigned long long)hits) - 1;
+            const uint32_t rh = r0 + (uint32_t)src;
+            const uint2 eh = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)e.x, src), (uint32_t)__builtin_amdgcn_readlane((int)e.y, src));
+            if ((int)lane != L) continue;            // the member's own lane rules on what the wave found
+            const uint32_t dl = eh.y - 1 + s.S;
+            if (dl <= t) { if (woke || dl == t) examine_with(rh, (eh.x & ~3u) | ST_DEAD, 1u, false, 0u, HAVE_CELL, eh, 0u, 0u); }
+            else if (woke && dl % s.S == row_now) tput(rh + 1);     // a pulled Suspect (since = t): this tick's own cell
+            else if (woke) {
+              const size_t ix = (size_t)(dl % s.S) * s.N + li;
+              const uint4 cell = s.trow[ix];
+              TimerCell c2; c2.lo = cell.x | ((unsigned long long)cell.y << 32); c2.hi = cell.z | ((unsigned long long)cell.w << 32); c2.n = 0;
+              while (c2.n < TR_PAY && tc_get(cell, c2.n)) c2.n++;
+              tc_put_simple(c2, rh + 1);
+              s.trow[ix] = tc_pack(c2);
+            }
+          }
         }
       }
+    }
+  }
+  if (act) {
+    if (woke || (uint32_t)(due.w >> 16) == TR_FULL) {
+      // (walked by the wave above)
     } else if (timer_due) {
       // the first DB view cells of this tick's cell were loaded above; a slot that is twice in the cell (two
       // suspicions of one subject accepted in one tick) is read again the second time: this thread may just have

@@ -369,10 +369,11 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   CK(dev_alloc(h, &d.trow, (size_t)N * d.S, 0));
   // overflow cells per (deadline row, cycle parity): members that accept more than 7 suspicions in one tick --
   // a few per mille of the members without loss, one in three at 1 % loss and a million members
-  // (measured at 30 % loss, profiles/r03w_*: with N / 2 cells the pools ran dry, the cells said "look at every view row" and
-  // 89 % of merge_kernel's wave time went into those scans -- under heavy loss most members accept more than 7 suspicions
-  // in a tick, several chained cells each)
-  d.tovf_cap = std::max<uint32_t>(1024u, c.loss_ppm >= 50000u ? 4u * N : c.loss_ppm >= 20000u ? 2u * N : c.loss_ppm ? N / 2 : N / 16);
+  // Sized for 288 GB: 4 cells per member and (row, parity), at most 24 GB in all.  Measured (profiles/r03w_*, r03ac_*): with
+  // N / 2 cells at 30 % loss, or N / 16 with 25 crashes and 25 rejoins per tick among 2 M members (every member accepts ~25
+  // suspicions per tick: four chained cells), the pools ran dry, the cells said "look at every view row" and 60-90 % of
+  // merge_kernel's wave time went into those scans.  The pools are only touched when used.
+  d.tovf_cap = (uint32_t)std::max<uint64_t>(1024u, std::min<uint64_t>(4ull * N, 24000000000ull / (32ull * d.S)));
   d.tovf_nsub = 1;
   while (d.tovf_nsub < 64u && d.tovf_nsub * 2u <= d.nblocks) d.tovf_nsub *= 2u;
   d.tovf_sub_cap = d.tovf_cap / d.tovf_nsub;
