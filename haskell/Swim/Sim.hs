@@ -28,7 +28,9 @@ module Swim.Sim
   ) where
 
 import           Control.Concurrent.MVar (MVar, newMVar, withMVar)
+import           Control.Exception (SomeException, bracket, throwIO, try)
 import           Control.Monad (forM, unless, when)
+import           Data.IORef (newIORef, readIORef, writeIORef)
 import           Control.Monad.IO.Class (liftIO)
 import           Data.Conduit (Source, yield)
 import           Data.Int (Int32, Int64)
@@ -65,6 +67,8 @@ data SimConfig = SimConfig
   , simDevice         :: Int32
   , simTargetScheme   :: Word32   -- 0 = kRandomMembers (the reference), 1 = robust round-robin (src/Core.hs:232 FIXME)
   , simJoinPull       :: Word32   -- 1 = a member that comes up merges a join host's member map (`joinHosts`, src/Types.hs:47)
+  , simShardIndex     :: Word32   -- this handle's shard of a cluster of simNShards handles (one per GPU); 0 of 1 = unsharded
+  , simNShards        :: Word32   -- 0 or 1 = one handle steps the whole population (stepN); > 1 = stepShard
   }
 
 data SwimsimT
@@ -100,7 +104,7 @@ foreign import ccall "wrapper" mkExchange :: ExchangeFn -> IO (FunPtr ExchangeFn
 foreign import ccall safe   "swimsim_shard_step"    c_shard_step    :: Ptr SwimsimT -> Word32 -> FunPtr ExchangeFn -> Ptr () -> IO CInt
 
 defaultSimConfig :: Config -> SimConfig
-defaultSimConfig c = SimConfig c 128 1 0 0 0 0 0 0 0 0
+defaultSimConfig c = SimConfig c 128 1 0 0 0 0 0 0 0 0 0 1
 
 memberNameOf :: Word32 -> String
 memberNameOf i = 'm' : show i
@@ -122,6 +126,8 @@ configureSim SimConfig{..} =
     pokeByteOff p swimsimConfig_device             simDevice
     pokeByteOff p swimsimConfig_target_scheme      simTargetScheme
     pokeByteOff p swimsimConfig_join_pull          simJoinPull
+    pokeByteOff p swimsimConfig_shard_index        simShardIndex
+    pokeByteOff p swimsimConfig_n_shards           (max 1 simNShards)
     -- the failure text comes back through OUR buffer: the library's per-thread text could belong to another
     -- OS thread by the time a second `safe` call reads it
     rc <- c_create p ph perr 512
@@ -213,11 +219,47 @@ foreign import ccall unsafe "swimwire_encode"     c_wire_encode :: Ptr () -> CSi
 foreign import ccall unsafe "swimwire_decode"     c_wire_decode :: Ptr Word8 -> CSize -> Ptr () -> CSize -> Ptr CSize -> IO CInt
 foreign import ccall unsafe "swimwire_last_error" c_wire_error  :: IO CString
 
+-- Names travel as UTF-8 (as swim_amd/wire.py sends them); a name longer than the record's field, or an Ack payload longer
+-- than its array, is REFUSED before anything is poked (`fits`): the C ABI promises to refuse over-long names, and a
+-- poke past the 408-byte swimwire_msg_t would corrupt the next message or the allocaBytes buffer.
+utf8 :: String -> [Word8]
+utf8 = concatMap enc
+  where enc ch | c < 0x80    = [fromIntegral c]
+               | c < 0x800   = [0xC0 + fromIntegral (c `div` 64), 0x80 + fromIntegral (c `mod` 64)]
+               | c < 0x10000 = [0xE0 + fromIntegral (c `div` 4096), 0x80 + fromIntegral ((c `div` 64) `mod` 64), 0x80 + fromIntegral (c `mod` 64)]
+               | otherwise   = [0xF0 + fromIntegral (c `div` 262144), 0x80 + fromIntegral ((c `div` 4096) `mod` 64),
+                                0x80 + fromIntegral ((c `div` 64) `mod` 64), 0x80 + fromIntegral (c `mod` 64)]
+          where c = ord ch
+
+unUtf8 :: [Word8] -> String
+unUtf8 [] = []
+unUtf8 (b : bs)
+  | b < 0x80  = chr (fromIntegral b) : unUtf8 bs
+  | b < 0xE0  = multi 1 (fromIntegral b - 0xC0)
+  | b < 0xF0  = multi 2 (fromIntegral b - 0xE0)
+  | otherwise = multi 3 (fromIntegral b - 0xF0)
+  where multi k hi = let (cont, rest) = splitAt k bs
+                     in chr (foldl (\acc x -> acc * 64 + (fromIntegral x - 0x80)) hi cont) : unUtf8 rest
+
+nameFits :: String -> Bool
+nameFits str = length (utf8 str) <= fromIntegral cSwimwireNameMax
+
+-- | Nothing = the message fits a swimwire_msg_t; Just reason otherwise (checked by encodeEnvelope before any poke).
+fits :: Message -> Maybe String
+fits m = case m of
+  Ping{..}         -> nm node
+  IndirectPing{..} -> nm node
+  Ack{..}          -> if length payload <= fromIntegral cSwimwirePayloadMax then Nothing else Just "Ack payload longer than SWIMWIRE_PAYLOAD_MAX"
+  Suspect{..}      -> nm node
+  Alive{..}        -> nm node
+  Dead{..}         -> maybe (nm deadFrom) Just (nm node)
+  where nm str = if nameFits str then Nothing else Just "node name longer than SWIMWIRE_NAME_MAX bytes of UTF-8"
+
 pokeName :: Ptr () -> Int -> String -> IO ()
-pokeName p off str = pokeArray (p `plusPtr` off) (map (fromIntegral . ord) (take (fromIntegral cSwimwireNameMax) str) ++ [0 :: Word8])
+pokeName p off str = pokeArray (p `plusPtr` off) (utf8 str ++ [0 :: Word8])      -- `fits` has checked the length
 
 peekName :: Ptr () -> Int -> IO String
-peekName p off = map (chr . fromIntegral) . takeWhile (/= 0) <$> peekArray (fromIntegral cSwimwireNameMax + 1) (p `plusPtr` off :: Ptr Word8)
+peekName p off = unUtf8 . takeWhile (/= 0) <$> peekArray (fromIntegral cSwimwireNameMax + 1) (p `plusPtr` off :: Ptr Word8)
 
 pokeMessage :: Ptr () -> Message -> IO ()
 pokeMessage p m = do
@@ -253,7 +295,9 @@ peekMessage p = do
 
 -- | `encode . Envelope` (src/Types.hs:96-103); Left = the codec's reason (more than 255 messages, > 65 535 bytes ..).
 encodeEnvelope :: [Message] -> IO (Either String BS.ByteString)
-encodeEnvelope msgs =
+encodeEnvelope msgs
+  | (why : _) <- [w | Just w <- map fits msgs] = return (Left why)
+  | otherwise =
   allocaBytes (max 1 (length msgs) * swimwireMsgSize) $ \arr -> allocaBytes (fromIntegral cSwimwireMaxDatagram) $ \buf -> alloca $ \pn -> do
     forM_' (zip [0 ..] msgs) $ \(k, m) -> pokeMessage (arr `plusPtr` (k * swimwireMsgSize)) m
     rc <- c_wire_encode arr (fromIntegral (length msgs)) buf (fromIntegral cSwimwireMaxDatagram) pn
@@ -281,13 +325,18 @@ decodeEnvelope bytes = BSU.unsafeUseAsCStringLen bytes $ \(src, len) ->
 -- the cluster must make the same call.  With SWIMSIM_SHARD_REPLICATED_MASKS=1 in the environment round 1 also
 -- all-gathers every shard's slice of the two tables of swimsim_shard_gather_buffers (counts of the 8-byte kind at
 -- [nShards .. 2 nShards), of the 1-byte kind at [2 nShards .. 3 nShards)).
+-- The handle must have been configured as a shard (simShardIndex / simNShards).  A Haskell exception in `exchange` does
+-- not cross the C frames: the callback reports failure (1), the library returns SWIMSIM_ERR_STATE and the exception is
+-- re-thrown here; the FunPtr is freed on every path.
 stepShard :: Sim -> Word32 -> Int -> (Int -> [Word32] -> IO [Word32]) -> IO ()
 stepShard s nticks nShards exchange = withSim s $ \h -> do
-  cb <- mkExchange $ \_ rnd pout pin -> do
-          out <- peekArray (3 * nShards) pout
-          got <- exchange (fromIntegral rnd) out
-          pokeArray pin (take (3 * nShards) (got ++ repeat 0))
-          return 0
-  rc <- c_shard_step h nticks cb nullPtr
-  freeHaskellFunPtr cb
-  check h rc
+  failure <- newIORef (Nothing :: Maybe SomeException)
+  let body _ rnd pout pin = do
+        r <- try $ do out <- peekArray (3 * nShards) pout
+                      got <- exchange (fromIntegral rnd) out
+                      pokeArray pin (take (3 * nShards) (got ++ repeat 0))
+        case r of
+          Right () -> return 0
+          Left e   -> writeIORef failure (Just e) >> return 1
+  rc <- bracket (mkExchange body) freeHaskellFunPtr $ \cb -> c_shard_step h nticks cb nullPtr
+  readIORef failure >>= maybe (check h rc) throwIO

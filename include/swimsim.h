@@ -122,8 +122,8 @@ typedef struct swimsim_config {
  * tick's changes are applied); none => no pull.  For every subject s != m that has a view row, m's entry becomes
  * max(own entry, the host's entry) -- the host itself counts as Alive at its own incarnation --, with
  * lastChange = t and a suspicion deadline t + suspicion_ticks for a pulled Suspect.  A pulled entry is a view
- * change like any other (counters, digest), but is not gossiped on and raises no event.  Not available on
- * sharded handles (the host may live on another shard). */
+ * change like any other (counters, digest), but is not gossiped on and raises no event.  On sharded handles the
+ * host may live on another shard: its owner sends what it knows in exchange round 0 (swimsim_shard_phase0 below). */
 
 #define SWIMSIM_GC_AUTO 0xFFFFFFFFu
 

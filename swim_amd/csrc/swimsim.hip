@@ -52,6 +52,8 @@ struct swimsim {
   double probe_ms = 0, merge_ms = 0; uint64_t timed_ticks = 0;
   bool poisoned = false;
   std::string err;
+  std::vector<swimsim_view_entry_t> settled_alive;   // settled subjects that stay listed (Alive at i > 0), as of settled_alive_tick
+  uint64_t settled_alive_tick = ~0ull;
   // sharded stepping (swimsim_shard_*): which phase of the current tick comes next, the tick's fault slice
   int shard_phase = 0;
   bool begun = false;                          // swimsim_shard_phase0 applied this tick's faults already (part A of begin_kernel)
@@ -319,7 +321,17 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   d.R_max = c.max_subjects; d.event_cap = c.event_cap; d.event_mask = c.event_mask;
   d.G = c.gc_ticks;
   // settled rows are cleared by the next merge and reusable the tick after: room for the rows in transit
-  d.R_phys = std::min<uint32_t>(65534u, d.R_max + (d.G ? std::min<uint32_t>(d.R_max, 1024u) : 0u));
+  // (rows in transit can be as many as were live: a correlated burst settling in one tick while new subjects arrive.  The
+  // oracle keeps 2 x max_subjects columns; so does the product while the view stays under 64 GB, else what fits, at least 1024)
+  {
+    uint32_t transit = 0;
+    if (d.G) {
+      const uint64_t row_bytes = 8ull * (VTILE ? (uint64_t)(N + VTILE - 1) / VTILE * VTILE : N);
+      const uint64_t fit = 64000000000ull / row_bytes;
+      transit = (uint32_t)std::min<uint64_t>(d.R_max, std::max<uint64_t>(1024u, fit > d.R_max ? fit - d.R_max : 0u));
+    }
+    d.R_phys = std::min<uint32_t>(65534u, d.R_max + transit);
+  }
   d.nblocks = (N + BLOCK - 1) / BLOCK;
   d.inbox_cap = c.inbox_cap;
   d.ovf_cap = std::max<uint32_t>(1u << 16, N / 8);
@@ -478,6 +490,10 @@ int swimsim_schedule_fault(swimsim_t* h, uint64_t tick, uint32_t member, uint8_t
   if (!h) return SWIMSIM_ERR_INVALID;
   if (member >= h->d.NT || up > 1) return set_err(h, SWIMSIM_ERR_INVALID, "schedule_fault: bad member/up");
   if (tick < h->tick || tick >= 0xFFFFFFFEull) return set_err(h, SWIMSIM_ERR_INVALID, "schedule_fault: tick in the past");
+  // a sharded tick in progress has applied (phase 0) or uploaded (phase 1) its slice of the schedule: a change for that very
+  // tick would shift the slice under it (an applied fault kept and applied again, the new one dropped)
+  if (tick == h->tick && (h->begun || h->shard_phase != 0))
+    return set_err(h, SWIMSIM_ERR_STATE, "schedule_fault: the current tick is in progress on this shard (schedule it before phase 0 / phase 1)");
   Fault f{(uint32_t)tick, member, up, h->fault_order++};
   auto pos = std::upper_bound(h->faults.begin(), h->faults.end(), f, [](const Fault& a, const Fault& b) {
     return a.tick != b.tick ? a.tick < b.tick : a.order < b.order; });
@@ -615,17 +631,25 @@ int swimsim_read_view(swimsim_t* h, uint32_t observer, swimsim_view_entry_t* buf
     own.push_back(subj[r]);
   }
   if (h->d.G) {
-    // settled subjects: Alive@i (i > 0) stays a listed member, Dead ones were removed (removeDeadNodes)
-    std::vector<uint32_t> bk(h->d.NT), bs(h->d.NT);
-    HIPCHK(h, hipMemcpy(bk.data(), h->d.base_key, (size_t)h->d.NT * 4, hipMemcpyDeviceToHost));
-    HIPCHK(h, hipMemcpy(bs.data(), h->d.base_since, (size_t)h->d.NT * 4, hipMemcpyDeviceToHost));
-    std::sort(own.begin(), own.end());
-    for (uint32_t sj = 0; sj < h->d.NT; ++sj) {
-      if (!bk[sj] || (bk[sj] & 3u) != ST_ALIVE || sj == observer || std::binary_search(own.begin(), own.end(), sj)) continue;
-      swimsim_view_entry_t e{};
-      e.subject = sj; e.incarnation = bk[sj] >> 2; e.state = ST_ALIVE; e.since_tick = bs[sj];
-      ents.push_back(e);
+    // settled subjects: Alive@i (i > 0) stays a listed member, Dead ones were removed (removeDeadNodes).  The list of
+    // settled-Alive subjects is the same for every observer: fetched once per tick (two N-sized copies and a scan per
+    // CALL made reading many observers' views quadratic)
+    if (h->settled_alive_tick != h->tick) {
+      std::vector<uint32_t> bk(h->d.NT), bs(h->d.NT);
+      HIPCHK(h, hipMemcpy(bk.data(), h->d.base_key, (size_t)h->d.NT * 4, hipMemcpyDeviceToHost));
+      HIPCHK(h, hipMemcpy(bs.data(), h->d.base_since, (size_t)h->d.NT * 4, hipMemcpyDeviceToHost));
+      h->settled_alive.clear();
+      for (uint32_t sj = 0; sj < h->d.NT; ++sj)
+        if (bk[sj] && (bk[sj] & 3u) == ST_ALIVE) {
+          swimsim_view_entry_t e{};
+          e.subject = sj; e.incarnation = bk[sj] >> 2; e.state = ST_ALIVE; e.since_tick = bs[sj];
+          h->settled_alive.push_back(e);
+        }
+      h->settled_alive_tick = h->tick;
     }
+    std::sort(own.begin(), own.end());
+    for (const swimsim_view_entry_t& e : h->settled_alive)
+      if (e.subject != observer && !std::binary_search(own.begin(), own.end(), e.subject)) ents.push_back(e);
   }
   std::sort(ents.begin(), ents.end(), [](const swimsim_view_entry_t& a, const swimsim_view_entry_t& b) { return a.subject < b.subject; });
   *n_out = ents.size();
@@ -978,7 +1002,7 @@ int swimsim_shard_step(swimsim_t* h, uint32_t nticks, swimsim_exchange_fn xchg, 
       if (rc) return rc;
       if (need) {
         std::fill(in.begin(), in.end(), 0u);
-        if (xchg(ctx, 0, out.data(), in.data())) return set_err(h, SWIMSIM_ERR_STATE, "shard_step: the exchange callback failed in round 0");
+        if (xchg(ctx, 0, out.data(), in.data())) { h->poisoned = true; return set_err(h, SWIMSIM_ERR_STATE, "shard_step: the exchange callback failed in round 0 (the tick is half done: the handle is poisoned)"); }
         rc = swimsim_shard_join_ingest(h, in.data());
         if (rc) return rc;
       }
@@ -991,11 +1015,11 @@ int swimsim_shard_step(swimsim_t* h, uint32_t nticks, swimsim_exchange_fn xchg, 
         out[2 * G + p] = p == h->d.shard ? 0u : h->d.N;
       }
     std::fill(in.begin(), in.end(), 0u);
-    if (xchg(ctx, 1, out.data(), in.data())) return set_err(h, SWIMSIM_ERR_STATE, "shard_step: the exchange callback failed in round 1");
+    if (xchg(ctx, 1, out.data(), in.data())) { h->poisoned = true; return set_err(h, SWIMSIM_ERR_STATE, "shard_step: the exchange callback failed in round 1 (the tick is half done: the handle is poisoned)"); }
     rc = swimsim_shard_phase2(h, in.data(), out.data());
     if (rc) return rc;
     std::fill(in.begin(), in.end(), 0u);
-    if (xchg(ctx, 2, out.data(), in.data())) return set_err(h, SWIMSIM_ERR_STATE, "shard_step: the exchange callback failed in round 2");
+    if (xchg(ctx, 2, out.data(), in.data())) { h->poisoned = true; return set_err(h, SWIMSIM_ERR_STATE, "shard_step: the exchange callback failed in round 2 (the tick is half done: the handle is poisoned)"); }
     rc = swimsim_shard_phase3(h, in.data() + G, in.data() + 2 * G);
     if (rc) return rc;
     if (h->d.G) {
@@ -1003,7 +1027,7 @@ int swimsim_shard_step(swimsim_t* h, uint32_t nticks, swimsim_exchange_fn xchg, 
       rc = swimsim_shard_settle_counts(h, out.data());
       if (rc) return rc;
       std::fill(in.begin(), in.end(), 0u);
-      if (xchg(ctx, 3, out.data(), in.data())) return set_err(h, SWIMSIM_ERR_STATE, "shard_step: the exchange callback failed in round 3");
+      if (xchg(ctx, 3, out.data(), in.data())) { h->poisoned = true; return set_err(h, SWIMSIM_ERR_STATE, "shard_step: the exchange callback failed in round 3 (the tick is half done: the handle is poisoned)"); }
       rc = swimsim_shard_settle_commit(h, in.data());
       if (rc) return rc;
     }

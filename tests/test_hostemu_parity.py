@@ -266,3 +266,4 @@ def test_state_by_pointer_build_gives_the_same_run(oracle_abi):
     sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=9, lossPpm=30000, eventMask=0x1F, suspicionTicks=6, maxSubjects=600)
     a, b = make_pair(oracle_abi, emu, sc, crashes, [(45, m, True) for (_, m) in crashes[:20]])
     run_lockstep(a, b, 60, 5, observers=(0, 1, n - 1), members=(0, 1, n - 1))
+
