@@ -71,6 +71,12 @@ __device__ inline unsigned long long wave_sum64(unsigned long long x) {
   return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, 63) |
          ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), 63) << 32);
 }
+// inclusive prefix sum over the lanes of a wave (the DPP steps of wave_sum leave it in every lane)
+__device__ inline unsigned wave_prefix_incl(unsigned x) {
+  x += SWIM_DPP(x, 0x111, 0xf); x += SWIM_DPP(x, 0x112, 0xf); x += SWIM_DPP(x, 0x114, 0xf); x += SWIM_DPP(x, 0x118, 0xf);
+  x += SWIM_DPP(x, 0x142, 0xa); x += SWIM_DPP(x, 0x143, 0xc);
+  return x;
+}
 // a per-lane count into the block's counter: one LDS atomic per wave (wave-uniform call)
 __device__ inline void ctr_add_wave(BlockCounters* sh, int which, unsigned x) {
   const unsigned tot = wave_sum(x);
@@ -199,11 +205,18 @@ __device__ inline void deliver_local(const DevState& s, uint32_t t, bool use_mas
 #ifndef SWIM_PROBE_WAVES
 #define SWIM_PROBE_WAVES 5
 #endif
+constexpr int PX_KG = 4;        // proxy indices per round of the wave's indirect-probe pass (probe_kernel pass 5)
 template <int PMAX>
 __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3 : PMAX <= 12 ? 2 : 1) void probe_kernel(SWIM_STATE_PARAM, uint32_t t, uint32_t tk, Offsets off) {
   SWIM_STATE_BIND
   __shared__ BlockCounters sh;
   __shared__ uint32_t ordn;                        // deliveries left to the exchange (sharded runs)
+  // pass 5, per wave: the (prober, proxy) pairs of a round, the probers' context, the chains' outcomes
+  __shared__ uint4 px_item[BLOCK / 64][64 * PX_KG];      // {proxy, its minfo, prober lane | proxy index << 8, -}
+  __shared__ uint4 px_ctx[BLOCK / 64][64];               // {prober's minfo, target, its minfo, -}
+  __shared__ unsigned long long px_mask[BLOCK / 64][64]; // the prober's queue mask
+  __shared__ unsigned long long px_got[BLOCK / 64][64];  // masks the prober pulled through relayed Acks
+  __shared__ uint32_t px_ack[BLOCK / 64][64];            // some proxy relayed an Ack
   if (threadIdx.x == 0) ordn = 0;
   ctr_init(&sh);
   const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
@@ -220,11 +233,25 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
   unsigned long long pubmask = 0; uint32_t pubq = 0;   // replicated masks (sharded, s.rm): what the peers learn about my queue
   bool wrote_rec = false;                          // this member left an explicit record somewhere: the records phase of merge_kernel has work
   SECT_BEGIN(32);
+  // what passes 1-4 leave for the wave's pass 5 (indirect probes) and for the outputs
+  const uint32_t mk = mix32(tk ^ i);
+  const uint32_t mycnt = mi_pbn(mi);
+  unsigned long long mymask = 0;
+  uint32_t picks[PMAX], pinfo[PMAX];
+  uint32_t failmask = 0;                           // probe indices that ended without an Ack (unlessAck; D2, D3)
+  uint32_t nfail = 0, nack = 0;
+  bool clean = false;
+#pragma unroll
+  for (int p = 0; p < PMAX; ++p) { picks[p] = 0; pinfo[p] = 0; }
+  // a delivery this shard cannot complete alone: the exchange routes it
+  auto emit_raw = [&](uint32_t x, uint32_t y, unsigned long long m) {
+    const uint32_t pos = atomicAdd(&ordn, 1u);
+    if (pos < s.ord_cap) s.ord[(size_t)blockIdx.x * s.ord_cap + pos] = make_uint4(x, y, (uint32_t)m, (uint32_t)(m >> 32));
+    else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG);
+  };
+  auto emit_order = [&](uint32_t dst, uint32_t src) { emit_raw(dst, src, 0ull); };
   if (act) {
-    const uint32_t mk = mix32(tk ^ i);
-    const uint32_t mycnt = mi_pbn(mi);
-    const unsigned long long mymask = (mycnt && use_mask) ? s.pk[li].x : 0ull;
-    uint32_t picks[PMAX], pinfo[PMAX];
+    mymask = (mycnt && use_mask) ? s.pk[li].x : 0ull;
     bool valid[PMAX];                               // probe index p is in use this period
     const bool robust = s.scheme == 1u;
     // the robust scheme's Ping payloads are PULLED by the target (its pingers are computable) -- on one handle; on
@@ -234,7 +261,6 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
     // replicated masks: a prober whose targets are simply its first draws, with a queue its mask expresses in full,
     // leaves its direct probes of REMOTE targets to remote_kernel on both sides (no records); anybody else says so
     // in its queue byte (Q_EXC) and sends records as before
-    bool clean = false;
     if (!robust) {
       // ms <- kRandomMembers store (numToGossip cfg) []        (src/Core.hs:239)
       bool all_first = false;
@@ -264,31 +290,6 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
       for (int p = 0; p < PMAX; ++p) if ((uint32_t)p < np && off.o[p] && !valid[p]) clean = false;
     }
     SECT(32);                                       // target selection
-    uint32_t nfail = 0, nack = 0;
-    // a delivery this shard cannot complete alone: the exchange routes it
-    auto emit_raw = [&](uint32_t x, uint32_t y, unsigned long long m) {
-      const uint32_t pos = atomicAdd(&ordn, 1u);
-      if (pos < s.ord_cap) s.ord[(size_t)blockIdx.x * s.ord_cap + pos] = make_uint4(x, y, (uint32_t)m, (uint32_t)(m >> 32));
-      else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG);
-    };
-    auto emit_order = [&](uint32_t dst, uint32_t src) { emit_raw(dst, src, 0ull); };
-    // "dst merges src's start-of-tick queue", any dst / src (global ids); msrc = minfo[src]
-    auto deliver = [&](uint32_t dst, uint32_t src, uint32_t msrc) {
-      if (!is_local(s, src)) { emit_order(dst, src); return; }       // the owner of src knows its queue
-      const uint32_t cnt = mi_pbn(msrc);
-      if (!cnt) return;                                             // empty payload
-      payloads++; rumors += cnt;
-      if (dst == i) {
-        // pulled by myself: no atomics, a private word and (rarely) a private explicit list
-        if (use_mask) ackacc |= src == i ? mymask : s.pk[src - s.lo].x;
-        if (!use_mask || (msrc & MI_OOW)) { push(s, t, li, mi_src(src - s.lo, msrc)); wrote_rec = true; }
-      } else if (is_local(s, dst)) {
-        deliver_local(s, t, use_mask, stale, dst - s.lo, src - s.lo, msrc, src == i ? mymask : (use_mask ? s.pk[src - s.lo].x : 0ull));
-        wrote_rec |= !use_mask || (msrc & MI_OOW);
-      } else {
-        emit_order(dst, src);
-      }
-    };
     // pass 1: outcome of every direct probe -- pure arithmetic on the gathered info words.
     //   Direct (Ping seq j) is delivered iff not lost and j is up (src/Core.hs:246);
     //   j answers Ack (src/Core.hs:97-99), which may be lost too.
@@ -372,47 +373,123 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
       }
     }
     SECT(35);                                       // Acks
-    // pass 5 (rare): probes without an ack -> k indirect probes -> maybe Suspect
-    for (int p = 0; p < PMAX; ++p) {
-      if ((uint32_t)p >= np) break;
-      if (!valid[p] || ack_ok[p]) continue;                  // unlessAck (D2, D3)
-      const uint32_t j = picks[p], mj = pinfo[p];
-      const bool upj = mi_up(mj);
-      dfail++;
-      // kRandomMembers store (numToGossip cfg) [] for proxies (src/Core.hs:249), D7: not the target
-      uint32_t qs[PMAX], qinfo[PMAX];
-      const uint32_t excl = j;
-      const uint32_t nq = select_members<PMAX>(s, mk, i, s.K, P_PROXY, p, &excl, 1, qs, qinfo, use_mask);
-      preqs += nq;
-      bool acked = false;
-      for (int k = 0; k < PMAX; ++k) {
-        if ((uint32_t)k >= nq) break;
-        const uint32_t q = qs[k], mq = qinfo[k];
-        const uint32_t idx = ((uint32_t)p << 8) | (uint32_t)k;
-        // i -> q : IndirectPing (src/Core.hs:250, 262-269)
-        if (lost(s, tk, P_L_REQ, i, q, idx) || !mi_up(mq)) continue;
-        deliver(q, i, mi);
-        // q -> j : Ping on behalf of i (src/Core.hs:105-108; D8, D12)
-        if (!upj || lost(s, tk, P_L_FWD, q, j, idx)) continue;
-        deliver(j, q, mq);
-        // j -> q : Ack
-        if (lost(s, tk, P_L_BACK, j, q, idx)) continue;
-        deliver(q, j, mj);
-        // q -> i : relayed Ack (D9)
-        if (lost(s, tk, P_L_RELAY, q, i, idx)) continue;
-        deliver(i, q, mq);
-        acked = true;
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p) if ((uint32_t)p < np && valid[p] && !ack_ok[p]) failmask |= 1u << p;
+  }
+  // pass 5 (rare without loss): probes without an Ack -> K indirect probes -> maybe Suspect (src/Core.hs:247-254).
+  // The WAVE does it: the K proxies of a failed probe are independent chains i -> q -> j -> q -> i of up to four
+  // deliveries each (an atomic with a returned position per delivery in a tick of explicit records), and a lane walking
+  // the chains of its failed probes one after the other kept its whole wave waiting -- with 1 % loss 98 % of the waves
+  // hold a failed probe and this pass was 48 % of the kernel's wave time (profiles/r03z_*).  Per probe index p: the
+  // lanes whose probe p failed draw their proxies (kRandomMembers, by the prober: the draws depend on each other), the
+  // (prober, proxy) pairs are dealt to the wave's lanes through LDS, every lane walks ONE chain, and the outcomes come
+  // back by LDS atomics -- "any proxy relayed an Ack" is an OR over the K lanes (the aggregation across k lanes of
+  // SURVEY D9).
+  {
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    // "dst merges src's start-of-tick queue" on behalf of prober pi (global id; local index pli, queue mask pmask):
+    // any dst / src (global ids); msrc = minfo[src]; what the prober itself pulls is ORed into *got
+    auto deliver_for = [&](uint32_t pi, uint32_t pli, unsigned long long pmask, uint32_t dst, uint32_t src, uint32_t msrc,
+                           unsigned long long* got) {
+      if (!is_local(s, src)) { emit_order(dst, src); return; }       // the owner of src knows its queue
+      const uint32_t cnt = mi_pbn(msrc);
+      if (!cnt) return;                                             // empty payload
+      payloads++; rumors += cnt;
+      if (dst == pi) {
+        // pulled by the prober itself: no atomics on the mask path, (rarely) an explicit record of its own
+        if (use_mask) *got |= src == pi ? pmask : s.pk[src - s.lo].x;
+        if (!use_mask || (msrc & MI_OOW)) { push(s, t, pli, mi_src(src - s.lo, msrc)); wrote_rec = true; }
+      } else if (is_local(s, dst)) {
+        deliver_local(s, t, use_mask, stale, dst - s.lo, src - s.lo, msrc, src == pi ? pmask : (use_mask ? s.pk[src - s.lo].x : 0ull));
+        wrote_rec |= !use_mask || (msrc & MI_OOW);
+      } else {
+        emit_order(dst, src);
       }
-      if (acked) continue;                                   // second unlessAck (src/Core.hs:251)
-      // suspectNode store (Suspect (memberIncarnation m) name)  (src/Core.hs:253): lands in merge
-      ensure_slot(s, j);
-      s.fail[(size_t)li * s.P + nfail] = j;
-      nfail++;
-      susp++;
-      if (upj) fsusp++;
-      else atomicMin(&s.first_suspect[j], t);
+    };
+    if (__ballot(failmask != 0u)) {
+      for (int p = 0; p < PMAX; ++p) {
+        const bool mine = ((failmask >> p) & 1u) != 0u;
+        if (!__ballot(mine)) continue;                             // wave-uniform
+        // stage A, by the probers: kRandomMembers store (numToGossip cfg) [] for proxies (src/Core.hs:249), D7: not the target
+        uint32_t qs[PMAX], qinfo[PMAX];
+        uint32_t nq = 0, j = 0, mj = 0;
+#pragma unroll
+        for (int k = 0; k < PMAX; ++k) { qs[k] = 0; qinfo[k] = 0; }
+        if (mine) {
+          j = picks[0]; mj = pinfo[0];
+#pragma unroll
+          for (int e = 1; e < PMAX; ++e) if (p == e) { j = picks[e]; mj = pinfo[e]; }
+          dfail++;
+          const uint32_t excl = j;
+          nq = select_members<PMAX>(s, mk, i, s.K, P_PROXY, (uint32_t)p, &excl, 1, qs, qinfo, use_mask);
+          preqs += nq;
+          px_ctx[wv][lane] = make_uint4(mi, j, mj, 0u);
+          px_mask[wv][lane] = mymask;
+          px_ack[wv][lane] = 0u;
+          px_got[wv][lane] = 0ull;
+        }
+        // stage B: the chains, PX_KG proxy indices at a time (at most 64 x PX_KG pairs in the wave's table)
+        for (uint32_t k0 = 0; k0 < (uint32_t)PMAX; k0 += PX_KG) {
+          const uint32_t nmine = (mine && nq > k0) ? min((uint32_t)PX_KG, nq - k0) : 0u;
+          const uint32_t incl = wave_prefix_incl(nmine);
+          const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+          if (!total) break;                                       // wave-uniform: nobody has a proxy index >= k0
+#pragma unroll
+          for (int kk = 0; kk < PX_KG; ++kk) {
+            if ((uint32_t)kk < nmine) {
+              uint32_t q = qs[0], mq = qinfo[0];
+#pragma unroll
+              for (int e = 1; e < PMAX; ++e) if (k0 + (uint32_t)kk == (uint32_t)e) { q = qs[e]; mq = qinfo[e]; }
+              px_item[wv][incl - nmine + (uint32_t)kk] = make_uint4(q, mq, lane | ((k0 + (uint32_t)kk) << 8), 0u);
+            }
+          }
+          lds_wave_sync();
+          for (uint32_t x = lane; x < total; x += 64u) {
+            const uint4 it = px_item[wv][x];
+            const uint32_t q = it.x, mq = it.y, src = it.z & 63u, k = it.z >> 8;
+            const uint4 cx = px_ctx[wv][src];
+            const unsigned long long pmask = px_mask[wv][src];
+            const uint32_t pli = (li - lane) + src, pi = s.lo + pli, pmi = cx.x, pj = cx.y, pmj = cx.z;
+            const uint32_t idx = ((uint32_t)p << 8) | k;
+            unsigned long long got = 0;
+            bool ok = false;
+            do {
+              // i -> q : IndirectPing (src/Core.hs:250, 262-269)
+              if (lost(s, tk, P_L_REQ, pi, q, idx) || !mi_up(mq)) break;
+              deliver_for(pi, pli, pmask, q, pi, pmi, &got);
+              // q -> j : Ping on behalf of i (src/Core.hs:105-108; D8, D12)
+              if (!mi_up(pmj) || lost(s, tk, P_L_FWD, q, pj, idx)) break;
+              deliver_for(pi, pli, pmask, pj, q, mq, &got);
+              // j -> q : Ack
+              if (lost(s, tk, P_L_BACK, pj, q, idx)) break;
+              deliver_for(pi, pli, pmask, q, pj, pmj, &got);
+              // q -> i : relayed Ack (D9)
+              if (lost(s, tk, P_L_RELAY, q, pi, idx)) break;
+              deliver_for(pi, pli, pmask, pi, q, mq, &got);
+              ok = true;
+            } while (false);
+            if (got) atomicOr(&px_got[wv][src], got);
+            if (ok) atomicOr(&px_ack[wv][src], 1u);
+          }
+          lds_wave_sync();
+        }
+        if (mine) {
+          ackacc |= px_got[wv][lane];
+          if (!px_ack[wv][lane]) {                                 // second unlessAck (src/Core.hs:251)
+            // suspectNode store (Suspect (memberIncarnation m) name)  (src/Core.hs:253): lands in merge
+            ensure_slot(s, j);
+            s.fail[(size_t)li * s.P + nfail] = j;
+            nfail++;
+            susp++;
+            if (mi_up(mj)) fsusp++;
+            else atomicMin(&s.first_suspect[j], t);
+          }
+        }
+      }
     }
-    SECT(36);                                       // indirect probes
+  }
+  SECT(36);                                         // indirect probes
+  if (act) {
     s.probe_out[li] = (uint16_t)(n_pings | (nfail << 5) | (nack << 10));
     pubmask = mymask;
     pubq = mycnt | (((mi & MI_OOW) || !use_mask) ? Q_OOW : 0u) | (clean ? 0u : Q_EXC);   // a tick without masks: no queue travels as one
@@ -530,12 +607,6 @@ __device__ inline uint32_t park_rid(uint32_t lo, uint32_t H) {
 // As a kernel of its own it costs 10 us per tick even when it leaves at once: every kernel boundary on this chip
 // writes the XCDs' L2s back and invalidates them (5-6 us gaps between the tick's kernels in the trace).  Here it
 // needs 62 registers with nothing else live, and the view cells are the todo loop's business, four at a time.
-// inclusive prefix sum over the lanes of a wave (the DPP steps of wave_sum leave it in every lane)
-__device__ inline unsigned wave_prefix_incl(unsigned x) {
-  x += SWIM_DPP(x, 0x111, 0xf); x += SWIM_DPP(x, 0x112, 0xf); x += SWIM_DPP(x, 0x114, 0xf); x += SWIM_DPP(x, 0x118, 0xf);
-  x += SWIM_DPP(x, 0x142, 0xa); x += SWIM_DPP(x, 0x143, 0xc);
-  return x;
-}
 // reserve n todo entries in the workgroup's region; NONE32 = no room (loud: ERRF_OVF)
 __device__ inline uint32_t todo_reserve(const DevState& s, uint32_t n) {
   const uint32_t region = blockIdx.x & (TODO_REGIONS - 1u);
