@@ -923,11 +923,11 @@ __global__ __launch_bounds__(BLOCK, 5) void records_kernel(DevState s, uint32_t 
 #ifndef SWIM_GOSSIP_BATCH       // rumours whose loads are issued together in merge_kernel
 #define SWIM_GOSSIP_BATCH 2
 #endif
-#ifndef SWIM_MERGE_WAVES         // 4: 106 VGPRs, nothing spilled; 5 (96 VGPRs) spills the todo loop's batch -- same speed without
-#define SWIM_MERGE_WAVES 4       // records, slower with (profiles/r03s_*)
+#ifndef SWIM_MERGE_WAVES         // measured with the todo batch (profiles/r03af_*; lossless / 1 % loss, us per merge): 4 waves x batch 2:
+#define SWIM_MERGE_WAVES 4       // 144 / 643; 5 x 2: 147 / 628; 4 x 4: 154 / 634; 5 x 4 (spills): 166 / 647
 #endif
 #ifndef SWIM_TODO_BATCH         // todo entries (explicit records' survivors) whose view cells merge_kernel loads together
-#define SWIM_TODO_BATCH 4
+#define SWIM_TODO_BATCH 2
 #endif
 constexpr int ASM_STRIDE = BLOCK + 2;   // words per LDS column: keeps the transposed line store conflict-free
 
