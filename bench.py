@@ -226,9 +226,13 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and saturated and not args.loss_ppm and args.num_to_gossip == 3 and args.scheme == "random":
             tj = json.load(open(tpath))
-            if tj.get("regime") == args.regime and tj.get("members") == n and tj.get("kernels_rev") == _abi.ABI_VERSION:
+            # keyed by the sha of the kernel sources the counters were collected on: never quoted for other kernels
+            if tj.get("regime") == args.regime and tj.get("members") == n and tj.get("kernels_sha") == _lib.kernel_sources_sha():
                 traffic = tj.get(dom + "_hbm_bytes_per_launch")
                 traffic_src = tj.get("source")
+            else:
+                traffic_src = "profiles/traffic.json was measured on other kernel sources (sha %s, these: %s): not quoted" % (
+                    tj.get("kernels_sha"), _lib.kernel_sources_sha())
         lat, nlat = lat_all
         out = {
             "metric": "member-ticks/sec at N=1M simulated members; mean first-detection latency (ticks)",

@@ -311,6 +311,13 @@ int swimsim_set_view(swimsim_t* h, uint32_t observer, uint32_t subject, uint8_t 
 /* Resolved configuration (defaults filled in). */
 int swimsim_get_config(const swimsim_t* h, swimsim_config_t* out);
 
+/* ---- the outside world (the live-node bridge, include/swimbridge.h) ----
+ * A Suspect / Alive / Dead message about `subject` that reaches simulated member `observer` from OUTSIDE the
+ * simulation -- what `process` does with such a message from the socket (src/Core.hs:110-117): it is delivered
+ * to `observer` in the next tick that is stepped, next to the rumours the tick's Pings and Acks carry (same state
+ * rule, same events, re-gossiped if accepted; nothing if `observer` is down then).  Unsharded handles only. */
+int swimsim_inject_rumor(swimsim_t* h, uint32_t observer, uint32_t subject, uint8_t state, uint32_t incarnation);
+
 /* ---- sharded clusters (one handle per GPU / process) -------------------------------
  * The population is split into n_shards contiguous id ranges.  Every shard gets the SAME
  * configuration (n_members = whole population) and the SAME fault schedule; ground truth and

@@ -75,6 +75,12 @@ static inline uint64_t mix64(uint64_t x) {
 static inline uint64_t h4(uint64_t tag, uint64_t a, uint64_t b, uint64_t c) {
   return mix64(mix64(mix64(mix64(tag) + a) + b) + c);
 }
+/* A view change of member i about subject s in tick t moves the running event digest by
+ * E(t, i, s) * (new key - old key), E = h3(TAG_EV, t << 32 | i, s) | 1: linear in the key, so several changes of one
+ * entry in one tick telescope to first -> last whatever the order they are applied in. */
+static inline uint64_t ev_weight(uint32_t t, uint32_t i, uint32_t s) {
+  return mix64(mix64(mix64((uint64_t)TAG_EV) + (((uint64_t)t << 32) | i)) + s) | 1ull;
+}
 
 /* ------------------------------------------------------------------------- */
 /* state                                                                      */
@@ -154,6 +160,8 @@ struct swimoracle {
   /* capture mode (unit-level hook swimoracle_process) */
   int capture; int capture_literal_d8;
   swimoracle_msg_t* cap_out; size_t cap_cap, cap_n;
+  /* rumours from outside the simulation (swimsim_inject_rumor): delivered in the next tick */
+  opend_t* inj; size_t ninj, inj_cap;
   int poisoned;
   char err[256];
 };
@@ -566,8 +574,7 @@ static int accept_key(octx_t* c, uint32_t i, uint32_t s, uint32_t key, uint8_t c
   } else if (key <= cur.key) return 0;             /* old incarnation / weaker state: ignore */
   oentry_t* e = view_ref(o, i, s);
   if (!e) return 0;
-  c->counters[SWIMSIM_CTR_EVDIGEST] += h4(TAG_EV, ((uint64_t)t << 32) | i, s, key)
-                                     - h4(TAG_EV, ((uint64_t)t << 32) | i, s, cur.key);
+  c->counters[SWIMSIM_CTR_EVDIGEST] += ev_weight(t, i, s) * (uint64_t)(key - cur.key);
   /* every worker writes the same tick into the same few words: look first, so that the line stays shared */
   if (__atomic_load_n(&o->last_change[s], __ATOMIC_RELAXED) != t) __atomic_store_n(&o->last_change[s], t, __ATOMIC_RELAXED);
   if (e->since1 != t + 1) c->counters[SWIMSIM_CTR_CHANGES]++;
@@ -674,7 +681,7 @@ static void join_pull(swimoracle_t* o, uint32_t t, uint32_t m, size_t nf) {
     oentry_t cur = view_get(o, m, s);
     if (kh <= cur.key) continue;
     oentry_t* e = view_ref(o, m, s);
-    o->counters[SWIMSIM_CTR_EVDIGEST] += h4(TAG_EV, ((uint64_t)t << 32) | m, s, kh) - h4(TAG_EV, ((uint64_t)t << 32) | m, s, cur.key);
+    o->counters[SWIMSIM_CTR_EVDIGEST] += ev_weight(t, m, s) * (uint64_t)(kh - cur.key);
     o->counters[SWIMSIM_CTR_CHANGES]++;
     e->key = kh; e->since1 = t + 1;
     o->last_change[s] = t;
@@ -734,6 +741,8 @@ static void phase_probe(octx_t* c) {
   swimoracle_t* o = c->o;
   c->nfails = 0;
   for (uint32_t g = 0; g < o->nworkers; g++) c->out[g].n = 0;
+  /* messages from outside the simulation reach their members like any datagram of the tick (src/Core.hs:110-117) */
+  if (c->w == 0) for (size_t x = 0; x < o->ninj; x++) if (o->up[o->inj[x].dst]) pend_add(c, o->inj[x].dst, o->inj[x].subject, o->inj[x].key);
   for (uint32_t i = c->lo; i < c->hi; i++) {
     o->nsent[i] = 0;
     if (o->up[i]) { failure_detector(c, i); c->counters[SWIMSIM_CTR_ACTIVE_MEMBERS]++; }
@@ -854,6 +863,7 @@ static int one_tick(swimoracle_t* o) {
   if (o->poisoned) return SWIMSIM_ERR_CAPACITY;
   settle(o, t);
   if (o->poisoned) return SWIMSIM_ERR_CAPACITY;
+  o->ninj = 0;
   o->tick++;
   return SWIMSIM_OK;
 }
@@ -1023,12 +1033,22 @@ void swimoracle_destroy(swimoracle_t* o) {
   workers_stop(o);
   for (uint32_t s = 0; s < o->nslots; s++) free(o->cols[s]);
   if (o->timers) for (uint32_t i = 0; i < o->N; i++) free(o->timers[i].v);
-  free(o->free_at); free(o->base); free(o->base_since); free(o->last_change);
+  free(o->free_at); free(o->base); free(o->base_since); free(o->last_change); free(o->inj);
   free(o->cols); free(o->subject_of); free(o->slot_of); free(o->up); free(o->self_inc); free(o->pb);
   free(o->timers); free(o->nsent); free(o->faults); free(o->first_suspect); free(o->crash_tick);
   free(o->events);
   pthread_mutex_destroy(&o->mu);
   free(o);
+}
+
+int swimoracle_inject_rumor(swimoracle_t* o, uint32_t observer, uint32_t subject, uint8_t state, uint32_t incarnation) {
+  if (!o) return SWIMSIM_ERR_INVALID;
+  if (observer >= o->N || subject >= o->N || state > 2 || incarnation > 0x3FFFFFu) return fail(o, SWIMSIM_ERR_INVALID, "inject_rumor: bad member / state / incarnation");
+  if (o->cfg.n_shards > 1) return fail(o, SWIMSIM_ERR_STATE, "inject_rumor: unsharded handles only");
+  if (o->ninj == o->inj_cap) { o->inj_cap = o->inj_cap ? o->inj_cap * 2 : 64; o->inj = (opend_t*)realloc(o->inj, o->inj_cap * sizeof *o->inj); }
+  o->inj[o->ninj].dst = observer; o->inj[o->ninj].subject = subject; o->inj[o->ninj].key = key_make(incarnation, state);
+  o->ninj++;
+  return SWIMSIM_OK;
 }
 
 int swimoracle_get_config(const swimoracle_t* o, swimsim_config_t* out) {

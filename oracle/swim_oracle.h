@@ -53,6 +53,7 @@ int swimoracle_k_random_members(swimoracle_t* h, uint32_t observer, uint32_t n,
 int swimoracle_set_view(swimoracle_t* h, uint32_t observer, uint32_t subject, uint8_t state,
                         uint32_t incarnation);
 int swimoracle_get_config(const swimoracle_t* h, swimsim_config_t* out);
+int swimoracle_inject_rumor(swimoracle_t* h, uint32_t observer, uint32_t subject, uint8_t state, uint32_t incarnation);
 
 /* ---- oracle-only hooks ---------------------------------------------------- */
 

@@ -7,7 +7,7 @@ usage: make_traffic_json.py <summary.txt> <tag>"""
 import ast, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from swim_amd import _abi
+from swim_amd import _abi, _lib
 text = open(sys.argv[1]).read()
 tag = sys.argv[2]
 vals = {}
@@ -19,7 +19,7 @@ for line in text.splitlines():
     if name:
         for k, v in ast.literal_eval(m.group(2)).items():
             vals.setdefault(name, {})[k] = v
-out = {"regime": "saturated", "members": 1 << 20, "kernels_rev": _abi.ABI_VERSION,
+out = {"regime": "saturated", "members": 1 << 20, "kernels_rev": _abi.ABI_VERSION, "kernels_sha": _lib.kernel_sources_sha(),
        "source": "profiles/%s_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, mean of the last 30 "
                  "dispatches, scripts/pmc_passes.sh)" % tag,
        "note": "FETCH_SIZE / WRITE_SIZE in KiB. Calibrated on known-size patterns (profiles/r01_pmc_calibration.txt): a scattered "

@@ -90,6 +90,7 @@ _SIGS = {
                                    C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_size_t)]),
     "set_view": (C.c_int, [_H, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint32]),
     "get_config": (C.c_int, [_H, C.POINTER(Config)]),
+    "inject_rumor": (C.c_int, [_H, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint32]),
 }
 
 # entry points only the product library has (measurement plumbing, sharded stepping; no oracle counterpart)
@@ -134,7 +135,24 @@ _WIRE = {
     "last_error": (C.c_char_p, []),
 }
 
+class BridgeStats(C.Structure):
+    """swimbridge_stats_t (include/swimbridge.h)"""
+    _fields_ = [(n, C.c_uint64) for n in ("datagrams_in", "datagrams_out", "decode_errors", "pings", "pings_unanswered",
+                                          "indirect_pings", "relayed_acks", "acks_in", "rumors_injected", "rumors_foreign")]
+
+
+# include/swimbridge.h: the live-node bridge (prefix swimbridge_, product library only)
+_BRIDGE = {
+    "open": (C.c_int, [_H, C.c_char_p, C.c_uint16, C.POINTER(C.c_void_p)]),
+    "port": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint16)]),
+    "poll": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
+    "stats": (C.c_int, [C.c_void_p, C.POINTER(BridgeStats)]),
+    "last_error": (C.c_char_p, [C.c_void_p]),
+    "close": (None, [C.c_void_p]),
+}
+
 ENTRY_POINTS = tuple(_SIGS) + tuple(_PRODUCT_ONLY)
+BRIDGE_ENTRY_POINTS = tuple("swimbridge_" + n for n in _BRIDGE)
 WIRE_ENTRY_POINTS = tuple("swimwire_" + n for n in _WIRE)
 
 
@@ -161,6 +179,11 @@ def bind(lib, prefix):
             fn.restype = res
             fn.argtypes = args
             setattr(ns, "wire_" + name, fn)
+        for name, (res, args) in _BRIDGE.items():
+            fn = getattr(lib, "swimbridge_" + name)
+            fn.restype = res
+            fn.argtypes = args
+            setattr(ns, "bridge_" + name, fn)
     ns.lib = lib
     ns.prefix = prefix
     return ns

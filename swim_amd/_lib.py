@@ -10,6 +10,18 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libswimsim.so")
 
 _cached = None
 
+KERNEL_SOURCES = ("swim_kernels.h", "swim_device.h", "swimsim.hip")
+
+
+def kernel_sources_sha():
+    """sha256 (first 16 hex digits) of the kernel sources the library is built from: what profiles/traffic.json is keyed
+    by, so that a PMC figure is never quoted for kernels it was not measured on (bench.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(_HERE, "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
 
 def load_variant(tag):
     """A test build of the same sources with a compile-time knob shrunk (__graft_entry__.VARIANTS)."""

@@ -1120,8 +1120,9 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
     if (s.G) s.slot_last[slot] = t;              // same value from every writer
     if (!(have & HAVE_SUBJ)) subject = s.subject_of[slot];
     if (!ha) ha = mix64(mix64((uint64_t)TAG_EV) + (((uint64_t)t << 32) | i));
-    const unsigned long long hx = mix64(ha + subject);                // h4(TAG_EV, a, subject, .) prefix
-    if (!ABL(ABL_EVD)) evd += mix64(hx + key) - mix64(hx + curk);
+    // the running event digest moves by E(t, i, subject) * (key - old key): linear in the key, so the changes of one
+    // entry in one tick telescope whatever their order -- one hash per change (three before: 6 % of the kernel)
+    if (!ABL(ABL_EVD)) evd += (mix64(ha + subject) | 1ull) * (unsigned long long)(key - curk);
     changes += (e.y != t + 1) ? 1u : 0u;
     if (cause == 1u) timers_fired++;
     if ((key & 3u) == ST_SUSPECT) tput(slot + 1);                     // deadline t + S (D4)
@@ -1953,7 +1954,7 @@ __device__ inline void pull_entry(const DevState& s, uint32_t t, uint32_t mbr, u
   if (kh <= curk) return;
   s.V[ix] = make_uint2(kh, t + 1);                             // its deadline, if Suspect: the cells are rebuilt by merge_kernel
   if (s.G) s.slot_last[slot] = t;
-  *evd += h4(TAG_EV, ((uint64_t)t << 32) | mbr, subject, kh) - h4(TAG_EV, ((uint64_t)t << 32) | mbr, subject, curk);
+  *evd += (mix64(mix64(mix64((uint64_t)TAG_EV) + (((uint64_t)t << 32) | mbr)) + subject) | 1ull) * (unsigned long long)(kh - curk);
   (*pulled)++;
 }
 
@@ -2156,6 +2157,27 @@ __global__ __launch_bounds__(BLOCK) void pull_send_kernel(DevState s, uint32_t t
       else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG);
     }
   }
+}
+
+// Rumours from outside the simulation (swimsim_inject_rumor; src/Core.hs:110-117 for a message off the socket): each
+// becomes a one-entry "foreign line" and an explicit record in its observer's inbox -- the path payloads from other
+// shards take -- so that this tick's merge rules on it next to everything else the member received.  After
+// begin_kernel (the tick's window head is fixed: an id handed out here is younger than it and travels unfiltered).
+struct InjectRec { uint32_t observer, subject, key, pad; };
+__global__ void inject_kernel(DevState s, uint32_t t, const InjectRec* recs, uint32_t n) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const InjectRec r = recs[k];
+  if (!mi_up(s.minfo[r.observer])) return;          // nobody listening
+  const uint32_t slot = get_slot(s, r.subject);
+  uint32_t num = 0;
+  const uint32_t rid0 = find_rid(s, slot, r.key, &num), rid = young_rid(rid0, num, s.g[G_HEAD]);
+  uint4* line = s.fl + (size_t)k * 4;
+  line[0] = make_uint4(pe_lo(slot, rid), pe_hi(r.key, 1u), 0u, 0u);
+  line[1] = make_uint4(0u, 0u, 0u, 0u); line[2] = make_uint4(0u, 0u, 0u, 0u); line[3] = make_uint4(0u, 0u, 0u, 0u);
+  __threadfence();
+  push(s, t, r.observer - s.lo, SRC_FOREIGN | k);
+  s.g[G_ANYREC] = 1u;
 }
 
 // full-state digest: Sum_i mix64(member_hash(i) + mix64(TAG_MEMBER + i)) + first-detection terms

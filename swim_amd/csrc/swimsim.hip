@@ -23,6 +23,8 @@ using namespace swim;
 
 namespace {
 
+constexpr uint32_t INJECT_CAP = 4096;   // rumours from outside the simulation per tick (swimsim_inject_rumor)
+
 struct Fault { uint32_t tick, member, up, order; };
 
 thread_local std::string g_create_err;
@@ -52,6 +54,8 @@ struct swimsim {
   double probe_ms = 0, merge_ms = 0; uint64_t timed_ticks = 0;
   bool poisoned = false;
   std::string err;
+  std::vector<InjectRec> injections;           // swimsim_inject_rumor: delivered in the next tick stepped
+  InjectRec* d_inject = nullptr;
   std::vector<swimsim_view_entry_t> settled_alive;   // settled subjects that stay listed (Alive at i > 0), as of settled_alive_tick
   uint64_t settled_alive_tick = ~0ull;
   // sharded stepping (swimsim_shard_*): which phase of the current tick comes next, the tick's fault slice
@@ -463,6 +467,10 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
       CK(dev_alloc(h, &d.j_recv, (size_t)d.n_shards * d.j_cap, 0));
     }
   }
+  if (d.n_shards == 1) {                         // the foreign lines of injected rumours (swimsim_inject_rumor)
+    CK(dev_alloc(h, &d.fl, (size_t)INJECT_CAP * 4, 0));
+    CK(dev_alloc(h, &h->d_inject, (size_t)INJECT_CAP, 0));
+  }
   CK(dev_alloc(h, &h->d_state, (size_t)1, 0));
   HK(hipMemcpyAsync(h->d_state, &d, sizeof d, hipMemcpyHostToDevice, h->stream));   // behind the allocation's memset
   hipLaunchKernelGGL(init_members_kernel, dim3((NT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, d.minfo, d.mb, NT);
@@ -478,6 +486,16 @@ int swimsim_create_msg(const swimsim_config_t* cfg, swimsim_t** out, char* err, 
   const int rc = swimsim_create(cfg, out);
   if (err && errcap) { std::snprintf(err, errcap, "%s", rc ? g_create_err.c_str() : ""); }
   return rc;
+}
+
+int swimsim_inject_rumor(swimsim_t* h, uint32_t observer, uint32_t subject, uint8_t state, uint32_t incarnation) {
+  if (!h) return SWIMSIM_ERR_INVALID;
+  if (observer >= h->d.NT || subject >= h->d.NT || state > 2 || incarnation > INC_MAX)
+    return set_err(h, SWIMSIM_ERR_INVALID, "inject_rumor: bad member / state / incarnation");
+  if (h->d.n_shards > 1) return set_err(h, SWIMSIM_ERR_STATE, "inject_rumor: unsharded handles only");
+  if (h->injections.size() >= INJECT_CAP) return set_err(h, SWIMSIM_ERR_BUFFER, "inject_rumor: more than 4096 rumours before the next tick");
+  h->injections.push_back(InjectRec{observer, subject, (incarnation << 2) | state, 0u});
+  return SWIMSIM_OK;
 }
 
 int swimsim_get_config(const swimsim_t* h, swimsim_config_t* out) {
@@ -553,6 +571,13 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
     const uint32_t tk = tick_key(h->cfg.seed, t);
     hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, (uint32_t)(fpos - f0),
                        h->d_joined, 3u, PeerCounts{});
+    if (!h->injections.empty()) {                 // messages from outside the simulation: into this tick's inboxes
+      const uint32_t ni = (uint32_t)h->injections.size();
+      HIPCHK(h, hipMemcpyAsync(h->d_inject, h->injections.data(), ni * sizeof(InjectRec), hipMemcpyHostToDevice, h->stream));
+      hipLaunchKernelGGL(inject_kernel, dim3((ni + 63) / 64), dim3(64), 0, h->stream, h->d, t, h->d_inject, ni);
+      HIPCHK(h, hipStreamSynchronize(h->stream));   // the host list is reused
+      h->injections.clear();
+    }
     const uint32_t pk = std::max(h->d.P, h->d.K);   // registers follow the probe / proxy arrays: four sizes
     if (pk <= 4) launch_tick<4>(h, t, tk, ev);
     else if (pk <= 8) launch_tick<8>(h, t, tk, ev);

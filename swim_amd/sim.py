@@ -206,5 +206,10 @@ class Sim:
         self._check(self._abi.k_random_members(self._h, observer, n, ex, len(excludes), out, n, C.byref(got)))
         return list(out[: got.value])
 
+    def injectRumor(self, observer: int, subject: int, state: int, incarnation: int = 0):
+        """A Suspect / Alive / Dead message about `subject` from OUTSIDE the simulation reaches `observer` in the next tick
+        (`process` on a message off the socket, src/Core.hs:110-117; the live-node bridge uses it)."""
+        self._check(self._abi.inject_rumor(self._h, observer, subject, int(state), incarnation))
+
     def setView(self, observer: int, subject: int, state: int, incarnation: int = 0):
         self._check(self._abi.set_view(self._h, observer, subject, int(state), incarnation))

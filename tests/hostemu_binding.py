@@ -19,13 +19,13 @@ _cached = None
 def build(lib=None, defines=()):
     lib = lib or LIB
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".cpp"))]
-    srcs += [os.path.join(EMU, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "swimsim.h")]
+    srcs += [os.path.join(EMU, "hip", "hip_runtime.h")] + [os.path.join(ROOT, "include", f) for f in ("swimsim.h", "swimwire.h", "swimbridge.h")]
     if os.path.exists(lib) and all(os.path.getmtime(s) <= os.path.getmtime(lib) for s in srcs):
         return
     os.makedirs(os.path.dirname(lib), exist_ok=True)
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-I", EMU,
                            "-Wno-unused-function", "-Wl,-Bsymbolic", *["-D" + d for d in defines], "-o", lib, os.path.join(CSRC, "swimsim.hip"),
-                           os.path.join(CSRC, "swim_wire.cpp")])
+                           os.path.join(CSRC, "swim_wire.cpp"), os.path.join(CSRC, "swim_bridge.cpp")])
 
 
 def load():

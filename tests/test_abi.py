@@ -54,6 +54,19 @@ def test_generated_haskell_offsets_are_current():
         assert name in open(os.path.join(ROOT, "haskell", "Swim", "Offsets.hs")).read(), name
 
 
+def test_bridge_symbols_are_exported_and_bound():
+    """include/swimbridge.h: every declared entry point is exported by the same library and bound in _abi."""
+    import __graft_entry__ as g
+    from swim_amd import _abi
+    g.build()
+    text = open(os.path.join(ROOT, "include", "swimbridge.h")).read()
+    syms = sorted(set(re.findall(r"\b(swimbridge_[a-z_0-9]+)\s*\(", text)))
+    lib = C.CDLL(os.path.join(ROOT, "swim_amd", "csrc", "libswimsim.so"))
+    assert syms == sorted(_abi.BRIDGE_ENTRY_POINTS)
+    for name in syms:
+        assert hasattr(lib, name), "missing export: " + name
+
+
 def test_python_binding_covers_the_header():
     from swim_amd import _abi
     declared = {s[len("swimsim_"):] for s in header_symbols()}

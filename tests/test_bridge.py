@@ -1,0 +1,124 @@
+"""The live-node bridge (include/swimbridge.h) against a Python test peer that restates the SEND side of
+the reference's node over the same wire codec -- `Core.main`'s exchange (src/Core.hs:79-117, 243-269): Ping -> Ack,
+IndirectPing -> relayed Ack, gossip messages that ride along.  The simulated population runs on the host emulation of the
+product kernels here (no GPU in this container); tests/test_hip_parity.py has the `-m gpu` twin.  "Real-node demo
+unverified": the reference itself cannot be built (no GHC); the codec's interoperability contract is tests/test_wire_codec.py."""
+import socket
+
+import pytest
+
+from swim_amd import Config, Sim, SimConfig, wire
+from swim_amd.bridge import Bridge
+from swim_amd.types import Ack, Alive, Dead, IndirectPing, Ping, Suspect
+
+
+@pytest.fixture(scope="module")
+def emu_abi():
+    from tests import hostemu_binding
+    return hostemu_binding.load()
+
+
+class Peer:
+    """What a `Core.main` node does on its socket, as far as the bridge can see it."""
+
+    def __init__(self, port):
+        self.sock = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+        self.sock.bind(("127.0.0.1", 0))
+        self.sock.settimeout(2.0)
+        self.to = ("127.0.0.1", port)
+
+    def send(self, *msgs):
+        self.sock.sendto(wire.encode(list(msgs)), self.to)
+
+    def recv(self):
+        data, _ = self.sock.recvfrom(65535)
+        err, msgs = wire.decode(data)
+        assert err is None, err
+        return msgs
+
+    def silent(self):
+        self.sock.settimeout(0.2)
+        try:
+            self.sock.recvfrom(65535)
+            return False
+        except socket.timeout:
+            return True
+        finally:
+            self.sock.settimeout(2.0)
+
+    def close(self):
+        self.sock.close()
+
+
+def bridge_scenario(abi):
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=500, seed=4, eventMask=0x1F, suspicionTicks=6)
+    sim = Sim.create(abi, sc)
+    sim.crash(9, 2)                                        # member 9 goes down at tick 2
+    sim.step(8)                                            # by now everybody passes rumours about m9 on
+    with Bridge(sim) as br:
+        peer = Peer(br.port)
+        # Ping for a member that is up -> Ack with the same seqNo (test/Spec.hs:150-153), its queue riding along
+        peer.send(Ping(seqNo=41, node="m3"))
+        assert br.poll(500) == 1
+        got = peer.recv()
+        assert got[0] == Ack(seqNo=41, payload=[])
+        assert any(isinstance(m, (Suspect, Dead)) and m.node == "m9" for m in got[1:])      # D5: the piggyback queue
+        # Ping for somebody else / for a member that is down -> nothing (src/Core.hs:100-101; test/Spec.hs:155-158)
+        peer.send(Ping(seqNo=42, node="unknown-node")); br.poll(500)
+        peer.send(Ping(seqNo=43, node="m9")); br.poll(500)
+        peer.send(Ping(seqNo=44, node="m500")); br.poll(500)             # not a member
+        assert peer.silent()
+        # IndirectPing about a simulated member: the proxy relays the answer (D9) iff the target is up
+        peer.send(IndirectPing(seqNo=50, target=0x7F000001, port=4001, node="m7")); br.poll(500)
+        assert peer.recv() == [Ack(seqNo=50, payload=[])]
+        peer.send(IndirectPing(seqNo=51, target=0x7F000001, port=4001, node="m9")); br.poll(500)
+        assert peer.silent()
+        # IndirectPing about a node OUTSIDE the simulation: Ping to (target, port) (src/Core.hs:105-108), its Ack relayed
+        other = Peer(br.port)
+        oport = other.sock.getsockname()[1]
+        peer.send(IndirectPing(seqNo=60, target=0x7F000001, port=oport, node="other")); br.poll(500)
+        assert other.recv() == [Ping(seqNo=60, node="other")]
+        other.send(Ack(seqNo=60, payload=[])); br.poll(500)
+        assert peer.recv() == [Ack(seqNo=60, payload=[])]
+        # gossip that rides along with a Ping reaches the member the Ping names, in the next tick (src/Core.hs:110-117)
+        peer.send(Ping(seqNo=70, node="m20"), Suspect(incarnation=0, node="m33"), Dead(incarnation=0, node="m34", deadFrom="other"),
+                  Alive(incarnation=0, node="someone-else", addr=1, port=2))
+        br.poll(500); peer.recv()
+        # an undecodable datagram is dropped, nothing dies (D16)
+        peer.sock.sendto(b"\x09garbage", peer.to); br.poll(500)
+        st = br.stats()
+        assert st["decode_errors"] == 1 and st["rumors_injected"] == 2 and st["rumors_foreign"] == 1
+        assert st["pings"] == 3 and st["pings_unanswered"] == 3 and st["relayed_acks"] == 2
+        sim.step(1)
+        view = {m.memberName: (int(m.memberAlive), m.memberIncarnation) for m in sim.members(20)}
+        assert view.get("m33") == (1, 0) and view.get("m34") == (2, 0)           # m20 took the outside world's word
+        sim.step(12)                                       # both are up and hear of it: they refute (src/Core.hs:155-166, D10)
+        view0 = {m.memberName: (int(m.memberAlive), m.memberIncarnation) for m in sim.members(0)}
+        assert view0.get("m33") == (0, 1) and view0.get("m34") == (0, 1) and sim.counters()["refutes"] >= 2
+        peer.close(); other.close()
+        return sim.digest()
+
+
+def test_bridge_answers_the_wire_protocol_for_the_simulated_members(emu_abi):
+    bridge_scenario(emu_abi)
+
+
+def test_injected_rumours_match_the_oracle(oracle_abi, emu_abi):
+    """swimsim_inject_rumor (what the bridge does with gossip from outside) in the product kernels and in the oracle:
+    same views, events, counters and digests -- refutation of a Suspect about an up member, a Dead that sticks, a
+    message for a member that is down, a member told about itself."""
+    from tests.helpers import compare_state, make_pair
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=600, seed=5, lossPpm=10000, eventMask=0x1F, suspicionTicks=6)
+    a, b = make_pair(oracle_abi, emu_abi, sc, [(3, 17)])
+    a.step(2); b.step(2)
+    for s in (a, b):
+        s.injectRumor(5, 40, 1, 0); s.injectRumor(6, 41, 2, 0); s.injectRumor(7, 7, 1, 0)
+        s.injectRumor(17, 3, 1, 0); s.injectRumor(8, 42, 0, 5)
+    for k in range(8):
+        a.step(3); b.step(3)
+        if k == 2:
+            for s in (a, b):
+                s.injectRumor(17, 50, 1, 0)                # m17 is down by now: nobody listening
+                s.injectRumor(9, 40, 2, 1)
+        compare_state(a, b, (0, 5, 6, 7, 41, 599), (5, 6, 7, 40), True, where="block %d:" % k)
+    assert b.counters()["refutes"] >= 2

@@ -560,3 +560,24 @@ def test_wire_datagram_of_a_hip_member_equals_the_oracle_members(oracle_abi, hip
             assert err is None and msgs[0] == ctl
             seen += len(msgs) - 1
     assert seen > 0                                                  # queues were not empty: rumours rode along
+
+
+def test_live_node_bridge_on_the_gpu(hip_abi):
+    """Row f-4 under the driver's GPU run: the UDP endpoint answers Ping / IndirectPing for simulated members and hands the
+    gossip that came in to the simulation (tests/test_bridge.py has the scenario; here the population is on the MI355X)."""
+    from tests.test_bridge import bridge_scenario
+    bridge_scenario(hip_abi)
+
+
+def test_injected_rumours_match_the_oracle_on_the_gpu(oracle_abi, hip_abi):
+    """swimsim_inject_rumor (messages from outside the simulation) at 20 000 members with loss: HIP vs oracle."""
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=20000, seed=8, lossPpm=10000, eventMask=0, suspicionTicks=8)
+    a, b = make_pair(oracle_abi, hip_abi, sc, [(3, 17), (4, 1900)])
+    a.step(2); b.step(2)
+    for k in range(6):
+        for s in (a, b):
+            for j in range(40):
+                s.injectRumor((977 * (k * 40 + j) + 5) % 20000, (1201 * (k * 40 + j) + 40) % 20000, 1 + (j & 1), j % 3)
+        a.step(3); b.step(3)
+        compare_state(a, b, (0, 5, 19999), (5, 40), False, where="block %d:" % k)
+    assert b.counters()["refutes"] > 50
