@@ -315,7 +315,9 @@ int swimsim_get_config(const swimsim_t* h, swimsim_config_t* out);
  * A Suspect / Alive / Dead message about `subject` that reaches simulated member `observer` from OUTSIDE the
  * simulation -- what `process` does with such a message from the socket (src/Core.hs:110-117): it is delivered
  * to `observer` in the next tick that is stepped, next to the rumours the tick's Pings and Acks carry (same state
- * rule, same events, re-gossiped if accepted; nothing if `observer` is down then).  Unsharded handles only. */
+ * rule, same events, re-gossiped if accepted) -- if `observer` is up when that tick starts and stays up through the
+ * tick's scheduled changes; nobody listens otherwise.  The subject gets a view row like any subject somebody states a
+ * rumour about.  Unsharded handles only. */
 int swimsim_inject_rumor(swimsim_t* h, uint32_t observer, uint32_t subject, uint8_t state, uint32_t incarnation);
 
 /* ---- sharded clusters (one handle per GPU / process) -------------------------------

@@ -742,7 +742,8 @@ static void phase_probe(octx_t* c) {
   c->nfails = 0;
   for (uint32_t g = 0; g < o->nworkers; g++) c->out[g].n = 0;
   /* messages from outside the simulation reach their members like any datagram of the tick (src/Core.hs:110-117) */
-  if (c->w == 0) for (size_t x = 0; x < o->ninj; x++) if (o->up[o->inj[x].dst]) pend_add(c, o->inj[x].dst, o->inj[x].subject, o->inj[x].key);
+  if (c->w == 0) for (size_t x = 0; x < o->ninj; x++)
+    if (o->inj[x].dst != NONE32 && o->up[o->inj[x].dst]) pend_add(c, o->inj[x].dst, o->inj[x].subject, o->inj[x].key);
   for (uint32_t i = c->lo; i < c->hi; i++) {
     o->nsent[i] = 0;
     if (o->up[i]) { failure_detector(c, i); c->counters[SWIMSIM_CTR_ACTIVE_MEMBERS]++; }
@@ -853,6 +854,14 @@ static void settle(swimoracle_t* o, uint32_t t) {
 
 static int one_tick(swimoracle_t* o) {
   uint32_t t = (uint32_t)o->tick;
+  /* A message from outside the simulation (swimsim_inject_rumor) reaches a member that is up when the tick starts and
+   * stays up through the tick's scheduled changes.  A rumour somebody states opens the subject's column even if the
+   * receiver ignores it -- at the start of the tick, so that a column nobody holds anything in settles
+   * at the end of it. */
+  for (size_t x = 0; x < o->ninj; x++) {
+    if (!o->up[o->inj[x].dst]) o->inj[x].dst = NONE32;            /* nobody listening */
+    else if (!view_ref(o, o->inj[x].dst, o->inj[x].subject)) return SWIMSIM_ERR_CAPACITY;
+  }
   apply_faults(o, t);
   fold_workers(o);                                /* JOIN events */
   if (o->poisoned) return SWIMSIM_ERR_CAPACITY;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # one GPU iteration: parity tests, bench lines, kernel-trace stats, PMC passes.
-# usage: gpu_cycle.sh <tag> [what...]   what = tests bench extra variants shard prof pmc (default: all)   -> gpurun_out/<tag>_*
+# usage: gpu_cycle.sh <tag> [what...]   what = tests bench extra variants shard prof pmc churn (default: all but churn)   -> gpurun_out/<tag>_*
 TAG=$1; shift; WHAT="${*:-tests bench extra variants shard prof pmc}"
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out; mkdir -p $O
 cd $R
@@ -21,7 +21,7 @@ if has extra; then
   # the lossy lines carry the same-cluster CPU figure and the oracle check (shorter windows: the threaded oracle needs them)
   b loss1pct_gc --steps 60 --warmup 20 --loss-ppm 10000 --gc
   b loss30pct_16k --steps 200 --warmup 20 --members 16384 --loss-ppm 300000
-  b loss30pct_64k --steps 100 --warmup 20 --members 65536 --loss-ppm 300000
+  b loss30pct_32k --steps 100 --warmup 20 --members 32768 --loss-ppm 300000   # (65 536 members at 30 % loss: every member a subject, beyond the 65 534 view rows a handle can have)
 fi
 if has variants; then
   # the tick kernels with the state by value (product) against by pointer (libswimsim_sptr.so): the same cluster, stepped in turn
@@ -33,9 +33,12 @@ if has shard; then
 fi
 cd /tmp && export TMPDIR=/tmp
 if has prof; then
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -o sat -- python $R/bench.py --steps 100 --warmup 50 --no-cpu-baseline > $O/${TAG}_prof.log 2>&1
-  find $O/${TAG}_prof -name "*kernel_stats.csv" -exec cut -d, -f1-4,6-7 {} \; | head -8
+  # kernel-trace statistics over the TIMED WINDOW of the driver-flag line (what roofline.kernels.*.avg_launch_us must reproduce)
+  bash $R/scripts/prof_timed_window.sh $TAG --steps 20 --warmup 5
 fi
 if has pmc; then
-  bash $R/scripts/pmc_passes.sh $O/${TAG}_pmc > $O/${TAG}_pmc.log 2>&1; tail -40 $O/${TAG}_pmc/summary.txt
+  PASSES="${PASSES:-p1 p2 p4}" bash $R/scripts/pmc_passes.sh $O/${TAG}_pmc > $O/${TAG}_pmc.log 2>&1; tail -40 $O/${TAG}_pmc/summary.txt
+fi
+if has churn; then
+  timeout 900 python $R/scripts/churn_time.py 2>&1 | tee $O/${TAG}_churn.txt
 fi

@@ -35,6 +35,10 @@ while time.time() < t_end:
     a = Sim.create(orc, sc)
     rm = shards > 1 and rng.random() < 0.5                       # replicated queue masks (read from the environment at create)
     os.environ["SWIMSIM_SHARD_REPLICATED_MASKS"] = "1" if rm else "0"
+    rk = rng.choice(["", "0", "1"])                              # explicit records: the handle's own choice / phase in merge_kernel / records_kernel
+    if rk: os.environ["SWIMSIM_RECORDS_KERNEL"] = rk
+    else: os.environ.pop("SWIMSIM_RECORDS_KERNEL", None)
+    inject = shards == 1 and rng.random() < 0.4                   # rumours from outside the simulation (swimsim_inject_rumor)
     b = Sim.create(variants[vname], sc) if shards == 1 else ShardedSim(variants[vname], sc, LocalFabric(shards))
     nf = rng.randrange(0, n // 4)
     for _ in range(nf):
@@ -43,10 +47,14 @@ while time.time() < t_end:
         if rng.random() < 0.7:
             t2 = t + rng.randrange(1, 150)
             for s in (a, b): s.scheduleFault(t2, m, True)
-    what = (vname, n, p, loss, gc, jp, S, ticks, sc.seed, nf, shards, scheme, rm)
+    what = (vname, n, p, loss, gc, jp, S, ticks, sc.seed, nf, shards, scheme, rm, "rk" + rk, inject)
     ok = True
     try:
         for _ in range(ticks // 20):
+            if inject:
+                for _j in range(rng.randrange(0, 12)):
+                    o_, s_, st_, inc_ = rng.randrange(n), rng.randrange(n), rng.randrange(3), rng.randrange(3)
+                    a.injectRumor(o_, s_, st_, inc_); b.injectRumor(o_, s_, st_, inc_)
             a.step(20); b.step(20)
             ca, cb = a.counters(), b.counters()
             da, db = ca.pop("events_dropped"), cb.pop("events_dropped")

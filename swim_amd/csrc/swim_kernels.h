@@ -1990,7 +1990,8 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
       if (!up) {
         // the process is gone: its piggyback queue with it (member map and deadlines stay: swimsim.h)
         s.crash_tick[mbr] = t;
-        if (is_local(s, mbr)) { set_mi(s, mbr, mi & ~(MI_UP | MI_PB)); s.pk[mbr - s.lo].x = 0ull; }
+        // (its inbox with it: a message from outside the simulation may have been delivered before the tick started)
+        if (is_local(s, mbr)) { set_mi(s, mbr, mi & ~(MI_UP | MI_PB)); s.pk[mbr - s.lo].x = 0ull; s.inbox_cnt[mbr - s.lo] = 0u; }
         else set_mi(s, mbr, mi & ~MI_UP);
         continue;
       }
@@ -2007,7 +2008,12 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
       mi = s.minfo[mbr];
       const uint32_t cur = mi_buf(mi);
       const uint32_t akey = (ni << 2) | ST_ALIVE;
-      const uint32_t arid = find_rid(s, sl, akey);
+      // a FRESH id, not find_rid's cached one: the mask written below says "the newest id", and the rumour may have been
+      // stated before -- a message from outside the simulation can name an incarnation the member has not reached yet
+      // (swimsim_inject_rumor; found by the soak: the announcement travelled under an id thousands of ids old, its mask
+      // bit read as another rumour).  Two ids for one rumour are harmless (an id is only a filter key).
+      const uint32_t arid = new_rid(s) & RID_MASK;
+      s.rum[arid] = make_uint2(sl, akey);
       uint64_t* line = s.pb + ((size_t)cur * s.N + ml) * PB_SLOTS;
       line[0] = ((uint64_t)pe_hi(akey, s.L) << 32) | pe_lo(sl, arid);
       for (int q = 1; q < PB_SLOTS; ++q) line[q] = 0ull;
@@ -2077,7 +2083,8 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
     if (changes_sh) s.blk[(size_t)s.nblocks * C_COUNT + C_CHANGES] += changes_sh;
     s.g[G_PREV] = s.g[G_HEAD];
     s.g[G_HEAD] = s.g[G_NRUM];
-    s.g[G_ANYREC] = s.n_shards > 1 ? 1u : 0u;       // set by whoever writes an explicit record (the exchange kernels may)
+    s.g[G_ANYREC] = (s.n_shards > 1 || (part & 4u)) ? 1u : 0u;   // set by whoever writes an explicit record (the exchange kernels may;
+                                                                  // part bit 2: inject_kernel already has)
     // a line is rewritten every tick and replaces ids outside [H - KW_BITS, H + RID_NEAR) by "no id"; an id born at
     // distance r < RID_NEAR above the head sits at r - D one tick later (D = ids of the tick) and would wrap
     // back INTO that zone for D > 2^RID_BITS - RID_NEAR - KW_BITS.  After such a tick (48 896 new rumours at once with
@@ -2171,13 +2178,13 @@ __global__ void inject_kernel(DevState s, uint32_t t, const InjectRec* recs, uin
   if (!mi_up(s.minfo[r.observer])) return;          // nobody listening
   const uint32_t slot = get_slot(s, r.subject);
   uint32_t num = 0;
-  const uint32_t rid0 = find_rid(s, slot, r.key, &num), rid = young_rid(rid0, num, s.g[G_HEAD]);
+  (void)num;
+  const uint32_t rid = find_rid(s, slot, r.key, &num);      // handed out before the tick's window head is taken: an id like any of the tick before
   uint4* line = s.fl + (size_t)k * 4;
   line[0] = make_uint4(pe_lo(slot, rid), pe_hi(r.key, 1u), 0u, 0u);
   line[1] = make_uint4(0u, 0u, 0u, 0u); line[2] = make_uint4(0u, 0u, 0u, 0u); line[3] = make_uint4(0u, 0u, 0u, 0u);
   __threadfence();
   push(s, t, r.observer - s.lo, SRC_FOREIGN | k);
-  s.g[G_ANYREC] = 1u;
 }
 
 // full-state digest: Sum_i mix64(member_hash(i) + mix64(TAG_MEMBER + i)) + first-detection terms

@@ -569,15 +569,20 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
     const size_t f0 = fpos;
     while (fpos < fend && h->faults[fpos].tick <= t) ++fpos;
     const uint32_t tk = tick_key(h->cfg.seed, t);
-    hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, (uint32_t)(fpos - f0),
-                       h->d_joined, 3u, PeerCounts{});
-    if (!h->injections.empty()) {                 // messages from outside the simulation: into this tick's inboxes
+    // messages from outside the simulation go into this tick's inboxes BEFORE the start of the tick: the rows they open
+    // count as stated in this tick (a row nobody holds anything in settles at the end of it, as in the oracle), the ids
+    // they take are older than the tick's window head
+    uint32_t part = 3u;
+    if (!h->injections.empty()) {
       const uint32_t ni = (uint32_t)h->injections.size();
       HIPCHK(h, hipMemcpyAsync(h->d_inject, h->injections.data(), ni * sizeof(InjectRec), hipMemcpyHostToDevice, h->stream));
       hipLaunchKernelGGL(inject_kernel, dim3((ni + 63) / 64), dim3(64), 0, h->stream, h->d, t, h->d_inject, ni);
       HIPCHK(h, hipStreamSynchronize(h->stream));   // the host list is reused
       h->injections.clear();
+      part |= 4u;                                   // begin_kernel: explicit records exist already
     }
+    hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, (uint32_t)(fpos - f0),
+                       h->d_joined, part, PeerCounts{});
     const uint32_t pk = std::max(h->d.P, h->d.K);   // registers follow the probe / proxy arrays: four sizes
     if (pk <= 4) launch_tick<4>(h, t, tk, ev);
     else if (pk <= 8) launch_tick<8>(h, t, tk, ev);

@@ -122,3 +122,35 @@ def test_injected_rumours_match_the_oracle(oracle_abi, emu_abi):
                 s.injectRumor(9, 40, 2, 1)
         compare_state(a, b, (0, 5, 6, 7, 41, 599), (5, 6, 7, 40), True, where="block %d:" % k)
     assert b.counters()["refutes"] >= 2
+
+
+@pytest.mark.parametrize("trial", [0, 3])
+def test_injected_rumours_under_churn_and_settling(oracle_abi, emu_abi, trial):
+    """Messages from outside next to crashes, rejoins, loss and settling (the cases a soak of this path found: an outsider
+    naming an incarnation the member reaches later -- its join announcement must not travel under the old rumour's id --,
+    a message for a member that comes up / goes down in the very tick, a no-news message whose row settles at once)."""
+    import random
+    from swim_amd import _abi
+    rng = random.Random(900 + trial)
+    n = 700
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=rng.randrange(1, 1 << 30), lossPpm=100000, eventMask=0x1F,
+                   suspicionTicks=7, retransmitMult=rng.choice([1, 2, 3]), maxSubjects=n, gcTicks=_abi.GC_AUTO)
+    a, b = Sim.create(oracle_abi, sc), Sim.create(emu_abi, sc)
+    for _ in range(93):
+        m, t = rng.randrange(n), rng.randrange(1, 200)
+        for s in (a, b):
+            s.scheduleFault(t, m, False)
+        if rng.random() < 0.7:
+            t2 = t + rng.randrange(1, 150)
+            for s in (a, b):
+                s.scheduleFault(t2, m, True)
+    for _blk in range(42):
+        for _j in range(rng.randrange(0, 12)):
+            o_, s_, st_, inc_ = rng.randrange(n), rng.randrange(n), rng.randrange(3), rng.randrange(3)
+            a.injectRumor(o_, s_, st_, inc_); b.injectRumor(o_, s_, st_, inc_)
+        a.step(5); b.step(5)
+        ca, cb = a.counters(), b.counters()
+        ca.pop("events_dropped"); cb.pop("events_dropped")        # implementation-defined once the ring overflows
+        assert ca == cb and a.digest() == b.digest(), "tick %d" % a.tick
+    assert a.firstDetection() == b.firstDetection()
+    a.close(); b.close()
