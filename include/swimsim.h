@@ -215,6 +215,8 @@ enum {
                                      exact count is implementation-defined, not protocol state) */
   SWIMSIM_CTR_ACTIVE_MEMBERS = 12,/* up-member ticks actually processed                  */
   SWIMSIM_CTR_EVDIGEST = 13,      /* running digest of every view / incarnation change   */
+  SWIMSIM_CTR_FALSE_DEADS = 14,   /* ... of a member that was actually up: the false-positive
+                                     Dead count of BASELINE config 5, per (observer, subject)  */
   SWIMSIM_CTR_SETTLED = 15,       /* subjects settled (view columns reclaimed; gc_ticks) */
   SWIMSIM_CTR_COUNT = 16
 };
@@ -286,6 +288,14 @@ int swimsim_first_detect(swimsim_t* h, uint64_t* out, size_t n);
 int swimsim_digest(swimsim_t* h, uint64_t* out);
 
 int swimsim_counters(swimsim_t* h, uint64_t* out, size_t n);
+
+/* How far a rumour has got -- the "dissemination ticks-to-all" of BASELINE config 5 is the first tick at which
+ * out[0] == out[1]:  out[1] = members that are up, `subject` itself not counted; out[0] = those of them whose entry
+ * about `subject` is at least {incarnation, state} in the merge order of the state rule (src/Core.hs:142-187: higher
+ * incarnation wins, then Dead > Suspect > Alive; an entry settling has folded into the base counts as that base).
+ * Reads state between ticks, changes nothing.  On a sharded handle both numbers cover the members the handle owns
+ * (the parts add up). */
+int swimsim_coverage(swimsim_t* h, uint32_t subject, uint8_t state, uint32_t incarnation, uint64_t out[2]);
 
 /* Occupancy of the bounded tables (what SWIMSIM_ERR_CAPACITY guards), for long runs:
  * out[0] = view rows ever handed out (high-water mark; bounded under settling), out[1] = subjects that hold a

@@ -579,7 +579,10 @@ static int accept_key(octx_t* c, uint32_t i, uint32_t s, uint32_t key, uint8_t c
   if (__atomic_load_n(&o->last_change[s], __ATOMIC_RELAXED) != t) __atomic_store_n(&o->last_change[s], t, __ATOMIC_RELAXED);
   if (e->since1 != t + 1) c->counters[SWIMSIM_CTR_CHANGES]++;
   e->key = key; e->since1 = t + 1;                 /* memberLastChange = now (:176) */
-  if (cause == SWIMSIM_CAUSE_TIMER) c->counters[SWIMSIM_CTR_TIMERS_FIRED]++;
+  if (cause == SWIMSIM_CAUSE_TIMER) {              /* `deadNode` after the timeout; a false positive if s is up all the same */
+    c->counters[SWIMSIM_CTR_TIMERS_FIRED]++;
+    if (o->up[s]) c->counters[SWIMSIM_CTR_FALSE_DEADS]++;
+  }
   if (key_state(key) == SWIMSIM_SUSPECT) timer_push(o, i, s, t + o->S);   /* D4 */
   cand_insert(cand, s, key, (uint8_t)o->L);        /* `Just msg` -> Broadcast -> enqueue (D5) */
   event_add(c, t, i, s, key, cause);
@@ -1152,6 +1155,21 @@ int swimoracle_read_member(swimoracle_t* o, uint32_t m, swimsim_member_t* out) {
 int swimoracle_first_detect(swimoracle_t* o, uint64_t* out, size_t n) {
   if (!o || !out || n != o->N) return SWIMSIM_ERR_INVALID;
   for (uint32_t j = 0; j < o->N; j++) out[j] = o->first_suspect[j] == NONE32 ? SWIMSIM_TICK_NONE : o->first_suspect[j];
+  return SWIMSIM_OK;
+}
+
+/* how far a rumour has got (include/swimsim.h, swimsim_coverage): the up members other than `subject` whose entry about it
+ * is at least {incarnation, state} in merge order, and the number of such members at all */
+int swimoracle_coverage(swimoracle_t* o, uint32_t subject, uint8_t state, uint32_t incarnation, uint64_t out[2]) {
+  if (!o || !out || subject >= o->N || state > SWIMSIM_DEAD || incarnation > INC_MAX) return SWIMSIM_ERR_INVALID;
+  const uint32_t key = (incarnation << 2) | state;
+  uint64_t hold = 0, up = 0;
+  for (uint32_t i = 0; i < o->N; i++) {
+    if (i == subject || !o->up[i]) continue;
+    up++;
+    if (view_get(o, i, subject).key >= key) hold++;
+  }
+  out[0] = hold; out[1] = up;
   return SWIMSIM_OK;
 }
 

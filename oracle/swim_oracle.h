@@ -46,6 +46,7 @@ int swimoracle_read_view(swimoracle_t* h, uint32_t observer, swimsim_view_entry_
 int swimoracle_read_member(swimoracle_t* h, uint32_t member, swimsim_member_t* out);
 int swimoracle_first_detect(swimoracle_t* h, uint64_t* out, size_t n);
 int swimoracle_digest(swimoracle_t* h, uint64_t* out);
+int swimoracle_coverage(swimoracle_t* h, uint32_t subject, uint8_t state, uint32_t incarnation, uint64_t out[2]);
 int swimoracle_counters(swimoracle_t* h, uint64_t* out, size_t n);
 int swimoracle_k_random_members(swimoracle_t* h, uint32_t observer, uint32_t n,
                                 const uint32_t* excludes, size_t n_excludes, uint32_t* out,

@@ -1,6 +1,6 @@
 #!/bin/bash
 # one GPU iteration: parity tests, bench lines, kernel-trace stats, PMC passes.
-# usage: gpu_cycle.sh <tag> [what...]   what = tests bench extra variants shard prof pmc churn (default: all but churn)   -> gpurun_out/<tag>_*
+# usage: gpu_cycle.sh <tag> [what...]   what = tests bench extra variants shard prof pmc churn config5 (default: all but churn, config5)   -> gpurun_out/<tag>_*
 TAG=$1; shift; WHAT="${*:-tests bench extra variants shard prof pmc}"
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out; mkdir -p $O
 cd $R
@@ -41,4 +41,7 @@ if has pmc; then
 fi
 if has churn; then
   timeout 900 python $R/scripts/churn_time.py 2>&1 | tee $O/${TAG}_churn.txt
+fi
+if has config5; then   # BASELINE config 5's reported numbers (ticks-to-all, false-positive Dead): 16 384 members oracle-checked, 32 768 alone
+  (ORACLE=1 timeout 900 python $R/scripts/config5.py 16384; timeout 600 python $R/scripts/config5.py 32768) 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_config5.txt
 fi

@@ -23,7 +23,7 @@ GC_AUTO = 0xFFFFFFFF
 CTR_NAMES = [
     "pings", "direct_failed", "ping_reqs", "suspects", "false_suspects", "payloads",
     "rumors_seen", "changes", "pb_writes", "timers_fired", "refutes", "events_dropped",
-    "active_members", "evdigest", "_14", "settled",
+    "active_members", "evdigest", "false_deads", "settled",
 ]
 CTR_COUNT = 16
 
@@ -91,6 +91,7 @@ _SIGS = {
     "set_view": (C.c_int, [_H, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint32]),
     "get_config": (C.c_int, [_H, C.POINTER(Config)]),
     "inject_rumor": (C.c_int, [_H, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint32]),
+    "coverage": (C.c_int, [_H, C.c_uint32, C.c_uint8, C.c_uint32, C.POINTER(C.c_uint64)]),
 }
 
 # entry points only the product library has (measurement plumbing, sharded stepping; no oracle counterpart)

@@ -47,7 +47,7 @@ enum { ERRF_SUBJECTS = 1, ERRF_ROWS = 2, ERRF_OVF = 4, ERRF_INC = 8, ERRF_XCHG =
 // counter slots (same order as SWIMSIM_CTR_* in include/swimsim.h)
 enum { C_PINGS = 0, C_DIRECT_FAILED, C_PING_REQS, C_SUSPECTS, C_FALSE_SUSPECTS, C_PAYLOADS,
        C_RUMORS_SEEN, C_CHANGES, C_PB_WRITES, C_TIMERS_FIRED, C_REFUTES, C_EVENTS_DROPPED,
-       C_ACTIVE, C_EVDIGEST, C_EXAMINED /* view lookups by merge_kernel (internal) */, C_SETTLED, C_COUNT = 16 };
+       C_ACTIVE, C_EVDIGEST, C_FALSE_DEADS /* timers fired about a member that is up */, C_SETTLED, C_COUNT = 16 };
 
 // ---- hashes (replace the global StdGen of src/Util.hs:40, F7) -----------
 __host__ __device__ inline uint32_t mix32(uint32_t x) {

@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
   const uint4* own_line = reinterpret_cast<const uint4*>(s.pb + ((size_t)cur * s.N + (li < s.N ? li : 0u)) * PB_SLOTS);
   const uint32_t my_slot1 = mi & MI_SLOT;          // slot+1 of rumours about me
   uint32_t refute = NONE32;
-  unsigned changes = 0, timers_fired = 0, evdropped = 0, examined = 0, refutes = 0, pb_writes = 0;
+  unsigned changes = 0, timers_fired = 0, evdropped = 0, refutes = 0, pb_writes = 0;   // timers_fired: low half; high half = ... about a member that is up
   unsigned long long evd = 0, ha = 0;
   TimerCell tnew; tnew.lo = 0; tnew.hi = 0; tnew.n = 0;   // deadlines t + S: go to the row just consumed
 
@@ -1110,7 +1110,6 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
       if ((key & 3u) != ST_ALIVE) refute = (refute == NONE32 || (key >> 2) > refute) ? (key >> 2) : refute;
       return;
     }
-    examined++;
     PSTAT(5); SECT_COUNT(20);
     if (!(have & HAVE_CELL) && !ABL(ABL_V_LOAD)) e = s.V[vidx(s, li, slot)];
     const uint32_t curk = e.x ? e.x : ((have & HAVE_BASE) ? sbase : s.slot_base[slot]);   // untouched cell: the settled base
@@ -1124,7 +1123,8 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
     // entry in one tick telescope whatever their order -- one hash per change (three before: 6 % of the kernel)
     if (!ABL(ABL_EVD)) evd += (mix64(ha + subject) | 1ull) * (unsigned long long)(key - curk);
     changes += (e.y != t + 1) ? 1u : 0u;
-    if (cause == 1u) timers_fired++;
+    // Suspect -> Dead by timeout; ... of a member that is up all the same (a false positive: ground truth, replicated)
+    if (cause == 1u) timers_fired += 1u + ((uint32_t)mi_up(s.minfo[subject]) << 16);
     if ((key & 3u) == ST_SUSPECT) tput(slot + 1);                     // deadline t + S (D4)
     const uint32_t rid = (hasrid || ABL(ABL_FIND_RID)) ? rid_in : find_rid(s, slot, key);
     if (!ABL(ABL_GROUP)) {
@@ -1396,13 +1396,13 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
   }
   ctr_add_wave(&sh, C_CHANGES, changes);
   ctr_add_wave(&sh, C_PB_WRITES, pb_writes);
-  ctr_add_wave(&sh, C_EXAMINED, examined);
   {
     const unsigned long long wevd = wave_sum64(evd);
     if ((tid & 63u) == 0u && wevd) atomicAdd(&sh.evd, wevd);
   }
   if (__ballot((timers_fired | refutes | evdropped) != 0u)) {   // the rare ones: a wave-uniform test first
-    ctr_add_wave(&sh, C_TIMERS_FIRED, timers_fired);
+    ctr_add_wave(&sh, C_TIMERS_FIRED, timers_fired & 0xFFFFu);   // a lane fires at most one timer per row: < 65 535
+    ctr_add_wave(&sh, C_FALSE_DEADS, timers_fired >> 16);
     ctr_add_wave(&sh, C_REFUTES, refutes);
     ctr_add_wave(&sh, C_EVENTS_DROPPED, evdropped);
   }
@@ -2032,7 +2032,7 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
     if (dropped) atomicAdd(&dropped_sh, dropped);
   }
   __syncthreads();
-  if (part == 1u) {                                 // the rest follows the exchange of the pulls (part 2)
+  if (!(part & 2u)) {                               // the rest follows the pulls (part 2)
     if (threadIdx.x == 0) {
       if (evd_sh) s.blk[(size_t)s.nblocks * C_COUNT + C_EVDIGEST] += evd_sh;
       if (dropped_sh) s.blk[(size_t)s.nblocks * C_COUNT + C_EVENTS_DROPPED] += dropped_sh;
@@ -2056,7 +2056,8 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
       }
     }
     __syncthreads();
-    const uint32_t nj = atomicOr(&s.g[G_NJOINED], 0u);       // counted with atomics by other waves of this block: read where they landed
+    const uint32_t nj = (part & 8u) ? 0u                     // join_pull_kernel has done (ii): a block per joiner
+                                    : atomicOr(&s.g[G_NJOINED], 0u);   // counted with atomics by other waves of this block: read where they landed
     for (uint32_t k = threadIdx.x; k < nj; k += blockDim.x) {
       const uint32_t mbr = joined[k];
       if (!is_local(s, mbr)) continue;
@@ -2141,6 +2142,59 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
   }
 }
 
+// The joiners' pulls from hosts on this shard, one BLOCK per joiner, between the two parts of begin_kernel (which then
+// skips its own loop over them: part bit 3).  A joiner walks every row of its host: one thread per joiner inside
+// begin_kernel's single block made a tick with joins cost 2 dependent gathers x rows, serially (5 ms for 25 joiners
+// over 8 000 rows, profiles/r03zz_churn.txt); here the rows go over the block's threads, four in flight per thread.
+// Hosts are members without a change this tick (join_host), never joiners: the blocks touch disjoint members.
+__global__ __launch_bounds__(BLOCK) void join_pull_kernel(DevState s, uint32_t t, uint32_t tk, const FaultRec* faults, uint32_t nfaults,
+                                                          const uint32_t* joined) {
+  __shared__ unsigned long long evd_sh;
+  __shared__ unsigned pulled_sh;
+  __shared__ uint32_t host_sh;
+  const uint32_t nj = s.g[G_NJOINED];
+  const uint32_t nrows = min(s.g[G_NSLOTS], s.R_phys);
+  constexpr int U = 4;
+  for (uint32_t k = blockIdx.x; k < nj; k += gridDim.x) {
+    const uint32_t mbr = joined[k];
+    if (threadIdx.x == 0) {
+      evd_sh = 0; pulled_sh = 0;
+      host_sh = is_local(s, mbr) ? join_host(s, tk, mbr, faults, nfaults) : NONE32;
+    }
+    __syncthreads();
+    const uint32_t host = host_sh;
+    if (host != NONE32 && is_local(s, host)) {
+      unsigned long long evd = 0; unsigned pulled = 0;
+      const uint32_t hl = host - s.lo;
+      const uint32_t hkey = (s.hot[hl].x << 2) | ST_ALIVE;
+      for (uint32_t r0 = threadIdx.x; r0 < nrows; r0 += BLOCK * U) {
+        uint32_t used[U], subj[U], vh[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t r = r0 + u * BLOCK;
+          used[u] = r < nrows ? s.slot_used[r] : 0u;
+          subj[u] = r < nrows ? s.subject_of[r] : 0u;
+          vh[u] = r < nrows ? s.V[vidx(s, hl, r)].x : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (!used[u] || subj[u] == mbr) continue;
+          const uint32_t kh = subj[u] == host ? hkey : vh[u];   // an untouched cell is the base: no news
+          if (kh) pull_entry(s, t, mbr, r0 + u * BLOCK, subj[u], kh, &evd, &pulled);
+        }
+      }
+      if (evd) atomicAdd(&evd_sh, evd);
+      if (pulled) atomicAdd(&pulled_sh, pulled);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (evd_sh) atomicAdd(reinterpret_cast<unsigned long long*>(&s.blk[(size_t)s.nblocks * C_COUNT + C_EVDIGEST]), evd_sh);
+      if (pulled_sh) atomicAdd(reinterpret_cast<unsigned long long*>(&s.blk[(size_t)s.nblocks * C_COUNT + C_CHANGES]), (unsigned long long)pulled_sh);
+    }
+    __syncthreads();
+  }
+}
+
 // Sharded clusters with join_pull: between the two parts of begin_kernel the owner of a join host sends what the host
 // knows to the joiner's owner -- one record {joiner, subject, entry} per entry that differs from the base (the host
 // itself as Alive at its own incarnation) -- exchange round 0.  One thread per member that came up this tick.
@@ -2188,6 +2242,25 @@ __global__ void inject_kernel(DevState s, uint32_t t, const InjectRec* recs, uin
 }
 
 // full-state digest: Sum_i mix64(member_hash(i) + mix64(TAG_MEMBER + i)) + first-detection terms
+// swimsim_coverage: how many of my up members (the subject apart) hold an entry about `subject` that is at least `key`
+// in merge order -- out[0]; how many such members there are -- out[1].  One coalesced walk along the subject's row.
+__global__ __launch_bounds__(BLOCK) void coverage_kernel(DevState s, uint32_t subject, uint32_t key, unsigned long long* out) {
+  const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
+  const uint32_t sl1 = s.minfo[subject] & MI_SLOT;           // 0: nobody here has heard of it (no row)
+  const uint32_t base = sl1 ? s.slot_base[sl1 - 1u] : s.base_key[subject];
+  uint32_t up = 0, hold = 0;
+  if (li < s.N && s.lo + li != subject && mi_up(s.minfo[s.lo + li])) {
+    up = 1;
+    const uint32_t k = sl1 ? s.V[vidx(s, li, sl1 - 1u)].x : 0u;
+    hold = (k ? k : base) >= key ? 1u : 0u;                   // an untouched cell is the settled base
+  }
+  const unsigned long long bh = __ballot(hold != 0u), bu = __ballot(up != 0u);
+  if ((threadIdx.x & 63u) == 0u) {
+    if (bh) atomicAdd(&out[0], (unsigned long long)__popcll(bh));
+    if (bu) atomicAdd(&out[1], (unsigned long long)__popcll(bu));
+  }
+}
+
 __global__ __launch_bounds__(BLOCK) void digest_kernel(DevState s, unsigned long long* out) {
   __shared__ unsigned long long acc;
   if (threadIdx.x == 0) acc = 0;

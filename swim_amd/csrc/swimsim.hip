@@ -417,7 +417,7 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   CK(dev_alloc(h, &d.ovf, (size_t)2 * d.ovf_cap, 0));
   CK(dev_alloc(h, &d.events, (size_t)d.event_cap, 0));
   CK(dev_alloc(h, &d.blk, ((size_t)d.nblocks + 1) * C_COUNT + 4096, 0));   // + the section-clock table of the measurement build
-  CK(dev_alloc(h, &h->d_scratch64, (size_t)1, 0));
+  CK(dev_alloc(h, &h->d_scratch64, (size_t)2, 0));
   if (d.n_shards > 1) {
     // exchange buffers, sized from the expected traffic (2P deliveries per member, spread over the shards)
     // with headroom; overruns are loud (SWIMSIM_ERR_CAPACITY), never silent drops
@@ -581,6 +581,16 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
       h->injections.clear();
       part |= 4u;                                   // begin_kernel: explicit records exist already
     }
+    uint32_t nup = 0;                               // upper bound of this tick's joins
+    if (h->d.join_pull) for (size_t f = f0; f < fpos; ++f) nup += h->faults[f].up != 0;
+    if (nup) {
+      // a tick with joins: the pulls between the two parts of the start of the tick, one block per joiner
+      hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, (uint32_t)(fpos - f0),
+                         h->d_joined, 1u, PeerCounts{});
+      hipLaunchKernelGGL(join_pull_kernel, dim3(std::min(nup, 4096u)), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0,
+                         (uint32_t)(fpos - f0), h->d_joined);
+      part = (part & ~1u) | 8u;
+    }
     hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, (uint32_t)(fpos - f0),
                        h->d_joined, part, PeerCounts{});
     const uint32_t pk = std::max(h->d.P, h->d.K);   // registers follow the probe / proxy arrays: four sizes
@@ -739,6 +749,20 @@ int swimsim_digest(swimsim_t* h, uint64_t* out) {
   HIPCHK(h, hipMemcpy(&acc, h->d_scratch64, sizeof acc, hipMemcpyDeviceToHost));
   // a shard returns its members' part; shard 0 adds the tick term, so the parts simply add up
   *out = (h->d.shard == 0 ? mix64((uint64_t)TAG_TICK + h->tick) : 0ull) + acc;
+  return SWIMSIM_OK;
+}
+
+int swimsim_coverage(swimsim_t* h, uint32_t subject, uint8_t state, uint32_t incarnation, uint64_t out[2]) {
+  if (!h || !out || subject >= h->d.NT || state > SWIMSIM_DEAD || incarnation > INC_MAX) return SWIMSIM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemsetAsync(h->d_scratch64, 0, 2 * sizeof(unsigned long long), h->stream));
+  hipLaunchKernelGGL(coverage_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, subject, (incarnation << 2) | state,
+                     h->d_scratch64);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  unsigned long long acc[2] = {0, 0};
+  HIPCHK(h, hipMemcpy(acc, h->d_scratch64, sizeof acc, hipMemcpyDeviceToHost));
+  out[0] = acc[0]; out[1] = acc[1];
   return SWIMSIM_OK;
 }
 
@@ -929,8 +953,14 @@ int swimsim_shard_phase1(swimsim_t* h, uint32_t* counts) {
   const uint32_t tk = tick_key(h->cfg.seed, t);
   // one launch does the whole start of the tick, unless swimsim_shard_phase0 ran its first part already (join-time
   // pulls to exchange in between)
+  if (h->begun) {                                   // the pulls from hosts on this shard: a block per joiner (the ones the peers
+    uint32_t nup = 0;                               // sent are merged by begin_kernel: other joiners, rows no local host holds)
+    for (size_t f = 0; f < fend; ++f) nup += h->faults[f].up != 0;
+    if (nup) hipLaunchKernelGGL(join_pull_kernel, dim3(std::min(nup, 4096u)), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults,
+                                (uint32_t)fend, h->d_joined);
+  }
   hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults, (uint32_t)fend,
-                     h->d_joined, h->begun ? 2u : 3u, peer_counts(h, h->j_in));
+                     h->d_joined, h->begun ? (2u | 8u) : 3u, peer_counts(h, h->j_in));
   h->begun = false;
   std::fill(h->j_in, h->j_in + MAX_SHARDS, 0u);
   h->faults.erase(h->faults.begin(), h->faults.begin() + (long)fend);

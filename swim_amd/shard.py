@@ -417,6 +417,12 @@ class ShardedSim:
         local = sum(s.sim.digest() for s in self.shards) & _M64
         return sum(self.fabric.gather(local)) & _M64
 
+    def coverage(self, subject: int, state: int, incarnation: int = 0):
+        """(holders, up) over the whole population: every shard counts the members it owns (collective)."""
+        local = [s.sim.coverage(subject, state, incarnation) for s in self.shards]
+        parts = [c for group in self.fabric.gather(local) for c in group]
+        return sum(p[0] for p in parts), sum(p[1] for p in parts)
+
     def drainEventsRaw(self):
         local = [e for s in self.shards for e in s.sim.drainEventsRaw()]
         return sorted(e for group in self.fabric.gather(local) for e in group)

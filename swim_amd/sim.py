@@ -206,6 +206,14 @@ class Sim:
         self._check(self._abi.k_random_members(self._h, observer, n, ex, len(excludes), out, n, C.byref(got)))
         return list(out[: got.value])
 
+    def coverage(self, subject: int, state: int, incarnation: int = 0):
+        """(holders, up): the up members other than `subject` whose entry about it is at least {incarnation, state} in the
+        state rule's merge order, and the number of up members other than `subject` -- a rumour has reached everybody
+        when the two are equal (BASELINE config 5: dissemination ticks-to-all)."""
+        out = (C.c_uint64 * 2)()
+        self._check(self._abi.coverage(self._h, subject, int(state), incarnation, out))
+        return int(out[0]), int(out[1])
+
     def injectRumor(self, observer: int, subject: int, state: int, incarnation: int = 0):
         """A Suspect / Alive / Dead message about `subject` from OUTSIDE the simulation reaches `observer` in the next tick
         (`process` on a message off the socket, src/Core.hs:110-117; the live-node bridge uses it)."""

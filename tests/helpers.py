@@ -22,6 +22,9 @@ def compare_state(a, b, observers=(), members=(), check_events=True, where=""):
     if check_events:
         ea, eb = a.drainEventsRaw(), b.drainEventsRaw()
         assert ea == eb, "%s events differ (%d vs %d)" % (where, len(ea), len(eb))
+    for o in observers:                              # how far the rumours about o have got (swimsim_coverage)
+        for (st, inc) in ((1, 0), (2, 0), (0, 1)):
+            assert a.coverage(o, st, inc) == b.coverage(o, st, inc), "%s coverage of %d (%d@%d) differs" % (where, o, st, inc)
     for o in observers:
         assert a.members(o) == b.members(o), "%s view of %d differs" % (where, o)
     for m in members:

@@ -3,6 +3,7 @@
 TEST-ONLY: lets the kernels' logic be parity-checked against the oracle on a machine with no GPU.
 The product package never imports this; libswimsim.so itself has no CPU path."""
 import ctypes as C
+import fcntl
 import os
 import subprocess
 
@@ -20,12 +21,21 @@ def build(lib=None, defines=()):
     lib = lib or LIB
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".cpp"))]
     srcs += [os.path.join(EMU, "hip", "hip_runtime.h")] + [os.path.join(ROOT, "include", f) for f in ("swimsim.h", "swimwire.h", "swimbridge.h")]
-    if os.path.exists(lib) and all(os.path.getmtime(s) <= os.path.getmtime(lib) for s in srcs):
+    fresh = lambda: os.path.exists(lib) and all(os.path.getmtime(s) <= os.path.getmtime(lib) for s in srcs)
+    if fresh():
         return
     os.makedirs(os.path.dirname(lib), exist_ok=True)
-    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-I", EMU,
-                           "-Wno-unused-function", "-Wl,-Bsymbolic", *["-D" + d for d in defines], "-o", lib, os.path.join(CSRC, "swimsim.hip"),
-                           os.path.join(CSRC, "swim_wire.cpp"), os.path.join(CSRC, "swim_bridge.cpp")])
+    # several test processes may want the same library at once (xdist, the soak): one builds, into a
+    # name of its own, and renames -- nobody ever maps a half-written file
+    with open(lib + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if fresh():
+            return
+        tmp = "%s.%d.tmp" % (lib, os.getpid())
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-I", EMU,
+                               "-Wno-unused-function", "-Wl,-Bsymbolic", *["-D" + d for d in defines], "-o", tmp, os.path.join(CSRC, "swimsim.hip"),
+                               os.path.join(CSRC, "swim_wire.cpp"), os.path.join(CSRC, "swim_bridge.cpp")])
+        os.replace(tmp, lib)
 
 
 def load():

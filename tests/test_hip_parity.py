@@ -581,3 +581,14 @@ def test_injected_rumours_match_the_oracle_on_the_gpu(oracle_abi, hip_abi):
         a.step(3); b.step(3)
         compare_state(a, b, (0, 5, 19999), (5, 40), False, where="block %d:" % k)
     assert b.counters()["refutes"] > 50
+
+
+@pytest.mark.parametrize("loss", [100000, 300000])
+def test_config5_metrics_on_the_gpu(oracle_abi, hip_abi, loss):
+    """BASELINE config 5's two reported numbers -- the false-positive Dead count and the dissemination ticks-to-all of a
+    crash (swimsim_coverage, polled every tick) -- and the whole coverage curve: MI355X = oracle, 4 096 members."""
+    from tests.test_hostemu_parity import config5_metrics
+    a = config5_metrics(oracle_abi, n=4096, loss=loss, ticks=90)
+    b = config5_metrics(hip_abi, n=4096, loss=loss, ticks=90)
+    assert a == b
+    assert a[0] > 0 and a[2][3] == (0, 4095)

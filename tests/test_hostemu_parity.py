@@ -267,3 +267,37 @@ def test_state_by_pointer_build_gives_the_same_run(oracle_abi):
     a, b = make_pair(oracle_abi, emu, sc, crashes, [(45, m, True) for (_, m) in crashes[:20]])
     run_lockstep(a, b, 60, 5, observers=(0, 1, n - 1), members=(0, 1, n - 1))
 
+
+
+def config5_metrics(abi, n=512, loss=300000, ticks=110):
+    """The two numbers BASELINE config 5 reports, on one backend: the false-positive Dead count and the ticks a crash needs
+    to be known (as Dead) by every up member; also the coverage curve they were read from."""
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=9, lossPpm=loss, eventMask=0, suspicionTicks=5, maxSubjects=n)
+    s = Sim.create(abi, sc)
+    s.crash(n // 3, tick=8)
+    curve, to_all = [], None
+    for _ in range(ticks):
+        s.step(1)
+        hold, up = s.coverage(n // 3, 2, 0)
+        curve.append((hold, up))
+        if to_all is None and hold == up:
+            to_all = s.tick - 8
+    return s.counters()["false_deads"], to_all, curve, s.digest()
+
+
+@pytest.mark.parametrize("loss", [100000, 300000])
+def test_config5_metrics_false_dead_count_and_ticks_to_all(oracle_abi, emu_abi, loss):
+    """Heavy message loss: members that are up get declared Dead (false positives), and a real crash takes its time to
+    reach everybody -- both numbers and the whole coverage curve equal the oracle's."""
+    a = config5_metrics(oracle_abi, loss=loss)
+    b = config5_metrics(emu_abi, loss=loss)
+    assert a == b
+    false_deads, to_all, curve, _ = a
+    assert false_deads > 0                           # loss this heavy does produce them
+    assert curve[3] == (0, 511)                      # before the crash: nobody holds it, everybody else is up
+    if loss == 100000:
+        assert 5 < to_all < 30                       # suspicion (5 ticks) + an epidemic's log n
+    else:
+        # 30 % loss with a 5-tick suspicion timeout: every queue is full of false Deads and their refutations, the one
+        # true rumour competes for 8 slots -- most, not all, have it after 100 ticks
+        assert to_all is None and curve[-1][0] > 450
