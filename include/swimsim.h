@@ -216,7 +216,9 @@ enum {
   SWIMSIM_CTR_ACTIVE_MEMBERS = 12,/* up-member ticks actually processed                  */
   SWIMSIM_CTR_EVDIGEST = 13,      /* running digest of every view / incarnation change   */
   SWIMSIM_CTR_FALSE_DEADS = 14,   /* ... of a member that was actually up: the false-positive
-                                     Dead count of BASELINE config 5, per (observer, subject)  */
+                                     Dead count of BASELINE config 5, per (observer, subject);
+                                     "up" whatever its incarnation -- an observer burying the old
+                                     incarnation of a member that has come back counts          */
   SWIMSIM_CTR_SETTLED = 15,       /* subjects settled (view columns reclaimed; gc_ticks) */
   SWIMSIM_CTR_COUNT = 16
 };

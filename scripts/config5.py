@@ -5,11 +5,12 @@ count -- next to ms/tick.  One JSON line per case.
   ticks-to-all: 8 members that are not part of the churn crash at tick T0 and stay down; swimsim_coverage(subject, Dead, 0)
       is polled after every tick: the first tick at which every up member holds Dead@0 (or something stronger) about the
       subject, minus T0.  null = not within the run.
-  false-positive Dead: the counter false_deads (suspicion timers that fired about a member that was up, per observer).
+  false-positive Dead: the counter false_deads (suspicion timers that fired about a member that was up, per observer --
+      whatever the incarnation: under churn this includes observers burying the old incarnation of a member that is back).
 
 usage (GPU box): config5.py [members ...]      default: 16384 32768  (65 536 at 30 % loss needs more view rows than a
 handle's 16-bit row ids allow: DESIGN.md section 11).   ORACLE=1: the same run on the CPU oracle (all host threads), numbers
-compared;  LOSS=<ppm>, TICKS=<n>, T0=<tick> override the defaults."""
+compared;  LOSS=<ppm>, TICKS=<n>, T0=<tick>, ROWS=<max subjects>, CHURN=<per-mille list> override the defaults."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from swim_amd import Config, Sim, SimConfig, _abi, _lib, workloads
@@ -21,7 +22,7 @@ NTRACK = 8
 
 
 def run(abi, n, per_mille, threads=0):
-    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=1, lossPpm=LOSS, maxSubjects=min(n, 65000), eventMask=0,
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=1, lossPpm=LOSS, maxSubjects=int(os.environ.get("ROWS", min(n, 65000))), eventMask=0,
                    gcTicks=_abi.GC_AUTO if per_mille else 0)
     s = Sim.create(abi, sc)
     if threads:                                      # the oracle only (scales to ~32 threads)
@@ -63,7 +64,7 @@ def main():
     sizes = [int(x) for x in sys.argv[1:]] or [16384, 32768]
     abi = _lib.load()
     for n in sizes:
-        for pm in (0, 1, 10):
+        for pm in [int(x) for x in os.environ.get("CHURN", "0,1,10").split(",")]:   # per mille of the members per 100 ticks
             out, cover = run(abi, n, pm)
             if os.environ.get("ORACLE"):
                 from tests import oracle_binding

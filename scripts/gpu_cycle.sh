@@ -40,8 +40,8 @@ if has pmc; then
   PASSES="${PASSES:-p1 p2 p4}" bash $R/scripts/pmc_passes.sh $O/${TAG}_pmc > $O/${TAG}_pmc.log 2>&1; tail -40 $O/${TAG}_pmc/summary.txt
 fi
 if has churn; then
-  timeout 900 python $R/scripts/churn_time.py 2>&1 | tee $O/${TAG}_churn.txt
+  ORACLE=300000 timeout 1200 python $R/scripts/churn_time.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_churn.txt
 fi
 if has config5; then   # BASELINE config 5's reported numbers (ticks-to-all, false-positive Dead): 16 384 members oracle-checked, 32 768 alone
-  (ORACLE=1 timeout 900 python $R/scripts/config5.py 16384; timeout 600 python $R/scripts/config5.py 32768) 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_config5.txt
+  (ORACLE=1 timeout 900 python $R/scripts/config5.py 16384; timeout 600 python $R/scripts/config5.py 32768; echo '# 5 % loss (the protocol still converges):'; LOSS=50000 ORACLE=1 timeout 900 python $R/scripts/config5.py 16384; echo '# 1 % loss, 1 M members:'; LOSS=10000 TICKS=220 T0=100 ROWS=12000 CHURN=0,1 timeout 900 python $R/scripts/config5.py 1048576) 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_config5.txt
 fi

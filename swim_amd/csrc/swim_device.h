@@ -42,7 +42,7 @@ enum { G_NSLOTS = 0 /* view rows ever handed out (high-water mark) */, G_ERR = 1
 // their own (todo_n[region * 16]): workgroup b reserves from region b mod TODO_REGIONS -- every wave of the grid bumping
 // ONE word was 12 % of merge_kernel's wave time at 1 % loss (same-address atomics serialise, profiles/r03t_*)
 constexpr uint32_t TODO_REGIONS = 64;
-enum { ERRF_SUBJECTS = 1, ERRF_ROWS = 2, ERRF_OVF = 4, ERRF_INC = 8, ERRF_XCHG = 16 };
+enum { ERRF_SUBJECTS = 1, ERRF_ROWS = 2, ERRF_OVF = 4, ERRF_INC = 8, ERRF_XCHG = 16, ERRF_TODO = 32 };
 
 // counter slots (same order as SWIMSIM_CTR_* in include/swimsim.h)
 enum { C_PINGS = 0, C_DIRECT_FAILED, C_PING_REQS, C_SUSPECTS, C_FALSE_SUSPECTS, C_PAYLOADS,

@@ -607,11 +607,11 @@ __device__ inline uint32_t park_rid(uint32_t lo, uint32_t H) {
 // As a kernel of its own it costs 10 us per tick even when it leaves at once: every kernel boundary on this chip
 // writes the XCDs' L2s back and invalidates them (5-6 us gaps between the tick's kernels in the trace).  Here it
 // needs 62 registers with nothing else live, and the view cells are the todo loop's business, four at a time.
-// reserve n todo entries in the workgroup's region; NONE32 = no room (loud: ERRF_OVF)
+// reserve n todo entries in the workgroup's region; NONE32 = no room (loud: ERRF_TODO)
 __device__ inline uint32_t todo_reserve(const DevState& s, uint32_t n) {
   const uint32_t region = blockIdx.x & (TODO_REGIONS - 1u);
   const uint32_t got = atomicAdd(&s.todo_n[region * 16u], n);
-  if (got + n > s.todo_cap || got + n < got) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_OVF); return NONE32; }
+  if (got + n > s.todo_cap || got + n < got) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_TODO); return NONE32; }
   return region * s.todo_cap + got;
 }
 // the member's wide known-ring as the records meet it: what it learnt since it was written forgotten position-wise, what
@@ -706,7 +706,7 @@ __device__ __forceinline__ void records_phase(const DevState& s, uint32_t t, uin
   uint32_t base = 0;
   if ((threadIdx.x & 63u) == 0u) base = todo_reserve(s, total);   // one atomic per wave
   base = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
-  if (base == NONE32) { if (has) s.inbox_cnt[li] = 0; return; }    // loud (ERRF_OVF), never a silent drop
+  if (base == NONE32) { if (has) s.inbox_cnt[li] = 0; return; }    // loud (ERRF_TODO), never a silent drop
   if (!has) return;
   const uint32_t off = base + incl - ub;
   // my 64-position ring as the rest of the kernel will hold it when it comes to the records: last tick's new ids

@@ -168,6 +168,7 @@ int check_device_errors(swimsim* h) {
     if (g[G_ERR] & ERRF_OVF) m += " inbox-overflow-list (" + std::to_string(std::max(g[G_OVF0], g[G_OVF1])) + " entries, room for " + std::to_string(h->d.ovf_cap) + ")";
     if (g[G_ERR] & ERRF_INC) m += " incarnation-bits";
     if (g[G_ERR] & ERRF_XCHG) m += " shard-exchange-buffers";
+    if (g[G_ERR] & ERRF_TODO) m += " explicit-record-entries (room for " + std::to_string(h->d.todo_cap) + " per region of the tick's list)";
     return set_err(h, SWIMSIM_ERR_CAPACITY, m);
   }
   return SWIMSIM_OK;
@@ -358,7 +359,10 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     const double lam = 2.0 * c.probes_per_tick + 4.0 * c.probes_per_tick * c.indirect_k * pf;
     // (per region: a workgroup reserves from region b mod TODO_REGIONS; small clusters have fewer workgroups than regions)
     const uint32_t nb = (N + BLOCK - 1) / BLOCK, share = std::min<uint32_t>(TODO_REGIONS, nb);
-    d.todo_cap = (uint32_t)std::min<double>(3.0e7, ((double)N * (1.25 * lam + 2.0) * PB_SLOTS) / share + 65536.0);
+    // (a shard of a small cluster: when the views degrade under heavy loss, everybody's few remaining targets may sit on
+    // ONE shard -- the soak: 8 shards of 37 members, P = K = 10, 20 % loss -- so up to 65 536 members count in full)
+    const double senders = std::max<double>(N, std::min<double>(NT, 65536.0));
+    d.todo_cap = (uint32_t)std::min<double>(3.0e7, (senders * (1.25 * lam + 2.0) * PB_SLOTS) / share + 65536.0);
   }
   d.ord_cap = 0; d.r_cap = d.p_cap = d.x_cap = 0;
   CK(dev_alloc(h, &d.minfo, NT, 0));
