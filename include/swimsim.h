@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SWIMSIM_ABI_VERSION 3u
+#define SWIMSIM_ABI_VERSION 4u
 
 /* ---- status codes ------------------------------------------------------ */
 typedef enum swimsim_status {
@@ -114,6 +114,9 @@ typedef struct swimsim_config {
                                   (`joinHosts`, src/Types.hs:47, src/Util.hs:46; the commented-out
                                   PushPullMsg, src/Types.hs:165,177) -- see below.  0: it keeps the map
                                   it had and learns the rest from gossip                       */
+  uint32_t pull_ticks;         /* T > 1: periodic state pull between up members, once per member every T
+                                  periods (memberlist's push-pull timer; the commented-out PushPullMsg,
+                                  src/Types.hs:165,177) -- see below.  0: off.  1: invalid            */
 } swimsim_config_t;
 
 /* Join-time state pull (join_pull = 1).  When member m comes up in tick t its join host
@@ -124,6 +127,19 @@ typedef struct swimsim_config {
  * lastChange = t and a suspicion deadline t + suspicion_ticks for a pulled Suspect.  A pulled entry is a view
  * change like any other (counters, digest), but is not gossiped on and raises no event.  On sharded handles the
  * host may live on another shard: its owner sends what it knows in exchange round 0 (swimsim_shard_phase0 below). */
+
+/* Periodic state pull (pull_ticks = T > 1) -- anti-entropy between members that are up, the pull
+ * half of memberlist's push-pull.  In tick t, after the tick's scheduled changes and the joiners' pulls, every member i
+ * with i mod T == t mod T that is up and has no scheduled change in this tick pulls from the first of the 8 draws
+ * mulhi(H(t, i, PULL<<24 | a, 0), N), a = 0..7, that is not i, is up, has no scheduled change in this tick and is not a
+ * puller of this tick itself (c mod T != t mod T) -- so nobody reads a member map that is being written, and the result
+ * does not depend on any order; none => no pull this period.  The merge is the join-time pull's: for every subject s != i
+ * with a view row, i's entry becomes max(own entry, the host's entry), the host counting as Alive at its own incarnation;
+ * lastChange = t, a pulled Suspect gets the deadline t + suspicion_ticks; a view change like any other (counters, digest),
+ * not gossiped on, no event.  With pull_ticks on, a join host is not one of the tick's periodic pullers either.  (The push
+ * half -- the host merging the puller's map in the same exchange -- would give one member map several writers per tick;
+ * every member pulls once per T periods instead, so news travels both ways within two periods.)  Not available on sharded
+ * handles (SWIMSIM_ERR_INVALID): a pull per member and period across shards is an exchange of its own. */
 
 #define SWIMSIM_GC_AUTO 0xFFFFFFFFu
 

@@ -38,7 +38,7 @@
 #define INC_MAX 0x3FFFFFu   /* incarnation must fit 22 bits (key = inc<<2|state)   */
 
 enum { P_SELECT = 1, P_PROXY = 2, P_L_PING = 3, P_L_ACK = 4, P_L_REQ = 5,
-       P_L_FWD = 6, P_L_BACK = 7, P_L_RELAY = 8, P_JOIN = 9 };
+       P_L_FWD = 6, P_L_BACK = 7, P_L_RELAY = 8, P_JOIN = 9, P_PULL = 10 };
 
 enum { TAG_SELF = 0x53454c46u, TAG_VIEW = 0x56494557u, TAG_PB = 0x50425546u,
        TAG_TIMER = 0x54494d52u, TAG_FD = 0x46444554u, TAG_EV = 0x45564e54u,
@@ -664,14 +664,16 @@ static int fault_cmp(const void* a, const void* b) {
   return x->order < y->order ? -1 : x->order > y->order;
 }
 
-/* Join-time state pull (include/swimsim.h; `joinHosts`, src/Types.hs:47): member m, just up,
- * merges the member map of a join host -- a member that was up before this tick and has no change scheduled
- * in it (faults[0..nf) are the tick's changes). */
-static void join_pull(swimoracle_t* o, uint32_t t, uint32_t m, size_t nf) {
+/* State pulls (include/swimsim.h): member m merges the member map of a host -- a member that is up, has
+ * no change scheduled in this tick (faults[0..nf) are the tick's changes) and, with pull_ticks = T on, is not one of the
+ * tick's periodic pullers (nobody reads a map that is being written).  purpose = P_JOIN: m just came up (`joinHosts`,
+ * src/Types.hs:47); P_PULL: m's periodic pull (the commented-out PushPullMsg, src/Types.hs:165,177). */
+static void state_pull(swimoracle_t* o, uint32_t t, uint32_t m, size_t nf, uint32_t purpose) {
   uint32_t tk = tick_key(o->cfg.seed, t), h = NONE32;
+  const uint32_t T = o->cfg.pull_ticks;
   for (uint32_t a = 0; a < SEL_ATTEMPTS && h == NONE32; a++) {
-    uint32_t c = (uint32_t)(((uint64_t)hash_h(tk, m, ((uint32_t)P_JOIN << 24) | a, 0) * o->N) >> 32);
-    int busy = (c == m) || !o->up[c];
+    uint32_t c = (uint32_t)(((uint64_t)hash_h(tk, m, (purpose << 24) | a, 0) * o->N) >> 32);
+    int busy = (c == m) || !o->up[c] || (T && c % T == t % T);
     for (size_t x = 0; x < nf && !busy; x++) busy = o->faults[x].member == c;
     if (!busy) h = c;
   }
@@ -716,7 +718,16 @@ static void apply_faults(swimoracle_t* o, uint32_t t) {
       o->last_change[m] = t;
       event_add(&o->ctx[0], t, m, m, key_make(ni, SWIMSIM_ALIVE), SWIMSIM_CAUSE_JOIN);
       o->first_suspect[m] = NONE32;
-      if (o->cfg.join_pull) join_pull(o, t, m, nf);
+      if (o->cfg.join_pull) state_pull(o, t, m, nf, P_JOIN);
+    }
+  }
+  /* the periodic pulls of the tick: members i = t mod T (mod T) that are up and have no change in this tick */
+  if (o->cfg.pull_ticks) {
+    const uint32_t T = o->cfg.pull_ticks;
+    for (uint32_t i = t % T; i < o->N; i += T) {
+      int busy = !o->up[i];
+      for (size_t x = 0; x < nf && !busy; x++) busy = o->faults[x].member == i;
+      if (!busy) state_pull(o, t, i, nf, P_PULL);
     }
   }
   if (k) { memmove(o->faults, o->faults + k, (o->nfaults - k) * sizeof *o->faults); o->nfaults -= k; }
@@ -990,6 +1001,7 @@ static int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, char*
   if (c->n_shards != 1 || c->shard_index != 0) { snprintf(err, errn, "oracle: sharding is driven from outside (n_shards must be 1)"); return SWIMSIM_ERR_INVALID; }
   if (c->target_scheme > SWIMSIM_TARGETS_ROBUST) { snprintf(err, errn, "unknown target_scheme"); return SWIMSIM_ERR_INVALID; }
   if (c->join_pull > 1) { snprintf(err, errn, "join_pull must be 0 or 1"); return SWIMSIM_ERR_INVALID; }
+  if (c->pull_ticks == 1) { snprintf(err, errn, "pull_ticks must be 0 (off) or >= 2"); return SWIMSIM_ERR_INVALID; }
   return SWIMSIM_OK;
 }
 

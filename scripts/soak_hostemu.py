@@ -28,10 +28,12 @@ while time.time() < t_end:
     gc = rng.random() < 0.6
     jp = rng.random() < 0.5
     S = rng.choice([4, 7, 12])
+    pt = rng.choice([0, 0, 2, 3, 9, 40]) if shards == 1 else 0   # periodic state pull (unsharded handles)
     ticks = rng.choice([200, 400, 800])
     sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=rng.randrange(1, 1 << 30), lossPpm=loss, eventMask=0x1F,
                    suspicionTicks=S, retransmitMult=rng.choice([1, 2, 3]), maxSubjects=n, gcTicks=_abi.GC_AUTO if gc else 0,
-                   joinPull=1 if jp else 0, inboxCap=rng.choice([0, 0, 2]), targetScheme=scheme)
+                   joinPull=1 if jp else 0, inboxCap=rng.choice([0, 0, 2]), targetScheme=scheme,
+                   pullTicks=pt)
     a = Sim.create(orc, sc)
     rm = shards > 1 and rng.random() < 0.5                       # replicated queue masks (read from the environment at create)
     os.environ["SWIMSIM_SHARD_REPLICATED_MASKS"] = "1" if rm else "0"
@@ -47,7 +49,7 @@ while time.time() < t_end:
         if rng.random() < 0.7:
             t2 = t + rng.randrange(1, 150)
             for s in (a, b): s.scheduleFault(t2, m, True)
-    what = (vname, n, p, loss, gc, jp, S, ticks, sc.seed, nf, shards, scheme, rm, "rk" + rk, inject)
+    what = (vname, n, p, loss, gc, jp, S, ticks, sc.seed, nf, shards, scheme, rm, "rk" + rk, inject, "pull%d" % pt)
     ok = True
     try:
         for _ in range(ticks // 20):

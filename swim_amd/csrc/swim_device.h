@@ -18,7 +18,7 @@ constexpr int BLOCK = 256;
 
 enum { ST_ALIVE = 0, ST_SUSPECT = 1, ST_DEAD = 2 };
 enum { P_SELECT = 1, P_PROXY = 2, P_L_PING = 3, P_L_ACK = 4, P_L_REQ = 5, P_L_FWD = 6, P_L_BACK = 7,
-       P_L_RELAY = 8, P_JOIN = 9 };
+       P_L_RELAY = 8, P_JOIN = 9, P_PULL = 10 };
 enum : uint64_t { TAG_SELF = 0x53454c46u, TAG_VIEW = 0x56494557u, TAG_PB = 0x50425546u,
                   TAG_TIMER = 0x54494d52u, TAG_FD = 0x46444554u, TAG_EV = 0x45564e54u,
                   TAG_INC = 0x494e4352u, TAG_TICK = 0x5449434bu, TAG_MEMBER = 0x4d454d42u,
@@ -86,6 +86,7 @@ struct DevState {
   uint32_t N, NT, lo, n_shards, shard;
   uint32_t scheme;         // SWIMSIM_TARGETS_*: how the direct probes of a period pick their targets
   uint32_t join_pull;      // a member that comes up merges a join host's member map (include/swimsim.h)
+  uint32_t pull_T;         // periodic state pull: member i pulls in the ticks t = i (mod pull_T); 0 = off (include/swimsim.h)
   uint32_t P, K, S, L, loss_thr, R_max /* max_subjects */, R_phys /* view rows allocated */, G /* settling horizon, 0 = off */;
   uint32_t event_cap, event_mask, nblocks;
   uint32_t inbox_cap, ovf_cap;  // per-member delivery slots; exact overflow list capacity

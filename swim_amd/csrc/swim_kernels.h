@@ -1929,21 +1929,32 @@ __global__ __launch_bounds__(BLOCK) void settle_commit_kernel(DevState s, uint32
   if (threadIdx.x == 0) { s.g[G_ZERO_N] = nz_new; s.g[G_SETTLE_N] = 0; s.g[G_SETTLE_PENDING] = 0; }
 }
 
-// the join host of member m in the tick whose changes are `faults` (sorted by member): the first of 8 draws that is
-// not m, has no change scheduled in this tick and was up before it (include/swimsim.h, "Join-time state pull").
+// does member c have a change scheduled in the tick whose changes are `faults` (sorted by member)?
+__device__ inline bool changes_this_tick(const FaultRec* faults, uint32_t nfaults, uint32_t c) {
+  uint32_t lo = 0, hi = nfaults;
+  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (faults[mid].member < c) lo = mid + 1; else hi = mid; }
+  return lo < nfaults && faults[lo].member == c;
+}
+
+// the host member m pulls from in tick t (include/swimsim.h, "Join-time state pull" / "Periodic state pull"; purpose =
+// P_JOIN / P_PULL): the first of 8 draws that is not m, has no change scheduled in this tick, is up -- its state before
+// the tick -- and, with periodic pulls on, is not one of the tick's pullers (nobody reads a map that is being written).
 // A pure function of replicated data (hashes, the schedule, ground truth): every shard finds the same host.
-__device__ inline uint32_t join_host(const DevState& s, uint32_t tk, uint32_t m, const FaultRec* faults, uint32_t nfaults) {
+__device__ inline uint32_t pull_host(const DevState& s, uint32_t t, uint32_t tk, uint32_t m, const FaultRec* faults, uint32_t nfaults,
+                                     uint32_t purpose) {
   const uint32_t mk = mix32(tk ^ m);
   for (uint32_t a = 0; a < SEL_ATTEMPTS; ++a) {
-    const uint32_t c = __umulhi(hash_mk(mk, ((uint32_t)P_JOIN << 24) | a, 0), s.NT);
+    const uint32_t c = __umulhi(hash_mk(mk, (purpose << 24) | a, 0), s.NT);
     if (c == m) continue;
-    uint32_t lo = 0, hi = nfaults;
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (faults[mid].member < c) lo = mid + 1; else hi = mid; }
-    if (lo < nfaults && faults[lo].member == c) continue;
-    if (!mi_up(s.minfo[c])) continue;                          // no change this tick: its state before the tick
+    if (s.pull_T && c % s.pull_T == t % s.pull_T) continue;
+    if (changes_this_tick(faults, nfaults, c)) continue;
+    if (!mi_up(s.minfo[c])) continue;
     return c;
   }
   return NONE32;
+}
+__device__ inline uint32_t join_host(const DevState& s, uint32_t tk, uint32_t m, const FaultRec* faults, uint32_t nfaults) {
+  return pull_host(s, 0u, tk, m, faults, nfaults, P_JOIN);     // (sharded handles: no periodic pulls, t is not looked at)
 }
 
 // one pulled entry: joiner ml's cell of `slot` becomes kh if that is news to it
@@ -2061,7 +2072,7 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
     for (uint32_t k = threadIdx.x; k < nj; k += blockDim.x) {
       const uint32_t mbr = joined[k];
       if (!is_local(s, mbr)) continue;
-      const uint32_t host = join_host(s, tk, mbr, faults, nfaults);
+      const uint32_t host = pull_host(s, t, tk, mbr, faults, nfaults, P_JOIN);
       if (host == NONE32 || !is_local(s, host)) continue;
       unsigned long long evd = 0; unsigned pulled = 0;
       const uint32_t nrows = min(s.g[G_NSLOTS], s.R_phys), hl = host - s.lo;
@@ -2142,29 +2153,38 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
   }
 }
 
-// The joiners' pulls from hosts on this shard, one BLOCK per joiner, between the two parts of begin_kernel (which then
-// skips its own loop over them: part bit 3).  A joiner walks every row of its host: one thread per joiner inside
-// begin_kernel's single block made a tick with joins cost 2 dependent gathers x rows, serially (5 ms for 25 joiners
-// over 8 000 rows, profiles/r03zz_churn.txt); here the rows go over the block's threads, four in flight per thread.
-// Hosts are members without a change this tick (join_host), never joiners: the blocks touch disjoint members.
+// The tick's state pulls from hosts on this shard, one BLOCK per puller, between the two parts of begin_kernel (which then
+// skips its own loop over the joiners: part bit 3).  Work items [0, nj_bound): the members that came up (`joined`, as many
+// as G_NJOINED says); then, with periodic pulls on, the members i = t mod T (mod T).  A puller walks every row of its
+// host: one thread per joiner inside begin_kernel's single block made a tick with joins cost 2 dependent gathers x rows,
+// serially (5 ms for 25 joiners over 8 000 rows, profiles/r03zz_churn.txt); here the rows go over the block's threads,
+// four in flight per thread.  Hosts are members without a change this tick that do not pull in it: the blocks touch
+// disjoint members.
 __global__ __launch_bounds__(BLOCK) void join_pull_kernel(DevState s, uint32_t t, uint32_t tk, const FaultRec* faults, uint32_t nfaults,
-                                                          const uint32_t* joined) {
+                                                          const uint32_t* joined, uint32_t nj_bound) {
   __shared__ unsigned long long evd_sh;
-  __shared__ unsigned pulled_sh;
+  __shared__ unsigned pulled_sh, suspects_sh;
   __shared__ uint32_t host_sh;
-  const uint32_t nj = s.g[G_NJOINED];
+  const uint32_t nj = s.join_pull ? min(s.g[G_NJOINED], nj_bound) : 0u;
+  const uint32_t T = s.pull_T, first = T ? t % T : 0u;
+  const uint32_t npp = (T && first < s.N) ? (s.N - first + T - 1u) / T : 0u;
   const uint32_t nrows = min(s.g[G_NSLOTS], s.R_phys);
   constexpr int U = 4;
-  for (uint32_t k = blockIdx.x; k < nj; k += gridDim.x) {
-    const uint32_t mbr = joined[k];
+  for (uint32_t k = blockIdx.x; k < nj_bound + npp; k += gridDim.x) {
+    const bool joiner = k < nj_bound;
+    if (joiner && k >= nj) continue;                           // (block-uniform)
+    const uint32_t mbr = joiner ? joined[k] : s.lo + first + (k - nj_bound) * T;
     if (threadIdx.x == 0) {
-      evd_sh = 0; pulled_sh = 0;
-      host_sh = is_local(s, mbr) ? join_host(s, tk, mbr, faults, nfaults) : NONE32;
+      evd_sh = 0; pulled_sh = 0; suspects_sh = 0;
+      uint32_t h = NONE32;
+      if (joiner) { if (is_local(s, mbr)) h = pull_host(s, t, tk, mbr, faults, nfaults, P_JOIN); }
+      else if (mi_up(s.minfo[mbr]) && !changes_this_tick(faults, nfaults, mbr)) h = pull_host(s, t, tk, mbr, faults, nfaults, P_PULL);
+      host_sh = h;
     }
     __syncthreads();
     const uint32_t host = host_sh;
     if (host != NONE32 && is_local(s, host)) {
-      unsigned long long evd = 0; unsigned pulled = 0;
+      unsigned long long evd = 0; unsigned pulled = 0, suspects = 0;
       const uint32_t hl = host - s.lo;
       const uint32_t hkey = (s.hot[hl].x << 2) | ST_ALIVE;
       for (uint32_t r0 = threadIdx.x; r0 < nrows; r0 += BLOCK * U) {
@@ -2180,16 +2200,23 @@ __global__ __launch_bounds__(BLOCK) void join_pull_kernel(DevState s, uint32_t t
         for (int u = 0; u < U; ++u) {
           if (!used[u] || subj[u] == mbr) continue;
           const uint32_t kh = subj[u] == host ? hkey : vh[u];   // an untouched cell is the base: no news
-          if (kh) pull_entry(s, t, mbr, r0 + u * BLOCK, subj[u], kh, &evd, &pulled);
+          if (!kh) continue;
+          const unsigned before = pulled;
+          pull_entry(s, t, mbr, r0 + u * BLOCK, subj[u], kh, &evd, &pulled);
+          suspects += (pulled != before && (kh & 3u) == ST_SUSPECT) ? 1u : 0u;
         }
       }
       if (evd) atomicAdd(&evd_sh, evd);
       if (pulled) atomicAdd(&pulled_sh, pulled);
+      if (suspects) atomicAdd(&suspects_sh, suspects);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
       if (evd_sh) atomicAdd(reinterpret_cast<unsigned long long*>(&s.blk[(size_t)s.nblocks * C_COUNT + C_EVDIGEST]), evd_sh);
       if (pulled_sh) atomicAdd(reinterpret_cast<unsigned long long*>(&s.blk[(size_t)s.nblocks * C_COUNT + C_CHANGES]), (unsigned long long)pulled_sh);
+      // a periodic puller that took a Suspect over: merge_kernel rebuilds its deadline cells from its view cells, as for a
+      // member that came back up (whose flag begin_kernel has set)
+      if (!joiner && suspects_sh) s.hot[mbr - s.lo].y |= 1u;
     }
     __syncthreads();
   }

@@ -154,6 +154,8 @@ int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, std::string*
   if (c->n_members % c->n_shards) { *err = "n_members must be a multiple of n_shards"; return SWIMSIM_ERR_INVALID; }
   if (c->target_scheme > SWIMSIM_TARGETS_ROBUST) { *err = "unknown target_scheme"; return SWIMSIM_ERR_INVALID; }
   if (c->join_pull > 1) { *err = "join_pull must be 0 or 1"; return SWIMSIM_ERR_INVALID; }
+  if (c->pull_ticks == 1) { *err = "pull_ticks must be 0 (off) or >= 2"; return SWIMSIM_ERR_INVALID; }
+  if (c->pull_ticks && c->n_shards > 1) { *err = "pull_ticks (periodic state pull) is not available on sharded handles"; return SWIMSIM_ERR_INVALID; }
   if (c->n_shards > 1 && c->n_members > (1u << 27)) { *err = "sharded clusters: n_members must be <= 2^27"; return SWIMSIM_ERR_INVALID; }
   return SWIMSIM_OK;
 }
@@ -317,6 +319,7 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   d.N = N; d.NT = NT; d.lo = c.shard_index * N; d.n_shards = c.n_shards; d.shard = c.shard_index;
   d.scheme = c.target_scheme;
   d.join_pull = c.join_pull;
+  d.pull_T = c.pull_ticks;
   d.P = (uint32_t)c.probes_per_tick; d.K = (uint32_t)c.indirect_k; d.S = c.suspicion_ticks;
   d.L = c.retransmit_mult * ceil_log2((uint64_t)NT + 1);
   {
@@ -587,12 +590,14 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
     }
     uint32_t nup = 0;                               // upper bound of this tick's joins
     if (h->d.join_pull) for (size_t f = f0; f < fpos; ++f) nup += h->faults[f].up != 0;
-    if (nup) {
-      // a tick with joins: the pulls between the two parts of the start of the tick, one block per joiner
+    const uint32_t T = h->d.pull_T, first = T ? t % T : 0u;
+    const uint32_t npp = (T && first < h->d.N) ? (h->d.N - first + T - 1u) / T : 0u;   // this tick's periodic pullers
+    if (nup + npp) {
+      // a tick with state pulls: between the two parts of the start of the tick, one block per puller
       hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, (uint32_t)(fpos - f0),
                          h->d_joined, 1u, PeerCounts{});
-      hipLaunchKernelGGL(join_pull_kernel, dim3(std::min(nup, 4096u)), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0,
-                         (uint32_t)(fpos - f0), h->d_joined);
+      hipLaunchKernelGGL(join_pull_kernel, dim3(std::min(nup + npp, 16384u)), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0,
+                         (uint32_t)(fpos - f0), h->d_joined, nup);
       part = (part & ~1u) | 8u;
     }
     hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, (uint32_t)(fpos - f0),
@@ -961,7 +966,7 @@ int swimsim_shard_phase1(swimsim_t* h, uint32_t* counts) {
     uint32_t nup = 0;                               // sent are merged by begin_kernel: other joiners, rows no local host holds)
     for (size_t f = 0; f < fend; ++f) nup += h->faults[f].up != 0;
     if (nup) hipLaunchKernelGGL(join_pull_kernel, dim3(std::min(nup, 4096u)), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults,
-                                (uint32_t)fend, h->d_joined);
+                                (uint32_t)fend, h->d_joined, nup);
   }
   hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults, (uint32_t)fend,
                      h->d_joined, h->begun ? (2u | 8u) : 3u, peer_counts(h, h->j_in));

@@ -43,6 +43,7 @@ def _to_c_config(sc: SimConfig, shard_index: int = 0, n_shards: int = 1) -> _abi
     c.n_shards = n_shards
     c.target_scheme = sc.targetScheme
     c.join_pull = sc.joinPull
+    c.pull_ticks = sc.pullTicks
     return c
 
 

@@ -370,7 +370,8 @@ def test_random_configurations_on_the_gpu(oracle_abi, hip_abi, block):
         sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, eventMask=0x1F if n <= 4096 else 0,
                        suspicionTicks=rng.choice([3, 6, 12]), retransmitMult=rng.choice([1, 3]), maxSubjects=min(n, 4096),
                        targetScheme=scheme, inboxCap=rng.choice([0, 0, 1, 2]) if n <= 4096 else 0, gcTicks=gc,
-                       joinPull=1 if shards == 1 and seed % 2 else 0)
+                       joinPull=1 if shards == 1 and seed % 2 else 0,
+                       pullTicks=(0, 0, 2, 5, 17)[(seed >> 3) % 5] if shards == 1 else 0)
         a = Sim.create(oracle_abi, sc)
         _oracle_threads(a)
         b = Sim.create(hip_abi, sc) if shards == 1 else ShardedSim(hip_abi, sc, LocalFabric(shards), device="cuda:0")
@@ -592,3 +593,18 @@ def test_config5_metrics_on_the_gpu(oracle_abi, hip_abi, loss):
     b = config5_metrics(hip_abi, n=4096, loss=loss, ticks=90)
     assert a == b
     assert a[0] > 0 and a[2][3] == (0, 4095)
+
+
+@pytest.mark.parametrize("T,gc,loss,n", [(2, 0, 0, 3000), (7, 1, 50000, 3000), (40, 1, 10000, 65536)])
+def test_periodic_state_pull_on_the_gpu(oracle_abi, hip_abi, T, gc, loss, n):
+    """pull_ticks = T (the periodic state pull between up members; include/swimsim.h): join_pull_kernel's second kind of
+    work item -- one block per puller of the tick --, with crashes, rejoins, join pulls, loss and settling: MI355X = oracle."""
+    from swim_amd import _abi
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=31 + T, lossPpm=loss, eventMask=0x1F if n <= 4096 else 0,
+                   suspicionTicks=6, maxSubjects=min(n, 4096), gcTicks=_abi.GC_AUTO if gc else 0, joinPull=1, pullTicks=T)
+    crashes = [(3 + 2 * k, (37 * k + 11) % n) for k in range(40)]
+    faults = [(t + 9 + (m % 13), m, True) for (t, m) in crashes[::2]]
+    a, b = make_pair(oracle_abi, hip_abi, sc, crashes, faults)
+    _oracle_threads(a)
+    run_lockstep(a, b, 120, 6, observers=(0, 11, n - 1, n // 2), members=(0, 11, n - 1), check_events=n <= 4096)
+    assert b.counters()["changes"] > 0

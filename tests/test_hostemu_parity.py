@@ -301,3 +301,41 @@ def test_config5_metrics_false_dead_count_and_ticks_to_all(oracle_abi, emu_abi, 
         # 30 % loss with a 5-tick suspicion timeout: every queue is full of false Deads and their refutations, the one
         # true rumour competes for 8 slots -- most, not all, have it after 100 ticks
         assert to_all is None and curve[-1][0] > 450
+
+
+@pytest.mark.parametrize("T,gc,loss", [(2, 0, 0), (7, 1, 50000), (30, 1, 150000), (5, 0, 300000)])
+def test_periodic_state_pull_parity(oracle_abi, emu_abi, T, gc, loss):
+    """pull_ticks = T: every up member merges a random up member's map once per T periods (the commented-out PushPullMsg,
+    src/Types.hs:165,177), with crashes, rejoins (join pull on: a join host is never one of the tick's pullers), loss and
+    settling; compared every few ticks -- counters, digest, views, queues, timers (via the digest) and events."""
+    from swim_amd import _abi
+    n = 700
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=31 + T, lossPpm=loss, eventMask=0x1F, suspicionTicks=6,
+                   maxSubjects=n, gcTicks=_abi.GC_AUTO if gc else 0, joinPull=1, pullTicks=T)
+    crashes = [(3 + 2 * k, (37 * k + 11) % n) for k in range(40)]
+    faults = [(t + 9 + (m % 13), m, True) for (t, m) in crashes[::2]]
+    a, b = make_pair(oracle_abi, emu_abi, sc, crashes, faults)
+    run_lockstep(a, b, 120, 3, observers=(0, 11, n - 1, n // 2), members=(0, 11, n - 1))
+    assert b.counters()["changes"] > 0
+
+
+def test_periodic_state_pull_spreads_what_gossip_lost(oracle_abi):
+    """What it is for: a rumour whose retransmissions ran out before everybody heard it (1 retransmission round, 20 % loss)
+    reaches everybody through the periodic pulls -- and does not without them."""
+    def left_behind(T):
+        sc = SimConfig(cfg=Config(numToGossip=1), nMembers=400, seed=5, lossPpm=200000, eventMask=0, suspicionTicks=4,
+                       retransmitMult=1, maxSubjects=400, pullTicks=T)
+        s = Sim.create(oracle_abi, sc)
+        s.crash(123, tick=3)
+        s.step(160)
+        hold, up = s.coverage(123, 2, 0)
+        return up - hold
+    assert left_behind(0) > 0
+    assert left_behind(8) == 0
+
+
+def test_pull_ticks_validation(oracle_abi, emu_abi):
+    from swim_amd.sim import SwimError
+    for abi in (oracle_abi, emu_abi):
+        with pytest.raises(SwimError):
+            Sim.create(abi, SimConfig(cfg=Config(numToGossip=3), nMembers=64, pullTicks=1))
