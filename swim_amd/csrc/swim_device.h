@@ -124,7 +124,8 @@ struct DevState {
   uint4* todo_seg;         // [N] a member's list in two segments {start 0, length 0, start 1, length 1} (the flattened pass of
                            //   records_kernel; what its serial pass adds: overflow-list sources, members with more sources than a chunk)
   unsigned long long* kn_rec;
-  uint32_t* todo_n;        // [TODO_REGIONS * 16] entries handed out per region this tick (begin_kernel zeroes them)
+  uint32_t* todo_n;        // [(TODO_REGIONS + 1) * 16] entries handed out per region this tick, the last one: of the spill area (begin_kernel zeroes them)
+  uint32_t todo_spill_at, todo_spill;   // the spill area all regions share: first entry, entries
   uint32_t todo_cap;       // entries per region
   uint2* hot;              // {storeIncarnation, flags: bit 0 = came back up, deadlines slept through not fired yet}
   uint32_t* subject_of;    // slot -> subject

@@ -607,12 +607,16 @@ __device__ inline uint32_t park_rid(uint32_t lo, uint32_t H) {
 // As a kernel of its own it costs 10 us per tick even when it leaves at once: every kernel boundary on this chip
 // writes the XCDs' L2s back and invalidates them (5-6 us gaps between the tick's kernels in the trace).  Here it
 // needs 62 registers with nothing else live, and the view cells are the todo loop's business, four at a time.
-// reserve n todo entries in the workgroup's region; NONE32 = no room (loud: ERRF_TODO)
+// reserve n todo entries in the workgroup's region -- or, when that is full, in the spill area all regions share (a
+// degraded cluster under heavy loss sends everything to the few members it still holds Alive: one workgroup's members then
+// take many times their share; found by the GPU sweep at 4 096 members, P = K = 10, 30 % loss); NONE32 = no room (loud: ERRF_TODO)
 __device__ inline uint32_t todo_reserve(const DevState& s, uint32_t n) {
   const uint32_t region = blockIdx.x & (TODO_REGIONS - 1u);
   const uint32_t got = atomicAdd(&s.todo_n[region * 16u], n);
-  if (got + n > s.todo_cap || got + n < got) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_TODO); return NONE32; }
-  return region * s.todo_cap + got;
+  if (got + n <= s.todo_cap && got + n >= got) return region * s.todo_cap + got;
+  const uint32_t got2 = atomicAdd(&s.todo_n[TODO_REGIONS * 16u], n);
+  if (got2 + n > s.todo_spill || got2 + n < got2) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_TODO); return NONE32; }
+  return s.todo_spill_at + got2;
 }
 // the member's wide known-ring as the records meet it: what it learnt since it was written forgotten position-wise, what
 // the 64-position ring knows copied in (its ids own one or two of the wide ring's words)
@@ -2104,7 +2108,7 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
     // are out of the game anyway (explicit records), exactness does not depend on them
     s.g[G_RIDS_OFF] = (s.g[G_HEAD] - s.g[G_PREV] > RID_MASK + 1u - RID_NEAR - KW_BITS) ? 1u : 0u;
   }
-  for (uint32_t k = threadIdx.x; k < TODO_REGIONS; k += blockDim.x) s.todo_n[k * 16u] = 0;   // the todo buffer's regions
+  for (uint32_t k = threadIdx.x; k <= TODO_REGIONS; k += blockDim.x) s.todo_n[k * 16u] = 0;   // the todo buffer's regions + the spill area
   if (t)                                                            // the deadline chains tick t-1 consumed
     for (uint32_t k = threadIdx.x; k < s.tovf_nsub; k += blockDim.x)
       s.tovf_n[((((t - 1u) % s.S) * 2u + ((((t - 1u) / s.S) & 1u) ^ 1u)) * s.tovf_nsub + k) * 16u] = 0;

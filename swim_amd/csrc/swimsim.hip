@@ -170,7 +170,7 @@ int check_device_errors(swimsim* h) {
     if (g[G_ERR] & ERRF_OVF) m += " inbox-overflow-list (" + std::to_string(std::max(g[G_OVF0], g[G_OVF1])) + " entries, room for " + std::to_string(h->d.ovf_cap) + ")";
     if (g[G_ERR] & ERRF_INC) m += " incarnation-bits";
     if (g[G_ERR] & ERRF_XCHG) m += " shard-exchange-buffers";
-    if (g[G_ERR] & ERRF_TODO) m += " explicit-record-entries (room for " + std::to_string(h->d.todo_cap) + " per region of the tick's list)";
+    if (g[G_ERR] & ERRF_TODO) m += " explicit-record-entries (room for " + std::to_string(h->d.todo_cap) + " per region of the tick's list + " + std::to_string(h->d.todo_spill) + " shared)";
     return set_err(h, SWIMSIM_ERR_CAPACITY, m);
   }
   return SWIMSIM_OK;
@@ -366,6 +366,14 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     // ONE shard -- the soak: 8 shards of 37 members, P = K = 10, 20 % loss -- so up to 65 536 members count in full)
     const double senders = std::max<double>(N, std::min<double>(NT, 65536.0));
     d.todo_cap = (uint32_t)std::min<double>(3.0e7, (senders * (1.25 * lam + 2.0) * PB_SLOTS) / share + 65536.0);
+    // ... and a spill area the regions share, for the workgroups whose members take many times their share: a degraded
+    // cluster under heavy loss sends everything to the few members it still holds Alive (the GPU sweep: 4 096 members,
+    // P = K = 10, 30 % loss, one workgroup's 256 members receive 4x the average).  Up to 65 536 senders it holds the hard
+    // bound -- every probe of every member failing, every hop of every indirect probe delivered --, beyond that a quarter of
+    // an average tick
+    const double hard = 2.0 * c.probes_per_tick + 4.0 * c.probes_per_tick * c.indirect_k;
+    d.todo_spill_at = d.todo_cap * share;
+    d.todo_spill = (uint32_t)std::min<double>(4.0e8, senders <= 65536.0 ? senders * hard * PB_SLOTS : senders * (1.25 * lam + 2.0) * PB_SLOTS / 4.0);
   }
   d.ord_cap = 0; d.r_cap = d.p_cap = d.x_cap = 0;
   CK(dev_alloc(h, &d.minfo, NT, 0));
@@ -375,9 +383,9 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   CK(dev_alloc(h, &d.inbox_cnt, N, 0));
   CK(dev_alloc(h, &d.inbox, (size_t)N * d.inbox_cap, 0));
   CK(dev_alloc(h, &d.hot, N, 0));
-  CK(dev_alloc(h, &d.todo, (size_t)d.todo_cap * TODO_REGIONS, 0));
+  CK(dev_alloc(h, &d.todo, (size_t)d.todo_spill_at + d.todo_spill, 0));   // workgroup b reserves from region b mod TODO_REGIONS; the spill area behind the regions in use
   CK(dev_alloc(h, &d.todo_seg, N, 0));
-  CK(dev_alloc(h, &d.todo_n, (size_t)TODO_REGIONS * 16, 0));
+  CK(dev_alloc(h, &d.todo_n, (size_t)(TODO_REGIONS + 1) * 16, 0));
   CK(dev_alloc(h, &d.kn_rec, N, 0));
   CK(dev_alloc(h, &d.pk, (size_t)N, 0));
   CK(dev_alloc(h, &d.inmask, (size_t)N, 0));
