@@ -339,3 +339,10 @@ def test_pull_ticks_validation(oracle_abi, emu_abi):
     for abi in (oracle_abi, emu_abi):
         with pytest.raises(SwimError):
             Sim.create(abi, SimConfig(cfg=Config(numToGossip=3), nMembers=64, pullTicks=1))
+
+
+def test_pull_ticks_is_refused_on_sharded_handles(emu_abi):
+    from swim_amd.shard import LocalFabric, ShardedSim
+    from swim_amd.sim import SwimError
+    with pytest.raises(SwimError):
+        ShardedSim(emu_abi, SimConfig(cfg=Config(numToGossip=3), nMembers=128, pullTicks=5), LocalFabric(2))
