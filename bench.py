@@ -14,8 +14,9 @@ circulate as well: r ~ 2), and the line reports the regime actually measured
 (`per_member_tick`).  `--regime quiescent` is the other regime of config 3 (one crash, empty payloads).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     : whole-tick algorithmic bytes / HIP-event kernel time vs 8 TB/s (`frac`), plus each kernel's
-                 own figure; `kernel` names the one with the larger share of the time
+  roofline     : the DOMINANT kernel (the larger share of the tick), per launch: algorithmic bytes / HIP-event launch time vs
+                 8 TB/s (`frac`), its PMC traffic and traffic_ratio; `whole_tick` and every kernel's own line (incl. the bytes
+                 this layout moves, `impl_bytes_per_member_tick`) are separate objects
   cpu_baseline : the CPU oracle (a "port": the Haskell reference cannot be built here, no GHC) stepping the
                  SAME cluster on this box's host cores (member-range threads, all cores) over a bounded
                  window, plus its single-thread rate; the same replay checks the GPU's state digest and
@@ -50,6 +51,20 @@ def algorithmic_bytes(rt, P, K):
     that moves them."""
     return {"probe_kernel": P + rt["f"] * K + 64.0 * rt["d"],         # liveness gathers + delivered payloads
             "merge_kernel": 16.0 + 16.0 * rt["r"] + 128.0 * rt["c"]}  # hot record, accepted rumours, own line r+w
+
+
+def implementation_bytes(rt, P, K):
+    """A restated with the constants of THIS layout (last sentence) -- what the kernels
+    move per member-tick when payloads travel as 8-byte masks instead of 64-byte lines.
+    probe_kernel: own minfo word 4 + own queue mask 8 + per probe a 1-byte `mb` gather and, for a reached target, ONE 16-byte
+    `pk` gather {queue mask, known-ring} (serves the Ack's payload and the push filter) + per pushed Ping payload an 8-byte
+    atomicOr (read + write = 16; d/2 is an upper bound: pushes the target's ring already covers are skipped) + proxy bytes
+    f k + its ackmask store 8 + probe_out 2.
+    merge_kernel: the coalesced per-member streams it reads and rewrites whatever happens (probe_out 2, inmask 8 r + 8 clear,
+    ackmask 8, hot 8, pk 16 r + 16 w, deadline cell 16 r + 16 w, minfo 4 r + 4 w + mb 1) + per accepted change a view cell
+    8 r + 8 w + per rewritten queue the own line 64 r + 64 w."""
+    return {"probe_kernel": 4.0 + 8.0 + P * (1.0 + 16.0) + 16.0 * rt["d"] / 2.0 + rt["f"] * K + 8.0 + 2.0,
+            "merge_kernel": 2.0 + 16.0 + 8.0 + 8.0 + 32.0 + 32.0 + 9.0 + 16.0 * rt["r"] + 128.0 * rt["c"]}
 
 
 def first_detection_latency(sim, crashes, lo_tick, hi_tick):
@@ -214,25 +229,40 @@ def main():
         a_by = algorithmic_bytes(rt, P, K)
         nk = max(1, kt["ticks"])
         secs = {"probe_kernel": kt["probe_ms"] / 1e3 / nk, "merge_kernel": kt["merge_ms"] / 1e3 / nk}
-        per_kernel = {k: {"algorithmic_bytes_per_member_tick": a_by[k], "avg_launch_us": secs[k] * 1e6,
-                          "achieved_GBs": (a_by[k] * n / secs[k] / 1e9) if secs[k] > 0 else 0.0,
-                          "frac": (a_by[k] * n / secs[k] / 1e9 / HBM_PEAK_GBS) if secs[k] > 0 else 0.0} for k in secs}
-        dom = max(secs, key=lambda k: secs[k])               # the kernel with the larger share of the tick
-        a_tot, t_tot = sum(a_by.values()), sum(secs.values())
-        whole = a_tot * n / t_tot / 1e9 if t_tot > 0 else 0.0
-        # HBM traffic of the dominant kernel: PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
-        # of THIS workload and regime, recorded by scripts/pmc_passes.sh -- a rocprof run cannot nest in here
-        traffic, traffic_src = None, None
+        a_impl = implementation_bytes(rt, P, K)
+        # HBM traffic per launch: PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs) of THIS workload and
+        # regime, recorded by scripts/pmc_passes.sh -- a rocprof run cannot nest in here
+        tj, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and saturated and not args.loss_ppm and args.num_to_gossip == 3 and args.scheme == "random":
             tj = json.load(open(tpath))
             # keyed by the sha of the kernel sources the counters were collected on: never quoted for other kernels
             if tj.get("regime") == args.regime and tj.get("members") == n and tj.get("kernels_sha") == _lib.kernel_sources_sha():
-                traffic = tj.get(dom + "_hbm_bytes_per_launch")
                 traffic_src = tj.get("source")
             else:
                 traffic_src = "profiles/traffic.json was measured on other kernel sources (sha %s, these: %s): not quoted" % (
                     tj.get("kernels_sha"), _lib.kernel_sources_sha())
+                tj = None
+
+        def kernel_line(k):
+            """One kernel, per launch: algorithmic bytes (SURVEY 8(d)'s A split by the kernel that moves them) x the members a
+            launch processes / the HIP-event launch time; the same with the bytes the LAYOUT moves (A_impl, DESIGN.md section 5);
+            the PMC traffic per launch and its ratio to the algorithmic bytes (> 1: re-reads / bookkeeping the model does not price)."""
+            t = secs[k]
+            alg = a_by[k] * n
+            tr = tj.get(k + "_hbm_bytes_per_launch") if tj else None
+            return {"algorithmic_bytes_per_member_tick": a_by[k], "algorithmic_bytes_per_launch": alg,
+                    "impl_bytes_per_member_tick": a_impl[k], "avg_launch_us": t * 1e6,
+                    "achieved_GBs": (alg / t / 1e9) if t > 0 else 0.0,
+                    "frac": (alg / t / 1e9 / HBM_PEAK_GBS) if t > 0 else 0.0,
+                    "frac_impl": (a_impl[k] * n / t / 1e9 / HBM_PEAK_GBS) if t > 0 else 0.0,
+                    "traffic": tr, "traffic_ratio": (tr / alg) if (tr and alg) else None,
+                    "frac_traffic": (tr / t / 1e9 / HBM_PEAK_GBS) if (tr and t > 0) else None}
+        per_kernel = {k: kernel_line(k) for k in secs}
+        dom = max(secs, key=lambda k: secs[k])               # the dominant kernel: the larger share of the tick
+        a_tot, t_tot = sum(a_by.values()), sum(secs.values())
+        whole = a_tot * n / t_tot / 1e9 if t_tot > 0 else 0.0
+        tr_tot = sum(per_kernel[k]["traffic"] for k in secs) if all(per_kernel[k]["traffic"] for k in secs) else None
         lat, nlat = lat_all
         out = {
             "metric": "member-ticks/sec at N=1M simulated members; mean first-detection latency (ticks)",
@@ -254,11 +284,25 @@ def main():
             "ticks_per_s": args.steps / dt,
             "mean_first_detection_latency_ticks": lat, "crashes_measured": nlat,
             "per_member_tick": rt,
-            "roofline": {"bound": "hbm", "kernel": dom, "scope": "whole tick (probe_kernel + merge_kernel)",
-                         "achieved": whole, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": whole / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_member_tick": a_tot, "kernel_us": t_tot * 1e6,
-                         "frac_of_wall": (a_tot * n / (dt / args.steps) / 1e9 / HBM_PEAK_GBS),
+            # every field of `roofline` describes the DOMINANT kernel, per launch (DESIGN.md section 5 has the formulas; the
+            # rocprofv3 kernel trace of the same command is profiles/*_rocprof_timed_window.txt, the PMC passes *_pmc_summary.txt);
+            # the whole tick is a separate object
+            "roofline": {"bound": "hbm", "kernel": dom, "scope": "dominant kernel, per launch",
+                         "achieved": per_kernel[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": per_kernel[dom]["frac"],
+                         "traffic": per_kernel[dom]["traffic"], "traffic_ratio": per_kernel[dom]["traffic_ratio"],
+                         "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": per_kernel[dom]["algorithmic_bytes_per_launch"],
+                         "avg_launch_us": per_kernel[dom]["avg_launch_us"],
+                         "formula": "achieved = A_kernel x members / avg launch time (HIP events on the library's stream); "
+                                    "A_probe = P + f k + 64 d, A_merge = 16 + 16 r + 128 c bytes per member-tick (SURVEY 8d) with d, r, c, f "
+                                    "from the kernels' event counters over the timed ticks (per_member_tick); traffic = FETCH_SIZE + "
+                                    "WRITE_SIZE per launch (PMC, separate passes); traffic_ratio = traffic / algorithmic bytes per launch",
+                         "whole_tick": {"scope": "probe_kernel + merge_kernel", "algorithmic_bytes_per_member_tick": a_tot,
+                                        "kernel_us": t_tot * 1e6, "achieved": whole, "frac": whole / HBM_PEAK_GBS,
+                                        "frac_of_wall": (a_tot * n / (dt / args.steps) / 1e9 / HBM_PEAK_GBS),
+                                        "traffic": tr_tot,
+                                        "frac_traffic_of_wall": (tr_tot / (dt / args.steps) / 1e9 / HBM_PEAK_GBS) if tr_tot else None},
                          "kernels": per_kernel},
         }
         if world > 1:

@@ -46,14 +46,25 @@ typedef struct swimbridge_stats {
   uint64_t indirect_pings, relayed_acks;   /* IndirectPing handled / Acks relayed for them                       */
   uint64_t acks_in;                        /* Acks nobody was waiting for                                        */
   uint64_t rumors_injected, rumors_foreign;/* Suspect/Alive/Dead handed to the simulation / about unknown names  */
+  uint64_t rumors_dropped;                 /* ... beyond what the simulation takes before its next tick (a flood) */
+  uint64_t sends_failed;                   /* sendto refused the ADDRESS a datagram named (0.0.0.0:0, broadcast, ..) */
+  uint64_t bare_in;                        /* datagrams that were a bare `Message` (swimbridge_accept_bare)       */
 } swimbridge_stats_t;
 
 /* Bind a UDP socket on bind_ip:port (port 0 = any free port; the reference binds 127.0.0.1:4000, src/Core.hs:278)
- * for the members of `sim`.  SWIMSIM_ERR_INVALID / SWIMSIM_ERR_DEVICE (socket errors; swimbridge_last_error). */
+ * for the members of `sim`.  SWIMSIM_ERR_INVALID (also: a sharded handle -- one endpoint answers for the whole
+ * population) / SWIMSIM_ERR_DEVICE (socket errors; swimbridge_last_error). */
 int swimbridge_open(swimsim_t* sim, const char* bind_ip, uint16_t port, swimbridge_t** out);
 int swimbridge_port(const swimbridge_t* b, uint16_t* port);
+/* The reference's send side encodes a bare `Message`, its receive side decodes an `Envelope` (D11; src/Core.hs:133-134
+ * against :84): with on = 1 the bridge also accepts bare-Message datagrams -- what a LITERAL reference node sends --
+ * and keeps answering with Envelopes, which is what that node's receiver parses.  Off by default. */
+int swimbridge_accept_bare(swimbridge_t* b, int on);
 /* Handle the datagrams that are waiting (at most max_datagrams; waits up to timeout_ms for the first one).
- * Returns the number handled (>= 0) or a negative swimsim status. */
+ * Returns the number handled (>= 0) or a negative swimsim status.  Failures caused by what a datagram SAYS (undecodable
+ * bytes, an address sendto refuses, more gossip than the simulation takes before its next tick) are counted in the
+ * statistics and dropped; only local socket / device failures are returned.
+ * Addresses: IndirectPing.target is the reference's HostAddress (network byte order as a word, include/swimwire.h). */
 int swimbridge_poll(swimbridge_t* b, int timeout_ms, uint32_t max_datagrams);
 int swimbridge_stats(const swimbridge_t* b, swimbridge_stats_t* out);
 const char* swimbridge_last_error(const swimbridge_t* b);

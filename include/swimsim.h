@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SWIMSIM_ABI_VERSION 4u
+#define SWIMSIM_ABI_VERSION 5u
 
 /* ---- status codes ------------------------------------------------------ */
 typedef enum swimsim_status {
@@ -117,7 +117,37 @@ typedef struct swimsim_config {
   uint32_t pull_ticks;         /* T > 1: periodic state pull between up members, once per member every T
                                   periods (memberlist's push-pull timer; the commented-out PushPullMsg,
                                   src/Types.hs:165,177) -- see below.  0: off.  1: invalid            */
+  uint32_t view_cap;           /* C > 0: BOUNDED member maps -- every member keeps at most C entries that differ
+                                  from the default (`Map String Member`, src/Types.hs:55, with a capacity), in
+                                  [SWIMSIM_VIEW_CAP_MIN, SWIMSIM_VIEW_CAP_MAX]; see "Bounded member maps" below.
+                                  0: unbounded (a view row per subject in circulation, max_subjects)   */
 } swimsim_config_t;
+
+/* Bounded member maps (view_cap = C > 0) -- what lets heavy message loss run at millions of members
+ * per GPU (BASELINE config 5): there nearly every member is a subject of somebody's false suspicion all the time, and a
+ * dense view row per subject cannot exist.  A member's map holds at most C exceptions {subject, incarnation<<2|state,
+ * lastChange} to the default "Alive at incarnation 0".  The end of a tick for member i, as a function of SETS (so that no
+ * processing order can matter):
+ *   proposals = its suspicion deadlines that are due (an entry Suspect since t' with t' + suspicion_ticks <= t -> Dead at the
+ *               same incarnation), its own probes that ended without an Ack (Suspect at the incarnation it holds), every
+ *               rumour delivered to it (rumours about itself go to the refutation rule as always);
+ *   for every subject the largest proposal wins against the entry (or the default) by the state rule's order; an entry that
+ *               grows is CHANGED: lastChange = t;
+ *   if more than C entries exist now, the C with the largest (lastChange, rank) stay, rank = mix32(subject ^ mix32(tk ^ i))
+ *               with the tick key tk of DESIGN.md 2.2 -- a keyed permutation of the subject ids, new for every member
+ *               and tick, so that no two entries tie and nobody is forgotten first by everybody; the others are EVICTED --
+ *               they return to the default (their deadlines with them), counter SWIMSIM_CTR_EVICTED.  An entry that changed or
+ *               appeared in this very tick and is evicted at once has no effect at all: no event, no counter, not gossiped on;
+ *   every entry that changed and stayed counts as a view change (counters, event -- cause of the winning proposal, a due
+ *               deadline before a probe before gossip when they propose the same --, digest) and becomes a rumour in the
+ *               member's queue with a full retransmission budget, as on an unbounded handle.
+ * Everything else of the tick (target selection among the members the map holds Alive -- evicted ones are Alive again --,
+ * probes, proxies, loss, queues, refutation, joins) is the unbounded tick's.  Not combinable with gc_ticks, join_pull,
+ * pull_ticks, the robust target scheme, sharding, swimsim_inject_rumor, swimsim_set_view and swimsim_k_random_members
+ * (SWIMSIM_ERR_INVALID).  A member that hears of more than ~750 subjects it does not know in ONE tick is beyond the device's
+ * per-tick working set: SWIMSIM_ERR_CAPACITY (loud, the handle is poisoned), never a silent drop. */
+#define SWIMSIM_VIEW_CAP_MIN 4u
+#define SWIMSIM_VIEW_CAP_MAX 256u
 
 /* Join-time state pull (join_pull = 1).  When member m comes up in tick t its join host
  * is the first of the 8 draws mulhi(H(t, m, JOIN<<24 | a, 0), N), a = 0..7, that is not m, was up before this
@@ -236,7 +266,8 @@ enum {
                                      "up" whatever its incarnation -- an observer burying the old
                                      incarnation of a member that has come back counts          */
   SWIMSIM_CTR_SETTLED = 15,       /* subjects settled (view columns reclaimed; gc_ticks) */
-  SWIMSIM_CTR_COUNT = 16
+  SWIMSIM_CTR_EVICTED = 16,       /* member-map entries evicted (view_cap): returned to the default */
+  SWIMSIM_CTR_COUNT = 17
 };
 
 #define SWIMSIM_TICK_NONE UINT64_MAX

@@ -66,6 +66,20 @@ int swimwire_encode(const swimwire_msg_t* msgs, size_t n, uint8_t* buf, size_t c
  * failure; SWIMSIM_ERR_BUFFER if cap is too small (*n_out = messages in the envelope). */
 int swimwire_decode(const uint8_t* buf, size_t len, swimwire_msg_t* out, size_t cap, size_t* n_out);
 
+/* The reference's SEND side does not frame (D11): `gossip msg addr = yield $ UDP.Message (encode msg) addr`
+ * (src/Core.hs:133-134) encodes a bare `Message` -- the msgpack body alone, no type byte -- while its receive side
+ * (`decode`, :84) expects an Envelope.  Two entry points for talking to such a literal node:
+ * swimwire_encode_bare = `encode msg` (instance Serialize Message, src/Types.hs:151-155);
+ * swimwire_decode_any accepts an Envelope OR a bare Message (*was_bare = 1): the first byte tells them apart (an
+ * Envelope starts with a type byte 0..6, a bare body with a msgpack map header 0x80..0x8f / 0xde / 0xdf). */
+int swimwire_encode_bare(const swimwire_msg_t* msg, uint8_t* buf, size_t cap, size_t* n_out);
+int swimwire_decode_any(const uint8_t* buf, size_t len, swimwire_msg_t* out, size_t cap, size_t* n_out, int* was_bare);
+
+/* Address convention: `IndirectPing.target` and `Alive.addr` are the `HostAddress` the reference takes out of a
+ * `SockAddrInet` (src/Core.hs:264-266) -- the IPv4 address as the network library holds it, i.e. the 32-bit word whose
+ * in-memory bytes are in NETWORK order (sin_addr.s_addr; on x86 127.0.0.1 is 0x0100007F).  The codec carries the word
+ * as a number; whoever turns it into a socket address must reinterpret it, not htonl() it (include/swimbridge.h). */
+
 /* Encoded size of the envelope without writing it (the byte model of a piggybacked datagram). */
 int swimwire_size(const swimwire_msg_t* msgs, size_t n, size_t* n_out);
 

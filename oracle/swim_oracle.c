@@ -103,6 +103,10 @@ typedef struct {
 } omsg_t;
 
 typedef struct { opend_t* v; size_t n, cap; } opendv_t;
+/* bounded member maps (view_cap; include/swimsim.h "Bounded member maps"): a member's exceptions to the default, sorted by
+ * subject -- `Map String Member` (src/Types.hs:55) with a capacity */
+typedef struct { uint32_t subject, key, since1; } osent_t;
+typedef struct { osent_t* v; uint32_t n; } otab_t;
 
 /* Worker context.  A tick is two parallel phases over contiguous member ranges (Jacobi semantics make
  * both embarrassingly parallel): A = every up member's failureDetector period (reads start-of-tick
@@ -143,6 +147,8 @@ struct swimoracle {
   uint32_t G;
   uint32_t* base; uint32_t* base_since;
   uint32_t* last_change;    /* [subject] last tick any view entry about it changed / it announced itself */
+  uint32_t C;               /* view_cap: 0 = unbounded (columns above), else every member keeps <= C entries in tab[] */
+  otab_t* tab;              /* [N] (view_cap > 0) */
   int literal_rule;         /* oracle-only: apply the LITERAL suspectOrDeadNode' instead of the merge */
   uint64_t d13_hits;        /* proposals on which the literal rule and the merge disagree            */
   /* fault schedule */
@@ -198,8 +204,18 @@ int swimoracle_default_config(swimsim_config_t* cfg) {
 /* ------------------------------------------------------------------------- */
 /* member i's entry about s; the default (no column, or an untouched cell) is the settled base --
  * Alive@0 until s is settled for the first time */
+static inline const osent_t* tab_find(const otab_t* tb, uint32_t s) {
+  uint32_t lo = 0, hi = tb->n;                       /* sorted by subject */
+  while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (tb->v[mid].subject < s) lo = mid + 1; else hi = mid; }
+  return (lo < tb->n && tb->v[lo].subject == s) ? &tb->v[lo] : NULL;
+}
 static inline oentry_t view_get(const swimoracle_t* o, uint32_t i, uint32_t s) {
   oentry_t z = {o->base[s], 0};
+  if (o->C) {                                        /* bounded map: an entry, or the default */
+    const osent_t* e = tab_find(&o->tab[i], s);
+    if (e) { oentry_t r = {e->key, e->since1}; return r; }
+    return z;
+  }
   uint32_t sl = __atomic_load_n(&o->slot_of[s], __ATOMIC_ACQUIRE);
   if (!sl) return z;
   oentry_t e = o->cols[sl - 1][i];
@@ -656,6 +672,130 @@ static void end_of_tick(octx_t* c, uint32_t i, const opend_t* pend, uint32_t npe
 }
 
 /* ------------------------------------------------------------------------- */
+/* end of tick with bounded member maps (view_cap; include/swimsim.h)          */
+/* ------------------------------------------------------------------------- */
+/* The same rules -- suspicion timers (D4), own failed probes (src/Core.hs:253), received rumours through
+ * suspectOrDeadNode' / aliveNode as the max-merge (src/Core.hs:142-218; H3, D6, D13), refutation (:155-166; D10), the
+ * piggyback queue (D5) -- stated over SETS, because a capacity makes "apply one proposal after the other" depend on the
+ * order: proposals -> the largest per subject -> entries that grow are CHANGED (lastChange = t) -> the C entries with the
+ * largest (lastChange, rank) stay, the rest is evicted (back to the default) -> what changed AND stayed is accounted
+ * (counters, events, digest, queue).  An entry that appears or changes and is evicted in the same tick has no effect. */
+typedef struct { uint32_t subject, key, prio; } oprop_t;          /* prio: 2 timer, 1 own probe, 0 gossip */
+static int prop_cmp(const void* a, const void* b) {
+  const oprop_t* x = (const oprop_t*)a; const oprop_t* y = (const oprop_t*)b;
+  if (x->subject != y->subject) return x->subject < y->subject ? -1 : 1;
+  if (x->key != y->key) return x->key > y->key ? -1 : 1;          /* the largest key first ... */
+  return x->prio > y->prio ? -1 : x->prio < y->prio;              /* ... stated by the earliest phase */
+}
+typedef struct { osent_t e; uint32_t k0, rank; uint8_t changed, cause, due; } ocand_t;
+/* who stays when the map is over capacity: the most recent lastChange first; among entries of one tick the order is a
+ * keyed permutation of the subject ids -- rank = mix32(subject ^ H(t, i)): mix32 is a bijection, so no two subjects tie,
+ * and no member is forgotten first by everybody all the time (an order by subject id would be that) */
+static int evict_cmp(const void* a, const void* b) {              /* best first */
+  const ocand_t* x = (const ocand_t*)a; const ocand_t* y = (const ocand_t*)b;
+  if (x->e.since1 != y->e.since1) return x->e.since1 > y->e.since1 ? -1 : 1;
+  return x->rank > y->rank ? -1 : x->rank < y->rank;
+}
+static int cand_subject_cmp(const void* a, const void* b) {
+  uint32_t x = ((const ocand_t*)a)->e.subject, y = ((const ocand_t*)b)->e.subject;
+  return x < y ? -1 : x > y;
+}
+
+static void end_of_tick_sparse(octx_t* c, uint32_t i, const opend_t* pend, uint32_t npend,
+                               const ofail_t* fails, uint32_t nfails) {
+  swimoracle_t* o = c->o;
+  const uint32_t t = (uint32_t)o->tick;
+  otab_t* tb = &o->tab[i];
+  const opb_t* old = &o->pb[i];
+  const uint32_t self_inc_start = o->self_inc[i];
+  uint32_t refute = NONE32;
+  oprop_t* props = (oprop_t*)malloc(((size_t)tb->n + nfails + npend + 1) * sizeof *props);
+  size_t np = 0;
+  /* suspicion deadlines that are due (the FIXME at src/Core.hs:141; D4): Suspect since t' with t' + S <= t */
+  for (uint32_t x = 0; x < tb->n; x++) {
+    const osent_t* e = &tb->v[x];
+    if (key_state(e->key) == SWIMSIM_SUSPECT && e->since1 - 1 + o->S <= t) {
+      props[np].subject = e->subject; props[np].key = key_make(key_inc(e->key), SWIMSIM_DEAD); props[np].prio = 2; np++;
+    }
+  }
+  /* own probes that ended without any ack: suspectNode (src/Core.hs:253) at the incarnation the map holds */
+  for (uint32_t f = 0; f < nfails; f++) {
+    const uint32_t j = fails[f].j;
+    props[np].subject = j; props[np].key = key_make(key_inc(view_get(o, i, j).key), SWIMSIM_SUSPECT); props[np].prio = 1; np++;
+  }
+  /* rumours received this tick; about self -> refute (src/Core.hs:155-166), old incarnations ignored (:151) */
+  for (uint32_t x = 0; x < npend; x++) {
+    if (pend[x].subject == i) {
+      if (key_state(pend[x].key) != SWIMSIM_ALIVE && key_inc(pend[x].key) >= self_inc_start)
+        if (refute == NONE32 || key_inc(pend[x].key) > refute) refute = key_inc(pend[x].key);
+      continue;
+    }
+    props[np].subject = pend[x].subject; props[np].key = pend[x].key; props[np].prio = 0; np++;
+  }
+  qsort(props, np, sizeof *props, prop_cmp);
+  /* the map after the merge: every old entry, every subject whose best proposal beats the entry / the default */
+  ocand_t* cand = (ocand_t*)malloc(((size_t)tb->n + np + 1) * sizeof *cand);
+  size_t nc = 0, xp = 0; uint32_t xt = 0;
+  while (xt < tb->n || xp < np) {
+    const uint32_t st = xt < tb->n ? tb->v[xt].subject : NONE32, sp = xp < np ? props[xp].subject : NONE32;
+    const uint32_t sj = st < sp ? st : sp;
+    ocand_t cd; memset(&cd, 0, sizeof cd);
+    cd.e.subject = sj;
+    if (st == sj) { cd.e = tb->v[xt]; cd.k0 = cd.e.key; cd.due = key_state(cd.e.key) == SWIMSIM_SUSPECT && cd.e.since1 - 1 + o->S <= t; xt++; }
+    else { cd.e.key = o->base[sj]; cd.k0 = cd.e.key; cd.e.since1 = 0; }
+    if (sp == sj) {
+      const oprop_t* best = &props[xp];                /* sorted: the first of its subject is the winner */
+      if (best->key > cd.e.key) {
+        cd.e.key = best->key; cd.e.since1 = t + 1; cd.changed = 1;   /* memberLastChange = now (:176) */
+        cd.cause = best->prio == 2 ? SWIMSIM_CAUSE_TIMER : best->prio == 1 ? SWIMSIM_CAUSE_PROBE : SWIMSIM_CAUSE_GOSSIP;
+      }
+      while (xp < np && props[xp].subject == sj) xp++;
+    }
+    if (st == sj || cd.changed) cand[nc++] = cd;       /* a proposal that loses against the default leaves nothing */
+  }
+  /* the capacity: the C entries with the largest (lastChange, subject) stay */
+  if (nc > o->C) {
+    const uint32_t mk = mix32(o->tk ^ i);
+    for (size_t x = 0; x < nc; x++) cand[x].rank = mix32(cand[x].e.subject ^ mk);
+    qsort(cand, nc, sizeof *cand, evict_cmp);
+    c->counters[SWIMSIM_CTR_EVICTED] += nc - o->C;
+    nc = o->C;
+    qsort(cand, nc, sizeof *cand, cand_subject_cmp);
+  }
+  /* the queue: aged survivors, then what changed and stayed (D5) */
+  opb_t q; q.n = 0;
+  const uint32_t age = o->nsent[i] ? o->nsent[i] : 1u;
+  for (int sl = 0; sl < old->n; sl++)
+    if (old->r[sl].tx > age) { q.r[q.n] = old->r[sl]; q.r[q.n].tx = (uint8_t)(old->r[sl].tx - age); q.n++; }
+  for (size_t x = 0; x < nc; x++) {
+    tb->v[x] = cand[x].e;
+    if (!cand[x].changed) continue;
+    const uint32_t sj = cand[x].e.subject, key = cand[x].e.key;
+    c->counters[SWIMSIM_CTR_EVDIGEST] += ev_weight(t, i, sj) * (uint64_t)(key - cand[x].k0);
+    c->counters[SWIMSIM_CTR_CHANGES]++;
+    if (cand[x].due) {                                 /* `deadNode` after the timeout; a false positive if the subject is up */
+      c->counters[SWIMSIM_CTR_TIMERS_FIRED]++;
+      if (o->up[sj]) c->counters[SWIMSIM_CTR_FALSE_DEADS]++;
+    }
+    cand_insert(&q, sj, key, (uint8_t)o->L);
+    event_add(c, t, i, sj, key, cand[x].cause);
+  }
+  tb->n = (uint32_t)nc;
+  free(cand); free(props);
+  if (refute != NONE32) {                              /* src/Core.hs:155-166; D10 */
+    uint32_t ni = refute + 1;
+    if (ni > INC_MAX) { fail(o, SWIMSIM_ERR_CAPACITY, "incarnation overflow"); return; }
+    o->self_inc[i] = ni;
+    c->counters[SWIMSIM_CTR_EVDIGEST] += h4(TAG_INC, ((uint64_t)t << 32) | i, ni, 0);
+    c->counters[SWIMSIM_CTR_REFUTES]++;
+    cand_insert(&q, i, key_make(ni, SWIMSIM_ALIVE), (uint8_t)o->L);
+    event_add(c, t, i, i, key_make(ni, SWIMSIM_ALIVE), SWIMSIM_CAUSE_REFUTE);
+  }
+  if (old->n > 0 || q.n > 0) c->counters[SWIMSIM_CTR_PB_WRITES]++;
+  o->pb[i] = q;
+}
+
+/* ------------------------------------------------------------------------- */
 /* faults                                                                     */
 /* ------------------------------------------------------------------------- */
 static int fault_cmp(const void* a, const void* b) {
@@ -702,7 +842,12 @@ static void apply_faults(swimoracle_t* o, uint32_t t) {
     uint32_t m = f.member;
     if (f.up == o->up[m]) continue;
     o->up[m] = f.up;
-    if (!f.up) { o->crash_tick[m] = t; o->first_suspect[m] = NONE32; o->pb[m].n = 0; /* the process's queue is lost */ }
+    if (!f.up) {
+      o->crash_tick[m] = t; o->first_suspect[m] = NONE32; o->pb[m].n = 0;   /* the process's queue is lost ... */
+      /* ... and its inbox: a message from outside the simulation reaches a member that STAYS up through the tick's
+       * scheduled changes (include/swimsim.h) -- down and up again in one tick is a new process that was not listening */
+      for (size_t x = 0; x < o->ninj; x++) if (o->inj[x].dst == m) o->inj[x].dst = NONE32;
+    }
     else {
       /* (re)join: new incarnation + announce Alive (memberlist-style; the reference's
        * joinHosts is dead config, src/Util.hs:46) */
@@ -714,7 +859,7 @@ static void apply_faults(swimoracle_t* o, uint32_t t) {
       /* the announcement is a rumour about m: m has a view column from now on, whether or not anybody ever stores
        * an entry in it (a member that goes down again before it is heard of: the column settles empty; counter 15,
        * max_subjects and base_since see it) */
-      if (!view_ref(o, m, m)) return;
+      if (!o->C && !view_ref(o, m, m)) return;
       o->last_change[m] = t;
       event_add(&o->ctx[0], t, m, m, key_make(ni, SWIMSIM_ALIVE), SWIMSIM_CAUSE_JOIN);
       o->first_suspect[m] = NONE32;
@@ -795,8 +940,10 @@ static void phase_merge(octx_t* c) {
     size_t f0 = fc;
     while (fc < c->nfails && c->fails[fc].i == i) fc++;
     if (!o->up[i]) continue;
-    end_of_tick(c, i, c->sorted + c->off[i - c->lo], c->off[i - c->lo + 1] - c->off[i - c->lo],
-                c->fails + f0, (uint32_t)(fc - f0));
+    if (o->C) end_of_tick_sparse(c, i, c->sorted + c->off[i - c->lo], c->off[i - c->lo + 1] - c->off[i - c->lo],
+                                 c->fails + f0, (uint32_t)(fc - f0));
+    else end_of_tick(c, i, c->sorted + c->off[i - c->lo], c->off[i - c->lo + 1] - c->off[i - c->lo],
+                     c->fails + f0, (uint32_t)(fc - f0));
     if (__atomic_load_n(&o->poisoned, __ATOMIC_RELAXED)) return;
   }
 }
@@ -1002,6 +1149,11 @@ static int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, char*
   if (c->target_scheme > SWIMSIM_TARGETS_ROBUST) { snprintf(err, errn, "unknown target_scheme"); return SWIMSIM_ERR_INVALID; }
   if (c->join_pull > 1) { snprintf(err, errn, "join_pull must be 0 or 1"); return SWIMSIM_ERR_INVALID; }
   if (c->pull_ticks == 1) { snprintf(err, errn, "pull_ticks must be 0 (off) or >= 2"); return SWIMSIM_ERR_INVALID; }
+  if (c->view_cap) {
+    if (c->view_cap < SWIMSIM_VIEW_CAP_MIN || c->view_cap > SWIMSIM_VIEW_CAP_MAX) { snprintf(err, errn, "view_cap must be 0 (unbounded) or in [%u, %u]", SWIMSIM_VIEW_CAP_MIN, SWIMSIM_VIEW_CAP_MAX); return SWIMSIM_ERR_INVALID; }
+    if (c->gc_ticks || c->join_pull || c->pull_ticks || c->target_scheme != SWIMSIM_TARGETS_RANDOM || c->n_shards > 1) {
+      snprintf(err, errn, "view_cap (bounded member maps) cannot be combined with gc_ticks, join_pull, pull_ticks, the robust target scheme or sharding"); return SWIMSIM_ERR_INVALID; }
+  }
   return SWIMSIM_OK;
 }
 
@@ -1034,8 +1186,15 @@ int swimoracle_create(const swimsim_config_t* cfg, swimoracle_t** out) {
   o->G = c.gc_ticks;
   o->base = (uint32_t*)calloc(N, 4); o->base_since = (uint32_t*)calloc(N, 4);
   o->last_change = (uint32_t*)malloc((size_t)N * 4);
+  o->C = c.view_cap;
+  if (o->C) {
+    o->tab = (otab_t*)calloc(N, sizeof *o->tab);
+    osent_t* pool = o->tab ? (osent_t*)malloc((size_t)N * o->C * sizeof *pool) : NULL;   /* one block, C entries per member */
+    if (!pool) { free(o->tab); o->tab = NULL; }
+    else for (uint32_t i = 0; i < N; i++) o->tab[i].v = pool + (size_t)i * o->C;
+  }
   pthread_mutex_init(&o->mu, NULL);
-  if (!o->up || !o->self_inc || !o->pb || !o->timers || !o->nsent || !o->slot_of || !o->first_suspect || !o->crash_tick ||
+  if ((o->C && !o->tab) || !o->up || !o->self_inc || !o->pb || !o->timers || !o->nsent || !o->slot_of || !o->first_suspect || !o->crash_tick ||
       !o->cols || !o->subject_of || !o->free_at || !o->base || !o->base_since || !o->last_change || workers_start(o, 1)) {
     swimoracle_destroy(o); return fail(NULL, SWIMSIM_ERR_NOMEM, "out of memory");
   }
@@ -1057,6 +1216,7 @@ void swimoracle_destroy(swimoracle_t* o) {
   workers_stop(o);
   for (uint32_t s = 0; s < o->nslots; s++) free(o->cols[s]);
   if (o->timers) for (uint32_t i = 0; i < o->N; i++) free(o->timers[i].v);
+  if (o->tab) { free(o->tab[0].v); free(o->tab); }
   free(o->free_at); free(o->base); free(o->base_since); free(o->last_change); free(o->inj);
   free(o->cols); free(o->subject_of); free(o->slot_of); free(o->up); free(o->self_inc); free(o->pb);
   free(o->timers); free(o->nsent); free(o->faults); free(o->first_suspect); free(o->crash_tick);
@@ -1069,6 +1229,7 @@ int swimoracle_inject_rumor(swimoracle_t* o, uint32_t observer, uint32_t subject
   if (!o) return SWIMSIM_ERR_INVALID;
   if (observer >= o->N || subject >= o->N || state > 2 || incarnation > 0x3FFFFFu) return fail(o, SWIMSIM_ERR_INVALID, "inject_rumor: bad member / state / incarnation");
   if (o->cfg.n_shards > 1) return fail(o, SWIMSIM_ERR_STATE, "inject_rumor: unsharded handles only");
+  if (o->C) return fail(o, SWIMSIM_ERR_INVALID, "inject_rumor: not available with bounded member maps (view_cap)");
   if (o->ninj == o->inj_cap) { o->inj_cap = o->inj_cap ? o->inj_cap * 2 : 64; o->inj = (opend_t*)realloc(o->inj, o->inj_cap * sizeof *o->inj); }
   o->inj[o->ninj].dst = observer; o->inj[o->ninj].subject = subject; o->inj[o->ninj].key = key_make(incarnation, state);
   o->ninj++;
@@ -1119,6 +1280,17 @@ static int ventry_cmp(const void* a, const void* b) {
 int swimoracle_read_view(swimoracle_t* o, uint32_t observer, swimsim_view_entry_t* buf, size_t cap, size_t* n_out) {
   if (!o || !n_out || observer >= o->N) return SWIMSIM_ERR_INVALID;
   size_t n = 0;
+  if (o->C) {                                          /* bounded map: its entries, already sorted by subject */
+    const otab_t* tb = &o->tab[observer];
+    *n_out = tb->n;
+    if (tb->n > cap || (tb->n && !buf)) return SWIMSIM_ERR_BUFFER;
+    for (uint32_t x = 0; x < tb->n; x++) {
+      memset(&buf[x], 0, sizeof buf[x]);
+      buf[x].subject = tb->v[x].subject; buf[x].incarnation = key_inc(tb->v[x].key);
+      buf[x].state = (uint8_t)key_state(tb->v[x].key); buf[x].since_tick = tb->v[x].since1 - 1;
+    }
+    return SWIMSIM_OK;
+  }
   for (uint32_t s = 0; s < o->nslots; s++) {
     oentry_t e = o->cols[s][observer];
     if (e.key == 0 || o->subject_of[s] == observer) continue;
@@ -1158,6 +1330,7 @@ int swimoracle_read_member(swimoracle_t* o, uint32_t m, swimsim_member_t* out) {
   }
   /* live timers = entries currently Suspect */
   uint32_t nt = 0;
+  if (o->C) for (uint32_t x = 0; x < o->tab[m].n; x++) nt += key_state(o->tab[m].v[x].key) == SWIMSIM_SUSPECT;
   for (uint32_t s = 0; s < o->nslots; s++)
     if (o->subject_of[s] != m && key_state(o->cols[s][m].key) == SWIMSIM_SUSPECT) nt++;
   out->n_timers = (uint16_t)nt;
@@ -1190,6 +1363,11 @@ int swimoracle_digest(swimoracle_t* o, uint64_t* out) {
   uint64_t D = mix64((uint64_t)TAG_TICK + o->tick);
   for (uint32_t i = 0; i < o->N; i++) {
     uint64_t mh = h4(TAG_SELF, i, o->self_inc[i], o->up[i]);
+    if (o->C) for (uint32_t x = 0; x < o->tab[i].n; x++) {
+      const osent_t* e = &o->tab[i].v[x];
+      mh += h4(TAG_VIEW, e->subject, e->key, e->since1);
+      if (key_state(e->key) == SWIMSIM_SUSPECT) mh += h4(TAG_TIMER, e->subject, (uint64_t)e->since1 - 1 + o->S, 0);
+    }
     for (uint32_t s = 0; s < o->nslots; s++) {
       oentry_t e = o->cols[s][i];
       if (e.key == 0 || o->subject_of[s] == i) continue;
@@ -1217,6 +1395,7 @@ int swimoracle_counters(swimoracle_t* o, uint64_t* out, size_t n) {
 int swimoracle_k_random_members(swimoracle_t* o, uint32_t observer, uint32_t n, const uint32_t* excludes,
                                 size_t n_excludes, uint32_t* out, size_t cap, size_t* n_out) {
   if (!o || !n_out || observer >= o->N || n > 255) return SWIMSIM_ERR_INVALID;
+  if (o->C) return fail(o, SWIMSIM_ERR_INVALID, "k_random_members: not available with bounded member maps (view_cap)");
   uint32_t tmp[256];
   o->tk = tick_key(o->cfg.seed, (uint32_t)o->tick);
   uint32_t np = k_random_members(o, observer, n, excludes, n_excludes, P_SELECT, 0, tmp);
@@ -1229,6 +1408,7 @@ int swimoracle_k_random_members(swimoracle_t* o, uint32_t observer, uint32_t n, 
 int swimoracle_set_view(swimoracle_t* o, uint32_t observer, uint32_t subject, uint8_t state, uint32_t incarnation) {
   if (!o || observer >= o->N || subject >= o->N || state > 2 || incarnation > INC_MAX || observer == subject)
     return SWIMSIM_ERR_INVALID;
+  if (o->C) return fail(o, SWIMSIM_ERR_INVALID, "set_view: not available with bounded member maps (view_cap)");
   oentry_t* e = view_ref(o, observer, subject);
   if (!e) return SWIMSIM_ERR_CAPACITY;
   e->key = key_make(incarnation, state); e->since1 = (uint32_t)o->tick + 1;
@@ -1275,7 +1455,7 @@ size_t swimoracle_remove_dead_nodes(swimsim_view_entry_t* entries, size_t n) {
  * commutative merge; *hits = proposals on which the two rules disagreed so far (D13).  While it stays 0 a
  * run is identical to the merge run -- which is how the tests narrow "parity unpinned". */
 int swimoracle_set_literal_rule(swimoracle_t* o, int on) {
-  if (!o) return SWIMSIM_ERR_INVALID;
+  if (!o || (on && o->C)) return SWIMSIM_ERR_INVALID;
   o->literal_rule = on != 0; return SWIMSIM_OK;
 }
 uint64_t swimoracle_d13_hits(const swimoracle_t* o) { return o ? o->d13_hits : 0; }

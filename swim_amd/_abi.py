@@ -8,7 +8,7 @@ that loading happens in tests/ only, never in this package.
 """
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OK = 0
 ERR_INVALID, ERR_DEVICE, ERR_NOMEM, ERR_CAPACITY, ERR_STATE, ERR_BUFFER = -1, -2, -3, -4, -5, -6
@@ -23,9 +23,9 @@ GC_AUTO = 0xFFFFFFFF
 CTR_NAMES = [
     "pings", "direct_failed", "ping_reqs", "suspects", "false_suspects", "payloads",
     "rumors_seen", "changes", "pb_writes", "timers_fired", "refutes", "events_dropped",
-    "active_members", "evdigest", "false_deads", "settled",
+    "active_members", "evdigest", "false_deads", "settled", "evicted",
 ]
-CTR_COUNT = 16
+CTR_COUNT = 17
 
 
 class Config(C.Structure):
@@ -41,6 +41,7 @@ class Config(C.Structure):
         ("inbox_cap", C.c_uint32),
         ("device", C.c_int32), ("shard_index", C.c_uint32), ("n_shards", C.c_uint32),
         ("target_scheme", C.c_uint32), ("join_pull", C.c_uint32), ("pull_ticks", C.c_uint32),
+        ("view_cap", C.c_uint32),
     ]
 
 
@@ -133,13 +134,17 @@ _WIRE = {
     "encode": (C.c_int, [C.POINTER(WireMsg), C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_size_t)]),
     "decode": (C.c_int, [C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(WireMsg), C.c_size_t, C.POINTER(C.c_size_t)]),
     "size": (C.c_int, [C.POINTER(WireMsg), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "encode_bare": (C.c_int, [C.POINTER(WireMsg), C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "decode_any": (C.c_int, [C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(WireMsg), C.c_size_t, C.POINTER(C.c_size_t),
+                             C.POINTER(C.c_int)]),
     "last_error": (C.c_char_p, []),
 }
 
 class BridgeStats(C.Structure):
     """swimbridge_stats_t (include/swimbridge.h)"""
     _fields_ = [(n, C.c_uint64) for n in ("datagrams_in", "datagrams_out", "decode_errors", "pings", "pings_unanswered",
-                                          "indirect_pings", "relayed_acks", "acks_in", "rumors_injected", "rumors_foreign")]
+                                          "indirect_pings", "relayed_acks", "acks_in", "rumors_injected", "rumors_foreign",
+                                          "rumors_dropped", "sends_failed", "bare_in")]
 
 
 # include/swimbridge.h: the live-node bridge (prefix swimbridge_, product library only)
@@ -148,6 +153,7 @@ _BRIDGE = {
     "port": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint16)]),
     "poll": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
     "stats": (C.c_int, [C.c_void_p, C.POINTER(BridgeStats)]),
+    "accept_bare": (C.c_int, [C.c_void_p, C.c_int]),
     "last_error": (C.c_char_p, [C.c_void_p]),
     "close": (None, [C.c_void_p]),
 }

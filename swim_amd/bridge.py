@@ -35,6 +35,10 @@ class Bridge:
             raise OSError("swimbridge_poll: status %d: %s" % (n, (self._abi.bridge_last_error(self._b) or b"").decode()))
         return n
 
+    def acceptBare(self, on: bool = True):
+        """Also accept the bare-`Message` datagrams a LITERAL reference node sends (D11; src/Core.hs:133-134)."""
+        self._abi.bridge_accept_bare(self._b, 1 if on else 0)
+
     def stats(self) -> dict:
         st = _abi.BridgeStats()
         self._abi.bridge_stats(self._b, C.byref(st))

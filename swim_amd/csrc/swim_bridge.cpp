@@ -29,6 +29,7 @@ struct swimbridge {
   std::vector<Pending> pending;
   std::vector<uint8_t> rx, tx;
   std::vector<swimwire_msg_t> in, out;
+  bool accept_bare = false;       // swimbridge_accept_bare: datagrams of the literal sender (a bare Message, D11)
 };
 
 namespace {
@@ -53,13 +54,22 @@ bool same_addr(const sockaddr_in& a, const sockaddr_in& b) { return a.sin_addr.s
 
 void name_of(uint32_t id, char* out) { std::snprintf(out, SWIMWIRE_NAME_MAX + 1, "m%u", id); }
 
+// `peer_chosen`: the destination address came out of a datagram (an IndirectPing's target) or is a remote peer's: a send
+// that fails because of the ADDRESS (0.0.0.0:0, a broadcast address, an unreachable net) is the input's fault -- counted
+// and dropped, never a failure of the poll (one garbled datagram must not take the bridge down: the reference's receiver
+// dies on bad input, D16; this one does not)
 int send_env(swimbridge* b, const std::vector<swimwire_msg_t>& msgs, const sockaddr_in& to) {
   size_t n = 0;
   b->tx.resize(SWIMWIRE_MAX_DATAGRAM);
   const int rc = swimwire_encode(msgs.data(), msgs.size(), b->tx.data(), b->tx.size(), &n);
   if (rc) return berr(b, rc, std::string("encode: ") + swimwire_last_error());
-  if (sendto(b->fd, b->tx.data(), n, 0, reinterpret_cast<const sockaddr*>(&to), sizeof to) < 0)
-    return berr(b, SWIMSIM_ERR_DEVICE, std::string("sendto: ") + std::strerror(errno));
+  if (sendto(b->fd, b->tx.data(), n, 0, reinterpret_cast<const sockaddr*>(&to), sizeof to) < 0) {
+    const int e = errno;
+    if (e == EBADF || e == ENOTSOCK || e == EFAULT || e == ENOMEM || e == ENOBUFS)      // the local socket / host
+      return berr(b, SWIMSIM_ERR_DEVICE, std::string("sendto: ") + std::strerror(e));
+    b->st.sends_failed++;                                                               // EINVAL, EACCES, ENETUNREACH, EHOSTUNREACH, ...
+    return SWIMSIM_OK;
+  }
   b->st.datagrams_out++;
   return SWIMSIM_OK;
 }
@@ -76,6 +86,7 @@ int answer_ping(swimbridge* b, uint32_t id, uint32_t seq, const sockaddr_in& to)
   b->out.push_back(ack_of(seq));
   for (uint32_t k = 0; k < mem.n_rumors; ++k) {
     const swimsim_rumor_t& r = mem.rumors[k];
+    if (r.subject >= b->n_members) continue;      // an entry whose view row was reclaimed names nobody: not on the wire
     swimwire_msg_t m{};
     m.type = r.state == SWIMSIM_SUSPECT ? SWIMWIRE_SUSPECT : r.state == SWIMSIM_DEAD ? SWIMWIRE_DEAD : SWIMWIRE_ALIVE;
     m.incarnation = r.incarnation;
@@ -90,7 +101,11 @@ int answer_ping(swimbridge* b, uint32_t id, uint32_t seq, const sockaddr_in& to)
 int handle(swimbridge* b, const sockaddr_in& from, size_t len) {
   size_t n = 0;
   b->in.resize(SWIMWIRE_MAX_MSGS);
-  if (swimwire_decode(b->rx.data(), len, b->in.data(), b->in.size(), &n) != SWIMSIM_OK) { b->st.decode_errors++; return SWIMSIM_OK; }   // D16: dropped
+  int bare = 0;
+  const int drc = b->accept_bare ? swimwire_decode_any(b->rx.data(), len, b->in.data(), b->in.size(), &n, &bare)
+                                 : swimwire_decode(b->rx.data(), len, b->in.data(), b->in.size(), &n);
+  if (drc != SWIMSIM_OK) { b->st.decode_errors++; return SWIMSIM_OK; }   // D16: dropped
+  if (bare) b->st.bare_in++;
   // the simulated member this datagram addresses: the one its Ping names
   uint32_t addressee = 0; bool have_addressee = false;
   for (size_t k = 0; k < n && !have_addressee; ++k)
@@ -111,7 +126,9 @@ int handle(swimbridge* b, const sockaddr_in& from, size_t len) {
           if (rc) return berr(b, rc, std::string("read_member: ") + swimsim_last_error(b->sim));
           if (mem.up) { b->out.assign(1, ack_of(m.seq_no)); const int rc2 = send_env(b, b->out, from); if (rc2) return rc2; b->st.relayed_acks++; }
         } else {
-          sockaddr_in via{}; via.sin_family = AF_INET; via.sin_addr.s_addr = htonl(m.target); via.sin_port = htons(m.port);
+          // target = the HostAddress the reference takes out of a SockAddrInet (src/Core.hs:264-266): already in network
+          // byte order as a word (include/swimwire.h) -- reinterpreted, not converted; the port is a PortNumber's value
+          sockaddr_in via{}; via.sin_family = AF_INET; via.sin_addr.s_addr = m.target; via.sin_port = htons(m.port);
           swimwire_msg_t p{}; p.type = SWIMWIRE_PING; p.seq_no = m.seq_no; std::memcpy(p.node, m.node, sizeof p.node);
           b->out.assign(1, p);
           const int rc = send_env(b, b->out, via);
@@ -139,7 +156,9 @@ int handle(swimbridge* b, const sockaddr_in& from, size_t len) {
         if (member_id(m.node, b->n_members, &id) && m.incarnation >= 0 && m.incarnation <= 0x3FFFFF) {
           const uint32_t obs = have_addressee ? addressee : (id + 1u) % b->n_members;
           const uint8_t st = m.type == SWIMWIRE_SUSPECT ? SWIMSIM_SUSPECT : m.type == SWIMWIRE_DEAD ? SWIMSIM_DEAD : SWIMSIM_ALIVE;
+          // more rumours than the simulation takes before its next tick (SWIMSIM_ERR_BUFFER): a flood, dropped and counted
           const int rc = swimsim_inject_rumor(b->sim, obs, id, st, (uint32_t)m.incarnation);
+          if (rc == SWIMSIM_ERR_BUFFER) { b->st.rumors_dropped++; break; }
           if (rc) return berr(b, rc, std::string("inject_rumor: ") + swimsim_last_error(b->sim));
           b->st.rumors_injected++;
         } else b->st.rumors_foreign++;
@@ -159,6 +178,9 @@ int swimbridge_open(swimsim_t* sim, const char* bind_ip, uint16_t port, swimbrid
   *out = nullptr;
   swimsim_config_t cfg;
   if (swimsim_get_config(sim, &cfg) != SWIMSIM_OK) return SWIMSIM_ERR_INVALID;
+  // one endpoint answers for the WHOLE population: a shard owns a slice of it (read_member of another shard's member
+  // and inject_rumor are refused there), so the bridge wants an unsharded handle
+  if (cfg.n_shards > 1) return SWIMSIM_ERR_INVALID;
   swimbridge* b = new (std::nothrow) swimbridge();
   if (!b) return SWIMSIM_ERR_NOMEM;
   b->sim = sim; b->n_members = cfg.n_members;
@@ -202,6 +224,12 @@ int swimbridge_poll(swimbridge_t* b, int timeout_ms, uint32_t max_datagrams) {
     handled++;
   }
   return handled;
+}
+
+int swimbridge_accept_bare(swimbridge_t* b, int on) {
+  if (!b) return SWIMSIM_ERR_INVALID;
+  b->accept_bare = on != 0;
+  return SWIMSIM_OK;
 }
 
 int swimbridge_stats(const swimbridge_t* b, swimbridge_stats_t* out) {

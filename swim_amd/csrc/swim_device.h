@@ -47,7 +47,8 @@ enum { ERRF_SUBJECTS = 1, ERRF_ROWS = 2, ERRF_OVF = 4, ERRF_INC = 8, ERRF_XCHG =
 // counter slots (same order as SWIMSIM_CTR_* in include/swimsim.h)
 enum { C_PINGS = 0, C_DIRECT_FAILED, C_PING_REQS, C_SUSPECTS, C_FALSE_SUSPECTS, C_PAYLOADS,
        C_RUMORS_SEEN, C_CHANGES, C_PB_WRITES, C_TIMERS_FIRED, C_REFUTES, C_EVENTS_DROPPED,
-       C_ACTIVE, C_EVDIGEST, C_FALSE_DEADS /* timers fired about a member that is up */, C_SETTLED, C_COUNT = 16 };
+       C_ACTIVE, C_EVDIGEST, C_FALSE_DEADS /* timers fired about a member that is up */, C_SETTLED,
+       C_EVICTED /* bounded member maps (view_cap): entries returned to the default */, C_COUNT = 17 };
 
 // ---- hashes (replace the global StdGen of src/Util.hs:40, F7) -----------
 __host__ __device__ inline uint32_t mix32(uint32_t x) {
@@ -188,6 +189,13 @@ struct DevState {
   uint8_t* q_all;                // [NT] bits 0-3 queue length, 4 = the mask cannot express the queue (MI_OOW), 5 = the member
                                  //   handles its direct probes of remote targets by records this tick (Q_EXC)
   uint32_t fl_dyn_base, fl_dyn_cap;   // region of `fl` for foreign lines that belong to no record (remote_kernel)
+  // ---- bounded member maps (view_cap = C > 0; swim_sparse.h): none of the view / mask / deadline tables above
+  uint32_t C;              // entries a member's map holds at most; 0 = the unbounded layout above
+  uint32_t* sp_tab;        // [N][3][C] the maps: subjects, keys, lastChange + 1 (three coalesced runs per member)
+  uint32_t* sp_tab_n;      // [N] entries in use
+  uint2* sp_q;             // [2][N][8] queue lines {subject, key | tx << 24}; buffer (t & 1) is read in tick t, the other written
+  uint32_t* sp_out;        // [N] probe -> merge: Pings sent | failed probes << 5 | own Ack sources << 10
+  uint32_t sp_ack_cap;     // own Ack sources per member: P (1 + K), in ackfrom[N][sp_ack_cap]
 #ifdef SWIM_ABLATE
   uint32_t dbg;            // measurement build (scripts/ablate.py): memory operations the tick kernels leave out
 #endif

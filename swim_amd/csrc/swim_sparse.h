@@ -1,0 +1,667 @@
+// swim_sparse.h -- the tick with BOUNDED member maps (view_cap = C > 0; include/swimsim.h "Bounded member maps",
+// DESIGN.md section 2.8): what runs BASELINE config 5 (30 % message loss x churn) at millions of members per GPU, where
+// nearly every member is the subject of somebody's false suspicion all the time and a dense view row per subject
+// (swim_kernels.h) cannot exist.
+//
+// A member's map is `Map String Member` (src/Types.hs:55) with a capacity: <= C exceptions {subject, key, lastChange} to the
+// default "Alive at incarnation 0", C x 12 bytes per member in HBM.  ONE WAVE steps one member -- the 64-wide wavefront is the
+// unit of work here, not the thread:
+//   * sp_probe_kernel : the member's map sits in the wave's registers (C / 64 entries per lane); "is c Alive in my view"
+//     (kRandomMembers, src/Core.hs:72-74) is one compare per lane and a ballot; the period's deliveries are dealt to the
+//     lanes, one inbox append (an atomic with a returned position) per lane, all in flight together;
+//   * sp_merge_kernel : the member's map is rebuilt in LDS as a hash table; the lanes are the RUMOURS of the tick (8 sources x
+//     8 queue entries per round of loads) and the state rule suspectOrDeadNode' / aliveNode (src/Core.hs:142-218) is an LDS
+//     atomicMax on the packed (incarnation, state) key -- the commutative merge of H3 / D13 in one instruction; who stays
+//     when the map is over capacity is a radix select over (lastChange, rank) in LDS; the map streams back coalesced.
+// Per member-tick at 30 % loss: ~190 rumours in, ~75 subjects the member did not know, 3 KB of map read and written.
+// The rules themselves are the unbounded tick's (swim_kernels.h cites them per line); what differs is stated over SETS in
+// include/swimsim.h, because a capacity makes "one proposal after the other" depend on the order.
+#pragma once
+#include "swim_kernels.h"
+
+namespace swim {
+
+constexpr uint32_t SP_WAVES = BLOCK / 64;      // members a workgroup steps at a time
+constexpr uint32_t SP_PRIO_TIMER = 2u, SP_PRIO_PROBE = 1u, SP_PRIO_GOSSIP = 0u;   // who states a key first (phase order)
+constexpr uint32_t SP_DUE = 1u << 31;          // h0 bit: the entry's suspicion deadline is due this tick
+constexpr uint32_t SP_KEPT = 1u << 30;         // h0 bit (after the selection): the entry stays in the map
+
+// ---- layout helpers ----------------------------------------------------------------------------------
+// tab[N][3][C]: subjects, keys, lastChange + 1 of member li, entry e -- three coalesced runs per member
+__device__ inline uint32_t* sp_row(const DevState& s, uint32_t li, uint32_t field) { return s.sp_tab + ((size_t)li * 3u + field) * s.C; }
+// queue lines sq[2][N][8] {subject, key | tx << 24}: buffer (t & 1) is read in tick t, the other one written
+__device__ inline uint2* sp_line(const DevState& s, uint32_t buf, uint32_t li) { return s.sp_q + ((size_t)buf * s.N + li) * PB_SLOTS; }
+// sb[NT]: bit 0 up (ground truth), bits 1-4 queue length -- the one byte a prober gathers about a target (the `mb` table)
+__device__ inline uint32_t sb_up(uint32_t b) { return b & MB_UP; }
+__device__ inline uint32_t sb_qn(uint32_t b) { return (b >> MB_PBN_SHIFT) & 0xFu; }
+
+// ================================================================================================
+// start of the tick: the scheduled ground-truth changes, one block
+// ================================================================================================
+__global__ __launch_bounds__(BLOCK) void sp_begin_kernel(DevState s, uint32_t t, const FaultRec* faults, uint32_t nfaults) {
+  __shared__ unsigned long long evd_sh;
+  __shared__ unsigned dropped_sh;
+  if (threadIdx.x == 0) { evd_sh = 0; dropped_sh = 0; }
+  __syncthreads();
+  const uint32_t cur = t & 1u;
+  for (uint32_t k0 = threadIdx.x; k0 < nfaults; k0 += blockDim.x) {
+    if (k0 && faults[k0 - 1].member == faults[k0].member) continue;      // not the first change of its member
+    unsigned long long evd = 0; unsigned dropped = 0;
+    for (uint32_t k = k0; k < nfaults && faults[k].member == faults[k0].member; ++k) {
+      const uint32_t mbr = faults[k].member, up = faults[k].up;
+      const uint32_t b = s.mb[mbr];
+      if (sb_up(b) == up) continue;
+      s.first_suspect[mbr] = NONE32;
+      if (!up) {                                    // the process is gone, its piggyback queue with it
+        s.crash_tick[mbr] = t;
+        s.mb[mbr] = 0;
+        continue;
+      }
+      // (re)join: new incarnation, announce Alive: the queue holds exactly that rumour
+      const uint2 hot = s.hot[mbr];
+      uint32_t ni = hot.x + 1;
+      if (ni > INC_MAX) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_INC); ni = INC_MAX; }
+      evd += h4(TAG_INC, ((uint64_t)t << 32) | mbr, ni, 0);
+      const uint32_t akey = (ni << 2) | ST_ALIVE;
+      uint2* line = sp_line(s, cur, mbr);
+      line[0] = make_uint2(mbr, pe_hi(akey, s.L));
+      for (int q = 1; q < PB_SLOTS; ++q) line[q] = make_uint2(0u, 0u);
+      s.mb[mbr] = (uint8_t)(MB_UP | (1u << MB_PBN_SHIFT));
+      s.hot[mbr] = make_uint2(ni, hot.y);
+      if (s.event_mask & (1u << 4)) {
+        const uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
+        if (pos < s.event_cap) s.events[pos] = make_uint4(t, mbr, mbr, (akey << 8) | 4u);
+        else dropped++;
+      }
+    }
+    if (evd) atomicAdd(&evd_sh, evd);
+    if (dropped) atomicAdd(&dropped_sh, dropped);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (evd_sh) s.blk[(size_t)s.nblocks * C_COUNT + C_EVDIGEST] += evd_sh;
+    if (dropped_sh) s.blk[(size_t)s.nblocks * C_COUNT + C_EVENTS_DROPPED] += dropped_sh;
+  }
+}
+
+// ================================================================================================
+// probe kernel: one period of failureDetector / probeNode' per member (src/Core.hs:233-269), one WAVE per member
+// ================================================================================================
+// Everything a lane computes here is wave-uniform (same member, same hashes) except two things: its slice of the member's
+// map (MT entries: "is c Alive in my view" is a compare per lane and a ballot) and its share of the period's deliveries.
+template <int MT>
+struct SpView {
+  uint32_t subj[MT], key[MT];
+};
+template <int MT>
+__device__ inline bool sp_alive(const SpView<MT>& v, uint32_t c) {
+  bool hit = false;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) hit |= v.subj[m] == c && (v.key[m] & 3u) != ST_ALIVE;
+  return __ballot(hit) == 0ull;                      // no entry, or an Alive one: `isAlive` (src/Core.hs:33-34)
+}
+// kRandomMembers (src/Core.hs:69-74) + shuffle (src/Util.hs:37-42): the draws of swim_device.h's select_members, evaluated
+// by the whole wave (out / outb: wave-uniform)
+template <int MT, int MAXN>
+__device__ inline uint32_t sp_select(const DevState& s, const SpView<MT>& v, uint32_t mk, uint32_t i, uint32_t n, uint32_t purpose,
+                                     uint32_t hi_idx, uint32_t excl, uint32_t (&out)[MAXN], uint32_t (&outb)[MAXN]) {
+  uint32_t np = 0;
+  const uint32_t N = s.NT;
+  for (uint32_t p = 0; p < (uint32_t)MAXN; ++p) {
+    if (p >= n) break;
+    uint32_t c = 0;
+    bool found = false;
+    const uint32_t base = (purpose << 24) | (purpose == P_SELECT ? (p << 8) : ((hi_idx << 16) | (p << 8)));
+    auto eligible = [&](uint32_t cand) -> bool {
+      if (cand == i || cand == excl) return false;   // D15; D7: the target is no proxy of itself
+      bool dup = false;
+#pragma unroll
+      for (int e = 0; e < MAXN; ++e) dup |= ((uint32_t)e < np) && (out[e] == cand);
+      if (dup) return false;
+      return sp_alive<MT>(v, cand);
+    };
+    for (uint32_t a = 0; a < SEL_ATTEMPTS; ++a) {
+      c = __umulhi(hash_mk(mk, base | a, 0), N);
+      if (eligible(c)) { found = true; break; }
+    }
+    if (!found) {                                    // fewer candidates than draws hit: the cyclic scan (test/Spec.hs:117-128)
+      const uint32_t cs = (c + 1 == N) ? 0 : c + 1;
+      for (uint32_t d = 0; d < N; ++d) {
+        c = cs + d; if (c >= N) c -= N;
+        if (eligible(c)) { found = true; break; }
+      }
+    }
+    if (!found) break;
+    const uint32_t b = s.mb[c];
+#pragma unroll
+    for (int e = 0; e < MAXN; ++e) if ((uint32_t)e == np) { out[e] = c; outb[e] = b; }
+    ++np;
+  }
+  return np;
+}
+
+template <int MT, int PMAX>
+__global__ __launch_bounds__(BLOCK) void sp_probe_kernel(DevState s, uint32_t t, uint32_t tk) {
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const uint32_t nwaves = gridDim.x * SP_WAVES;
+  // per-lane counters, summed over the wave's members, reduced once at the end
+  unsigned c_pings = 0, c_active = 0, c_payloads = 0, c_rumors = 0, c_dfail = 0, c_preqs = 0, c_susp = 0, c_fsusp = 0;
+  __shared__ BlockCounters sh;
+  ctr_init(&sh);
+  for (uint32_t li = blockIdx.x * SP_WAVES + wv; li < s.N; li += nwaves) {
+    const uint32_t i = li;
+    const uint32_t myb = s.mb[i];
+    if (!sb_up(myb)) continue;                       // wave-uniform
+    const uint32_t mk = mix32(tk ^ i), myqn = sb_qn(myb);
+    SpView<MT> v;
+    {
+      const uint32_t n = s.sp_tab_n[li];
+      const uint32_t* rs = sp_row(s, li, 0); const uint32_t* rk = sp_row(s, li, 1);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const uint32_t e = lane + 64u * (uint32_t)m;
+        v.subj[m] = e < n ? rs[e] : NONE32;
+        v.key[m] = e < n ? rk[e] : 0u;
+      }
+    }
+    // the period's deliveries "dst merges src's start-of-tick queue", dealt to the lanes: delivery number x goes to lane
+    // x mod 64; a full round is flushed -- every lane appends its delivery to its destination's inbox, the atomics of a round
+    // in flight together.  Deliveries to the member itself (Acks, relayed Acks) go to its own list without atomics.
+    uint32_t nd = 0, my_dst = NONE32, my_src = 0;     // my_*: this lane's delivery of the current round
+    uint32_t nack = 0, nfail = 0;
+    auto flush = [&]() {
+      if (my_dst != NONE32) push(s, t, my_dst, my_src);
+      my_dst = NONE32;
+    };
+    auto deliver = [&](uint32_t dst, uint32_t src, uint32_t srcb) {    // wave-uniform arguments
+      const uint32_t cnt = sb_qn(srcb);
+      if (!cnt) return;                               // empty payload
+      if (lane == 0) { c_payloads++; c_rumors += cnt; }
+      if (dst == i) {
+        if (lane == 0) s.ackfrom[(size_t)li * s.sp_ack_cap + nack] = src;
+        nack++;
+        return;
+      }
+      if (lane == (nd & 63u)) { my_dst = dst; my_src = src; }
+      nd++;
+      if ((nd & 63u) == 0u) flush();
+    };
+    uint32_t picks[PMAX], pinfo[PMAX];
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p) { picks[p] = 0; pinfo[p] = 0; }
+    // ms <- kRandomMembers store (numToGossip cfg) []        (src/Core.hs:239)
+    const uint32_t np = sp_select<MT, PMAX>(s, v, mk, i, s.P, P_SELECT, 0, NONE32, picks, pinfo);
+    if (lane == 0) { c_pings += np; c_active++; }
+    for (uint32_t p = 0; p < (uint32_t)PMAX; ++p) {
+      if (p >= np) break;
+      uint32_t j = picks[0], bj = pinfo[0];
+#pragma unroll
+      for (int e = 1; e < PMAX; ++e) if (p == (uint32_t)e) { j = picks[e]; bj = pinfo[e]; }
+      // Direct (Ping seq j) is delivered iff not lost and j is up (src/Core.hs:246); j answers Ack (:97-99), which may be lost too
+      const bool ping_ok = sb_up(bj) && !lost(s, tk, P_L_PING, i, j, p);
+      const bool ack_ok = ping_ok && !lost(s, tk, P_L_ACK, j, i, p);
+      if (ping_ok) deliver(j, i, myb);
+      if (ack_ok) { deliver(i, j, bj); continue; }
+      // unlessAck (D2, D3): K proxies, not the target (src/Core.hs:249; D7)
+      if (lane == 0) c_dfail++;
+      uint32_t qs[PMAX], qb[PMAX];
+#pragma unroll
+      for (int k = 0; k < PMAX; ++k) { qs[k] = 0; qb[k] = 0; }
+      const uint32_t nq = sp_select<MT, PMAX>(s, v, mk, i, s.K, P_PROXY, p, j, qs, qb);
+      if (lane == 0) c_preqs += nq;
+      bool acked = false;
+      for (uint32_t k = 0; k < (uint32_t)PMAX; ++k) {
+        if (k >= nq) break;
+        uint32_t q = qs[0], bq = qb[0];
+#pragma unroll
+        for (int e = 1; e < PMAX; ++e) if (k == (uint32_t)e) { q = qs[e]; bq = qb[e]; }
+        const uint32_t idx = (p << 8) | k;
+        // i -> q : IndirectPing (src/Core.hs:250, 262-269)
+        if (lost(s, tk, P_L_REQ, i, q, idx) || !sb_up(bq)) continue;
+        deliver(q, i, myb);
+        // q -> j : Ping on behalf of i (src/Core.hs:105-108; D8, D12)
+        if (!sb_up(bj) || lost(s, tk, P_L_FWD, q, j, idx)) continue;
+        deliver(j, q, bq);
+        // j -> q : Ack
+        if (lost(s, tk, P_L_BACK, j, q, idx)) continue;
+        deliver(q, j, bj);
+        // q -> i : relayed Ack (D9)
+        if (lost(s, tk, P_L_RELAY, q, i, idx)) continue;
+        deliver(i, q, bq);
+        acked = true;
+      }
+      if (!acked) {                                  // second unlessAck (src/Core.hs:251): suspectNode (:253) lands in merge
+        if (lane == 0) {
+          s.fail[(size_t)li * s.P + nfail] = j;
+          c_susp++;
+          if (sb_up(bj)) c_fsusp++;
+          else atomicMin(&s.first_suspect[j], t);
+        }
+        nfail++;
+      }
+    }
+    flush();
+    if (lane == 0) s.sp_out[li] = np | (nfail << 5) | (nack << 10);
+  }
+  ctr_add_wave(&sh, C_PINGS, c_pings);
+  ctr_add_wave(&sh, C_ACTIVE, c_active);
+  ctr_add_wave(&sh, C_PAYLOADS, c_payloads);
+  ctr_add_wave(&sh, C_RUMORS_SEEN, c_rumors);
+  ctr_add_wave(&sh, C_DIRECT_FAILED, c_dfail);
+  ctr_add_wave(&sh, C_PING_REQS, c_preqs);
+  ctr_add_wave(&sh, C_SUSPECTS, c_susp);
+  ctr_add_wave(&sh, C_FALSE_SUSPECTS, c_fsusp);
+  ctr_flush(s, &sh, blockIdx.x);
+}
+
+// ================================================================================================
+// merge kernel: one member's end of tick per WAVE, its map as a hash table in LDS
+// ================================================================================================
+template <uint32_t CPHYS>
+struct SpTable {
+  uint32_t hs[CPHYS];       // subject, NONE32 = free
+  uint32_t hk[CPHYS];       // (key << 2) | who stated it first: the atomicMax target of every proposal
+  uint32_t h0[CPHYS];       // the entry's key at the start of the tick (0: no entry = the default) | SP_DUE | SP_KEPT
+  uint32_t hsince[CPHYS];   // lastChange + 1 at the start of the tick
+  uint32_t hist[256];       // radix select
+  uint32_t cl[SWIMSIM_VIEW_CAP_MAX + 8];   // slots of the entries that changed and stayed
+  uint32_t ncl, refute1, full, pos, sel_b, sel_need, sel_cnt, smin, smax, qmin[2];
+  uint2 qnew[PB_SLOTS];     // the head of the next queue line: this tick's rumours, by subject
+};
+template <uint32_t CPHYS>
+__device__ inline uint32_t sp_hash(uint32_t subject) {
+  uint32_t bits = 0;
+  while ((1u << bits) < CPHYS) ++bits;
+  return (subject * 0x9E3779B1u) >> (32u - bits);
+}
+// slot of `subject`, NONE32 if it has none
+template <uint32_t CPHYS>
+__device__ inline uint32_t sp_find(const SpTable<CPHYS>& T, uint32_t subject) {
+  uint32_t h = sp_hash<CPHYS>(subject);
+  for (uint32_t probe = 0; probe < CPHYS; ++probe) {
+    const uint32_t cur = T.hs[h];
+    if (cur == subject) return h;
+    if (cur == NONE32) return NONE32;
+    h = (h + 1u) & (CPHYS - 1u);
+  }
+  return NONE32;
+}
+// The state rule on one proposal: entry := max(entry, (incarnation, state)) -- suspectOrDeadNode' (src/Core.hs:142-187) and
+// the unwritten aliveNode (:197-218, D6) as the commutative merge (H3, D13), here literally one LDS atomicMax.  A subject
+// without an entry gets one if the proposal beats the default (key 0 = Alive@0); one that does not leaves nothing.
+template <uint32_t CPHYS>
+__device__ inline void sp_propose(SpTable<CPHYS>& T, uint32_t subject, uint32_t key, uint32_t prio) {
+  uint32_t h = sp_hash<CPHYS>(subject);
+  for (uint32_t probe = 0; probe < CPHYS; ++probe) {
+    uint32_t cur = T.hs[h];
+    if (cur == NONE32) {
+      if (key == 0u) return;
+      cur = atomicCAS(&T.hs[h], NONE32, subject);    // claimed by whoever comes first; another lane may hold the same rumour
+      if (cur == NONE32) cur = subject;
+    }
+    if (cur == subject) { atomicMax(&T.hk[h], (key << 2) | prio); return; }
+    h = (h + 1u) & (CPHYS - 1u);
+  }
+  T.full = 1u;                                        // more subjects in one tick than the working set holds: loud (ERRF_SUBJECTS)
+}
+
+// WAVES members per workgroup: the tables of a workgroup must fit its LDS allocation (CPHYS = 1024: 18 KB per wave)
+template <uint32_t CPHYS, uint32_t WAVES>
+__global__ __launch_bounds__(64 * WAVES) void sp_merge_kernel(DevState s, uint32_t t, uint32_t tk) {
+  __shared__ SpTable<CPHYS> tabs[WAVES];
+  __shared__ BlockCounters sh;
+  constexpr uint32_t SPL = CPHYS / 64u;              // slots per lane
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const uint32_t nwaves = gridDim.x * WAVES;
+  SpTable<CPHYS>& T = tabs[wv];
+  unsigned c_changes = 0, c_timers = 0, c_fdead = 0, c_refutes = 0, c_evicted = 0, c_pbw = 0, c_evdrop = 0;
+  unsigned long long evd = 0;
+  ctr_init(&sh);
+  if (blockIdx.x == 0 && threadIdx.x == 0) s.g[G_OVF0 + ((t + 1) & 1u)] = 0;   // next tick's overflow list
+  for (uint32_t k = 0; k < SPL; ++k) { const uint32_t x = lane + 64u * k; T.hs[x] = NONE32; T.hk[x] = 0; T.h0[x] = 0; T.hsince[x] = 0; }
+  if (lane == 0) T.full = 0;
+  lds_wave_sync();
+  const uint32_t cur = t & 1u;
+  for (uint32_t li = blockIdx.x * WAVES + wv; li < s.N; li += nwaves) {
+    const uint32_t i = li;
+    const uint32_t myb = s.mb[i];
+    if (!sb_up(myb)) continue;                       // wave-uniform: a member that is down does nothing and receives nothing
+    const uint32_t mk = mix32(tk ^ i);
+    const uint2 hot0 = s.hot[li];
+    const uint32_t po = s.sp_out[li];
+    const uint32_t nsent = po & 31u, nfail = (po >> 5) & 31u, nack = po >> 10;
+    const uint32_t cnt = s.inbox_cnt[li];
+    const uint32_t n0 = s.sp_tab_n[li];
+    if (lane == 0) { T.ncl = 0; T.refute1 = 0; T.pos = 0; T.smin = NONE32; T.smax = 0; }
+    // ---- the map into the hash table; suspicion deadlines that are due (the FIXME at src/Core.hs:141; D4)
+    {
+      const uint32_t* rs = sp_row(s, li, 0); const uint32_t* rk = sp_row(s, li, 1); const uint32_t* rt = sp_row(s, li, 2);
+      for (uint32_t e = lane; e < n0; e += 64u) {
+        const uint32_t subject = rs[e], key = rk[e], since1 = rt[e];
+        uint32_t h = sp_hash<CPHYS>(subject);
+        for (;;) {                                     // subjects of a map are distinct: a free slot is mine
+          if (atomicCAS(&T.hs[h], NONE32, subject) == NONE32) break;
+          h = (h + 1u) & (CPHYS - 1u);
+        }
+        const bool due = (key & 3u) == ST_SUSPECT && since1 - 1u + s.S <= t;
+        T.hk[h] = due ? ((((key & ~3u) | ST_DEAD) << 2) | SP_PRIO_TIMER) : (key << 2);
+        T.h0[h] = key | (due ? SP_DUE : 0u);
+        T.hsince[h] = since1;
+      }
+    }
+    lds_wave_sync();
+    // ---- own probes that ended without any Ack: Suspect at the incarnation the map holds (src/Core.hs:253)
+    if (lane < nfail) {
+      const uint32_t j = s.fail[(size_t)li * s.P + lane];
+      const uint32_t sl = sp_find<CPHYS>(T, j);
+      const uint32_t k0 = sl == NONE32 ? 0u : (T.h0[sl] & 0xFFFFFFu);
+      sp_propose<CPHYS>(T, j, (k0 & ~3u) | ST_SUSPECT, SP_PRIO_PROBE);
+    }
+    // ---- the rumours received this tick (src/Core.hs:110-117): 8 sources x 8 queue entries per round of loads
+    {
+      const uint32_t nin = cnt < s.inbox_cap ? cnt : s.inbox_cap;
+      const uint32_t nsrc = nack + nin;
+      auto entry = [&](uint2 e) {
+        if (!pe_tx(e.y)) return;
+        const uint32_t key = pe_key(e.y);
+        if (e.x == i) {                               // about self -> refute (:155-166); incarnations below my own are stale (:151)
+          if ((key & 3u) != ST_ALIVE && (key >> 2) >= hot0.x) atomicMax(&T.refute1, (key >> 2) + 1u);
+          return;
+        }
+        sp_propose<CPHYS>(T, e.x, key, SP_PRIO_GOSSIP);
+      };
+      for (uint32_t x0 = 0; x0 < nsrc; x0 += 8u) {
+        const uint32_t x = x0 + (lane >> 3);
+        if (x < nsrc) {
+          const uint32_t src = x < nack ? s.ackfrom[(size_t)li * s.sp_ack_cap + x] : s.inbox[(size_t)li * s.inbox_cap + (x - nack)];
+          entry(sp_line(s, cur, src)[lane & 7u]);
+        }
+      }
+      if (cnt > s.inbox_cap) {                        // the exact overflow list (rare): my entries of it, one source at a time
+        const uint32_t novf = min(s.g[G_OVF0 + (t & 1u)], s.ovf_cap);
+        for (uint32_t y0 = 0; y0 < novf; y0 += 64u) {
+          const uint32_t y = y0 + lane;
+          uint2 o = make_uint2(NONE32, 0u);
+          if (y < novf) o = s.ovf[(size_t)(t & 1u) * s.ovf_cap + y];
+          unsigned long long hits = __ballot(o.x == li);
+          for (; hits; hits &= hits - 1ull) {
+            const int L = __ffsll((unsigned long long)hits) - 1;
+            const uint32_t src = (uint32_t)__builtin_amdgcn_readlane((int)o.y, L);
+            if (lane < 8u) entry(sp_line(s, cur, src)[lane]);
+          }
+        }
+      }
+    }
+    lds_wave_sync();
+    // ---- what changed; how many entries there are now
+    uint32_t nvalid = 0, nchanged = 0;
+    for (uint32_t k = 0; k < SPL; ++k) {
+      const uint32_t x = lane + 64u * k;
+      if (T.hs[x] == NONE32) continue;
+      nvalid++;
+      const bool changed = (T.hk[x] >> 2) > (T.h0[x] & 0xFFFFFFu);
+      nchanged += changed ? 1u : 0u;
+      const uint32_t since = changed ? t + 1u : T.hsince[x];
+      atomicMin(&T.smin, since); atomicMax(&T.smax, since);
+    }
+    const uint32_t total = wave_sum(nvalid);
+    if (T.full) atomicOr(&s.g[G_ERR], (uint32_t)ERRF_SUBJECTS);
+    // ---- the capacity: the C entries with the largest (lastChange, rank) stay; rank = mix32(subject ^ mk) is a keyed
+    // permutation of the ids (no ties).  Radix select of the C-th largest 64-bit priority, a byte per pass, in LDS.
+    unsigned long long thr = 0ull;                   // stay iff priority >= thr
+    if (total > s.C) {
+      lds_wave_sync();
+      const uint32_t smin = T.smin, smax = T.smax;
+      auto prio_of = [&](uint32_t x) -> unsigned long long {
+        const bool changed = (T.hk[x] >> 2) > (T.h0[x] & 0xFFFFFFu);
+        return ((unsigned long long)(changed ? t + 1u : T.hsince[x]) << 32) | mix32(T.hs[x] ^ mk);
+      };
+      // the bytes of lastChange every entry shares need no pass
+      int pass = 7;
+      unsigned long long prefix = 0ull;               // the decided high bytes of the threshold
+      while (pass >= 4 && (smin >> (8 * (pass - 4))) == (smax >> (8 * (pass - 4)))) {
+        prefix = smin >> (8 * (pass - 4));
+        pass--;
+      }
+      uint32_t need = s.C;
+      bool done = false;
+      for (; pass >= 0 && !done; --pass) {
+        for (uint32_t b = lane; b < 256u; b += 64u) T.hist[b] = 0;
+        lds_wave_sync();
+        for (uint32_t k = 0; k < SPL; ++k) {
+          const uint32_t x = lane + 64u * k;
+          if (T.hs[x] == NONE32) continue;
+          const unsigned long long p = prio_of(x);
+          if (pass == 7 || (p >> (8 * (pass + 1))) == prefix) atomicAdd(&T.hist[(uint32_t)(p >> (8 * pass)) & 0xFFu], 1u);
+        }
+        lds_wave_sync();
+        // the bin in which the need-th largest lies: lane l owns bins 4l .. 4l+3
+        const uint32_t b0 = T.hist[4u * lane], b1 = T.hist[4u * lane + 1u], b2 = T.hist[4u * lane + 2u], b3 = T.hist[4u * lane + 3u];
+        const uint32_t mine = b0 + b1 + b2 + b3;
+        const uint32_t incl = wave_prefix_incl(mine);
+        const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t above = all - incl;             // entries in the bins of higher lanes
+        if (above < need && need <= above + mine) {    // exactly one lane
+          uint32_t a = above, b = 4u * lane + 3u, hb = b3;
+          if (a + b3 < need) { a += b3; b = 4u * lane + 2u; hb = b2;
+            if (a + b2 < need) { a += b2; b = 4u * lane + 1u; hb = b1;
+              if (a + b1 < need) { a += b1; b = 4u * lane; hb = b0; } } }
+          T.sel_b = b; T.sel_need = need - a; T.sel_cnt = hb;
+        }
+        lds_wave_sync();
+        prefix = (prefix << 8) | T.sel_b;
+        need = T.sel_need;
+        if (T.sel_cnt == need) { thr = prefix << (8 * pass); done = true; }   // the whole bin stays
+      }
+      if (!done) thr = prefix;
+    }
+    // ---- mark who stays; list the entries that changed AND stayed
+    uint32_t nkept = 0;
+    for (uint32_t k = 0; k < SPL; ++k) {
+      const uint32_t x = lane + 64u * k;
+      if (T.hs[x] == NONE32) continue;
+      const bool changed = (T.hk[x] >> 2) > (T.h0[x] & 0xFFFFFFu);
+      bool kept = true;
+      if (total > s.C) {
+        const unsigned long long p = ((unsigned long long)(changed ? t + 1u : T.hsince[x]) << 32) | mix32(T.hs[x] ^ mk);
+        kept = p >= thr;
+      }
+      if (!kept) continue;
+      nkept++;
+      T.h0[x] |= SP_KEPT;
+      if (changed) T.cl[atomicAdd(&T.ncl, 1u)] = x;
+    }
+    c_evicted += total > s.C ? (nvalid - nkept) : 0u;
+    lds_wave_sync();
+    const uint32_t ncl = T.ncl;
+    // ---- account for what changed and stayed (`saveMember m'`, src/Core.hs:169-179): digest, counters, events
+    const unsigned long long ha = mix64(mix64((uint64_t)TAG_EV) + (((uint64_t)t << 32) | i));
+    for (uint32_t c0 = 0; c0 < ncl; c0 += 64u) {
+      const uint32_t c = c0 + lane;
+      bool ev = false; uint32_t subject = 0, key = 0, cause = 0;
+      if (c < ncl) {
+        const uint32_t x = T.cl[c];
+        subject = T.hs[x]; key = T.hk[x] >> 2;
+        const uint32_t pr = T.hk[x] & 3u, k0 = T.h0[x] & 0xFFFFFFu;
+        cause = pr == SP_PRIO_TIMER ? 1u : pr == SP_PRIO_PROBE ? 0u : 2u;
+        evd += (mix64(ha + subject) | 1ull) * (unsigned long long)(key - k0);
+        c_changes++;
+        if (T.h0[x] & SP_DUE) { c_timers++; c_fdead += sb_up(s.mb[subject]) ? 1u : 0u; }   // `deadNode` after the timeout
+        ev = (s.event_mask & (1u << cause)) != 0u;
+      }
+      const unsigned long long evb = __ballot(ev);
+      if (evb) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&s.g[G_EVCUR], (uint32_t)__popcll(evb));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
+        if (ev) {
+          const uint32_t pos = base + (uint32_t)__popcll(evb & ((1ull << lane) - 1ull));
+          if (pos < s.event_cap) s.events[pos] = make_uint4(t, i, subject, (key << 8) | cause);
+          else c_evdrop++;
+        }
+      }
+    }
+    // ---- refutation: bump own incarnation past the rumour's (src/Core.hs:155-166; D10)
+    uint32_t self_inc = hot0.x;
+    const uint32_t refute1 = T.refute1;
+    const bool refuted = refute1 != 0u;
+    uint32_t akey = 0;
+    if (refuted) {
+      uint32_t ni = refute1;                          // = the largest non-Alive incarnation about me + 1
+      if (ni > INC_MAX) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_INC); ni = INC_MAX; }
+      self_inc = ni;
+      akey = (ni << 2) | ST_ALIVE;
+      if (lane == 0) {
+        evd += h4(TAG_INC, ((uint64_t)t << 32) | i, ni, 0);
+        c_refutes++;
+        if (s.event_mask & (1u << 3)) {
+          const uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
+          if (pos < s.event_cap) s.events[pos] = make_uint4(t, i, i, (akey << 8) | 3u /*REFUTE*/);
+          else c_evdrop++;
+        }
+      }
+    }
+    // ---- the queue (D5): this tick's rumours -- what changed and stayed, the refutation -- with a full budget, by subject;
+    // then the aged survivors in their order; the 8 best.  The up-to-8 smallest subjects of the tick by repeated wave minimum.
+    uint32_t gn = 0;
+    {
+      uint32_t last = 0; bool first = true;
+      for (; gn < (uint32_t)PB_SLOTS; ++gn) {
+        // (two words in turn: a lane may still be reading round g - 1's minimum when lane 0 prepares round g)
+        uint32_t* const qmin = &T.qmin[gn & 1u];
+        if (lane == 0) *qmin = NONE32;
+        lds_wave_sync();
+        uint32_t best = NONE32;
+        for (uint32_t c = lane; c < ncl; c += 64u) {
+          const uint32_t sj = T.hs[T.cl[c]];
+          if ((first || sj > last) && sj < best) best = sj;
+        }
+        if (lane == 0 && refuted && (first || i > last) && i < best) best = i;
+        if (best != NONE32) atomicMin(qmin, best);
+        lds_wave_sync();
+        const uint32_t m = *qmin;
+        if (m == NONE32) break;
+        if (lane == 0) {
+          uint32_t key = akey;
+          if (!(refuted && m == i)) key = T.hk[sp_find<CPHYS>(T, m)] >> 2;
+          T.qnew[gn] = make_uint2(m, pe_hi(key, s.L));
+        }
+        last = m; first = false;
+      }
+    }
+    lds_wave_sync();
+    const uint32_t age = nsent ? nsent : 1u;
+    const uint32_t oldn = sb_qn(myb);
+    uint32_t nout = gn;
+    {
+      // lanes 0..7 look at one old entry each; it survives if its budget lasts and no rumour of this tick supersedes it
+      bool keep = false; uint2 oe = make_uint2(0u, 0u);
+      if (lane < oldn) {
+        oe = sp_line(s, cur, li)[lane];
+        const uint32_t tx = pe_tx(oe.y);
+        bool superseded = refuted && oe.x == i;
+        if (!superseded && oe.x != i) {
+          const uint32_t sl = sp_find<CPHYS>(T, oe.x);
+          superseded = sl != NONE32 && (T.h0[sl] & SP_KEPT) && (T.hk[sl] >> 2) > (T.h0[sl] & 0xFFFFFFu);
+        }
+        keep = tx > age && !superseded;
+        oe.y = pe_hi(pe_key(oe.y), tx - age);
+      }
+      const unsigned long long kb = __ballot(keep);
+      const uint32_t rank = (uint32_t)__popcll(kb & ((1ull << lane) - 1ull));
+      uint2* out = sp_line(s, cur ^ 1u, li);
+      if (keep && gn + rank < (uint32_t)PB_SLOTS) out[gn + rank] = oe;
+      nout = min((uint32_t)PB_SLOTS, gn + (uint32_t)__popcll(kb));
+      if (lane < gn) out[lane] = T.qnew[lane];
+      if (lane >= nout && lane < (uint32_t)PB_SLOTS) out[lane] = make_uint2(0u, 0u);
+    }
+    if (lane == 0) {
+      c_pbw += (oldn || nout) ? 1u : 0u;
+      s.mb[i] = (uint8_t)(MB_UP | (nout << MB_PBN_SHIFT));
+      if (self_inc != hot0.x) s.hot[li] = make_uint2(self_inc, hot0.y);
+      s.inbox_cnt[li] = 0;
+    }
+    // ---- the map back to HBM (who stays, in any order), the table cleared for the wave's next member
+    {
+      uint32_t* rs = sp_row(s, li, 0); uint32_t* rk = sp_row(s, li, 1); uint32_t* rt = sp_row(s, li, 2);
+      for (uint32_t k = 0; k < SPL; ++k) {
+        const uint32_t x = lane + 64u * k;
+        const uint32_t subject = T.hs[x];
+        if (subject == NONE32) continue;
+        if (T.h0[x] & SP_KEPT) {
+          const uint32_t key = T.hk[x] >> 2;
+          const bool changed = key > (T.h0[x] & 0xFFFFFFu);
+          const uint32_t pos = atomicAdd(&T.pos, 1u);
+          rs[pos] = subject; rk[pos] = key; rt[pos] = changed ? t + 1u : T.hsince[x];
+        }
+        T.hs[x] = NONE32; T.hk[x] = 0; T.h0[x] = 0; T.hsince[x] = 0;
+      }
+      lds_wave_sync();
+      if (lane == 0) { s.sp_tab_n[li] = T.pos; T.full = 0; }
+    }
+    lds_wave_sync();
+  }
+  ctr_add_wave(&sh, C_CHANGES, c_changes);
+  ctr_add_wave(&sh, C_PB_WRITES, c_pbw);
+  ctr_add_wave(&sh, C_TIMERS_FIRED, c_timers);
+  ctr_add_wave(&sh, C_FALSE_DEADS, c_fdead);
+  ctr_add_wave(&sh, C_REFUTES, c_refutes);
+  ctr_add_wave(&sh, C_EVENTS_DROPPED, c_evdrop);
+  ctr_add_wave(&sh, C_EVICTED, c_evicted);
+  {
+    const unsigned long long wevd = wave_sum64(evd);
+    if (lane == 0u && wevd) atomicAdd(&sh.evd, wevd);
+  }
+  ctr_flush(s, &sh, blockIdx.x);
+}
+
+// ================================================================================================
+// observables
+// ================================================================================================
+__global__ __launch_bounds__(BLOCK) void sp_digest_kernel(DevState s, uint32_t t, unsigned long long* out) {
+  __shared__ unsigned long long acc;
+  if (threadIdx.x == 0) acc = 0;
+  __syncthreads();
+  const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
+  if (li < s.N) {
+    const uint32_t i = li, b = s.mb[i];
+    unsigned long long mh = h4(TAG_SELF, i, s.hot[li].x, sb_up(b) ? 1u : 0u);
+    const uint32_t n = s.sp_tab_n[li];
+    const uint32_t* rs = sp_row(s, li, 0); const uint32_t* rk = sp_row(s, li, 1); const uint32_t* rt = sp_row(s, li, 2);
+    for (uint32_t e = 0; e < n; ++e) {
+      mh += h4(TAG_VIEW, rs[e], rk[e], rt[e]);
+      if ((rk[e] & 3u) == ST_SUSPECT) mh += h4(TAG_TIMER, rs[e], (uint64_t)rt[e] - 1 + s.S, 0);
+    }
+    const uint32_t qn = sb_qn(b);
+    const uint2* line = sp_line(s, t & 1u, li);        // the buffer the NEXT tick reads
+    for (uint32_t q = 0; q < qn; ++q) mh += h4(TAG_PB, line[q].x, pe_key(line[q].y), pe_tx(line[q].y));
+    unsigned long long d = mix64(mh + mix64((uint64_t)TAG_MEMBER + i));
+    const uint32_t fs = s.first_suspect[i];
+    if (fs != NONE32) d += h4(TAG_FD, i, fs, 0);
+    atomicAdd(&acc, d);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && acc) atomicAdd(out, acc);
+}
+
+// swimsim_coverage on bounded maps: a member holds the rumour if its entry about `subject` is at least `key` (no entry = the
+// default, Alive@0)
+__global__ __launch_bounds__(BLOCK) void sp_coverage_kernel(DevState s, uint32_t subject, uint32_t key, unsigned long long* out) {
+  const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
+  uint32_t up = 0, hold = 0;
+  if (li < s.N && li != subject && sb_up(s.mb[li])) {
+    up = 1;
+    uint32_t k = 0;
+    const uint32_t n = s.sp_tab_n[li];
+    const uint32_t* rs = sp_row(s, li, 0);
+    for (uint32_t e = 0; e < n; ++e) if (rs[e] == subject) { k = sp_row(s, li, 1)[e]; break; }
+    hold = k >= key ? 1u : 0u;
+  }
+  const unsigned long long bh = __ballot(hold != 0u), bu = __ballot(up != 0u);
+  if ((threadIdx.x & 63u) == 0u) {
+    if (bh) atomicAdd(&out[0], (unsigned long long)__popcll(bh));
+    if (bu) atomicAdd(&out[1], (unsigned long long)__popcll(bu));
+  }
+}
+
+}  // namespace swim

@@ -251,6 +251,34 @@ int swimwire_encode(const swimwire_msg_t* msgs, size_t n, uint8_t* buf, size_t c
   return SWIMSIM_OK;
 }
 
+// `encode msg` of a bare `Message` (instance Serialize Message, src/Types.hs:151-155): the msgpack body alone, no type byte --
+// what the reference's send side literally puts on the wire (src/Core.hs:133-134; D11)
+int swimwire_encode_bare(const swimwire_msg_t* msg, uint8_t* buf, size_t cap, size_t* n_out) {
+  if (!n_out || !msg) return SWIMSIM_ERR_INVALID;
+  W w;
+  const int rc = put_body(w, *msg);
+  if (rc) { *n_out = 0; return rc; }
+  if (w.b.size() > SWIMWIRE_MAX_DATAGRAM) return fail(SWIMSIM_ERR_CAPACITY, "encode: datagram beyond 65 535 bytes (src/Core.hs:280)");
+  *n_out = w.b.size();
+  if (w.b.size() > cap || !buf) return SWIMSIM_ERR_BUFFER;
+  memcpy(buf, w.b.data(), w.b.size());
+  return SWIMSIM_OK;
+}
+
+// An Envelope, or the bare `Message` of the literal sender.  The two cannot be confused: an Envelope starts with a type
+// byte 0..6, a bare Message with the header of a msgpack map (0x80..0x8f, 0xde, 0xdf).
+int swimwire_decode_any(const uint8_t* buf, size_t len, swimwire_msg_t* out, size_t cap, size_t* n_out, int* was_bare) {
+  if (was_bare) *was_bare = 0;
+  if (!n_out || (!buf && len)) return SWIMSIM_ERR_INVALID;
+  if (len && ((buf[0] & 0xf0) == 0x80 || buf[0] == 0xde || buf[0] == 0xdf)) {
+    if (was_bare) *was_bare = 1;
+    *n_out = 1;
+    if (cap < 1 || !out) return SWIMSIM_ERR_BUFFER;
+    return get_body(buf, len, &out[0]);
+  }
+  return swimwire_decode(buf, len, out, cap, n_out);
+}
+
 int swimwire_decode(const uint8_t* buf, size_t len, swimwire_msg_t* out, size_t cap, size_t* n_out) {
   if (!n_out || (!buf && len)) return SWIMSIM_ERR_INVALID;
   *n_out = 0;

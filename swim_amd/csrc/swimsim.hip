@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "swim_kernels.h"
+#include "swim_sparse.h"
 
 using namespace swim;
 
@@ -157,6 +158,12 @@ int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, std::string*
   if (c->pull_ticks == 1) { *err = "pull_ticks must be 0 (off) or >= 2"; return SWIMSIM_ERR_INVALID; }
   if (c->pull_ticks && c->n_shards > 1) { *err = "pull_ticks (periodic state pull) is not available on sharded handles"; return SWIMSIM_ERR_INVALID; }
   if (c->n_shards > 1 && c->n_members > (1u << 27)) { *err = "sharded clusters: n_members must be <= 2^27"; return SWIMSIM_ERR_INVALID; }
+  if (c->view_cap) {
+    if (c->view_cap < SWIMSIM_VIEW_CAP_MIN || c->view_cap > SWIMSIM_VIEW_CAP_MAX) {
+      *err = "view_cap must be 0 (unbounded) or in [" + std::to_string(SWIMSIM_VIEW_CAP_MIN) + ", " + std::to_string(SWIMSIM_VIEW_CAP_MAX) + "]"; return SWIMSIM_ERR_INVALID; }
+    if (c->gc_ticks || c->join_pull || c->pull_ticks || c->target_scheme != SWIMSIM_TARGETS_RANDOM || c->n_shards > 1) {
+      *err = "view_cap (bounded member maps) cannot be combined with gc_ticks, join_pull, pull_ticks, the robust target scheme or sharding"; return SWIMSIM_ERR_INVALID; }
+  }
   return SWIMSIM_OK;
 }
 
@@ -165,7 +172,7 @@ int check_device_errors(swimsim* h) {
   HIPCHK(h, hipMemcpy(g, h->d.g, sizeof g, hipMemcpyDeviceToHost));
   if (g[G_ERR]) {
     std::string m = "capacity exceeded:";
-    if (g[G_ERR] & ERRF_SUBJECTS) m += " max_subjects";
+    if (g[G_ERR] & ERRF_SUBJECTS) m += h->d.C ? " subjects-a-member-hears-of-in-one-tick (bounded member maps: the per-tick working set)" : " max_subjects";
     if (g[G_ERR] & ERRF_ROWS) m += " view-rows-in-transit (settled rows wait two ticks before reuse)";
     if (g[G_ERR] & ERRF_OVF) m += " inbox-overflow-list (" + std::to_string(std::max(g[G_OVF0], g[G_OVF1])) + " entries, room for " + std::to_string(h->d.ovf_cap) + ")";
     if (g[G_ERR] & ERRF_INC) m += " incarnation-bits";
@@ -261,6 +268,25 @@ void launch_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev) {
   const bool rk = records_kernel_every_tick(h);
   if (rk) hipLaunchKernelGGL(records_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
   hipLaunchKernelGGL(merge_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, rk ? 0u : 1u);
+  if (ev) (void)hipEventRecord(ev[2], h->stream);
+}
+
+// bounded member maps: probe (map entries per lane by view_cap, probe / proxy arrays by P, K) and merge (LDS table by view_cap)
+template <int MT>
+void launch_sparse_probe(swimsim* h, uint32_t t, uint32_t tk) {
+  const uint32_t pk = std::max(h->d.P, h->d.K);
+  if (pk <= 4) hipLaunchKernelGGL((sp_probe_kernel<MT, 4>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk);
+  else hipLaunchKernelGGL((sp_probe_kernel<MT, 16>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk);
+}
+void launch_sparse_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev) {
+  if (ev) (void)hipEventRecord(ev[0], h->stream);
+  if (h->d.C <= 64) launch_sparse_probe<1>(h, t, tk);
+  else if (h->d.C <= 128) launch_sparse_probe<2>(h, t, tk);
+  else launch_sparse_probe<4>(h, t, tk);
+  if (ev) (void)hipEventRecord(ev[1], h->stream);
+  // the per-tick working set of a member: its map + the subjects it hears of for the first time (4 x the capacity, >= 512 slots)
+  if (h->d.C <= 128) hipLaunchKernelGGL((sp_merge_kernel<512, 4>), dim3(h->d.nblocks), dim3(256), 0, h->stream, h->d, t, tk);
+  else hipLaunchKernelGGL((sp_merge_kernel<1024, 2>), dim3(h->d.nblocks), dim3(128), 0, h->stream, h->d, t, tk);   // (one counter row per workgroup: the same grid)
   if (ev) (void)hipEventRecord(ev[2], h->stream);
 }
 
@@ -375,6 +401,35 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     d.todo_spill_at = d.todo_cap * share;
     d.todo_spill = (uint32_t)std::min<double>(4.0e8, senders <= 65536.0 ? senders * hard * PB_SLOTS : senders * (1.25 * lam + 2.0) * PB_SLOTS / 4.0);
   }
+  d.C = c.view_cap;
+  if (d.C) {
+    // bounded member maps (swim_sparse.h): the maps, the queue lines, the inboxes -- none of the view / mask / deadline tables
+    d.ord_cap = 0; d.r_cap = d.p_cap = d.x_cap = 0;
+    d.R_phys = 0;
+    d.sp_ack_cap = std::max(1u, d.P) * (1u + d.K);
+    // one wave per member, persistent: enough workgroups to fill the chip several times over (256 CUs)
+    d.nblocks = std::min<uint32_t>((N + SP_WAVES - 1) / SP_WAVES, 4096u);
+    CK(dev_alloc(h, &d.mb, ((size_t)NT + 3) & ~(size_t)3, 0));
+    CK(dev_alloc(h, &d.hot, N, 0));
+    CK(dev_alloc(h, &d.sp_tab, (size_t)N * 3 * d.C, 0));
+    CK(dev_alloc(h, &d.sp_tab_n, N, 0));
+    CK(dev_alloc(h, &d.sp_q, (size_t)2 * N * PB_SLOTS, 0));
+    CK(dev_alloc(h, &d.sp_out, N, 0));
+    CK(dev_alloc(h, &d.ackfrom, (size_t)N * d.sp_ack_cap, 0));
+    CK(dev_alloc(h, &d.fail, (size_t)N * (d.P ? d.P : 1), 0));
+    CK(dev_alloc(h, &d.inbox_cnt, N, 0));
+    CK(dev_alloc(h, &d.inbox, (size_t)N * d.inbox_cap, 0));
+    CK(dev_alloc(h, &d.first_suspect, NT, 0xFF));
+    CK(dev_alloc(h, &d.crash_tick, NT, 0xFF));
+    CK(dev_alloc(h, &d.g, (size_t)G_WORDS, 0));
+    d.send_cnt = d.g + G_SEND;
+    HK(hipHostMalloc(reinterpret_cast<void**>(&h->h_sync), G_WORDS * sizeof(uint32_t)));
+    CK(dev_alloc(h, &d.ovf, (size_t)2 * d.ovf_cap, 0));
+    CK(dev_alloc(h, &d.events, (size_t)d.event_cap, 0));
+    CK(dev_alloc(h, &d.blk, ((size_t)d.nblocks + 1) * C_COUNT, 0));
+    CK(dev_alloc(h, &h->d_scratch64, (size_t)2, 0));
+    HK(hipMemsetAsync(d.mb, (int)MB_UP, NT, h->stream));           // every member up, empty queue
+  } else {
   d.ord_cap = 0; d.r_cap = d.p_cap = d.x_cap = 0;
   CK(dev_alloc(h, &d.minfo, NT, 0));
   CK(dev_alloc(h, &d.mb, ((size_t)NT + 3) & ~(size_t)3, 0));
@@ -486,9 +541,10 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     CK(dev_alloc(h, &d.fl, (size_t)INJECT_CAP * 4, 0));
     CK(dev_alloc(h, &h->d_inject, (size_t)INJECT_CAP, 0));
   }
+  }
   CK(dev_alloc(h, &h->d_state, (size_t)1, 0));
   HK(hipMemcpyAsync(h->d_state, &d, sizeof d, hipMemcpyHostToDevice, h->stream));   // behind the allocation's memset
-  hipLaunchKernelGGL(init_members_kernel, dim3((NT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, d.minfo, d.mb, NT);
+  if (!d.C) hipLaunchKernelGGL(init_members_kernel, dim3((NT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, d.minfo, d.mb, NT);
   HK(hipGetLastError());
   HK(hipStreamSynchronize(h->stream));
 #undef CK
@@ -508,6 +564,7 @@ int swimsim_inject_rumor(swimsim_t* h, uint32_t observer, uint32_t subject, uint
   if (observer >= h->d.NT || subject >= h->d.NT || state > 2 || incarnation > INC_MAX)
     return set_err(h, SWIMSIM_ERR_INVALID, "inject_rumor: bad member / state / incarnation");
   if (h->d.n_shards > 1) return set_err(h, SWIMSIM_ERR_STATE, "inject_rumor: unsharded handles only");
+  if (h->d.C) return set_err(h, SWIMSIM_ERR_INVALID, "inject_rumor: not available with bounded member maps (view_cap)");
   if (h->injections.size() >= INJECT_CAP) return set_err(h, SWIMSIM_ERR_BUFFER, "inject_rumor: more than 4096 rumours before the next tick");
   h->injections.push_back(InjectRec{observer, subject, (incarnation << 2) | state, 0u});
   return SWIMSIM_OK;
@@ -584,6 +641,12 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
     const size_t f0 = fpos;
     while (fpos < fend && h->faults[fpos].tick <= t) ++fpos;
     const uint32_t tk = tick_key(h->cfg.seed, t);
+    if (h->d.C) {                                   // bounded member maps: swim_sparse.h, one wave per member
+      if (fpos > f0) hipLaunchKernelGGL(sp_begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, h->d_faults + f0, (uint32_t)(fpos - f0));
+      launch_sparse_tick(h, t, tk, ev);
+      h->tick++;
+      continue;
+    }
     // messages from outside the simulation go into this tick's inboxes BEFORE the start of the tick: the rows they open
     // count as stated in this tick (a row nobody holds anything in settles at the end of it, as in the oracle), the ids
     // they take are older than the tick's window head
@@ -672,9 +735,36 @@ static int read_column(swimsim_t* h, uint32_t observer, std::vector<uint2>* col,
   return SWIMSIM_OK;
 }
 
+// bounded member maps: one member's map as stored, rows[0..C) subjects, [C..2C) keys, [2C..3C) lastChange + 1; *n entries in use
+static int read_sparse_map(swimsim_t* h, uint32_t member, std::vector<uint32_t>* rows, uint32_t* n) {
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  rows->resize((size_t)3 * h->d.C);
+  HIPCHK(h, hipMemcpy(rows->data(), h->d.sp_tab + (size_t)member * 3 * h->d.C, rows->size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(n, h->d.sp_tab_n + member, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (*n > h->d.C) *n = h->d.C;
+  return SWIMSIM_OK;
+}
+
 int swimsim_read_view(swimsim_t* h, uint32_t observer, swimsim_view_entry_t* buf, size_t cap, size_t* n_out) {
   if (!h || !n_out || observer - h->d.lo >= h->d.N) return SWIMSIM_ERR_INVALID;   // not a member this handle owns
   HIPCHK(h, hipSetDevice(h->device));
+  if (h->d.C) {                                     // bounded map: its entries, sorted by subject
+    std::vector<uint32_t> rows;
+    uint32_t n = 0;
+    int rc0 = read_sparse_map(h, observer, &rows, &n);
+    if (rc0) return rc0;
+    std::vector<swimsim_view_entry_t> es(n);
+    for (uint32_t e = 0; e < n; ++e) {
+      es[e] = swimsim_view_entry_t{};
+      es[e].subject = rows[e]; es[e].incarnation = rows[h->d.C + e] >> 2; es[e].state = (uint8_t)(rows[h->d.C + e] & 3u);
+      es[e].since_tick = rows[2 * h->d.C + e] - 1;
+    }
+    std::sort(es.begin(), es.end(), [](const swimsim_view_entry_t& a, const swimsim_view_entry_t& b) { return a.subject < b.subject; });
+    *n_out = n;
+    if (n > cap || (n && !buf)) return SWIMSIM_ERR_BUFFER;
+    if (n) std::memcpy(buf, es.data(), n * sizeof *buf);
+    return SWIMSIM_OK;
+  }
   std::vector<uint2> col; std::vector<uint32_t> subj;
   int rc = read_column(h, observer - h->d.lo, &col, &subj);
   if (rc) return rc;
@@ -719,6 +809,30 @@ int swimsim_read_member(swimsim_t* h, uint32_t m, swimsim_member_t* out) {
   if (!h || !out || m - h->d.lo >= h->d.N) return SWIMSIM_ERR_INVALID;           // not a member this handle owns
   HIPCHK(h, hipSetDevice(h->device));
   const uint32_t ml = m - h->d.lo;
+  if (h->d.C) {
+    std::vector<uint32_t> rows;
+    uint32_t n = 0;
+    int rc0 = read_sparse_map(h, m, &rows, &n);
+    if (rc0) return rc0;
+    uint2 hot; uint8_t b;
+    HIPCHK(h, hipMemcpy(&hot, h->d.hot + ml, sizeof hot, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(&b, h->d.mb + m, 1, hipMemcpyDeviceToHost));
+    std::memset(out, 0, sizeof *out);
+    out->id = m; out->incarnation = hot.x; out->up = b & MB_UP;
+    const uint32_t qn = (b >> MB_PBN_SHIFT) & 0xFu;
+    if (qn) {
+      uint2 line[PB_SLOTS];
+      HIPCHK(h, hipMemcpy(line, h->d.sp_q + ((size_t)(h->tick & 1u) * h->d.N + ml) * PB_SLOTS, sizeof line, hipMemcpyDeviceToHost));
+      for (uint32_t q = 0; q < qn && q < (uint32_t)PB_SLOTS; ++q) {
+        swimsim_rumor_t& r = out->rumors[out->n_rumors++];
+        r.subject = line[q].x; r.incarnation = pe_key(line[q].y) >> 2; r.state = (uint8_t)(pe_key(line[q].y) & 3u); r.tx_left = (uint8_t)pe_tx(line[q].y);
+      }
+    }
+    uint32_t nt = 0;
+    for (uint32_t e = 0; e < n; ++e) nt += (rows[h->d.C + e] & 3u) == ST_SUSPECT;
+    out->n_timers = (uint16_t)nt;
+    return SWIMSIM_OK;
+  }
   std::vector<uint2> col; std::vector<uint32_t> subj;
   int rc = read_column(h, ml, &col, &subj);
   if (rc) return rc;
@@ -759,7 +873,8 @@ int swimsim_digest(swimsim_t* h, uint64_t* out) {
   if (!h || !out) return SWIMSIM_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemsetAsync(h->d_scratch64, 0, sizeof(unsigned long long), h->stream));
-  hipLaunchKernelGGL(digest_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, h->d_scratch64);
+  if (h->d.C) hipLaunchKernelGGL(sp_digest_kernel, dim3((h->d.N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, h->d, (uint32_t)h->tick, h->d_scratch64);
+  else hipLaunchKernelGGL(digest_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, h->d_scratch64);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   unsigned long long acc = 0;
@@ -773,7 +888,9 @@ int swimsim_coverage(swimsim_t* h, uint32_t subject, uint8_t state, uint32_t inc
   if (!h || !out || subject >= h->d.NT || state > SWIMSIM_DEAD || incarnation > INC_MAX) return SWIMSIM_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemsetAsync(h->d_scratch64, 0, 2 * sizeof(unsigned long long), h->stream));
-  hipLaunchKernelGGL(coverage_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, subject, (incarnation << 2) | state,
+  if (h->d.C) hipLaunchKernelGGL(sp_coverage_kernel, dim3((h->d.N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, h->d, subject, (incarnation << 2) | state,
+                                 h->d_scratch64);
+  else hipLaunchKernelGGL(coverage_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, subject, (incarnation << 2) | state,
                      h->d_scratch64);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -802,7 +919,7 @@ int swimsim_table_stats(swimsim_t* h, uint64_t* out, size_t n) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   uint32_t g[G_WORDS];
   HIPCHK(h, hipMemcpy(g, h->d.g, sizeof g, hipMemcpyDeviceToHost));
-  out[0] = g[G_NSLOTS]; out[1] = g[G_NLIVE]; out[2] = g[G_NFREE]; out[3] = g[G_NRUM]; out[4] = h->d.R_phys;
+  out[0] = g[G_NSLOTS]; out[1] = g[G_NLIVE]; out[2] = g[G_NFREE]; out[3] = g[G_NRUM]; out[4] = h->d.R_phys;   // (bounded member maps: all zero, no view rows)
   if (n >= 7) { out[5] = std::max(g[G_OVF0], g[G_OVF1]); out[6] = h->d.ovf_cap; }
 #ifdef SWIM_REC_STATS
   if (n >= 10) { out[7] = g[90]; out[8] = g[91]; out[9] = g[92]; }
@@ -832,6 +949,7 @@ int swimsim_debug_sections(swimsim_t* h, uint64_t* out) {
 int swimsim_k_random_members(swimsim_t* h, uint32_t observer, uint32_t n, const uint32_t* excludes,
                              size_t n_excludes, uint32_t* out, size_t cap, size_t* n_out) {
   if (!h || !n_out || observer - h->d.lo >= h->d.N || n > 255 || (n_excludes && !excludes)) return SWIMSIM_ERR_INVALID;
+  if (h->d.C) return set_err(h, SWIMSIM_ERR_INVALID, "k_random_members: not available with bounded member maps (view_cap)");
   HIPCHK(h, hipSetDevice(h->device));
   const size_t need = 257 + n_excludes;
   if (need > h->d_sel_cap) {
@@ -1064,6 +1182,7 @@ int swimsim_shard_settle_commit(swimsim_t* h, const uint32_t* counts_in) {
   HIPCHK(h, hipSetDevice(h->device));
   hipLaunchKernelGGL(settle_commit_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, (uint32_t)(h->tick - 1), peer_counts(h, counts_in));
   HIPCHK(h, hipGetLastError());
+  h->settled_alive_tick = ~0ull;                  // the bases just changed: a list read_view cached between phase 3 and now is stale
   h->shard_phase = 0;
   return SWIMSIM_OK;
 }
@@ -1146,6 +1265,7 @@ int swimsim_kernel_timing(swimsim_t* h, double* out, size_t n) {
 int swimsim_set_view(swimsim_t* h, uint32_t observer, uint32_t subject, uint8_t state, uint32_t incarnation) {
   if (!h || observer - h->d.lo >= h->d.N || subject >= h->d.NT || state > 2 || incarnation > INC_MAX || observer == subject)
     return SWIMSIM_ERR_INVALID;
+  if (h->d.C) return set_err(h, SWIMSIM_ERR_INVALID, "set_view: not available with bounded member maps (view_cap)");
   HIPCHK(h, hipSetDevice(h->device));
   hipLaunchKernelGGL(set_view_kernel, dim3(1), dim3(64), 0, h->stream, h->d, (uint32_t)h->tick, observer, subject,
                      (incarnation << 2) | state);

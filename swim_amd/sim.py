@@ -44,6 +44,7 @@ def _to_c_config(sc: SimConfig, shard_index: int = 0, n_shards: int = 1) -> _abi
     c.target_scheme = sc.targetScheme
     c.join_pull = sc.joinPull
     c.pull_ticks = sc.pullTicks
+    c.view_cap = sc.viewCap
     return c
 
 

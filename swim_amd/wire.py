@@ -80,6 +80,32 @@ def decode(data: bytes) -> Tuple[Optional[str], Optional[List[Message]]]:
     return (None, [_from_c(out[k]) for k in range(n.value)])
 
 
+def encode_bare(m: Message) -> bytes:
+    """`encode msg` of a bare Message (instance Serialize Message, src/Types.hs:151-155): what the reference's send
+    side literally puts on the wire (src/Core.hs:133-134; D11) -- the msgpack body, no type byte."""
+    lib = _lib()
+    w = _to_c(m)
+    n = C.c_size_t()
+    buf = (C.c_uint8 * MAX_DATAGRAM)()
+    rc = lib.wire_encode_bare(C.byref(w), buf, MAX_DATAGRAM, C.byref(n))
+    if rc != _abi.OK:
+        raise ValueError((lib.wire_last_error() or b"").decode())
+    return bytes(buf[: n.value])
+
+
+def decode_any(data: bytes) -> Tuple[Optional[str], Optional[List[Message]], bool]:
+    """An Envelope or a bare Message (the literal sender's datagram): (error, None, bare) or (None, messages, bare)."""
+    lib = _lib()
+    buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(data) if data else (C.c_uint8 * 1)()
+    out = (_abi.WireMsg * MAX_MSGS)()
+    n = C.c_size_t()
+    bare = C.c_int()
+    rc = lib.wire_decode_any(buf, len(data), out, MAX_MSGS, C.byref(n), C.byref(bare))
+    if rc != _abi.OK:
+        return ((lib.wire_last_error() or b"").decode() or "error %d" % rc, None, bool(bare.value))
+    return (None, [_from_c(out[k]) for k in range(n.value)], bool(bare.value))
+
+
 def rumor_message(subject: int, incarnation: int, state: int, sender: int) -> Message:
     """A piggybacked rumour as the reference's Message (state: 0 Alive, 1 Suspect, 2 Dead).  The simulator has
     no addresses: Alive.addr is the member id, the port the reference's 4000; Dead.deadFrom names the sender."""

@@ -18,7 +18,6 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
-#include <ucontext.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -93,9 +92,23 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t
 // ---- the fibre scheduler -------------------------------------------------------------------------
 namespace hostemu {
 constexpr size_t STACK_BYTES = 512 * 1024;
-struct Fibre { ucontext_t ctx; void* stack; int state; };   // 0 runnable, 1 at block barrier, 2 done, 3 in a wave exchange
+// A fibre switch = the callee-saved registers and the stack pointer (x86-64 System V): ~10 ns.  glibc's swapcontext also
+// saves and restores the signal mask -- a system call per switch, and a wave intrinsic is two switches per lane: the
+// emulated suites spent most of their time there.
+#if !defined(__x86_64__)
+#error "tests/hostemu: the fibre switch is written for x86-64"
+#endif
+__attribute__((naked, noinline)) static void fibre_switch(void** /*save_sp: rdi*/, void* /*load_sp: rsi*/) {
+  asm volatile(
+      "pushq %rbp\n\tpushq %rbx\n\tpushq %r12\n\tpushq %r13\n\tpushq %r14\n\tpushq %r15\n\t"
+      "movq %rsp, (%rdi)\n\t"
+      "movq %rsi, %rsp\n\t"
+      "popq %r15\n\tpopq %r14\n\tpopq %r13\n\tpopq %r12\n\tpopq %rbx\n\tpopq %rbp\n\t"
+      "ret\n\t");
+}
+struct Fibre { void* sp; void* stack; int state; };   // 0 runnable, 1 at block barrier, 2 done, 3 in a wave exchange
 struct Sched {
-  ucontext_t main_ctx;
+  void* main_sp = nullptr;
   std::vector<Fibre> f;
   uint32_t nthreads = 0, cur = 0;
   void (*entry)(void*) = nullptr; void* arg = nullptr;
@@ -114,19 +127,20 @@ inline void barrier() {
   Sched& s = sched();
   Fibre& me = s.f[s.cur];
   me.state = 1;
-  swapcontext(&me.ctx, &s.main_ctx);
+  fibre_switch(&me.sp, s.main_sp);
 }
 inline void wave_yield() {
   Sched& s = sched();
   Fibre& me = s.f[s.cur];
   me.state = 3;
-  swapcontext(&me.ctx, &s.main_ctx);
+  fibre_switch(&me.sp, s.main_sp);
 }
 inline void trampoline() {
   Sched& s = sched();
   s.entry(s.arg);
   s.f[s.cur].state = 2;
-  swapcontext(&s.f[s.cur].ctx, &s.main_ctx);
+  fibre_switch(&s.f[s.cur].sp, s.main_sp);
+  abort();                                                 // a finished fibre is never resumed
 }
 // run one block of nthreads fibres to completion
 inline void run_block(uint32_t nthreads, void (*entry)(void*), void* arg) {
@@ -139,11 +153,14 @@ inline void run_block(uint32_t nthreads, void (*entry)(void*), void* arg) {
   s.nthreads = nthreads; s.entry = entry; s.arg = arg;
   memset(s.par, 0, sizeof s.par);
   for (uint32_t k = 0; k < nthreads; ++k) {
-    getcontext(&s.f[k].ctx);
-    s.f[k].ctx.uc_stack.ss_sp = s.f[k].stack;
-    s.f[k].ctx.uc_stack.ss_size = STACK_BYTES;
-    s.f[k].ctx.uc_link = nullptr;
-    makecontext(&s.f[k].ctx, (void (*)())trampoline, 0);
+    // a fresh stack as fibre_switch expects to find a suspended one: six register slots, then the address it "returns"
+    // to (the trampoline, entered with the stack pointer 8 modulo 16 as after a call), then a null return address
+    uintptr_t top = ((uintptr_t)s.f[k].stack + STACK_BYTES) & ~(uintptr_t)15;
+    void** sp = reinterpret_cast<void**>(top);
+    *--sp = nullptr;
+    *--sp = reinterpret_cast<void*>(&trampoline);
+    for (int r = 0; r < 6; ++r) *--sp = nullptr;
+    s.f[k].sp = sp;
     s.f[k].state = 0;
   }
   for (;;) {
@@ -152,7 +169,7 @@ inline void run_block(uint32_t nthreads, void (*entry)(void*), void* arg) {
       if (s.f[k].state != 0) continue;
       s.cur = k;
       tidx() = dim3(k, 0, 0);
-      swapcontext(&s.main_ctx, &s.f[k].ctx);
+      fibre_switch(&s.main_sp, s.f[k].sp);
     }
     uint32_t in_wave = 0;
     for (uint32_t k = 0; k < nthreads; ++k) if (s.f[k].state == 3) { s.f[k].state = 0; in_wave++; live++; }

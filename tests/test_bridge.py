@@ -4,6 +4,7 @@ IndirectPing -> relayed Ack, gossip messages that ride along.  The simulated pop
 product kernels here (no GPU in this container); tests/test_hip_parity.py has the `-m gpu` twin.  "Real-node demo
 unverified": the reference itself cannot be built (no GHC); the codec's interoperability contract is tests/test_wire_codec.py."""
 import socket
+import struct
 
 import pytest
 
@@ -16,6 +17,11 @@ from swim_amd.types import Ack, Alive, Dead, IndirectPing, Ping, Suspect
 def emu_abi():
     from tests import hostemu_binding
     return hostemu_binding.load()
+
+
+# IndirectPing.target as the reference fills it: the HostAddress out of a SockAddrInet (src/Core.hs:264-266) -- the word whose
+# bytes in memory are in network order (0x0100007F on x86), not the host-order number 0x7F000001 (include/swimwire.h)
+LOCALHOST = struct.unpack("=I", socket.inet_aton("127.0.0.1"))[0]
 
 
 class Peer:
@@ -69,14 +75,14 @@ def bridge_scenario(abi):
         peer.send(Ping(seqNo=44, node="m500")); br.poll(500)             # not a member
         assert peer.silent()
         # IndirectPing about a simulated member: the proxy relays the answer (D9) iff the target is up
-        peer.send(IndirectPing(seqNo=50, target=0x7F000001, port=4001, node="m7")); br.poll(500)
+        peer.send(IndirectPing(seqNo=50, target=LOCALHOST, port=4001, node="m7")); br.poll(500)
         assert peer.recv() == [Ack(seqNo=50, payload=[])]
-        peer.send(IndirectPing(seqNo=51, target=0x7F000001, port=4001, node="m9")); br.poll(500)
+        peer.send(IndirectPing(seqNo=51, target=LOCALHOST, port=4001, node="m9")); br.poll(500)
         assert peer.silent()
         # IndirectPing about a node OUTSIDE the simulation: Ping to (target, port) (src/Core.hs:105-108), its Ack relayed
         other = Peer(br.port)
         oport = other.sock.getsockname()[1]
-        peer.send(IndirectPing(seqNo=60, target=0x7F000001, port=oport, node="other")); br.poll(500)
+        peer.send(IndirectPing(seqNo=60, target=LOCALHOST, port=oport, node="other")); br.poll(500)
         assert other.recv() == [Ping(seqNo=60, node="other")]
         other.send(Ack(seqNo=60, payload=[])); br.poll(500)
         assert peer.recv() == [Ack(seqNo=60, payload=[])]
@@ -86,9 +92,24 @@ def bridge_scenario(abi):
         br.poll(500); peer.recv()
         # an undecodable datagram is dropped, nothing dies (D16)
         peer.sock.sendto(b"\x09garbage", peer.to); br.poll(500)
+        # ... and so is what a datagram merely SAYS wrong: an IndirectPing whose (target, port) no socket can send to
+        # (0.0.0.0:0) is counted, the poll goes on (it used to come back as an OSError and lose the rest of the datagram)
+        peer.send(IndirectPing(seqNo=61, target=0, port=0, node="nobody"), Ping(seqNo=62, node="m3"))
+        assert br.poll(500) == 1
+        assert peer.recv()[0] == Ack(seqNo=62, payload=[])
+        # the literal reference sender does not frame (D11): a bare Message is a decode error ...
+        peer.sock.sendto(wire.encode_bare(Ping(seqNo=63, node="m3")), peer.to); br.poll(500)
+        assert peer.silent()
+        # ... until the bridge is told to accept it; the answer is an Envelope (what that node's receiver decodes)
+        br.acceptBare(True)
+        peer.sock.sendto(wire.encode_bare(Ping(seqNo=64, node="m3")), peer.to); br.poll(500)
+        assert peer.recv()[0] == Ack(seqNo=64, payload=[])
+        peer.sock.sendto(wire.encode_bare(Suspect(incarnation=0, node="m35")), peer.to); br.poll(500)   # no Ping in it: member 36 hears it
+        br.acceptBare(False)
         st = br.stats()
-        assert st["decode_errors"] == 1 and st["rumors_injected"] == 2 and st["rumors_foreign"] == 1
-        assert st["pings"] == 3 and st["pings_unanswered"] == 3 and st["relayed_acks"] == 2
+        assert st["decode_errors"] == 2 and st["rumors_injected"] == 3 and st["rumors_foreign"] == 1
+        assert st["pings"] == 5 and st["pings_unanswered"] == 3 and st["relayed_acks"] == 2
+        assert st["sends_failed"] == 1 and st["bare_in"] == 2 and st["rumors_dropped"] == 0
         sim.step(1)
         view = {m.memberName: (int(m.memberAlive), m.memberIncarnation) for m in sim.members(20)}
         assert view.get("m33") == (1, 0) and view.get("m34") == (2, 0)           # m20 took the outside world's word
@@ -101,6 +122,35 @@ def bridge_scenario(abi):
 
 def test_bridge_answers_the_wire_protocol_for_the_simulated_members(emu_abi):
     bridge_scenario(emu_abi)
+
+
+def test_a_flood_of_gossip_is_dropped_and_counted_not_an_error(emu_abi):
+    """More Suspect / Alive / Dead messages than the simulation takes before its next tick (4 096): the excess is counted
+    and dropped, swimbridge_poll does not fail (it returned SWIMSIM_ERR_BUFFER and lost the rest of the datagram)."""
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=300, seed=2, suspicionTicks=6)
+    sim = Sim.create(emu_abi, sc)
+    with Bridge(sim) as br:
+        peer = Peer(br.port)
+        for k in range(17):                                # (one at a time: the socket's receive buffer is small)
+            peer.send(Ping(seqNo=k, node="m1"), *[Suspect(incarnation=0, node="m%d" % (2 + (k * 254 + j) % 290)) for j in range(254)])
+            assert br.poll(500) == 1
+            peer.recv()
+        st = br.stats()
+        assert st["rumors_injected"] == 4096 and st["rumors_dropped"] == 17 * 254 - 4096
+        sim.step(1)                                        # the queue is taken: the next datagram's gossip goes in again
+        peer.send(Ping(seqNo=99, node="m1"), Suspect(incarnation=0, node="m7"))
+        br.poll(500)
+        assert br.stats()["rumors_injected"] == 4097
+        peer.close()
+    sim.close()
+
+
+def test_the_bridge_wants_an_unsharded_handle(emu_abi):
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=256, seed=2)
+    sim = Sim.create(emu_abi, sc, shard_index=0, n_shards=2)
+    with pytest.raises(OSError):
+        Bridge(sim)
+    sim.close()
 
 
 def test_injected_rumours_match_the_oracle(oracle_abi, emu_abi):
@@ -122,6 +172,31 @@ def test_injected_rumours_match_the_oracle(oracle_abi, emu_abi):
                 s.injectRumor(9, 40, 2, 1)
         compare_state(a, b, (0, 5, 6, 7, 41, 599), (5, 6, 7, 40), True, where="block %d:" % k)
     assert b.counters()["refutes"] >= 2
+
+
+def test_a_message_for_a_member_that_goes_down_and_comes_up_in_one_tick_is_lost(oracle_abi, emu_abi):
+    """include/swimsim.h: an injected rumour reaches a member that is up when the tick starts and STAYS up through the tick's
+    scheduled changes.  Down and up again in one tick is a new process: the oracle used to deliver (it only looked at `up`
+    before and after the tick's changes), the kernels drop the inbox with the process."""
+    from tests.helpers import compare_state
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=300, seed=11, eventMask=0x1F, suspicionTicks=6)
+    a, b = Sim.create(oracle_abi, sc), Sim.create(emu_abi, sc)
+    for s in (a, b):
+        s.scheduleFault(4, 20, False); s.scheduleFault(4, 20, True)          # m20: down and up again in tick 4
+        s.scheduleFault(4, 21, False); s.scheduleFault(6, 21, True)
+    a.step(4); b.step(4)
+    for s in (a, b):
+        s.injectRumor(20, 50, 2, 0)                        # lost with the old process
+        s.injectRumor(22, 51, 2, 0)                        # control: delivered
+    a.step(1); b.step(1)
+    for s in (a, b):
+        view = {m.memberName: int(m.memberAlive) for m in s.members(20)}
+        assert "m50" not in view
+        assert {m.memberName: int(m.memberAlive) for m in s.members(22)}.get("m51") == 2
+    for k in range(4):
+        a.step(3); b.step(3)
+        compare_state(a, b, (20, 21, 22, 50, 51), (20, 50, 51), True, where="block %d:" % k)
+    a.close(); b.close()
 
 
 @pytest.mark.parametrize("trial", [0, 3])
