@@ -136,16 +136,16 @@ typedef struct swimsim_config {
  *   if more than C entries exist now, the C with the largest (lastChange, rank) stay, rank = mix32(subject ^ mix32(tk ^ i))
  *               with the tick key tk of DESIGN.md 2.2 -- a keyed permutation of the subject ids, new for every member
  *               and tick, so that no two entries tie and nobody is forgotten first by everybody; the others are EVICTED --
- *               they return to the default (their deadlines with them), counter SWIMSIM_CTR_EVICTED.  An entry that changed or
- *               appeared in this very tick and is evicted at once has no effect at all: no event, no counter, not gossiped on;
+ *               they return to the default (their deadlines with them); counter SWIMSIM_CTR_EVICTED counts the entries of the
+ *               START of the tick that leave.  An entry that appeared in this very tick and is evicted at once has no effect
+ *               at all (no event, no counter, not gossiped on), and neither has the change of an older entry that leaves;
  *   every entry that changed and stayed counts as a view change (counters, event -- cause of the winning proposal, a due
  *               deadline before a probe before gossip when they propose the same --, digest) and becomes a rumour in the
  *               member's queue with a full retransmission budget, as on an unbounded handle.
  * Everything else of the tick (target selection among the members the map holds Alive -- evicted ones are Alive again --,
  * probes, proxies, loss, queues, refutation, joins) is the unbounded tick's.  Not combinable with gc_ticks, join_pull,
  * pull_ticks, the robust target scheme, sharding, swimsim_inject_rumor, swimsim_set_view and swimsim_k_random_members
- * (SWIMSIM_ERR_INVALID).  A member that hears of more than ~750 subjects it does not know in ONE tick is beyond the device's
- * per-tick working set: SWIMSIM_ERR_CAPACITY (loud, the handle is poisoned), never a silent drop. */
+ * (SWIMSIM_ERR_INVALID). */
 #define SWIMSIM_VIEW_CAP_MIN 4u
 #define SWIMSIM_VIEW_CAP_MAX 256u
 
@@ -266,7 +266,8 @@ enum {
                                      "up" whatever its incarnation -- an observer burying the old
                                      incarnation of a member that has come back counts          */
   SWIMSIM_CTR_SETTLED = 15,       /* subjects settled (view columns reclaimed; gc_ticks) */
-  SWIMSIM_CTR_EVICTED = 16,       /* member-map entries evicted (view_cap): returned to the default */
+  SWIMSIM_CTR_EVICTED = 16,       /* member-map entries evicted (view_cap): in the map when the tick started, back at the
+                                     default when it ended */
   SWIMSIM_CTR_COUNT = 17
 };
 

@@ -687,7 +687,7 @@ static int prop_cmp(const void* a, const void* b) {
   if (x->key != y->key) return x->key > y->key ? -1 : 1;          /* the largest key first ... */
   return x->prio > y->prio ? -1 : x->prio < y->prio;              /* ... stated by the earliest phase */
 }
-typedef struct { osent_t e; uint32_t k0, rank; uint8_t changed, cause, due; } ocand_t;
+typedef struct { osent_t e; uint32_t k0, rank; uint8_t changed, cause, due, was; } ocand_t;
 /* who stays when the map is over capacity: the most recent lastChange first; among entries of one tick the order is a
  * keyed permutation of the subject ids -- rank = mix32(subject ^ H(t, i)): mix32 is a bijection, so no two subjects tie,
  * and no member is forgotten first by everybody all the time (an order by subject id would be that) */
@@ -741,7 +741,7 @@ static void end_of_tick_sparse(octx_t* c, uint32_t i, const opend_t* pend, uint3
     const uint32_t sj = st < sp ? st : sp;
     ocand_t cd; memset(&cd, 0, sizeof cd);
     cd.e.subject = sj;
-    if (st == sj) { cd.e = tb->v[xt]; cd.k0 = cd.e.key; cd.due = key_state(cd.e.key) == SWIMSIM_SUSPECT && cd.e.since1 - 1 + o->S <= t; xt++; }
+    if (st == sj) { cd.e = tb->v[xt]; cd.k0 = cd.e.key; cd.was = 1; cd.due = key_state(cd.e.key) == SWIMSIM_SUSPECT && cd.e.since1 - 1 + o->S <= t; xt++; }
     else { cd.e.key = o->base[sj]; cd.k0 = cd.e.key; cd.e.since1 = 0; }
     if (sp == sj) {
       const oprop_t* best = &props[xp];                /* sorted: the first of its subject is the winner */
@@ -758,7 +758,7 @@ static void end_of_tick_sparse(octx_t* c, uint32_t i, const opend_t* pend, uint3
     const uint32_t mk = mix32(o->tk ^ i);
     for (size_t x = 0; x < nc; x++) cand[x].rank = mix32(cand[x].e.subject ^ mk);
     qsort(cand, nc, sizeof *cand, evict_cmp);
-    c->counters[SWIMSIM_CTR_EVICTED] += nc - o->C;
+    for (size_t x = o->C; x < nc; x++) c->counters[SWIMSIM_CTR_EVICTED] += cand[x].was;   /* entries of the start of the tick that leave */
     nc = o->C;
     qsort(cand, nc, sizeof *cand, cand_subject_cmp);
   }

@@ -8,8 +8,9 @@ count -- next to ms/tick.  One JSON line per case.
   false-positive Dead: the counter false_deads (suspicion timers that fired about a member that was up, per observer --
       whatever the incarnation: under churn this includes observers burying the old incarnation of a member that is back).
 
-usage (GPU box): config5.py [members ...]      default: 16384 32768  (65 536 at 30 % loss needs more view rows than a
-handle's 16-bit row ids allow: DESIGN.md section 11).   ORACLE=1: the same run on the CPU oracle (all host threads), numbers
+usage (GPU box): config5.py [members ...]      default: 16384 32768  (a dense view stops there: 65 536 members at 30 % loss
+need more view rows than a handle has).  CAP=<C>: bounded member maps (view_cap = C; include/swimsim.h) -- what runs config 5 at
+its per-GPU size: `CAP=64 config5.py 2097152`.   ORACLE=1: the same run on the CPU oracle (all host threads), numbers
 compared;  LOSS=<ppm>, TICKS=<n>, T0=<tick>, ROWS=<max subjects>, CHURN=<per-mille list> override the defaults."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,8 +23,9 @@ NTRACK = 8
 
 
 def run(abi, n, per_mille, threads=0):
-    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=1, lossPpm=LOSS, maxSubjects=int(os.environ.get("ROWS", min(n, 65000))), eventMask=0,
-                   gcTicks=_abi.GC_AUTO if per_mille else 0)
+    cap = int(os.environ.get("CAP", 0))
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=1, lossPpm=LOSS, maxSubjects=int(os.environ.get("ROWS", min(n, 60000))), eventMask=0x10 if cap else 0,
+                   gcTicks=_abi.GC_AUTO if (per_mille and not cap) else 0, viewCap=cap)
     s = Sim.create(abi, sc)
     if threads:                                      # the oracle only (scales to ~32 threads)
         from tests import oracle_binding
@@ -36,6 +38,7 @@ def run(abi, n, per_mille, threads=0):
     for m in tracked:
         s.crash(m, T0)
     t0 = time.time(); s.step(T0); warm = time.time() - t0
+    c_warm = s.counters()
     to_all = {m: None for m in tracked}
     cover = []
     for _ in range(T - T0):
@@ -49,7 +52,9 @@ def run(abi, n, per_mille, threads=0):
         cover.append(row)
     c = s.counters()
     hold_end, up_end = s.coverage(tracked[0], 2, 0)
-    out = {"members": n, "loss_ppm": LOSS, "churn_percent_per_100_ticks": per_mille / 10.0, "ticks": T, "crash_rejoin_pairs": len(churn),
+    out = {"members": n, "loss_ppm": LOSS, "view_cap": cap, "churn_percent_per_100_ticks": per_mille / 10.0, "ticks": T, "crash_rejoin_pairs": len(churn),
+           "evicted_per_member_tick": round(c.get("evicted", 0) / float(n * T), 3), "changes_per_member_tick": round(c["changes"] / float(n * T), 2),
+           "payloads_per_member_tick": round(c["payloads"] / float(n * T), 2),
            "ms_per_tick_first_%d_ticks" % T0: round(warm / T0 * 1e3, 3),
            "false_positive_dead": c["false_deads"], "false_positive_dead_per_member_tick": round(c["false_deads"] / float(n * T), 4),
            "false_suspects": c["false_suspects"], "timers_fired": c["timers_fired"], "refutes": c["refutes"],

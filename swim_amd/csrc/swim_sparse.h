@@ -289,20 +289,23 @@ __device__ inline uint32_t sp_find(const SpTable<CPHYS>& T, uint32_t subject) {
 // The state rule on one proposal: entry := max(entry, (incarnation, state)) -- suspectOrDeadNode' (src/Core.hs:142-187) and
 // the unwritten aliveNode (:197-218, D6) as the commutative merge (H3, D13), here literally one LDS atomicMax.  A subject
 // without an entry gets one if the proposal beats the default (key 0 = Alive@0); one that does not leaves nothing.
+// `floor_rank` (0 in all but the rarest ticks): a subject WITHOUT an entry whose rank is below it is not taken in -- see the
+// retry loop of sp_merge_kernel.
 template <uint32_t CPHYS>
-__device__ inline void sp_propose(SpTable<CPHYS>& T, uint32_t subject, uint32_t key, uint32_t prio) {
+__device__ inline void sp_propose(SpTable<CPHYS>& T, uint32_t subject, uint32_t key, uint32_t prio, uint32_t mk, uint32_t floor_rank) {
   uint32_t h = sp_hash<CPHYS>(subject);
   for (uint32_t probe = 0; probe < CPHYS; ++probe) {
     uint32_t cur = T.hs[h];
     if (cur == NONE32) {
       if (key == 0u) return;
+      if (floor_rank && mix32(subject ^ mk) < floor_rank) return;
       cur = atomicCAS(&T.hs[h], NONE32, subject);    // claimed by whoever comes first; another lane may hold the same rumour
       if (cur == NONE32) cur = subject;
     }
     if (cur == subject) { atomicMax(&T.hk[h], (key << 2) | prio); return; }
     h = (h + 1u) & (CPHYS - 1u);
   }
-  T.full = 1u;                                        // more subjects in one tick than the working set holds: loud (ERRF_SUBJECTS)
+  T.full = 1u;                                        // more subjects in one tick than the working set holds: the caller retries with a floor
 }
 
 // WAVES members per workgroup: the tables of a workgroup must fit its LDS allocation (CPHYS = 1024: 18 KB per wave)
@@ -333,6 +336,15 @@ __global__ __launch_bounds__(64 * WAVES) void sp_merge_kernel(DevState s, uint32
     const uint32_t cnt = s.inbox_cnt[li];
     const uint32_t n0 = s.sp_tab_n[li];
     if (lane == 0) { T.ncl = 0; T.refute1 = 0; T.pos = 0; T.smin = NONE32; T.smax = 0; }
+    // The working set of a tick -- the map and every subject the member hears of for the first time -- has CPHYS >= 4 C
+    // slots.  When a tick brings more (a member with hundreds of sources: large P and K under heavy loss, a degraded
+    // cluster), subjects without an entry are taken in only above a rank FLOOR: they would be the first to go anyway -- an
+    // entry that appears in this tick stays only if its rank is among the C largest of the tick's changes -- PROVIDED at
+    // least C of the tick's changes lie at or above the floor, which is checked; the floor is found by bisection (every
+    // step a full pass over the member's inputs: the rare path buys exactness, not speed).
+    uint32_t floor_rank = 0, floor_lo = 0, floor_hi = 0xFFFFFFFFu;
+    uint32_t nvalid = 0, total = 0;
+    for (;;) {
     // ---- the map into the hash table; suspicion deadlines that are due (the FIXME at src/Core.hs:141; D4)
     {
       const uint32_t* rs = sp_row(s, li, 0); const uint32_t* rk = sp_row(s, li, 1); const uint32_t* rt = sp_row(s, li, 2);
@@ -355,7 +367,7 @@ __global__ __launch_bounds__(64 * WAVES) void sp_merge_kernel(DevState s, uint32
       const uint32_t j = s.fail[(size_t)li * s.P + lane];
       const uint32_t sl = sp_find<CPHYS>(T, j);
       const uint32_t k0 = sl == NONE32 ? 0u : (T.h0[sl] & 0xFFFFFFu);
-      sp_propose<CPHYS>(T, j, (k0 & ~3u) | ST_SUSPECT, SP_PRIO_PROBE);
+      sp_propose<CPHYS>(T, j, (k0 & ~3u) | ST_SUSPECT, SP_PRIO_PROBE, mk, floor_rank);
     }
     // ---- the rumours received this tick (src/Core.hs:110-117): 8 sources x 8 queue entries per round of loads
     {
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(64 * WAVES) void sp_merge_kernel(DevState s, uint32
           if ((key & 3u) != ST_ALIVE && (key >> 2) >= hot0.x) atomicMax(&T.refute1, (key >> 2) + 1u);
           return;
         }
-        sp_propose<CPHYS>(T, e.x, key, SP_PRIO_GOSSIP);
+        sp_propose<CPHYS>(T, e.x, key, SP_PRIO_GOSSIP, mk, floor_rank);
       };
       for (uint32_t x0 = 0; x0 < nsrc; x0 += 8u) {
         const uint32_t x = x0 + (lane >> 3);
@@ -394,18 +406,29 @@ __global__ __launch_bounds__(64 * WAVES) void sp_merge_kernel(DevState s, uint32
     }
     lds_wave_sync();
     // ---- what changed; how many entries there are now
-    uint32_t nvalid = 0, nchanged = 0;
+    nvalid = 0;
+    uint32_t nabove = 0;                               // the tick's changes at or above the floor
     for (uint32_t k = 0; k < SPL; ++k) {
       const uint32_t x = lane + 64u * k;
       if (T.hs[x] == NONE32) continue;
       nvalid++;
       const bool changed = (T.hk[x] >> 2) > (T.h0[x] & 0xFFFFFFu);
-      nchanged += changed ? 1u : 0u;
+      nabove += (changed && (!floor_rank || mix32(T.hs[x] ^ mk) >= floor_rank)) ? 1u : 0u;
       const uint32_t since = changed ? t + 1u : T.hsince[x];
       atomicMin(&T.smin, since); atomicMax(&T.smax, since);
     }
-    const uint32_t total = wave_sum(nvalid);
-    if (T.full) atomicOr(&s.g[G_ERR], (uint32_t)ERRF_SUBJECTS);
+    total = wave_sum(nvalid);
+    const bool full = T.full != 0u;
+    if (!full && (!floor_rank || wave_sum(nabove) >= s.C)) break;     // wave-uniform
+    // the working set overflowed (raise the floor) or the floor cut into the C that stay (lower it): once more
+    if (full) floor_lo = floor_rank; else floor_hi = floor_rank;
+    floor_rank = floor_lo + (floor_hi - floor_lo) / 2u;
+    if (floor_rank == floor_lo) floor_rank = floor_lo + 1u;
+    lds_wave_sync();
+    for (uint32_t k = 0; k < SPL; ++k) { const uint32_t x = lane + 64u * k; T.hs[x] = NONE32; T.hk[x] = 0; T.h0[x] = 0; T.hsince[x] = 0; }
+    if (lane == 0) { T.full = 0; T.smin = NONE32; T.smax = 0; }
+    lds_wave_sync();
+    }
     // ---- the capacity: the C entries with the largest (lastChange, rank) stay; rank = mix32(subject ^ mk) is a keyed
     // permutation of the ids (no ties).  Radix select of the C-th largest 64-bit priority, a byte per pass, in LDS.
     unsigned long long thr = 0ull;                   // stay iff priority >= thr
@@ -466,12 +489,11 @@ __global__ __launch_bounds__(64 * WAVES) void sp_merge_kernel(DevState s, uint32
         const unsigned long long p = ((unsigned long long)(changed ? t + 1u : T.hsince[x]) << 32) | mix32(T.hs[x] ^ mk);
         kept = p >= thr;
       }
-      if (!kept) continue;
+      if (!kept) { c_evicted += (T.h0[x] & 0xFFFFFFu) ? 1u : 0u; continue; }   // counted: an entry of the start of the tick that leaves
       nkept++;
       T.h0[x] |= SP_KEPT;
       if (changed) T.cl[atomicAdd(&T.ncl, 1u)] = x;
     }
-    c_evicted += total > s.C ? (nvalid - nkept) : 0u;
     lds_wave_sync();
     const uint32_t ncl = T.ncl;
     // ---- account for what changed and stayed (`saveMember m'`, src/Core.hs:169-179): digest, counters, events

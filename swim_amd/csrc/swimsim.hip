@@ -285,6 +285,10 @@ void launch_sparse_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev) {
   else launch_sparse_probe<4>(h, t, tk);
   if (ev) (void)hipEventRecord(ev[1], h->stream);
   // the per-tick working set of a member: its map + the subjects it hears of for the first time (4 x the capacity, >= 512 slots)
+#ifdef SWIM_SP_PHYS   // test builds: a tiny working set, so that ordinary ticks overflow it and take the rank-floor retries (view_cap <= SWIM_SP_PHYS / 4)
+  if (h->d.C * 4u <= SWIM_SP_PHYS) hipLaunchKernelGGL((sp_merge_kernel<SWIM_SP_PHYS, 4>), dim3(h->d.nblocks), dim3(256), 0, h->stream, h->d, t, tk);
+  else
+#endif
   if (h->d.C <= 128) hipLaunchKernelGGL((sp_merge_kernel<512, 4>), dim3(h->d.nblocks), dim3(256), 0, h->stream, h->d, t, tk);
   else hipLaunchKernelGGL((sp_merge_kernel<1024, 2>), dim3(h->d.nblocks), dim3(128), 0, h->stream, h->d, t, tk);   // (one counter row per workgroup: the same grid)
   if (ev) (void)hipEventRecord(ev[2], h->stream);

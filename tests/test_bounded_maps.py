@@ -1,0 +1,152 @@
+"""Bounded member maps (view_cap = C; include/swimsim.h "Bounded member maps"): every member keeps at most C
+entries that differ from the default, the oldest evicted -- `Map String Member` (src/Types.hs:55) with a capacity, the
+structure that lets BASELINE config 5 (30 % message loss x churn) run at millions of members per GPU.
+
+CPU side of the parity ladder (no GPU in this container): the oracle's set-based end of tick against its own sequential one
+where the capacity does not bind, the semantics of eviction, and the product kernels (swim_sparse.h: one wave per member, the
+map as a hash table in LDS) on the host emulation against the oracle.  tests/test_hip_parity.py has the `-m gpu` twins at
+65 536 and 262 144 members."""
+import dataclasses
+import random
+
+import pytest
+
+from swim_amd import Config, Sim, SimConfig, SwimError, _abi
+from tests.helpers import compare_state
+
+
+@pytest.fixture(scope="module")
+def emu_abi():
+    from tests import hostemu_binding
+    return hostemu_binding.load()
+
+
+def _faults(rng, n, horizon, crashes, rejoin=0.6):
+    out = []
+    for _ in range(crashes):
+        m, t = rng.randrange(n), rng.randrange(1, horizon)
+        out.append((t, m, False))
+        if rng.random() < rejoin:
+            out.append((t + rng.randrange(1, horizon), m, True))
+    return out
+
+
+@pytest.mark.parametrize("trial", range(5))
+def test_a_capacity_that_does_not_bind_is_the_unbounded_tick(oracle_abi, trial):
+    """The bounded tick is stated over sets (largest proposal per subject, then the capacity), the unbounded one applies one
+    proposal after the other: where nothing is evicted the two must agree in every observable -- events with their causes,
+    counters incl. the running event digest, views, queues, first-detection ticks.  Pins the restatement to the rules of
+    src/Core.hs:142-218 as the sequential oracle has them."""
+    rng = random.Random(100 + trial)
+    n = rng.choice([40, 150, 256])
+    sc = SimConfig(cfg=Config(numToGossip=rng.choice([2, 3, 4])), nMembers=n, seed=trial + 1, lossPpm=rng.choice([0, 20000, 100000]),
+                   eventMask=0x1F, suspicionTicks=rng.choice([4, 7]), maxSubjects=n, retransmitMult=rng.choice([1, 2, 3]))
+    a, b = Sim.create(oracle_abi, sc), Sim.create(oracle_abi, dataclasses.replace(sc, viewCap=256))
+    for (t, m, u) in _faults(rng, n, 40, 6):
+        a.scheduleFault(t, m, u); b.scheduleFault(t, m, u)
+    for blk in range(12):
+        a.step(5); b.step(5)
+        compare_state(a, b, (0, 1, n - 1), (0, 1, n - 1), True, where="block %d:" % blk)
+    assert a.firstDetection() == b.firstDetection() and b.counters()["evicted"] == 0
+    a.close(); b.close()
+
+
+def test_eviction_keeps_the_most_recent_entries_and_counts_what_leaves(oracle_abi):
+    """Under 30 % loss every member hears of far more subjects than 8: the map never holds more than C entries, what it holds
+    are the most recent changes (nothing older than what was evicted stays... by lastChange), entries that leave are counted,
+    and an evicted subject is Alive again in that view -- it is probed again."""
+    n, C = 600, 8
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=5, lossPpm=300000, eventMask=0x1F, viewCap=C)
+    s = Sim.create(oracle_abi, sc)
+    s.step(30)
+    c = s.counters()
+    assert c["evicted"] > 0
+    full = 0
+    for o in range(0, n, 7):
+        v = s.members(o)
+        assert len(v) <= C
+        full += len(v) == C
+        assert all(m.memberLastChange >= s.tick - 3 for m in v), v      # ~75 new subjects per tick through 8 entries: nothing grows old
+    assert full > n // 7 // 2
+    # the digest and the counters do not depend on how the members are split over threads
+    from tests import oracle_binding
+    s2 = Sim.create(oracle_abi, sc)
+    oracle_binding.set_threads(s2, 3)
+    s2.step(30)
+    assert s2.digest() == s.digest() and s2.counters() == c
+    s.close(); s2.close()
+
+
+def test_what_cannot_be_combined_with_bounded_maps_is_refused(oracle_abi, emu_abi):
+    base = SimConfig(cfg=Config(numToGossip=3), nMembers=64, viewCap=16)
+    for abi in (oracle_abi, emu_abi):
+        for bad in (dict(viewCap=3), dict(viewCap=257), dict(gcTicks=_abi.GC_AUTO), dict(joinPull=1), dict(pullTicks=5), dict(targetScheme=1)):
+            with pytest.raises(SwimError):
+                Sim.create(abi, dataclasses.replace(base, **bad))
+        s = Sim.create(abi, base)
+        with pytest.raises(SwimError):
+            s.injectRumor(1, 2, 1, 0)
+        with pytest.raises(SwimError):
+            s.setView(1, 2, 1, 0)
+        s.close()
+    with pytest.raises(SwimError):
+        Sim.create(emu_abi, base, shard_index=0, n_shards=2)
+
+
+CASES = [
+    # members, view_cap, loss ppm, P = K, suspicion ticks, retransmit mult, crashes, ticks
+    (64, 8, 0, 3, 5, 0, 3, 40),            # lossless: crashes detected, buried, rejoined; the capacity binds only mildly
+    (200, 16, 100000, 3, 6, 0, 6, 30),     # 10 % loss
+    (300, 64, 300000, 3, 8, 0, 5, 24),     # BASELINE config 5's loss rate; one map entry per lane
+    (150, 4, 300000, 4, 5, 1, 5, 24),      # the smallest capacity: nearly everything is evicted at once
+    (300, 200, 300000, 3, 8, 0, 4, 12),    # four map entries per lane, the 1 024-slot table, timers fire (nothing evicted before)
+    (120, 130, 200000, 5, 4, 2, 6, 12),    # P = K = 5: the 16-wide probe arrays
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "n%d_cap%d_loss%d_k%d" % c[:4])
+def test_kernels_on_the_emulation_match_the_oracle(oracle_abi, emu_abi, case):
+    """swim_sparse.h (host emulation) vs the oracle, every tick: digest, every counter, the event stream record by record,
+    views, queues, coverage, first-detection ticks -- with crashes and rejoins (churn) next to the loss."""
+    n, cap, loss, P, S, rm, crashes, ticks = case
+    rng = random.Random(n * 31 + cap)
+    sc = SimConfig(cfg=Config(numToGossip=P), nMembers=n, seed=n + cap, lossPpm=loss, eventMask=0x1F, suspicionTicks=S, retransmitMult=rm, viewCap=cap)
+    a, b = Sim.create(oracle_abi, sc), Sim.create(emu_abi, sc)
+    for (t, m, u) in _faults(rng, n, ticks // 2, crashes):
+        a.scheduleFault(t, m, u); b.scheduleFault(t, m, u)
+    for _ in range(ticks):
+        a.step(1); b.step(1)
+        compare_state(a, b, (0, 1, n - 1), (0, 1, n - 1), True, where="tick %d:" % a.tick)
+    assert a.firstDetection() == b.firstDetection()
+    assert b.counters()["changes"] > 0
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("case", [(400, 16, 300000, 3, 5, 20), (400, 8, 300000, 6, 5, 12), (100, 4, 0, 3, 5, 20)], ids=lambda c: "n%d_cap%d_k%d" % (c[0], c[1], c[3]))
+def test_a_tick_that_overflows_the_working_set_takes_the_rank_floor(oracle_abi, case):
+    """The per-tick working set of a member (its map + every subject it hears of for the first time) is a 512- / 1 024-slot
+    table in LDS.  A test build with 64 slots makes ordinary lossy ticks overflow it: subjects without an entry are then taken
+    in only above a rank floor found by bisection (swim_sparse.h) -- exact, checked here against the oracle, which has no
+    such table."""
+    from tests import hostemu_binding
+    emu = hostemu_binding.load_variant("spphys64", ["SWIM_SP_PHYS=64"])
+    n, cap, loss, P, S, ticks = case
+    sc = SimConfig(cfg=Config(numToGossip=P), nMembers=n, seed=7 + cap, lossPpm=loss, eventMask=0x1F, suspicionTicks=S, viewCap=cap)
+    a, b = Sim.create(oracle_abi, sc), Sim.create(emu, sc)
+    for s in (a, b):
+        s.scheduleFault(2, 7, False); s.scheduleFault(9, 7, True)
+    for _ in range(ticks):
+        a.step(1); b.step(1)
+        compare_state(a, b, (0, 7, n - 1), (0, 7), True, where="tick %d:" % a.tick)
+    a.close(); b.close()
+
+
+def test_inboxes_smaller_than_the_fan_in_go_through_the_overflow_list(oracle_abi, emu_abi):
+    """inbox_cap = 16 against ~25 deliveries per member-tick: the exact overflow list (one source at a time) carries the rest."""
+    n = 256
+    sc = SimConfig(cfg=Config(numToGossip=4), nMembers=n, seed=3, lossPpm=250000, eventMask=0x1F, suspicionTicks=6, viewCap=32, inboxCap=16)
+    a, b = Sim.create(oracle_abi, sc), Sim.create(emu_abi, sc)
+    for _ in range(10):
+        a.step(1); b.step(1)
+        compare_state(a, b, (0, n - 1), (0,), True, where="tick %d:" % a.tick)
+    a.close(); b.close()

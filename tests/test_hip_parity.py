@@ -608,3 +608,88 @@ def test_periodic_state_pull_on_the_gpu(oracle_abi, hip_abi, T, gc, loss, n):
     _oracle_threads(a)
     run_lockstep(a, b, 120, 6, observers=(0, 11, n - 1, n // 2), members=(0, 11, n - 1), check_events=n <= 4096)
     assert b.counters()["changes"] > 0
+
+
+# ---- bounded member maps (view_cap; swim_sparse.h): BASELINE config 5 at the sizes a dense view cannot reach --------------------
+def _config5_case(n, cap, churn_per_mille, ticks, seed=1):
+    """30 % message loss x `churn_per_mille`/1000 of the members crash-and-rejoin per 100 ticks."""
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=seed, lossPpm=300000, eventMask=0x18, eventCap=1 << 22, viewCap=cap)
+    churn = workloads.hashed_crashes(n, 9, max(1, churn_per_mille * ticks // 100), 1000, 2, ticks - 8) if churn_per_mille else []
+    faults = [(t + 6 + (m % 7), m, True) for (t, m) in churn]
+    tracked = [(3, n // 3), (5, n // 2 + 1)]            # two crashes that stay down: their dissemination is polled
+    return sc, churn + tracked, faults
+
+
+@pytest.mark.parametrize("n,cap,churn", [(65536, 64, 0), (65536, 64, 1), (65536, 256, 10), (262144, 64, 0), (262144, 128, 1), (262144, 64, 10)])
+def test_config5_with_bounded_maps_vs_oracle(oracle_abi, hip_abi, n, cap, churn):
+    """BASELINE config 5 -- 30 % loss x churn {0, 0.1, 1} % per 100 ticks -- at 65 536 and 262 144 members, where every member is
+    somebody's subject all the time: bounded member maps (one wave per member, the map as a hash table in LDS) against the
+    oracle's set-based end of tick.  Digest, every counter, JOIN / REFUTE events record by record, first-detection ticks,
+    sampled views and queues, how far two real crashes have spread."""
+    ticks = 36
+    sc, crashes, faults = _config5_case(n, cap, churn, ticks)
+    a, b = make_pair(oracle_abi, hip_abi, sc, crashes, faults)
+    _oracle_threads(a)
+    run_lockstep(a, b, ticks, 12, observers=(n // 3, n // 2 + 1, 0, n - 1), members=(0, 1, n - 1), check_events=True)
+    c = b.counters()
+    assert c["evicted"] > 0 and c["direct_failed"] > 0.3 * c["pings"] and c["refutes"] > 0
+    if churn:
+        assert c["active_members"] < n * ticks
+
+
+@pytest.mark.parametrize("n,cap,loss,p,S,rm", [(64, 8, 0, 3, 5, 0), (200, 16, 100000, 3, 6, 0), (300, 64, 300000, 3, 8, 0), (150, 4, 300000, 4, 5, 1),
+                                                (300, 200, 300000, 3, 8, 0), (120, 130, 200000, 5, 4, 2), (5000, 32, 300000, 10, 6, 0)])
+def test_bounded_maps_small_cases_every_tick(oracle_abi, hip_abi, n, cap, loss, p, S, rm):
+    """The cases of tests/test_bounded_maps.py on the real thing (lanes run concurrently here: the LDS atomics race for real),
+    every tick, every observable, the full event stream; plus the reference's default numToGossip = 10 at 30 % loss."""
+    import random
+    rng = random.Random(n * 31 + cap)
+    sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=n + cap, lossPpm=loss, eventMask=0x1F, eventCap=1 << 22, suspicionTicks=S,
+                   retransmitMult=rm, viewCap=cap)
+    faults = []
+    for _ in range(6):
+        m, t = rng.randrange(n), rng.randrange(1, 12)
+        faults.append((t, m, False))
+        if rng.random() < 0.6:
+            faults.append((t + rng.randrange(1, 12), m, True))
+    a, b = make_pair(oracle_abi, hip_abi, sc, [], faults)
+    _oracle_threads(a)
+    run_lockstep(a, b, 24 if n <= 300 else 10, 1, observers=(0, 1, n - 1), members=(0, 1, n - 1), check_events=True)
+
+
+def test_bounded_maps_rank_floor_on_the_gpu(oracle_abi):
+    """The gfx950 build whose per-tick working set is 64 slots (-DSWIM_SP_PHYS=64): lossy ticks overflow it and take the
+    rank-floor retries of swim_sparse.h -- exact, oracle-checked, at a size where the lanes' insertions race."""
+    from swim_amd import _lib
+    hip = _lib.load_variant("spphys")
+    n = 30000
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=12, lossPpm=300000, eventMask=0x18, eventCap=1 << 22, suspicionTicks=6, viewCap=16)
+    crashes = workloads.hashed_crashes(n, 5, 1, 100, 2, 12)
+    a, b = make_pair(oracle_abi, hip, sc, crashes, [(t + 5, m, True) for (t, m) in crashes[:100]])
+    _oracle_threads(a)
+    run_lockstep(a, b, 24, 6, observers=(0, 1, n - 1), members=(0, 1, n - 1), check_events=True)
+
+
+def test_bounded_maps_two_million_members_properties(hip_abi):
+    """BASELINE config 5's shard size -- 2 097 152 members on one GPU at 30 % loss -- stepped (no oracle at this size within a
+    test's time): size-independent properties.  No map exceeds its capacity, the probe statistics are the loss model's
+    (P[direct probe fails] = 1 - 0.7^2 = 0.51, P[probe ends in Suspect] = 0.51 x (1 - 0.7^4)^3 = 0.223), two runs give the
+    same digest, and a crash is detected in its first tick by somebody."""
+    n, cap = 1 << 21, 64
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=3, lossPpm=300000, eventMask=0x10, viewCap=cap)
+    digests = []
+    for _ in range(2):
+        s = Sim.create(hip_abi, sc)
+        s.crash(n // 2, 4)
+        s.step(10)
+        c = s.counters()
+        digests.append((s.digest(), tuple(sorted(c.items()))))
+        assert abs(c["direct_failed"] / c["pings"] - 0.51) < 0.002
+        assert abs(c["suspects"] / c["pings"] - 0.51 * (1 - 0.7 ** 4) ** 3) < 0.002
+        assert c["evicted"] > 0
+        for o in (0, 12345, n - 1):
+            assert len(s.members(o)) <= cap
+        fd = s.firstDetection()
+        assert fd[n // 2] == 4
+        s.close()
+    assert digests[0] == digests[1]
