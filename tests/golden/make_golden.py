@@ -22,6 +22,9 @@ SPECS = {
     # the robust (round-robin) target scheme, with loss, a crash and a rejoin
     "robust_n96_k3": {"n": 96, "k": 3, "seed": 11, "loss_ppm": 100000, "suspicion": 7, "ticks": 120, "every": 10, "scheme": 1,
                       "faults": [[4, 10, 0], [9, 50, 0], [60, 10, 1]]},
+    # bounded member maps (view_cap = 8) under 30 % loss: evictions every tick, a crash and a rejoin
+    "bounded_n96_cap8": {"n": 96, "k": 3, "seed": 13, "loss_ppm": 300000, "suspicion": 6, "ticks": 60, "every": 5, "view_cap": 8,
+                         "faults": [[4, 10, 0], [9, 50, 0], [30, 10, 1]]},
 }
 
 if __name__ == "__main__":
