@@ -87,6 +87,12 @@ __device__ inline unsigned wave_max(unsigned x) {            // lane 0 holds the
   return x;
 }
 
+// the maximum over the 64 lanes of a wave, in every lane (all lanes executing)
+__device__ inline unsigned wave_max_all(unsigned x) {
+  for (int o = 32; o > 0; o >>= 1) { const unsigned y = __shfl_down(x, o, 64); x = y > x ? y : x; }
+  return (unsigned)__builtin_amdgcn_readlane((int)x, 0);
+}
+
 __device__ inline void ctr_flush(const DevState& s, BlockCounters* sh, uint32_t row) {
   lds_barrier();
   if (threadIdx.x < C_COUNT) {

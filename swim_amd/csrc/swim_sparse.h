@@ -23,7 +23,6 @@ namespace swim {
 
 constexpr uint32_t SP_WAVES = BLOCK / 64;      // members a workgroup steps at a time
 constexpr uint32_t SP_PRIO_TIMER = 2u, SP_PRIO_PROBE = 1u, SP_PRIO_GOSSIP = 0u;   // who states a key first (phase order)
-constexpr uint32_t SP_DUE = 1u << 31;          // h0 bit: the entry's suspicion deadline is due this tick
 constexpr uint32_t SP_KEPT = 1u << 30;         // h0 bit (after the selection): the entry stays in the map
 
 // ---- layout helpers ----------------------------------------------------------------------------------
@@ -100,47 +99,49 @@ __device__ inline bool sp_alive(const SpView<MT>& v, uint32_t c) {
   for (int m = 0; m < MT; ++m) hit |= v.subj[m] == c && (v.key[m] & 3u) != ST_ALIVE;
   return __ballot(hit) == 0ull;                      // no entry, or an Alive one: `isAlive` (src/Core.hs:33-34)
 }
-// kRandomMembers (src/Core.hs:69-74) + shuffle (src/Util.hs:37-42): the draws of swim_device.h's select_members, evaluated
-// by the whole wave (out / outb: wave-uniform)
-template <int MT, int MAXN>
+// kRandomMembers (src/Core.hs:69-74) + shuffle (src/Util.hs:37-42): the draws of swim_device.h's select_members.  The hashes
+// of eight picks x eight attempts are evaluated by the LANES (one draw each: a wave in which every lane computes the same
+// hash spends its time in quarter-rate multiplies -- 4 400 of the kernel's 5 000 us at 2 M members, profiles/r04c_*), the
+// sequential part -- a draw is rejected if it is the member itself, excluded, picked before or not Alive in the member's
+// view -- consumes them in order through lane reads.  Pick p ends up in lane p's `mine`; returns the number of picks.
+template <int MT>
 __device__ inline uint32_t sp_select(const DevState& s, const SpView<MT>& v, uint32_t mk, uint32_t i, uint32_t n, uint32_t purpose,
-                                     uint32_t hi_idx, uint32_t excl, uint32_t (&out)[MAXN], uint32_t (&outb)[MAXN]) {
+                                     uint32_t hi_idx, uint32_t excl, uint32_t lane, uint32_t& mine) {
   uint32_t np = 0;
   const uint32_t N = s.NT;
-  for (uint32_t p = 0; p < (uint32_t)MAXN; ++p) {
-    if (p >= n) break;
-    uint32_t c = 0;
-    bool found = false;
-    const uint32_t base = (purpose << 24) | (purpose == P_SELECT ? (p << 8) : ((hi_idx << 16) | (p << 8)));
-    auto eligible = [&](uint32_t cand) -> bool {
-      if (cand == i || cand == excl) return false;   // D15; D7: the target is no proxy of itself
-      bool dup = false;
-#pragma unroll
-      for (int e = 0; e < MAXN; ++e) dup |= ((uint32_t)e < np) && (out[e] == cand);
-      if (dup) return false;
-      return sp_alive<MT>(v, cand);
-    };
-    for (uint32_t a = 0; a < SEL_ATTEMPTS; ++a) {
-      c = __umulhi(hash_mk(mk, base | a, 0), N);
-      if (eligible(c)) { found = true; break; }
-    }
-    if (!found) {                                    // fewer candidates than draws hit: the cyclic scan (test/Spec.hs:117-128)
-      const uint32_t cs = (c + 1 == N) ? 0 : c + 1;
-      for (uint32_t d = 0; d < N; ++d) {
-        c = cs + d; if (c >= N) c -= N;
+  mine = NONE32;
+  auto eligible = [&](uint32_t cand) -> bool {       // wave-uniform argument and result
+    if (cand == i || cand == excl) return false;     // D15; D7: the target is no proxy of itself
+    if (__ballot(lane < np && mine == cand)) return false;
+    return sp_alive<MT>(v, cand);
+  };
+  for (uint32_t p0 = 0; p0 < n; p0 += 8u) {
+    const uint32_t pl = p0 + (lane >> 3);
+    const uint32_t base = (purpose << 24) | (purpose == P_SELECT ? (pl << 8) : ((hi_idx << 16) | (pl << 8)));
+    const uint32_t draw = __umulhi(hash_mk(mk, base | (lane & 7u), 0), N);      // lane = pick * 8 + attempt
+    for (uint32_t p = p0; p < n && p < p0 + 8u; ++p) {
+      uint32_t c = 0;
+      bool found = false;
+      for (uint32_t a = 0; a < SEL_ATTEMPTS; ++a) {
+        c = (uint32_t)__builtin_amdgcn_readlane((int)draw, (int)((p - p0) * 8u + a));
         if (eligible(c)) { found = true; break; }
       }
+      if (!found) {                                  // fewer candidates than draws hit: the cyclic scan (test/Spec.hs:117-128)
+        const uint32_t cs = (c + 1 == N) ? 0 : c + 1;
+        for (uint32_t d = 0; d < N; ++d) {
+          c = cs + d; if (c >= N) c -= N;
+          if (eligible(c)) { found = true; break; }
+        }
+      }
+      if (!found) return np;
+      if (lane == np) mine = c;
+      ++np;
     }
-    if (!found) break;
-    const uint32_t b = s.mb[c];
-#pragma unroll
-    for (int e = 0; e < MAXN; ++e) if ((uint32_t)e == np) { out[e] = c; outb[e] = b; }
-    ++np;
   }
   return np;
 }
 
-template <int MT, int PMAX>
+template <int MT>
 __global__ __launch_bounds__(BLOCK) void sp_probe_kernel(DevState s, uint32_t t, uint32_t tk) {
   const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
   const uint32_t nwaves = gridDim.x * SP_WAVES;
@@ -148,11 +149,11 @@ __global__ __launch_bounds__(BLOCK) void sp_probe_kernel(DevState s, uint32_t t,
   unsigned c_pings = 0, c_active = 0, c_payloads = 0, c_rumors = 0, c_dfail = 0, c_preqs = 0, c_susp = 0, c_fsusp = 0;
   __shared__ BlockCounters sh;
   ctr_init(&sh);
+  SECT_BEGIN(32);
   for (uint32_t li = blockIdx.x * SP_WAVES + wv; li < s.N; li += nwaves) {
     const uint32_t i = li;
+    // one round of loads: the member's byte, its map's length and the map itself (whatever its length: the loads do not wait for it)
     const uint32_t myb = s.mb[i];
-    if (!sb_up(myb)) continue;                       // wave-uniform
-    const uint32_t mk = mix32(tk ^ i), myqn = sb_qn(myb);
     SpView<MT> v;
     {
       const uint32_t n = s.sp_tab_n[li];
@@ -160,10 +161,14 @@ __global__ __launch_bounds__(BLOCK) void sp_probe_kernel(DevState s, uint32_t t,
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const uint32_t e = lane + 64u * (uint32_t)m;
-        v.subj[m] = e < n ? rs[e] : NONE32;
-        v.key[m] = e < n ? rk[e] : 0u;
+        const uint32_t sj = e < s.C ? rs[e] : NONE32, ky = e < s.C ? rk[e] : 0u;
+        v.subj[m] = e < n ? sj : NONE32;
+        v.key[m] = e < n ? ky : 0u;
       }
     }
+    if (!sb_up(myb)) continue;                       // wave-uniform
+    const uint32_t mk = mix32(tk ^ i);
+    SECT(32);                                         // own byte + map
     // the period's deliveries "dst merges src's start-of-tick queue", dealt to the lanes: delivery number x goes to lane
     // x mod 64; a full round is flushed -- every lane appends its delivery to its destination's inbox, the atomics of a round
     // in flight together.  Deliveries to the member itself (Acks, relayed Acks) go to its own list without atomics.
@@ -186,47 +191,62 @@ __global__ __launch_bounds__(BLOCK) void sp_probe_kernel(DevState s, uint32_t t,
       nd++;
       if ((nd & 63u) == 0u) flush();
     };
-    uint32_t picks[PMAX], pinfo[PMAX];
-#pragma unroll
-    for (int p = 0; p < PMAX; ++p) { picks[p] = 0; pinfo[p] = 0; }
-    // ms <- kRandomMembers store (numToGossip cfg) []        (src/Core.hs:239)
-    const uint32_t np = sp_select<MT, PMAX>(s, v, mk, i, s.P, P_SELECT, 0, NONE32, picks, pinfo);
+    // ms <- kRandomMembers store (numToGossip cfg) []        (src/Core.hs:239): target p in lane p, its byte gathered by lane p
+    uint32_t pick = NONE32;
+    const uint32_t np = sp_select<MT>(s, v, mk, i, s.P, P_SELECT, 0, NONE32, lane, pick);
+    const uint32_t pickb = lane < np ? s.mb[pick] : 0u;
     if (lane == 0) { c_pings += np; c_active++; }
-    for (uint32_t p = 0; p < (uint32_t)PMAX; ++p) {
-      if (p >= np) break;
-      uint32_t j = picks[0], bj = pinfo[0];
-#pragma unroll
-      for (int e = 1; e < PMAX; ++e) if (p == (uint32_t)e) { j = picks[e]; bj = pinfo[e]; }
-      // Direct (Ping seq j) is delivered iff not lost and j is up (src/Core.hs:246); j answers Ack (:97-99), which may be lost too
-      const bool ping_ok = sb_up(bj) && !lost(s, tk, P_L_PING, i, j, p);
-      const bool ack_ok = ping_ok && !lost(s, tk, P_L_ACK, j, i, p);
+    SECT(33);                                         // target selection (+ their bytes issued)
+    // Direct (Ping seq j) is delivered iff not lost and j is up (src/Core.hs:246); j answers Ack (:97-99), which may be lost
+    // too: lane 2p evaluates the Ping's loss hash, lane 2p + 1 the Ack's
+    unsigned long long lostm;
+    {
+      const uint32_t p = lane >> 1;
+      const uint32_t j = __shfl(pick, (int)p, 64);
+      const bool l = lane < 2u * np && ((lane & 1u) ? lost(s, tk, P_L_ACK, j, i, p) : lost(s, tk, P_L_PING, i, j, p));
+      lostm = __ballot(l);
+    }
+    const unsigned long long upm = __ballot(lane < np && sb_up(pickb));
+    for (uint32_t p = 0; p < np; ++p) {
+      const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)pick, (int)p), bj = (uint32_t)__builtin_amdgcn_readlane((int)pickb, (int)p);
+      const bool ping_ok = ((upm >> p) & 1ull) && !((lostm >> (2u * p)) & 1ull);
+      const bool ack_ok = ping_ok && !((lostm >> (2u * p + 1u)) & 1ull);
       if (ping_ok) deliver(j, i, myb);
       if (ack_ok) { deliver(i, j, bj); continue; }
-      // unlessAck (D2, D3): K proxies, not the target (src/Core.hs:249; D7)
+      // unlessAck (D2, D3): K proxies, not the target (src/Core.hs:249; D7): proxy k in lane k, its byte gathered by lane k
       if (lane == 0) c_dfail++;
-      uint32_t qs[PMAX], qb[PMAX];
-#pragma unroll
-      for (int k = 0; k < PMAX; ++k) { qs[k] = 0; qb[k] = 0; }
-      const uint32_t nq = sp_select<MT, PMAX>(s, v, mk, i, s.K, P_PROXY, p, j, qs, qb);
+      uint32_t q_ = NONE32;
+      const uint32_t nq = sp_select<MT>(s, v, mk, i, s.K, P_PROXY, p, j, lane, q_);
+      const uint32_t qb_ = lane < nq ? s.mb[q_] : 0u;
       if (lane == 0) c_preqs += nq;
+      // the chains i -> q -> j -> q -> i: lane 4k + h evaluates the loss hash of hop h of proxy k
+      unsigned long long lm;
+      {
+        const uint32_t k = lane >> 2, h = lane & 3u, idx = (p << 8) | k;
+        const uint32_t q = __shfl(q_, (int)k, 64);
+        bool l = false;
+        if (lane < 4u * nq)
+          l = h == 0u ? lost(s, tk, P_L_REQ, i, q, idx) : h == 1u ? lost(s, tk, P_L_FWD, q, j, idx)
+            : h == 2u ? lost(s, tk, P_L_BACK, j, q, idx) : lost(s, tk, P_L_RELAY, q, i, idx);
+        lm = __ballot(l);
+      }
+      const unsigned long long qup = __ballot(lane < nq && sb_up(qb_));
+      const bool jup = sb_up(bj) != 0u;
       bool acked = false;
-      for (uint32_t k = 0; k < (uint32_t)PMAX; ++k) {
-        if (k >= nq) break;
-        uint32_t q = qs[0], bq = qb[0];
-#pragma unroll
-        for (int e = 1; e < PMAX; ++e) if (k == (uint32_t)e) { q = qs[e]; bq = qb[e]; }
-        const uint32_t idx = (p << 8) | k;
+      for (uint32_t k = 0; k < nq; ++k) {
+        const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)q_, (int)k), bq = (uint32_t)__builtin_amdgcn_readlane((int)qb_, (int)k);
+        const uint32_t lk = (uint32_t)(lm >> (4u * k)) & 15u;
         // i -> q : IndirectPing (src/Core.hs:250, 262-269)
-        if (lost(s, tk, P_L_REQ, i, q, idx) || !sb_up(bq)) continue;
+        if ((lk & 1u) || !((qup >> k) & 1ull)) continue;
         deliver(q, i, myb);
         // q -> j : Ping on behalf of i (src/Core.hs:105-108; D8, D12)
-        if (!sb_up(bj) || lost(s, tk, P_L_FWD, q, j, idx)) continue;
+        if (!jup || (lk & 2u)) continue;
         deliver(j, q, bq);
         // j -> q : Ack
-        if (lost(s, tk, P_L_BACK, j, q, idx)) continue;
+        if (lk & 4u) continue;
         deliver(q, j, bj);
         // q -> i : relayed Ack (D9)
-        if (lost(s, tk, P_L_RELAY, q, i, idx)) continue;
+        if (lk & 8u) continue;
         deliver(i, q, bq);
         acked = true;
       }
@@ -234,14 +254,16 @@ __global__ __launch_bounds__(BLOCK) void sp_probe_kernel(DevState s, uint32_t t,
         if (lane == 0) {
           s.fail[(size_t)li * s.P + nfail] = j;
           c_susp++;
-          if (sb_up(bj)) c_fsusp++;
+          if (jup) c_fsusp++;
           else atomicMin(&s.first_suspect[j], t);
         }
         nfail++;
       }
     }
+    SECT(34);                                         // outcomes, proxies, chains
     flush();
     if (lane == 0) s.sp_out[li] = np | (nfail << 5) | (nack << 10);
+    SECT(35);                                         // inbox appends
   }
   ctr_add_wave(&sh, C_PINGS, c_pings);
   ctr_add_wave(&sh, C_ACTIVE, c_active);
@@ -261,11 +283,14 @@ template <uint32_t CPHYS>
 struct SpTable {
   uint32_t hs[CPHYS];       // subject, NONE32 = free
   uint32_t hk[CPHYS];       // (key << 2) | who stated it first: the atomicMax target of every proposal
-  uint32_t h0[CPHYS];       // the entry's key at the start of the tick (0: no entry = the default) | SP_DUE | SP_KEPT
-  uint32_t hsince[CPHYS];   // lastChange + 1 at the start of the tick
+  uint32_t h0[CPHYS];       // the entry's key at the start of the tick (0: no entry = the default) | SP_KEPT
+  uint32_t newl[CPHYS];     // slots of the subjects that got an entry in this tick, in the order their creators came
+  uint32_t newr[CPHYS];     // ... and their ranks (filled when the capacity needs them)
   uint32_t hist[256];       // radix select
-  uint32_t cl[SWIMSIM_VIEW_CAP_MAX + 8];   // slots of the entries that changed and stayed
-  uint32_t ncl, refute1, full, pos, sel_b, sel_need, sel_cnt, smin, smax, qmin[2];
+  uint32_t cl[CPHYS / 4u + 8u];            // slots of the entries that changed and stayed (<= C <= CPHYS / 4)
+  uint32_t cs[CPHYS / 4u + 8u];            // ... and their subjects
+  uint32_t srcs[128];       // the first 64 own-Ack sources and the first 64 inbox sources of the member, staged for the lanes
+  uint32_t nnew, refute1, full, sel_b, sel_need, sel_cnt;
   uint2 qnew[PB_SLOTS];     // the head of the next queue line: this tick's rumours, by subject
 };
 template <uint32_t CPHYS>
@@ -300,7 +325,7 @@ __device__ inline void sp_propose(SpTable<CPHYS>& T, uint32_t subject, uint32_t 
       if (key == 0u) return;
       if (floor_rank && mix32(subject ^ mk) < floor_rank) return;
       cur = atomicCAS(&T.hs[h], NONE32, subject);    // claimed by whoever comes first; another lane may hold the same rumour
-      if (cur == NONE32) cur = subject;
+      if (cur == NONE32) { cur = subject; T.newl[atomicAdd(&T.nnew, 1u)] = h; }   // the creator lists the new entry
     }
     if (cur == subject) { atomicMax(&T.hk[h], (key << 2) | prio); return; }
     h = (h + 1u) & (CPHYS - 1u);
@@ -308,8 +333,15 @@ __device__ inline void sp_propose(SpTable<CPHYS>& T, uint32_t subject, uint32_t 
   T.full = 1u;                                        // more subjects in one tick than the working set holds: the caller retries with a floor
 }
 
-// WAVES members per workgroup: the tables of a workgroup must fit its LDS allocation (CPHYS = 1024: 18 KB per wave)
-template <uint32_t CPHYS, uint32_t WAVES>
+// position of a lane's item among the items of the lanes below it, and their total (wave-uniform call)
+__device__ inline uint32_t sp_rank_of(bool flag, uint32_t lane, uint32_t* total) {
+  const unsigned long long b = __ballot(flag);
+  *total = (uint32_t)__popcll(b);
+  return (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+}
+
+// WAVES members per workgroup: the tables of a workgroup must fit its LDS allocation
+template <uint32_t CPHYS, int MT, uint32_t WAVES>
 __global__ __launch_bounds__(64 * WAVES) void sp_merge_kernel(DevState s, uint32_t t, uint32_t tk) {
   __shared__ SpTable<CPHYS> tabs[WAVES];
   __shared__ BlockCounters sh;
@@ -319,23 +351,51 @@ __global__ __launch_bounds__(64 * WAVES) void sp_merge_kernel(DevState s, uint32
   SpTable<CPHYS>& T = tabs[wv];
   unsigned c_changes = 0, c_timers = 0, c_fdead = 0, c_refutes = 0, c_evicted = 0, c_pbw = 0, c_evdrop = 0;
   unsigned long long evd = 0;
+  SECT_BEGIN(0);
   ctr_init(&sh);
   if (blockIdx.x == 0 && threadIdx.x == 0) s.g[G_OVF0 + ((t + 1) & 1u)] = 0;   // next tick's overflow list
-  for (uint32_t k = 0; k < SPL; ++k) { const uint32_t x = lane + 64u * k; T.hs[x] = NONE32; T.hk[x] = 0; T.h0[x] = 0; T.hsince[x] = 0; }
-  if (lane == 0) T.full = 0;
+  for (uint32_t k = 0; k < SPL; ++k) { const uint32_t x = lane + 64u * k; T.hs[x] = NONE32; T.hk[x] = 0; T.h0[x] = 0; }
+  if (lane == 0) { T.full = 0; T.nnew = 0; T.refute1 = 0; }
   lds_wave_sync();
   const uint32_t cur = t & 1u;
   for (uint32_t li = blockIdx.x * WAVES + wv; li < s.N; li += nwaves) {
     const uint32_t i = li;
+    // ---- ONE round of loads for everything the member's end of tick reads that depends on nothing else: its byte, counts,
+    // the whole map (C entries whatever its length), the first 64 sources of either kind, its failed probes, its queue line.
+    // (One member after the other with every load waiting for the one before was 20 round trips per member-tick.)
     const uint32_t myb = s.mb[i];
-    if (!sb_up(myb)) continue;                       // wave-uniform: a member that is down does nothing and receives nothing
-    const uint32_t mk = mix32(tk ^ i);
     const uint2 hot0 = s.hot[li];
     const uint32_t po = s.sp_out[li];
-    const uint32_t nsent = po & 31u, nfail = (po >> 5) & 31u, nack = po >> 10;
     const uint32_t cnt = s.inbox_cnt[li];
     const uint32_t n0 = s.sp_tab_n[li];
-    if (lane == 0) { T.ncl = 0; T.refute1 = 0; T.pos = 0; T.smin = NONE32; T.smax = 0; }
+    uint32_t msub[MT], mkey[MT], msince[MT];
+    {
+      const uint32_t* rs = sp_row(s, li, 0); const uint32_t* rk = sp_row(s, li, 1); const uint32_t* rt = sp_row(s, li, 2);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const uint32_t e = lane + 64u * (uint32_t)m;
+        msub[m] = e < s.C ? rs[e] : NONE32; mkey[m] = e < s.C ? rk[e] : 0u; msince[m] = e < s.C ? rt[e] : 0u;
+      }
+    }
+    const uint32_t w_ack = lane < s.sp_ack_cap ? s.ackfrom[(size_t)li * s.sp_ack_cap + lane] : 0u;
+    const uint32_t w_in = lane < s.inbox_cap ? s.inbox[(size_t)li * s.inbox_cap + lane] : 0u;
+    const uint32_t w_fail = lane < s.P ? s.fail[(size_t)li * s.P + lane] : 0u;
+    uint2 oe = make_uint2(0u, 0u);
+    if (lane < (uint32_t)PB_SLOTS) oe = sp_line(s, cur, li)[lane];
+    if (!sb_up(myb)) continue;                       // wave-uniform: a member that is down does nothing and receives nothing
+    const uint32_t mk = mix32(tk ^ i);
+    const uint32_t nsent = po & 31u, nfail = (po >> 5) & 31u, nack = po >> 10;
+    T.srcs[lane] = w_ack; T.srcs[64u + lane] = w_in;
+    SECT(0);                                          // the member's inputs (one round of loads)
+    // this lane's entries of the map: which exist, whose suspicion deadline is due (the FIXME at src/Core.hs:141; D4)
+    bool mhave[MT], mdue[MT];
+    uint32_t mslot[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      mhave[m] = lane + 64u * (uint32_t)m < n0;
+      mdue[m] = mhave[m] && (mkey[m] & 3u) == ST_SUSPECT && msince[m] - 1u + s.S <= t;
+      mslot[m] = 0;
+    }
     // The working set of a tick -- the map and every subject the member hears of for the first time -- has CPHYS >= 4 C
     // slots.  When a tick brings more (a member with hundreds of sources: large P and K under heavy loss, a degraded
     // cluster), subjects without an entry are taken in only above a rank FLOOR: they would be the first to go anyway -- an
@@ -343,172 +403,222 @@ __global__ __launch_bounds__(64 * WAVES) void sp_merge_kernel(DevState s, uint32
     // least C of the tick's changes lie at or above the floor, which is checked; the floor is found by bisection (every
     // step a full pass over the member's inputs: the rare path buys exactness, not speed).
     uint32_t floor_rank = 0, floor_lo = 0, floor_hi = 0xFFFFFFFFu;
-    uint32_t nvalid = 0, total = 0;
+    uint32_t nnew = 0, nchold = 0;                    // entries that appeared; old entries that changed
+    bool mch[MT];
     for (;;) {
-    // ---- the map into the hash table; suspicion deadlines that are due (the FIXME at src/Core.hs:141; D4)
-    {
-      const uint32_t* rs = sp_row(s, li, 0); const uint32_t* rk = sp_row(s, li, 1); const uint32_t* rt = sp_row(s, li, 2);
-      for (uint32_t e = lane; e < n0; e += 64u) {
-        const uint32_t subject = rs[e], key = rk[e], since1 = rt[e];
-        uint32_t h = sp_hash<CPHYS>(subject);
+      // ---- the map into the hash table
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        if (!mhave[m]) continue;
+        uint32_t h = sp_hash<CPHYS>(msub[m]);
         for (;;) {                                     // subjects of a map are distinct: a free slot is mine
-          if (atomicCAS(&T.hs[h], NONE32, subject) == NONE32) break;
+          if (atomicCAS(&T.hs[h], NONE32, msub[m]) == NONE32) break;
           h = (h + 1u) & (CPHYS - 1u);
         }
-        const bool due = (key & 3u) == ST_SUSPECT && since1 - 1u + s.S <= t;
-        T.hk[h] = due ? ((((key & ~3u) | ST_DEAD) << 2) | SP_PRIO_TIMER) : (key << 2);
-        T.h0[h] = key | (due ? SP_DUE : 0u);
-        T.hsince[h] = since1;
+        T.hk[h] = mdue[m] ? ((((mkey[m] & ~3u) | ST_DEAD) << 2) | SP_PRIO_TIMER) : (mkey[m] << 2);
+        T.h0[h] = mkey[m];
+        mslot[m] = h;
       }
-    }
-    lds_wave_sync();
-    // ---- own probes that ended without any Ack: Suspect at the incarnation the map holds (src/Core.hs:253)
-    if (lane < nfail) {
-      const uint32_t j = s.fail[(size_t)li * s.P + lane];
-      const uint32_t sl = sp_find<CPHYS>(T, j);
-      const uint32_t k0 = sl == NONE32 ? 0u : (T.h0[sl] & 0xFFFFFFu);
-      sp_propose<CPHYS>(T, j, (k0 & ~3u) | ST_SUSPECT, SP_PRIO_PROBE, mk, floor_rank);
-    }
-    // ---- the rumours received this tick (src/Core.hs:110-117): 8 sources x 8 queue entries per round of loads
-    {
-      const uint32_t nin = cnt < s.inbox_cap ? cnt : s.inbox_cap;
-      const uint32_t nsrc = nack + nin;
-      auto entry = [&](uint2 e) {
-        if (!pe_tx(e.y)) return;
-        const uint32_t key = pe_key(e.y);
-        if (e.x == i) {                               // about self -> refute (:155-166); incarnations below my own are stale (:151)
-          if ((key & 3u) != ST_ALIVE && (key >> 2) >= hot0.x) atomicMax(&T.refute1, (key >> 2) + 1u);
-          return;
-        }
-        sp_propose<CPHYS>(T, e.x, key, SP_PRIO_GOSSIP, mk, floor_rank);
-      };
-      for (uint32_t x0 = 0; x0 < nsrc; x0 += 8u) {
-        const uint32_t x = x0 + (lane >> 3);
-        if (x < nsrc) {
-          const uint32_t src = x < nack ? s.ackfrom[(size_t)li * s.sp_ack_cap + x] : s.inbox[(size_t)li * s.inbox_cap + (x - nack)];
-          entry(sp_line(s, cur, src)[lane & 7u]);
-        }
+      lds_wave_sync();
+      SECT(1);                                        // map -> hash table
+      // ---- own probes that ended without any Ack: Suspect at the incarnation the map holds (src/Core.hs:253)
+      if (lane < nfail) {
+        const uint32_t j = w_fail;
+        const uint32_t sl = sp_find<CPHYS>(T, j);
+        const uint32_t k0 = sl == NONE32 ? 0u : (T.h0[sl] & 0xFFFFFFu);
+        sp_propose<CPHYS>(T, j, (k0 & ~3u) | ST_SUSPECT, SP_PRIO_PROBE, mk, floor_rank);
       }
-      if (cnt > s.inbox_cap) {                        // the exact overflow list (rare): my entries of it, one source at a time
-        const uint32_t novf = min(s.g[G_OVF0 + (t & 1u)], s.ovf_cap);
-        for (uint32_t y0 = 0; y0 < novf; y0 += 64u) {
-          const uint32_t y = y0 + lane;
-          uint2 o = make_uint2(NONE32, 0u);
-          if (y < novf) o = s.ovf[(size_t)(t & 1u) * s.ovf_cap + y];
-          unsigned long long hits = __ballot(o.x == li);
-          for (; hits; hits &= hits - 1ull) {
-            const int L = __ffsll((unsigned long long)hits) - 1;
-            const uint32_t src = (uint32_t)__builtin_amdgcn_readlane((int)o.y, L);
-            if (lane < 8u) entry(sp_line(s, cur, src)[lane]);
+      // ---- the rumours received this tick (src/Core.hs:110-117): 8 sources x 8 queue entries per round of loads
+      {
+        const uint32_t nin = cnt < s.inbox_cap ? cnt : s.inbox_cap;
+        const uint32_t nsrc = nack + nin;
+        auto entry = [&](uint2 e) {
+          if (!pe_tx(e.y)) return;
+          const uint32_t key = pe_key(e.y);
+          if (e.x == i) {                             // about self -> refute (:155-166); incarnations below my own are stale (:151)
+            if ((key & 3u) != ST_ALIVE && (key >> 2) >= hot0.x) atomicMax(&T.refute1, (key >> 2) + 1u);
+            return;
+          }
+          sp_propose<CPHYS>(T, e.x, key, SP_PRIO_GOSSIP, mk, floor_rank);
+        };
+        // source x of the member: its own Ack sources first, then its inbox (the first 64 of either are staged in LDS)
+        auto src_of = [&](uint32_t x) -> uint32_t {
+          if (x < nack) return x < 64u ? T.srcs[x] : s.ackfrom[(size_t)li * s.sp_ack_cap + x];
+          const uint32_t y = x - nack;
+          return y < 64u ? T.srcs[64u + y] : s.inbox[(size_t)li * s.inbox_cap + y];
+        };
+        // four rounds (32 sources) of queue entries in flight at a time
+        for (uint32_t x0 = 0; x0 < nsrc; x0 += 32u) {
+          uint2 en[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const uint32_t x = x0 + 8u * (uint32_t)r + (lane >> 3);
+            en[r] = make_uint2(0u, 0u);
+            if (x < nsrc) en[r] = sp_line(s, cur, src_of(x))[lane & 7u];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) entry(en[r]);
+        }
+        if (cnt > s.inbox_cap) {                      // the exact overflow list (rare): my entries of it, one source at a time
+          const uint32_t novf = min(s.g[G_OVF0 + (t & 1u)], s.ovf_cap);
+          for (uint32_t y0 = 0; y0 < novf; y0 += 64u) {
+            const uint32_t y = y0 + lane;
+            uint2 o = make_uint2(NONE32, 0u);
+            if (y < novf) o = s.ovf[(size_t)(t & 1u) * s.ovf_cap + y];
+            unsigned long long hits = __ballot(o.x == li);
+            for (; hits; hits &= hits - 1ull) {
+              const int L = __ffsll((unsigned long long)hits) - 1;
+              const uint32_t src = (uint32_t)__builtin_amdgcn_readlane((int)o.y, L);
+              if (lane < 8u) entry(sp_line(s, cur, src)[lane]);
+            }
           }
         }
       }
-    }
-    lds_wave_sync();
-    // ---- what changed; how many entries there are now
-    nvalid = 0;
-    uint32_t nabove = 0;                               // the tick's changes at or above the floor
-    for (uint32_t k = 0; k < SPL; ++k) {
-      const uint32_t x = lane + 64u * k;
-      if (T.hs[x] == NONE32) continue;
-      nvalid++;
-      const bool changed = (T.hk[x] >> 2) > (T.h0[x] & 0xFFFFFFu);
-      nabove += (changed && (!floor_rank || mix32(T.hs[x] ^ mk) >= floor_rank)) ? 1u : 0u;
-      const uint32_t since = changed ? t + 1u : T.hsince[x];
-      atomicMin(&T.smin, since); atomicMax(&T.smax, since);
-    }
-    total = wave_sum(nvalid);
-    const bool full = T.full != 0u;
-    if (!full && (!floor_rank || wave_sum(nabove) >= s.C)) break;     // wave-uniform
-    // the working set overflowed (raise the floor) or the floor cut into the C that stay (lower it): once more
-    if (full) floor_lo = floor_rank; else floor_hi = floor_rank;
-    floor_rank = floor_lo + (floor_hi - floor_lo) / 2u;
-    if (floor_rank == floor_lo) floor_rank = floor_lo + 1u;
-    lds_wave_sync();
-    for (uint32_t k = 0; k < SPL; ++k) { const uint32_t x = lane + 64u * k; T.hs[x] = NONE32; T.hk[x] = 0; T.h0[x] = 0; T.hsince[x] = 0; }
-    if (lane == 0) { T.full = 0; T.smin = NONE32; T.smax = 0; }
-    lds_wave_sync();
-    }
-    // ---- the capacity: the C entries with the largest (lastChange, rank) stay; rank = mix32(subject ^ mk) is a keyed
-    // permutation of the ids (no ties).  Radix select of the C-th largest 64-bit priority, a byte per pass, in LDS.
-    unsigned long long thr = 0ull;                   // stay iff priority >= thr
-    if (total > s.C) {
       lds_wave_sync();
-      const uint32_t smin = T.smin, smax = T.smax;
-      auto prio_of = [&](uint32_t x) -> unsigned long long {
-        const bool changed = (T.hk[x] >> 2) > (T.h0[x] & 0xFFFFFFu);
-        return ((unsigned long long)(changed ? t + 1u : T.hsince[x]) << 32) | mix32(T.hs[x] ^ mk);
-      };
-      // the bytes of lastChange every entry shares need no pass
-      int pass = 7;
-      unsigned long long prefix = 0ull;               // the decided high bytes of the threshold
-      while (pass >= 4 && (smin >> (8 * (pass - 4))) == (smax >> (8 * (pass - 4)))) {
-        prefix = smin >> (8 * (pass - 4));
-        pass--;
+      SECT(2);                                        // failed probes + received rumours (lines, proposals)
+      // ---- what changed: this lane's entries of the map (the entries that appeared are listed in newl)
+      nnew = T.nnew;
+      uint32_t myabove = 0;                           // this lane's share of the tick's changes at or above the floor
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        mch[m] = mhave[m] && (T.hk[mslot[m]] >> 2) > mkey[m];
+        myabove += (mch[m] && (!floor_rank || mix32(msub[m] ^ mk) >= floor_rank)) ? 1u : 0u;
       }
-      uint32_t need = s.C;
-      bool done = false;
-      for (; pass >= 0 && !done; --pass) {
-        for (uint32_t b = lane; b < 256u; b += 64u) T.hist[b] = 0;
-        lds_wave_sync();
-        for (uint32_t k = 0; k < SPL; ++k) {
-          const uint32_t x = lane + 64u * k;
-          if (T.hs[x] == NONE32) continue;
-          const unsigned long long p = prio_of(x);
-          if (pass == 7 || (p >> (8 * (pass + 1))) == prefix) atomicAdd(&T.hist[(uint32_t)(p >> (8 * pass)) & 0xFFu], 1u);
-        }
-        lds_wave_sync();
-        // the bin in which the need-th largest lies: lane l owns bins 4l .. 4l+3
-        const uint32_t b0 = T.hist[4u * lane], b1 = T.hist[4u * lane + 1u], b2 = T.hist[4u * lane + 2u], b3 = T.hist[4u * lane + 3u];
-        const uint32_t mine = b0 + b1 + b2 + b3;
-        const uint32_t incl = wave_prefix_incl(mine);
-        const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        const uint32_t above = all - incl;             // entries in the bins of higher lanes
-        if (above < need && need <= above + mine) {    // exactly one lane
-          uint32_t a = above, b = 4u * lane + 3u, hb = b3;
-          if (a + b3 < need) { a += b3; b = 4u * lane + 2u; hb = b2;
-            if (a + b2 < need) { a += b2; b = 4u * lane + 1u; hb = b1;
-              if (a + b1 < need) { a += b1; b = 4u * lane; hb = b0; } } }
-          T.sel_b = b; T.sel_need = need - a; T.sel_cnt = hb;
-        }
-        lds_wave_sync();
-        prefix = (prefix << 8) | T.sel_b;
-        need = T.sel_need;
-        if (T.sel_cnt == need) { thr = prefix << (8 * pass); done = true; }   // the whole bin stays
-      }
-      if (!done) thr = prefix;
+      const bool full = T.full != 0u;
+      bool ok = !full;
+      if (ok && floor_rank) ok = wave_sum(myabove) + nnew >= s.C;   // (an entry that appeared lies above the floor by construction)
+      if (ok) break;                                  // wave-uniform
+      // the working set overflowed (raise the floor) or the floor cut into the C that stay (lower it): once more
+      if (full) floor_lo = floor_rank; else floor_hi = floor_rank;
+      floor_rank = floor_lo + (floor_hi - floor_lo) / 2u;
+      if (floor_rank == floor_lo) floor_rank = floor_lo + 1u;
+      lds_wave_sync();
+      for (uint32_t k = 0; k < SPL; ++k) { const uint32_t x = lane + 64u * k; T.hs[x] = NONE32; T.hk[x] = 0; T.h0[x] = 0; }
+      if (lane == 0) { T.full = 0; T.nnew = 0; }
+      lds_wave_sync();
     }
-    // ---- mark who stays; list the entries that changed AND stayed
-    uint32_t nkept = 0;
-    for (uint32_t k = 0; k < SPL; ++k) {
-      const uint32_t x = lane + 64u * k;
-      if (T.hs[x] == NONE32) continue;
-      const bool changed = (T.hk[x] >> 2) > (T.h0[x] & 0xFFFFFFu);
-      bool kept = true;
-      if (total > s.C) {
-        const unsigned long long p = ((unsigned long long)(changed ? t + 1u : T.hsince[x]) << 32) | mix32(T.hs[x] ^ mk);
-        kept = p >= thr;
+    {
+      uint32_t mine = 0;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) mine += mch[m] ? 1u : 0u;
+      nchold = MT == 1 ? (uint32_t)__popcll(__ballot(mch[0])) : wave_sum(mine);
+    }
+    const uint32_t total = n0 + nnew, nchanged = nchold + nnew;
+    SECT(3);                                          // what changed, how many
+    // ---- the capacity: the C entries with the largest (lastChange, rank) stay; rank = mix32(subject ^ mk) is a keyed
+    // permutation of the ids (no ties).  Everything that changed in this tick has the same, the largest, lastChange: so either
+    // the changes fit (A: all of them stay, the C - changes most recent of the others with them) or they do not (B: the C
+    // changes of the largest rank stay, nothing else).  Radix select of the threshold in LDS, a byte per pass, over the
+    // candidates only: in case A the untouched entries of the map, which sit in the lanes' registers.
+    const bool evicting = total > s.C;
+    const bool caseB = nchanged > s.C;
+    unsigned long long thr = 0ull;                   // a candidate stays iff its priority >= thr
+    uint32_t mrank[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) mrank[m] = 0;
+    if (evicting) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) mrank[m] = mhave[m] ? mix32(msub[m] ^ mk) : 0u;
+      if (caseB) for (uint32_t x = lane; x < nnew; x += 64u) T.newr[x] = mix32(T.hs[T.newl[x]] ^ mk);
+      uint32_t need = caseB ? s.C : s.C - nchanged;  // candidates that stay
+      // a lane's candidates: case A the untouched entries it holds; case B the changed ones it holds and its share of the new ones
+      auto for_candidates = [&](auto&& f) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          if (mhave[m] && mch[m] == caseB) f(((unsigned long long)(caseB ? 0u : msince[m]) << 32) | mrank[m]);
+        if (caseB) for (uint32_t x = lane; x < nnew; x += 64u) f((unsigned long long)T.newr[x]);
+      };
+      if (need == 0u) thr = ~0ull;                    // (case A with exactly C changes: no untouched entry stays)
+      else {
+        // the bytes of lastChange every candidate shares need no pass (case B: all of them)
+        uint32_t smin = NONE32, smax = 0;
+        if (!caseB) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) if (mhave[m] && !mch[m]) { smin = min(smin, msince[m]); smax = max(smax, msince[m]); }
+          smin = NONE32 - wave_max_all(NONE32 - smin); smax = wave_max_all(smax);
+        } else { smin = 0; smax = 0; }
+        lds_wave_sync();
+        int pass = 7;
+        unsigned long long prefix = 0ull;             // the decided high bytes of the threshold
+        while (pass >= 4 && (smin >> (8 * (pass - 4))) == (smax >> (8 * (pass - 4)))) { prefix = smin >> (8 * (pass - 4)); pass--; }
+        bool done = false;
+        for (; pass >= 0 && !done; --pass) {
+          for (uint32_t b = lane; b < 256u; b += 64u) T.hist[b] = 0;
+          lds_wave_sync();
+          for_candidates([&](unsigned long long p) {
+            if (pass == 7 || (p >> (8 * (pass + 1))) == prefix) atomicAdd(&T.hist[(uint32_t)(p >> (8 * pass)) & 0xFFu], 1u);
+          });
+          lds_wave_sync();
+          // the bin in which the need-th largest lies: lane l owns bins 4l .. 4l+3
+          const uint32_t b0 = T.hist[4u * lane], b1 = T.hist[4u * lane + 1u], b2 = T.hist[4u * lane + 2u], b3 = T.hist[4u * lane + 3u];
+          const uint32_t mine = b0 + b1 + b2 + b3;
+          const uint32_t incl = wave_prefix_incl(mine);
+          const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+          const uint32_t above = all - incl;           // candidates in the bins of higher lanes
+          if (above < need && need <= above + mine) {  // exactly one lane
+            uint32_t a = above, b = 4u * lane + 3u, hb = b3;
+            if (a + b3 < need) { a += b3; b = 4u * lane + 2u; hb = b2;
+              if (a + b2 < need) { a += b2; b = 4u * lane + 1u; hb = b1;
+                if (a + b1 < need) { a += b1; b = 4u * lane; hb = b0; } } }
+            T.sel_b = b; T.sel_need = need - a; T.sel_cnt = hb;
+          }
+          lds_wave_sync();
+          prefix = (prefix << 8) | T.sel_b;
+          need = T.sel_need;
+          if (T.sel_cnt == need) { thr = prefix << (8 * pass); done = true; }   // the whole bin stays
+        }
+        if (!done) thr = prefix;
       }
-      if (!kept) { c_evicted += (T.h0[x] & 0xFFFFFFu) ? 1u : 0u; continue; }   // counted: an entry of the start of the tick that leaves
-      nkept++;
-      T.h0[x] |= SP_KEPT;
-      if (changed) T.cl[atomicAdd(&T.ncl, 1u)] = x;
+    }
+    SECT(4);                                          // radix select
+    // ---- who stays; the entries that changed AND stayed are listed (slot, subject), the map's first, then the new ones
+    bool mkeep[MT];
+    uint32_t ncl = 0, nkept_old = 0;
+    {
+      uint32_t base_cl = 0, base_keep = 0;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const unsigned long long p = ((unsigned long long)((caseB || mch[m]) ? 0u : msince[m]) << 32) | mrank[m];
+        mkeep[m] = mhave[m] && (!evicting || (mch[m] ? (!caseB || p >= thr) : (!caseB && p >= thr)));
+        if (mhave[m] && !mkeep[m]) c_evicted++;       // an entry of the start of the tick that leaves
+        uint32_t tot = 0;
+        const uint32_t r = sp_rank_of(mkeep[m] && mch[m], lane, &tot);
+        if (mkeep[m] && mch[m]) { T.cl[base_cl + r] = mslot[m]; T.cs[base_cl + r] = msub[m]; }
+        base_cl += tot;
+        uint32_t totk = 0;
+        (void)sp_rank_of(mkeep[m], lane, &totk);
+        base_keep += totk;
+        if (mkeep[m]) T.h0[mslot[m]] |= SP_KEPT;
+      }
+      nkept_old = base_keep;
+      for (uint32_t x0 = 0; x0 < nnew; x0 += 64u) {
+        const uint32_t x = x0 + lane;
+        bool keep = false; uint32_t sl = 0;
+        if (x < nnew) { sl = T.newl[x]; keep = !caseB || (unsigned long long)T.newr[x] >= thr; }
+        uint32_t tot = 0;
+        const uint32_t r = sp_rank_of(keep, lane, &tot);
+        if (keep) { T.cl[base_cl + r] = sl; T.cs[base_cl + r] = T.hs[sl]; T.h0[sl] |= SP_KEPT; }
+        base_cl += tot;
+      }
+      ncl = base_cl;
     }
     lds_wave_sync();
-    const uint32_t ncl = T.ncl;
+    SECT(5);                                          // who stays
     // ---- account for what changed and stayed (`saveMember m'`, src/Core.hs:169-179): digest, counters, events
     const unsigned long long ha = mix64(mix64((uint64_t)TAG_EV) + (((uint64_t)t << 32) | i));
+#pragma unroll
+    for (int m = 0; m < MT; ++m)                      // `deadNode` after the timeout, for the deadlines whose entry stayed
+      if (mdue[m] && mkeep[m]) { c_timers++; c_fdead += sb_up(s.mb[msub[m]]) ? 1u : 0u; }
     for (uint32_t c0 = 0; c0 < ncl; c0 += 64u) {
       const uint32_t c = c0 + lane;
       bool ev = false; uint32_t subject = 0, key = 0, cause = 0;
       if (c < ncl) {
         const uint32_t x = T.cl[c];
-        subject = T.hs[x]; key = T.hk[x] >> 2;
+        subject = T.cs[c]; key = T.hk[x] >> 2;
         const uint32_t pr = T.hk[x] & 3u, k0 = T.h0[x] & 0xFFFFFFu;
         cause = pr == SP_PRIO_TIMER ? 1u : pr == SP_PRIO_PROBE ? 0u : 2u;
         evd += (mix64(ha + subject) | 1ull) * (unsigned long long)(key - k0);
         c_changes++;
-        if (T.h0[x] & SP_DUE) { c_timers++; c_fdead += sb_up(s.mb[subject]) ? 1u : 0u; }   // `deadNode` after the timeout
         ev = (s.event_mask & (1u << cause)) != 0u;
       }
       const unsigned long long evb = __ballot(ev);
@@ -523,6 +633,7 @@ __global__ __launch_bounds__(64 * WAVES) void sp_merge_kernel(DevState s, uint32
         }
       }
     }
+    SECT(6);                                          // accounting: digest, counters, events
     // ---- refutation: bump own incarnation past the rumour's (src/Core.hs:155-166; D10)
     uint32_t self_inc = hot0.x;
     const uint32_t refute1 = T.refute1;
@@ -541,45 +652,30 @@ __global__ __launch_bounds__(64 * WAVES) void sp_merge_kernel(DevState s, uint32
           if (pos < s.event_cap) s.events[pos] = make_uint4(t, i, i, (akey << 8) | 3u /*REFUTE*/);
           else c_evdrop++;
         }
+        T.cs[ncl] = i;                                // the refutation is one more rumour of the tick
       }
     }
     // ---- the queue (D5): this tick's rumours -- what changed and stayed, the refutation -- with a full budget, by subject;
-    // then the aged survivors in their order; the 8 best.  The up-to-8 smallest subjects of the tick by repeated wave minimum.
-    uint32_t gn = 0;
-    {
-      uint32_t last = 0; bool first = true;
-      for (; gn < (uint32_t)PB_SLOTS; ++gn) {
-        // (two words in turn: a lane may still be reading round g - 1's minimum when lane 0 prepares round g)
-        uint32_t* const qmin = &T.qmin[gn & 1u];
-        if (lane == 0) *qmin = NONE32;
-        lds_wave_sync();
-        uint32_t best = NONE32;
-        for (uint32_t c = lane; c < ncl; c += 64u) {
-          const uint32_t sj = T.hs[T.cl[c]];
-          if ((first || sj > last) && sj < best) best = sj;
-        }
-        if (lane == 0 && refuted && (first || i > last) && i < best) best = i;
-        if (best != NONE32) atomicMin(qmin, best);
-        lds_wave_sync();
-        const uint32_t m = *qmin;
-        if (m == NONE32) break;
-        if (lane == 0) {
-          uint32_t key = akey;
-          if (!(refuted && m == i)) key = T.hk[sp_find<CPHYS>(T, m)] >> 2;
-          T.qnew[gn] = make_uint2(m, pe_hi(key, s.L));
-        }
-        last = m; first = false;
-      }
+    // then the aged survivors in their order; the 8 best.  Every rumour of the tick counts the subjects below its own: the
+    // 8 smallest take the head of the line in that order.
+    const uint32_t ncand = ncl + (refuted ? 1u : 0u);
+    const uint32_t gn = min(ncand, (uint32_t)PB_SLOTS);
+    lds_wave_sync();
+    for (uint32_t c = lane; c < ncand; c += 64u) {
+      const uint32_t sj = T.cs[c];
+      uint32_t below = 0;
+      for (uint32_t o = 0; o < ncand; ++o) below += T.cs[o] < sj ? 1u : 0u;
+      if (below < (uint32_t)PB_SLOTS) T.qnew[below] = make_uint2(sj, pe_hi(c < ncl ? (T.hk[T.cl[c]] >> 2) : akey, s.L));
     }
     lds_wave_sync();
+    SECT(7);                                          // the tick's rumours by subject
     const uint32_t age = nsent ? nsent : 1u;
     const uint32_t oldn = sb_qn(myb);
     uint32_t nout = gn;
     {
       // lanes 0..7 look at one old entry each; it survives if its budget lasts and no rumour of this tick supersedes it
-      bool keep = false; uint2 oe = make_uint2(0u, 0u);
+      bool keep = false;
       if (lane < oldn) {
-        oe = sp_line(s, cur, li)[lane];
         const uint32_t tx = pe_tx(oe.y);
         bool superseded = refuted && oe.x == i;
         if (!superseded && oe.x != i) {
@@ -603,25 +699,39 @@ __global__ __launch_bounds__(64 * WAVES) void sp_merge_kernel(DevState s, uint32
       if (self_inc != hot0.x) s.hot[li] = make_uint2(self_inc, hot0.y);
       s.inbox_cnt[li] = 0;
     }
-    // ---- the map back to HBM (who stays, in any order), the table cleared for the wave's next member
+    SECT(8);                                          // queue line + member state stores
+    // ---- the map back to HBM: the entries of the map that stay, then the new ones that do; the slots in use cleared
     {
       uint32_t* rs = sp_row(s, li, 0); uint32_t* rk = sp_row(s, li, 1); uint32_t* rt = sp_row(s, li, 2);
-      for (uint32_t k = 0; k < SPL; ++k) {
-        const uint32_t x = lane + 64u * k;
-        const uint32_t subject = T.hs[x];
-        if (subject == NONE32) continue;
-        if (T.h0[x] & SP_KEPT) {
-          const uint32_t key = T.hk[x] >> 2;
-          const bool changed = key > (T.h0[x] & 0xFFFFFFu);
-          const uint32_t pos = atomicAdd(&T.pos, 1u);
-          rs[pos] = subject; rk[pos] = key; rt[pos] = changed ? t + 1u : T.hsince[x];
+      uint32_t base = 0;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        uint32_t tot = 0;
+        const uint32_t r = sp_rank_of(mkeep[m], lane, &tot);
+        if (mkeep[m]) {
+          rs[base + r] = msub[m]; rk[base + r] = T.hk[mslot[m]] >> 2; rt[base + r] = mch[m] ? t + 1u : msince[m];
         }
-        T.hs[x] = NONE32; T.hk[x] = 0; T.h0[x] = 0; T.hsince[x] = 0;
+        base += tot;
       }
-      lds_wave_sync();
-      if (lane == 0) { s.sp_tab_n[li] = T.pos; T.full = 0; }
+      for (uint32_t x0 = 0; x0 < nnew; x0 += 64u) {
+        const uint32_t x = x0 + lane;
+        bool keep = false; uint32_t sl = 0;
+        if (x < nnew) { sl = T.newl[x]; keep = (T.h0[sl] & SP_KEPT) != 0u; }
+        uint32_t tot = 0;
+        const uint32_t r = sp_rank_of(keep, lane, &tot);
+        if (keep) { rs[base + r] = T.hs[sl]; rk[base + r] = T.hk[sl] >> 2; rt[base + r] = t + 1u; }
+        base += tot;
+      }
+      if (lane == 0) s.sp_tab_n[li] = base;
+      (void)nkept_old;
+      lds_wave_sync();                                // every lane has read what it needs of the table
+#pragma unroll
+      for (int m = 0; m < MT; ++m) if (mhave[m]) { T.hs[mslot[m]] = NONE32; T.hk[mslot[m]] = 0; T.h0[mslot[m]] = 0; }
+      for (uint32_t x = lane; x < nnew; x += 64u) { const uint32_t sl = T.newl[x]; T.hs[sl] = NONE32; T.hk[sl] = 0; T.h0[sl] = 0; }
+      if (lane == 0) { T.full = 0; T.nnew = 0; T.refute1 = 0; }
     }
     lds_wave_sync();
+    SECT(9);                                          // map write-back, table clear
   }
   ctr_add_wave(&sh, C_CHANGES, c_changes);
   ctr_add_wave(&sh, C_PB_WRITES, c_pbw);

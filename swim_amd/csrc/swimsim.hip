@@ -271,26 +271,22 @@ void launch_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev) {
   if (ev) (void)hipEventRecord(ev[2], h->stream);
 }
 
-// bounded member maps: probe (map entries per lane by view_cap, probe / proxy arrays by P, K) and merge (LDS table by view_cap)
-template <int MT>
-void launch_sparse_probe(swimsim* h, uint32_t t, uint32_t tk) {
-  const uint32_t pk = std::max(h->d.P, h->d.K);
-  if (pk <= 4) hipLaunchKernelGGL((sp_probe_kernel<MT, 4>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk);
-  else hipLaunchKernelGGL((sp_probe_kernel<MT, 16>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk);
-}
+// bounded member maps: probe (map entries per lane by view_cap) and merge (LDS table by view_cap)
 void launch_sparse_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev) {
   if (ev) (void)hipEventRecord(ev[0], h->stream);
-  if (h->d.C <= 64) launch_sparse_probe<1>(h, t, tk);
-  else if (h->d.C <= 128) launch_sparse_probe<2>(h, t, tk);
-  else launch_sparse_probe<4>(h, t, tk);
+  if (h->d.C <= 64) hipLaunchKernelGGL((sp_probe_kernel<1>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk);
+  else if (h->d.C <= 128) hipLaunchKernelGGL((sp_probe_kernel<2>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk);
+  else hipLaunchKernelGGL((sp_probe_kernel<4>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk);
   if (ev) (void)hipEventRecord(ev[1], h->stream);
-  // the per-tick working set of a member: its map + the subjects it hears of for the first time (4 x the capacity, >= 512 slots)
+  // the per-tick working set of a member: its map + the subjects it hears of for the first time = 4 x the capacity, a table in LDS
+  // (256 / 512 / 1 024 slots; beyond it the rank floor of swim_sparse.h)
 #ifdef SWIM_SP_PHYS   // test builds: a tiny working set, so that ordinary ticks overflow it and take the rank-floor retries (view_cap <= SWIM_SP_PHYS / 4)
-  if (h->d.C * 4u <= SWIM_SP_PHYS) hipLaunchKernelGGL((sp_merge_kernel<SWIM_SP_PHYS, 4>), dim3(h->d.nblocks), dim3(256), 0, h->stream, h->d, t, tk);
+  if (h->d.C * 4u <= SWIM_SP_PHYS) hipLaunchKernelGGL((sp_merge_kernel<SWIM_SP_PHYS, 1, 4>), dim3(h->d.nblocks), dim3(256), 0, h->stream, h->d, t, tk);
   else
 #endif
-  if (h->d.C <= 128) hipLaunchKernelGGL((sp_merge_kernel<512, 4>), dim3(h->d.nblocks), dim3(256), 0, h->stream, h->d, t, tk);
-  else hipLaunchKernelGGL((sp_merge_kernel<1024, 2>), dim3(h->d.nblocks), dim3(128), 0, h->stream, h->d, t, tk);   // (one counter row per workgroup: the same grid)
+  if (h->d.C <= 64) hipLaunchKernelGGL((sp_merge_kernel<256, 1, 4>), dim3(h->d.nblocks), dim3(256), 0, h->stream, h->d, t, tk);
+  else if (h->d.C <= 128) hipLaunchKernelGGL((sp_merge_kernel<512, 2, 4>), dim3(h->d.nblocks), dim3(256), 0, h->stream, h->d, t, tk);
+  else hipLaunchKernelGGL((sp_merge_kernel<1024, 4, 2>), dim3(h->d.nblocks), dim3(128), 0, h->stream, h->d, t, tk);   // (one counter row per workgroup: the same grid)
   if (ev) (void)hipEventRecord(ev[2], h->stream);
 }
 
@@ -412,7 +408,7 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     d.R_phys = 0;
     d.sp_ack_cap = std::max(1u, d.P) * (1u + d.K);
     // one wave per member, persistent: enough workgroups to fill the chip several times over (256 CUs)
-    d.nblocks = std::min<uint32_t>((N + SP_WAVES - 1) / SP_WAVES, 4096u);
+    d.nblocks = std::min<uint32_t>((N + SP_WAVES - 1) / SP_WAVES, 2560u);
     CK(dev_alloc(h, &d.mb, ((size_t)NT + 3) & ~(size_t)3, 0));
     CK(dev_alloc(h, &d.hot, N, 0));
     CK(dev_alloc(h, &d.sp_tab, (size_t)N * 3 * d.C, 0));
@@ -430,7 +426,7 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     HK(hipHostMalloc(reinterpret_cast<void**>(&h->h_sync), G_WORDS * sizeof(uint32_t)));
     CK(dev_alloc(h, &d.ovf, (size_t)2 * d.ovf_cap, 0));
     CK(dev_alloc(h, &d.events, (size_t)d.event_cap, 0));
-    CK(dev_alloc(h, &d.blk, ((size_t)d.nblocks + 1) * C_COUNT, 0));
+    CK(dev_alloc(h, &d.blk, ((size_t)d.nblocks + 1) * C_COUNT + 4096, 0));   // + the section-clock table of the measurement build
     CK(dev_alloc(h, &h->d_scratch64, (size_t)2, 0));
     HK(hipMemsetAsync(d.mb, (int)MB_UP, NT, h->stream));           // every member up, empty queue
   } else {
