@@ -86,11 +86,14 @@ def oracle_replay(sc, crashes, t_window, t_end, gpu_digest, gpu_counters, budget
     cores = min(avail, 32)
     n = sc.nMembers
     # rough cost model (1.0 M member-ticks/s per core, ~55 % parallel efficiency): skip what cannot finish
-    est = n * t_end / (1.0e6 * max(1.0, 0.55 * cores))
+    est = n * t_end / ((0.1e6 if sc.viewCap else 1.0e6) * max(1.0, 0.55 * cores))     # (the set-based end of tick of bounded maps sorts: ~10x slower)
     if est > budget_s:
         return {"skipped": "oracle replay of %d ticks x %d members needs ~%.0f s on %d cores" % (t_end, n, est, cores)}, None
     s = Sim.create(oracle_binding.load(), sc)
     workloads.apply_crashes(s, crashes)
+    if sc.viewCap:
+        for (t, m) in crashes:
+            s.scheduleFault(t + 8 + (m % 5), m, True)
     oracle_binding.set_threads(s, cores)
     s.step(t_window)
     t0 = time.perf_counter()
@@ -125,6 +128,10 @@ def main():
     ap.add_argument("--loss-ppm", type=int, default=0, help="per-message loss (BASELINE config 5 uses 300000)")
     ap.add_argument("--num-to-gossip", type=int, default=3, help="P = k (the reference's default config has 10)")
     ap.add_argument("--gc", action="store_true", help="settling on (gc_ticks = auto): view rows are reclaimed")
+    ap.add_argument("--view-cap", type=int, default=0,
+                    help="bounded member maps (view_cap = C; include/swimsim.h): BASELINE config 5's regime at its per-GPU size, e.g. "
+                         "--members 2097152 --loss-ppm 300000 --view-cap 64 [--churn 10]; no crash schedule of its own, no pre-roll")
+    ap.add_argument("--churn", type=int, default=0, help="with --view-cap: per mille of the members crash and rejoin per 100 ticks")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle replay (baseline + verification)")
     ap.add_argument("--replicated-masks", action="store_true",
                     help="multi-GPU: the direct probes between shards through all-gathered queue masks instead of records "
@@ -153,12 +160,16 @@ def main():
     from swim_amd import Sim, _abi, _lib, workloads
     n = args.members                          # per GPU: weak scaling, ONE cluster of world * n members
     nt = n * world
-    saturated = args.regime == "saturated"
+    saturated = args.regime == "saturated" and not args.view_cap
     horizon = (PREROLL_MAX if saturated else 0) + args.warmup + args.steps + 16
     # the same global failure rate at every size (~1 crash per tick from tick 0 on): per-member rumour load,
     # and so the per-GPU work, stays what it is on one GPU
     if saturated:
         sc, crashes, _ = workloads.saturated(nt, horizon, seed=1, t0=0, loss_ppm=args.loss_ppm, num_to_gossip=args.num_to_gossip)
+    elif args.view_cap:
+        from swim_amd import Config, SimConfig
+        sc = SimConfig(cfg=Config(numToGossip=args.num_to_gossip), nMembers=nt, seed=1, lossPpm=args.loss_ppm, eventMask=0x10, viewCap=args.view_cap)
+        crashes = workloads.hashed_crashes(nt, 9, max(1, args.churn * horizon // 100), 1000, 2, horizon) if args.churn else []
     else:
         sc, crashes, _ = workloads.quiescent(nt, horizon, seed=1)
         sc.cfg.numToGossip = args.num_to_gossip
@@ -179,6 +190,9 @@ def main():
         exchange = "torch.distributed p2p, transport=%s%s%s" % (fabric.transport, (" [" + fabric.note + "]") if fabric.note else "",
                                                                  ", replicated queue masks" if args.replicated_masks else "")
     workloads.apply_crashes(sim, crashes)
+    if args.view_cap:
+        for (t, m) in crashes:
+            sim.scheduleFault(t + 8 + (m % 5), m, True)       # churn: back after 8-12 ticks
 
     def barrier():
         torch.cuda.synchronize()
@@ -260,6 +274,14 @@ def main():
                     "frac_traffic": (tr / t / 1e9 / HBM_PEAK_GBS) if (tr and t > 0) else None}
         per_kernel = {k: kernel_line(k) for k in secs}
         dom = max(secs, key=lambda k: secs[k])               # the dominant kernel: the larger share of the tick
+        if args.view_cap:                                    # bounded member maps: the same two phases are swim_sparse.h's kernels
+            per_kernel = {"sp_" + k: v for k, v in per_kernel.items()}
+            for v in per_kernel.values():
+                v["impl_bytes_per_member_tick"] = None       # (A_impl above is the dense layout's; the map streams 2 x 12 C bytes per member-tick)
+                v["frac_impl"] = None
+            secs = {"sp_" + k: v for k, v in secs.items()}
+            a_by = {"sp_" + k: v for k, v in a_by.items()}
+            dom = "sp_" + dom
         a_tot, t_tot = sum(a_by.values()), sum(secs.values())
         whole = a_tot * n / t_tot / 1e9 if t_tot > 0 else 0.0
         tr_tot = sum(per_kernel[k]["traffic"] for k in secs) if all(per_kernel[k]["traffic"] for k in secs) else None
@@ -272,10 +294,11 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "config3(%s): %d members/GPU, k=%d, %s, loss %d ppm, suspicion %d ticks, retransmit %dx log2 N%s" % (
-                           args.regime, n, args.num_to_gossip,
+            "config": {"workload": "%s: %d members/GPU, k=%d, %s, loss %d ppm, suspicion %d ticks, retransmit %dx log2 N%s" % (
+                           ("config5(bounded member maps, view_cap %d, churn %d per mille / 100 ticks)" % (args.view_cap, args.churn)) if args.view_cap else "config3(%s)" % args.regime,
+                           n, args.num_to_gossip,
                            "~1 crash per tick from tick 0 (hashed schedule); untimed pre-roll of %d ticks until d >= %.1f and "
-                           "the suspicion timeout has passed, then the warm-up" % (preroll, SATURATED_D) if saturated else "one crash at tick 2",
+                           "the suspicion timeout has passed, then the warm-up" % (preroll, SATURATED_D) if saturated else ("message loss is the load: no pre-roll" if args.view_cap else "one crash at tick 2"),
                            args.loss_ppm, sim.resolved.suspicion_ticks, sim.resolved.retransmit_mult,
                            ", settling every %d quiet ticks" % sim.resolved.gc_ticks if sim.resolved.gc_ticks else ""),
                        "members_per_gpu": n, "num_to_gossip": sim.resolved.num_to_gossip, "target_scheme": args.scheme,

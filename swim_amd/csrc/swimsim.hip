@@ -66,6 +66,7 @@ struct swimsim {
   uint32_t j_in[MAX_SHARDS] = {};              // join-pull records received in round 0
   uint32_t* h_sync = nullptr;                  // pinned host copy of the globals (flags + send counts)
   hipEvent_t tick_ev[3] = {nullptr, nullptr, nullptr};
+  uint32_t sp_grid_probe = 0, sp_grid_merge = 0;   // bounded member maps: persistent grids = what the chip holds at once (occupancy x CUs)
 };
 
 // the tick kernels' state argument: by value, or (-DSWIM_STATE_BY_POINTER, measurement knob) a pointer to a device copy
@@ -271,22 +272,44 @@ void launch_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev) {
   if (ev) (void)hipEventRecord(ev[2], h->stream);
 }
 
-// bounded member maps: probe (map entries per lane by view_cap) and merge (LDS table by view_cap)
+// bounded member maps: probe (map entries per lane by view_cap) and merge (LDS table by view_cap).  Both are persistent: a grid of
+// exactly the workgroups the chip holds at once (a grid 1.25 x that runs a second, quarter-full round: +20 % on the probe kernel)
+template <typename K>
+uint32_t resident_blocks(K kernel, int block_threads, uint32_t members, uint32_t waves_per_block) {
+  int per_cu = 0, dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1024u;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+  const uint32_t want = (uint32_t)per_cu * (uint32_t)std::max(1, prop.multiProcessorCount);
+  return std::max(1u, std::min(want, (members + waves_per_block - 1) / waves_per_block));
+}
+void size_sparse_grids(swimsim* h) {
+  const uint32_t N = h->d.N, C = h->d.C;
+  h->sp_grid_probe = C <= 64 ? resident_blocks(sp_probe_kernel<1>, BLOCK, N, SP_WAVES) : C <= 128 ? resident_blocks(sp_probe_kernel<2>, BLOCK, N, SP_WAVES)
+                                                                                                   : resident_blocks(sp_probe_kernel<4>, BLOCK, N, SP_WAVES);
+#ifdef SWIM_SP_PHYS
+  if (C * 4u <= SWIM_SP_PHYS) h->sp_grid_merge = resident_blocks(sp_merge_kernel<SWIM_SP_PHYS, 1, 4>, 256, N, 4);
+  else
+#endif
+  h->sp_grid_merge = C <= 64 ? resident_blocks(sp_merge_kernel<256, 1, 4>, 256, N, 4) : C <= 128 ? resident_blocks(sp_merge_kernel<512, 2, 4>, 256, N, 4)
+                                                                                                  : resident_blocks(sp_merge_kernel<1024, 4, 2>, 128, N, 2);
+}
 void launch_sparse_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev) {
   if (ev) (void)hipEventRecord(ev[0], h->stream);
-  if (h->d.C <= 64) hipLaunchKernelGGL((sp_probe_kernel<1>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk);
-  else if (h->d.C <= 128) hipLaunchKernelGGL((sp_probe_kernel<2>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk);
-  else hipLaunchKernelGGL((sp_probe_kernel<4>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, tk);
+  const dim3 gp(h->sp_grid_probe), gm(h->sp_grid_merge);
+  if (h->d.C <= 64) hipLaunchKernelGGL((sp_probe_kernel<1>), gp, dim3(BLOCK), 0, h->stream, h->d, t, tk);
+  else if (h->d.C <= 128) hipLaunchKernelGGL((sp_probe_kernel<2>), gp, dim3(BLOCK), 0, h->stream, h->d, t, tk);
+  else hipLaunchKernelGGL((sp_probe_kernel<4>), gp, dim3(BLOCK), 0, h->stream, h->d, t, tk);
   if (ev) (void)hipEventRecord(ev[1], h->stream);
   // the per-tick working set of a member: its map + the subjects it hears of for the first time = 4 x the capacity, a table in LDS
   // (256 / 512 / 1 024 slots; beyond it the rank floor of swim_sparse.h)
 #ifdef SWIM_SP_PHYS   // test builds: a tiny working set, so that ordinary ticks overflow it and take the rank-floor retries (view_cap <= SWIM_SP_PHYS / 4)
-  if (h->d.C * 4u <= SWIM_SP_PHYS) hipLaunchKernelGGL((sp_merge_kernel<SWIM_SP_PHYS, 1, 4>), dim3(h->d.nblocks), dim3(256), 0, h->stream, h->d, t, tk);
+  if (h->d.C * 4u <= SWIM_SP_PHYS) hipLaunchKernelGGL((sp_merge_kernel<SWIM_SP_PHYS, 1, 4>), gm, dim3(256), 0, h->stream, h->d, t, tk);
   else
 #endif
-  if (h->d.C <= 64) hipLaunchKernelGGL((sp_merge_kernel<256, 1, 4>), dim3(h->d.nblocks), dim3(256), 0, h->stream, h->d, t, tk);
-  else if (h->d.C <= 128) hipLaunchKernelGGL((sp_merge_kernel<512, 2, 4>), dim3(h->d.nblocks), dim3(256), 0, h->stream, h->d, t, tk);
-  else hipLaunchKernelGGL((sp_merge_kernel<1024, 4, 2>), dim3(h->d.nblocks), dim3(128), 0, h->stream, h->d, t, tk);   // (one counter row per workgroup: the same grid)
+  if (h->d.C <= 64) hipLaunchKernelGGL((sp_merge_kernel<256, 1, 4>), gm, dim3(256), 0, h->stream, h->d, t, tk);
+  else if (h->d.C <= 128) hipLaunchKernelGGL((sp_merge_kernel<512, 2, 4>), gm, dim3(256), 0, h->stream, h->d, t, tk);
+  else hipLaunchKernelGGL((sp_merge_kernel<1024, 4, 2>), gm, dim3(128), 0, h->stream, h->d, t, tk);
   if (ev) (void)hipEventRecord(ev[2], h->stream);
 }
 
@@ -408,7 +431,8 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     d.R_phys = 0;
     d.sp_ack_cap = std::max(1u, d.P) * (1u + d.K);
     // one wave per member, persistent: enough workgroups to fill the chip several times over (256 CUs)
-    d.nblocks = std::min<uint32_t>((N + SP_WAVES - 1) / SP_WAVES, 2560u);
+    size_sparse_grids(h);
+    d.nblocks = std::max(h->sp_grid_probe, h->sp_grid_merge);     // one counter row per workgroup of the larger grid
     CK(dev_alloc(h, &d.mb, ((size_t)NT + 3) & ~(size_t)3, 0));
     CK(dev_alloc(h, &d.hot, N, 0));
     CK(dev_alloc(h, &d.sp_tab, (size_t)N * 3 * d.C, 0));

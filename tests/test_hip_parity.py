@@ -693,3 +693,26 @@ def test_bounded_maps_two_million_members_properties(hip_abi):
         assert fd[n // 2] == 4
         s.close()
     assert digests[0] == digests[1]
+
+
+def test_full_event_stream_at_65536_members(oracle_abi, hip_abi):
+    """Above 4 096 members the parity tests run with the event ring off and cover the event stream through the running event
+    digest only -- which is linear in the key and cannot see a wrong CAUSE or a dropped intermediate record.  Here: 65 536
+    members, every cause recorded (an 8 M-record ring, drained every 4 ticks), ~3 M records compared one by one: probes'
+    suspicions, the gossip that spreads them, suspicion timers, refutations under 1 % loss, joins."""
+    n = 65536
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=17, lossPpm=10000, eventMask=0x1F, eventCap=1 << 23, suspicionTicks=12, maxSubjects=4096)
+    crashes = workloads.hashed_crashes(n, 17, 1, 4096, 2, 26)         # ~16 crashes over 24 ticks
+    faults = [(t + 20, m, True) for (t, m) in crashes[:6]]
+    a, b = make_pair(oracle_abi, hip_abi, sc, crashes, faults)
+    _oracle_threads(a)
+    total = 0
+    for _ in range(14):
+        a.step(4); b.step(4)
+        ea, eb = a.drainEventsRaw(), b.drainEventsRaw()
+        assert len(ea) == len(eb) and ea == eb, "event streams differ at tick %d (%d vs %d records)" % (a.tick, len(ea), len(eb))
+        total += len(ea)
+        assert a.digest() == b.digest() and a.counters() == b.counters()
+    causes = {e[5] for e in ea}
+    assert total > 1000000 and b.counters()["events_dropped"] == 0
+    assert a.firstDetection() == b.firstDetection()
