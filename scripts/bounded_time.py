@@ -16,7 +16,8 @@ for n, cap in zip(args[0::2], args[1::2]):
     t0 = time.time(); s.step(TICKS); dt = time.time() - t0
     kt = s.kernelTiming(); c1 = s.counters()
     mt = float(n) * TICKS
-    print(json.dumps({"members": n, "view_cap": cap, "loss_ppm": LOSS, "ms_per_tick_wall": round(dt / TICKS * 1e3, 3),
+    ts = (C.c_uint64 * 9)(); abi.table_stats(s._h, ts, 9)
+    print(json.dumps({"members": n, "view_cap": cap, "grids": [int(ts[7]), int(ts[8])], "loss_ppm": LOSS, "ms_per_tick_wall": round(dt / TICKS * 1e3, 3),
                       "probe_us": round(kt["probe_ms"] / kt["ticks"] * 1e3, 1), "merge_us": round(kt["merge_ms"] / kt["ticks"] * 1e3, 1),
                       "member_ticks_per_s": round(mt / dt), "payloads": round((c1["payloads"] - c0["payloads"]) / mt, 2),
                       "changes": round((c1["changes"] - c0["changes"]) / mt, 2), "evicted": round((c1["evicted"] - c0["evicted"]) / mt, 2),

@@ -17,9 +17,9 @@ for path in libs:
     s = Sim.create(abi, sc); workloads.apply_crashes(s, crashes)
     s.step(WARM)
     s.kernelTimingEnable(True)
-    raw0 = (C.c_uint64 * 16)(); abi.counters(s._h, raw0, 16)
+    raw0 = (C.c_uint64 * _abi.CTR_COUNT)(); abi.counters(s._h, raw0, _abi.CTR_COUNT)
     t0 = time.time(); s.step(TICKS); dt = time.time() - t0
-    raw1 = (C.c_uint64 * 16)(); abi.counters(s._h, raw1, 16)
+    raw1 = (C.c_uint64 * _abi.CTR_COUNT)(); abi.counters(s._h, raw1, _abi.CTR_COUNT)
     kt = s.kernelTiming()
     print(json.dumps({"lib": os.path.basename(path), "regime": REGIME, "us_per_tick": round(dt / TICKS * 1e6, 1),
                       "probe_us": round(kt["probe_ms"] * 1e3 / kt["ticks"], 1),

@@ -211,9 +211,18 @@ __device__ inline void deliver_local(const DevState& s, uint32_t t, bool use_mas
 #ifndef SWIM_PROBE_WAVES
 #define SWIM_PROBE_WAVES 5
 #endif
+#ifndef SWIM_PROBE_WAVES8       // occupancy asked of the wider instantiations (numToGossip 5-8 / 9-12 / 13-16)
+#define SWIM_PROBE_WAVES8 3
+#endif
+#ifndef SWIM_PROBE_WAVES12
+#define SWIM_PROBE_WAVES12 3
+#endif
+#ifndef SWIM_PROBE_WAVES16
+#define SWIM_PROBE_WAVES16 2
+#endif
 constexpr int PX_KG = 4;        // proxy indices per round of the wave's indirect-probe pass (probe_kernel pass 5)
 template <int PMAX>
-__global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3 : PMAX <= 12 ? 2 : 1) void probe_kernel(SWIM_STATE_PARAM, uint32_t t, uint32_t tk, Offsets off) {
+__global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? SWIM_PROBE_WAVES8 : PMAX <= 12 ? SWIM_PROBE_WAVES12 : SWIM_PROBE_WAVES16) void probe_kernel(SWIM_STATE_PARAM, uint32_t t, uint32_t tk, Offsets off) {
   SWIM_STATE_BIND
   __shared__ BlockCounters sh;
   __shared__ uint32_t ordn;                        // deliveries left to the exchange (sharded runs)
@@ -296,43 +305,52 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
       for (int p = 0; p < PMAX; ++p) if ((uint32_t)p < np && off.o[p] && !valid[p]) clean = false;
     }
     SECT(32);                                       // target selection
+    // Passes 1-4 run over the probe indices CH at a time: what a pass keeps per probe -- outcomes, the 16-byte `pk` of the
+    // target, inbox positions -- is live for CH probes only.  With every index of a 12-wide kernel live at once (the
+    // reference's default numToGossip = 10, src/Util.hs:48) the kernel held 162 registers and ran at 2 waves per SIMD.
+    constexpr int CH = PMAX <= 4 ? PMAX : 4;
+#pragma unroll
+    for (int c0 = 0; c0 < PMAX; c0 += CH) {
     // pass 1: outcome of every direct probe -- pure arithmetic on the gathered info words.
     //   Direct (Ping seq j) is delivered iff not lost and j is up (src/Core.hs:246);
     //   j answers Ack (src/Core.hs:97-99), which may be lost too.
-    bool ping_ok[PMAX], ack_ok[PMAX];
+    bool ping_ok[CH], ack_ok[CH];
 #pragma unroll
-    for (int p = 0; p < PMAX; ++p) {
-      ping_ok[p] = false; ack_ok[p] = false;
+    for (int q = 0; q < CH; ++q) {
+      const int p = c0 + q;
+      ping_ok[q] = false; ack_ok[q] = false;
       if (valid[p]) {
-        ping_ok[p] = mi_up(pinfo[p]) && !lost(s, tk, P_L_PING, i, picks[p], p);
-        ack_ok[p] = ping_ok[p] && !lost(s, tk, P_L_ACK, picks[p], i, p);
+        ping_ok[q] = mi_up(pinfo[p]) && !lost(s, tk, P_L_PING, i, picks[p], p);
+        ack_ok[q] = ping_ok[q] && !lost(s, tk, P_L_ACK, picks[p], i, p);
       }
     }
     // pass 2: one 16-byte gather per reached LOCAL target, issued together: its queue mask (the Ack's
     // payload, pulled by the prober itself) and its known-ring (what my Ping's payload can still tell it)
-    ulonglong2 tk2[PMAX];
+    ulonglong2 tk2[CH];
 #pragma unroll
-    for (int p = 0; p < PMAX; ++p) {
-      tk2[p] = make_ulonglong2(0ull, 0ull);
-      if (use_mask && ping_ok[p] && is_local(s, picks[p]) && (mymask || (ack_ok[p] && mi_pbn(pinfo[p]))) && !ABL(ABL_PK_GATHER))
-        tk2[p] = s.pk[picks[p] - s.lo];
+    for (int q = 0; q < CH; ++q) {
+      const int p = c0 + q;
+      tk2[q] = make_ulonglong2(0ull, 0ull);
+      if (use_mask && ping_ok[q] && is_local(s, picks[p]) && (mymask || (ack_ok[q] && mi_pbn(pinfo[p]))) && !ABL(ABL_PK_GATHER))
+        tk2[q] = s.pk[picks[p] - s.lo];
     }
     SECT(33);                                       // outcomes + the targets' pk gathers issued
     // pass 3: the Pings' piggyback payloads: at most one atomicOr per target
     if (mycnt) {
-      uint32_t pos[PMAX];
+      uint32_t pos[CH];
       const bool expl = !use_mask || (mi & MI_OOW);
 #pragma unroll
-      for (int p = 0; p < PMAX; ++p) {
-        pos[p] = 0;
-        if (ping_ok[p]) {
+      for (int q = 0; q < CH; ++q) {
+        const int p = c0 + q;
+        pos[q] = 0;
+        if (ping_ok[q]) {
           payloads++; rumors += mycnt;
           if (pull) continue;                        // the target pulls it (below): its pingers are computable
           if (is_local(s, picks[p])) {
             const uint32_t dl = picks[p] - s.lo;
-            const unsigned long long m = mymask & ~(tk2[p].y & ~stale);   // only what the target does not know
+            const unsigned long long m = mymask & ~(tk2[q].y & ~stale);   // only what the target does not know
             if (m && !ABL(ABL_PUSH_ATOMIC)) atomicOr(&s.inmask[dl], m);
-            if (expl) { pos[p] = atomicAdd(&s.inbox_cnt[dl], 1u); wrote_rec = true; }
+            if (expl) { pos[q] = atomicAdd(&s.inbox_cnt[dl], 1u); wrote_rec = true; }
           } else if (expl) {
             emit_order(picks[p], i);                 // my queue as an explicit payload record
           }
@@ -340,8 +358,8 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
       }
       if (expl && !pull) {
 #pragma unroll
-        for (int p = 0; p < PMAX; ++p)
-          if (ping_ok[p] && is_local(s, picks[p])) push_commit(s, t, picks[p] - s.lo, mi_src(li, mi), pos[p]);
+        for (int q = 0; q < CH; ++q)
+          if (ping_ok[q] && is_local(s, picks[c0 + q])) push_commit(s, t, picks[c0 + q] - s.lo, mi_src(li, mi), pos[q]);
       }
     }
     SECT(34);                                       // pushes
@@ -349,7 +367,8 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
       // the Pings that reach ME this period: probe p of member q = i - o(t,p), if q is up, sees me Alive
       // and the Ping is not lost.  I merge q's queue: a gather instead of q's atomicOr.
 #pragma unroll
-      for (int p = 0; p < PMAX; ++p) {
+      for (int qq = 0; qq < CH; ++qq) {
+        const int p = c0 + qq;
         if ((uint32_t)p >= s.P || !off.o[p]) continue;
         uint32_t q = i + s.NT - off.o[p]; if (q >= s.NT) q -= s.NT;
         const uint32_t mq = probe_mi(s, q, use_mask);
@@ -361,26 +380,29 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? 3
     // remote targets: ONE record per probe carries my queue's mask (if it says everything) and the request
     // for the target's queue (if its Ack arrived); the answer lands in my slot p without an atomic
 #pragma unroll
-    for (int p = 0; p < PMAX; ++p) {
-      if (pull || clean || !ping_ok[p] || is_local(s, picks[p])) continue;
-      const uint32_t fl = ((mymask && !(mi & MI_OOW)) ? OF_PAYLOAD : 0u) | (ack_ok[p] ? OF_WANTS_ACK : 0u);
+    for (int q = 0; q < CH; ++q) {
+      const int p = c0 + q;
+      if (pull || clean || !ping_ok[q] || is_local(s, picks[p])) continue;
+      const uint32_t fl = ((mymask && !(mi & MI_OOW)) ? OF_PAYLOAD : 0u) | (ack_ok[q] ? OF_WANTS_ACK : 0u);
       if (fl) emit_raw(picks[p] | ((uint32_t)(p + 1) << ID_BITS), i | (fl << ID_BITS), (fl & OF_PAYLOAD) ? mymask : 0ull);
     }
     // pass 4: the Acks' payloads, pulled by the prober itself
 #pragma unroll
-    for (int p = 0; p < PMAX; ++p) {
-      if (!ack_ok[p]) continue;
+    for (int q = 0; q < CH; ++q) {
+      const int p = c0 + q;
+      if (!ack_ok[q]) continue;
       if (!is_local(s, picks[p])) continue;          // asked for above
       const uint32_t pj = mi_pbn(pinfo[p]);
       if (pj) {
-        ackacc |= tk2[p].x;
+        ackacc |= tk2[q].x;
         if (!use_mask || (pinfo[p] & MI_OOW)) { s.ackfrom[(size_t)li * s.P + nack] = mi_src(picks[p] - s.lo, pinfo[p]); nack++; wrote_rec = true; }
         payloads++; rumors += pj;
       }
     }
-    SECT(35);                                       // Acks
 #pragma unroll
-    for (int p = 0; p < PMAX; ++p) if ((uint32_t)p < np && valid[p] && !ack_ok[p]) failmask |= 1u << p;
+    for (int q = 0; q < CH; ++q) if ((uint32_t)(c0 + q) < np && valid[c0 + q] && !ack_ok[q]) failmask |= 1u << (c0 + q);
+    }
+    SECT(35);                                       // Acks
   }
   // pass 5 (rare without loss): probes without an Ack -> K indirect probes -> maybe Suspect (src/Core.hs:247-254).
   // The WAVE does it: the K proxies of a failed probe are independent chains i -> q -> j -> q -> i of up to four

@@ -141,6 +141,9 @@ __device__ inline uint32_t sp_select(const DevState& s, const SpView<MT>& v, uin
   return np;
 }
 
+// (Measured and dropped, profiles/r04g_*: drawing the proxies of EVERY probe ahead of the outcomes, so that the targets' and all
+// proxies' bytes travel in one round of gathers instead of one round per failed probe -- 3.9 ms against 3.2 ms per launch at
+// 2 M members: the kernel is bound by the instructions of the selection, not by those round trips.)
 template <int MT>
 __global__ __launch_bounds__(BLOCK) void sp_probe_kernel(DevState s, uint32_t t, uint32_t tk) {
   const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;

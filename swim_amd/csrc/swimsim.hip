@@ -66,7 +66,7 @@ struct swimsim {
   uint32_t j_in[MAX_SHARDS] = {};              // join-pull records received in round 0
   uint32_t* h_sync = nullptr;                  // pinned host copy of the globals (flags + send counts)
   hipEvent_t tick_ev[3] = {nullptr, nullptr, nullptr};
-  uint32_t sp_grid_probe = 0, sp_grid_merge = 0;   // bounded member maps: persistent grids = what the chip holds at once (occupancy x CUs)
+  uint32_t sp_grid_probe = 0, sp_grid_merge = 0;   // bounded member maps: workgroups of the two tick kernels
 };
 
 // the tick kernels' state argument: by value, or (-DSWIM_STATE_BY_POINTER, measurement knob) a pointer to a device copy
@@ -272,27 +272,23 @@ void launch_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev) {
   if (ev) (void)hipEventRecord(ev[2], h->stream);
 }
 
-// bounded member maps: probe (map entries per lane by view_cap) and merge (LDS table by view_cap).  Both are persistent: a grid of
-// exactly the workgroups the chip holds at once (a grid 1.25 x that runs a second, quarter-full round: +20 % on the probe kernel)
-template <typename K>
-uint32_t resident_blocks(K kernel, int block_threads, uint32_t members, uint32_t waves_per_block) {
-  int per_cu = 0, dev = 0;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1024u;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-  const uint32_t want = (uint32_t)per_cu * (uint32_t)std::max(1, prop.multiProcessorCount);
-  return std::max(1u, std::min(want, (members + waves_per_block - 1) / waves_per_block));
-}
+// bounded member maps: probe (map entries per lane by view_cap) and merge (LDS table by view_cap); every wave steps the members
+// w, w + W, ... of its grid of W waves.  Measured at 2 M members (profiles/r04f_*, r04g_*): a grid of exactly the workgroups the
+// chip holds at once is 15-25 % SLOWER than 16 384 workgroups (the members' work differs: many short-lived workgroups balance,
+// a few long ones wait for the slowest); beyond 65 536 the per-workgroup counter flush shows
 void size_sparse_grids(swimsim* h) {
-  const uint32_t N = h->d.N, C = h->d.C;
-  h->sp_grid_probe = C <= 64 ? resident_blocks(sp_probe_kernel<1>, BLOCK, N, SP_WAVES) : C <= 128 ? resident_blocks(sp_probe_kernel<2>, BLOCK, N, SP_WAVES)
-                                                                                                   : resident_blocks(sp_probe_kernel<4>, BLOCK, N, SP_WAVES);
-#ifdef SWIM_SP_PHYS
-  if (C * 4u <= SWIM_SP_PHYS) h->sp_grid_merge = resident_blocks(sp_merge_kernel<SWIM_SP_PHYS, 1, 4>, 256, N, 4);
-  else
-#endif
-  h->sp_grid_merge = C <= 64 ? resident_blocks(sp_merge_kernel<256, 1, 4>, 256, N, 4) : C <= 128 ? resident_blocks(sp_merge_kernel<512, 2, 4>, 256, N, 4)
-                                                                                                  : resident_blocks(sp_merge_kernel<1024, 4, 2>, 128, N, 2);
+  const uint32_t N = h->d.N;
+  h->sp_grid_probe = std::max(1u, std::min<uint32_t>((N + SP_WAVES - 1) / SP_WAVES, 16384u));
+  const uint32_t mw = h->d.C <= 128 ? 4u : 2u;      // members per workgroup of the merge kernel (its LDS tables)
+  h->sp_grid_merge = std::max(1u, std::min<uint32_t>((N + mw - 1) / mw, 16384u));
+  // measurement knob: SWIMSIM_SP_GRID="<probe workgroups>,<merge workgroups>" (0 = keep)
+  if (const char* e = std::getenv("SWIMSIM_SP_GRID")) {
+    unsigned a = 0, b = 0;
+    if (std::sscanf(e, "%u,%u", &a, &b) == 2) {
+      if (a) h->sp_grid_probe = std::min<uint32_t>(a, (N + SP_WAVES - 1) / SP_WAVES);
+      if (b) h->sp_grid_merge = std::min<uint32_t>(b, (N + 1) / 2);
+    }
+  }
 }
 void launch_sparse_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev) {
   if (ev) (void)hipEventRecord(ev[0], h->stream);
@@ -945,6 +941,7 @@ int swimsim_table_stats(swimsim_t* h, uint64_t* out, size_t n) {
   HIPCHK(h, hipMemcpy(g, h->d.g, sizeof g, hipMemcpyDeviceToHost));
   out[0] = g[G_NSLOTS]; out[1] = g[G_NLIVE]; out[2] = g[G_NFREE]; out[3] = g[G_NRUM]; out[4] = h->d.R_phys;   // (bounded member maps: all zero, no view rows)
   if (n >= 7) { out[5] = std::max(g[G_OVF0], g[G_OVF1]); out[6] = h->d.ovf_cap; }
+  if (n >= 9 && h->d.C) { out[7] = h->sp_grid_probe; out[8] = h->sp_grid_merge; }   // bounded member maps: the persistent grids (workgroups)
 #ifdef SWIM_REC_STATS
   if (n >= 10) { out[7] = g[90]; out[8] = g[91]; out[9] = g[92]; }
 #endif   // inbox overflow list: entries in the fuller of the two, room

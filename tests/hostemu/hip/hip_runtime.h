@@ -62,11 +62,6 @@ static inline const char* hipGetErrorString(hipError_t e) { return e == hipSucce
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
-static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
-struct hipDeviceProp_t { int multiProcessorCount; };
-static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 3; return hipSuccess; }
-// "what the device holds at once": the emulation pretends 3 CUs x 2 workgroups, so that persistent kernels loop
-template <typename K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 2; return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t bytes) {
   *p = aligned_alloc(256, (bytes + 255) & ~(size_t)255);
   return *p ? hipSuccess : hipErrorOutOfMemory;

@@ -150,3 +150,19 @@ def test_inboxes_smaller_than_the_fan_in_go_through_the_overflow_list(oracle_abi
         a.step(1); b.step(1)
         compare_state(a, b, (0, n - 1), (0,), True, where="tick %d:" % a.tick)
     a.close(); b.close()
+
+
+def test_waves_that_step_several_members(oracle_abi, emu_abi, monkeypatch):
+    """At millions of members a wave steps hundreds of members one after the other (grids of 16 384 workgroups); the small
+    clusters above give every wave one.  Here 5 / 3 workgroups step 300 members: the per-wave tables are cleared and refilled
+    between members, counters accumulate across them."""
+    monkeypatch.setenv("SWIMSIM_SP_GRID", "5,3")           # measurement knob of the library, read at create
+    n = 300
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=41, lossPpm=300000, eventMask=0x1F, suspicionTicks=6, viewCap=24)
+    a, b = Sim.create(oracle_abi, sc), Sim.create(emu_abi, sc)
+    for s in (a, b):
+        s.scheduleFault(2, 9, False); s.scheduleFault(8, 9, True); s.scheduleFault(3, 200, False)
+    for _ in range(16):
+        a.step(1); b.step(1)
+        compare_state(a, b, (0, 9, 200, n - 1), (0, 9), True, where="tick %d:" % a.tick)
+    a.close(); b.close()
