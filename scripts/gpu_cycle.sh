@@ -1,6 +1,6 @@
 #!/bin/bash
 # one GPU iteration: parity tests, bench lines, kernel-trace stats, PMC passes.
-# usage: gpu_cycle.sh <tag> [what...]   what = tests bench extra variants shard prof pmc churn config5 (default: all but churn, config5)   -> gpurun_out/<tag>_*
+# usage: gpu_cycle.sh <tag> [what...]   what = tests bench extra variants shard prof pmc churn config5 bounded (default: all but churn, config5, bounded)   -> gpurun_out/<tag>_*
 TAG=$1; shift; WHAT="${*:-tests bench extra variants shard prof pmc}"
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out; mkdir -p $O
 cd $R
@@ -30,6 +30,16 @@ fi
 if has shard; then
   # one population as 1 / 2 / 4 / 8 handles on this GPU, record path against replicated queue masks
   timeout 600 python scripts/shard_time.py 1 2 4 8 2>&1 | tee $O/${TAG}_shard_overhead_one_gpu.txt
+fi
+if has bounded; then
+  # BASELINE config 5 at its per-GPU size with bounded member maps (view_cap; swim_sparse.h): bench lines (oracle-verified in the
+  # same run), kernel times by capacity, the config's two reported numbers (false-positive Dead, ticks-to-all) x churn
+  b config5_2m_cap64 --steps 20 --warmup 5 --members 2097152 --loss-ppm 300000 --view-cap 64
+  b config5_2m_cap64_churn1pct --steps 20 --warmup 5 --members 2097152 --loss-ppm 300000 --view-cap 64 --churn 10
+  b config5_1m_cap256 --steps 20 --warmup 5 --members 1048576 --loss-ppm 300000 --view-cap 256
+  timeout 600 python scripts/bounded_time.py 65536 64 262144 64 1048576 64 2097152 64 2097152 128 2097152 256 4194304 64 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_bounded_time.txt
+  (CAP=64 TICKS=160 T0=60 timeout 600 python scripts/config5.py 2097152; CAP=256 TICKS=200 T0=60 timeout 900 python scripts/config5.py 2097152; echo '# oracle-checked at 262 144 members:'; CAP=64 TICKS=80 T0=30 ORACLE=1 timeout 900 python scripts/config5.py 262144) 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_config5_bounded.txt
+  timeout 300 python scripts/bounded_sections.py 2097152 64 2>&1 | grep -v amdgpu.ids > $O/${TAG}_bounded_sections_2m_cap64.json
 fi
 cd /tmp && export TMPDIR=/tmp
 if has prof; then
