@@ -144,8 +144,9 @@ typedef struct swimsim_config {
  *               member's queue with a full retransmission budget, as on an unbounded handle.
  * Everything else of the tick (target selection among the members the map holds Alive -- evicted ones are Alive again --,
  * probes, proxies, loss, queues, refutation, joins) is the unbounded tick's.  Not combinable with gc_ticks, join_pull,
- * pull_ticks, the robust target scheme, sharding, swimsim_inject_rumor, swimsim_set_view and swimsim_k_random_members
- * (SWIMSIM_ERR_INVALID). */
+ * pull_ticks, the robust target scheme, swimsim_inject_rumor, swimsim_set_view and swimsim_k_random_members
+ * (SWIMSIM_ERR_INVALID).  Sharded clusters of bounded handles (n_shards > 1) use the same phase calls as dense ones with a
+ * simpler exchange -- see "sharded clusters" below. */
 #define SWIMSIM_VIEW_CAP_MIN 4u
 #define SWIMSIM_VIEW_CAP_MAX 256u
 
@@ -401,6 +402,16 @@ int swimsim_inject_rumor(swimsim_t* h, uint32_t observer, uint32_t subject, uint
  * on sharded handles; digest / counters / events return this shard's part (the parts add up /
  * concatenate); view and member reads are answered by the owner only; first-detection ticks must be
  * combined (element-wise minimum) and set back before digest or first_detect are read. */
+/* Bounded handles (view_cap > 0) shard the same way and are stepped by the same calls, with a simpler exchange:
+ *   phase1  the tick's scheduled changes; this shard's slice of two replicated tables is ready to be ALL-GATHERED in round 1
+ *           (swimsim_shard_gather_buffers): everybody's start-of-tick queue line (64-byte records, kind 5) and member byte
+ *           (1 byte: up, queue length; kind 6).  No records of kind 0 (shard_info reports r_cap = x_cap = 0).
+ *   phase2  one period of failureDetector for this shard's members; round 2 carries 16-byte records {dst, src, -, -} of kind 1:
+ *           "dst merges src's queue" for members dst of the peer (the receiver appends src to dst's inbox and reads src's line
+ *           from its replica).  Nothing of kind 2.
+ *   phase3  end of tick.
+ * swimsim_shard_step drives it like a dense cluster with replicated masks: xchg(ctx, 1, ..) gathers (kind-5 counts at
+ * [n_shards + p], kind-6 at [2 n_shards + p], n_local each), xchg(ctx, 2, ..) delivers the kind-1 records. */
 #define SWIMSIM_RREC_BYTES 16u
 #define SWIMSIM_PREC_BYTES 16u
 #define SWIMSIM_XREC_BYTES 72u
@@ -450,7 +461,8 @@ int swimsim_shard_join_ingest(swimsim_t* h, const uint32_t* counts_in /*[n_shard
  * section 7).  It travels WITH round 1: in that mode swimsim_shard_step's xchg(ctx, 1, ..) finds the kind-5 counts at
  * [n_shards + p] and the kind-6 counts at [2 n_shards + p] (n_local for every peer) next to the kind-0 counts at [p].
  * n_local = 0: the mode is off, there is nothing to gather. */
-#define SWIMSIM_GREC5_BYTES 8u
+#define SWIMSIM_GREC5_BYTES 8u          /* dense handles; bounded handles gather 64-byte queue lines: */
+#define SWIMSIM_GREC5_BOUNDED_BYTES 64u
 #define SWIMSIM_GREC6_BYTES 1u
 int swimsim_shard_gather_buffers(swimsim_t* h, void** send /*[2]*/, void** recv /*[2]*/, uint32_t* n_local);
 int swimsim_shard_get_first_suspect(swimsim_t* h, uint32_t* out, size_t n);

@@ -1151,8 +1151,8 @@ static int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, char*
   if (c->pull_ticks == 1) { snprintf(err, errn, "pull_ticks must be 0 (off) or >= 2"); return SWIMSIM_ERR_INVALID; }
   if (c->view_cap) {
     if (c->view_cap < SWIMSIM_VIEW_CAP_MIN || c->view_cap > SWIMSIM_VIEW_CAP_MAX) { snprintf(err, errn, "view_cap must be 0 (unbounded) or in [%u, %u]", SWIMSIM_VIEW_CAP_MIN, SWIMSIM_VIEW_CAP_MAX); return SWIMSIM_ERR_INVALID; }
-    if (c->gc_ticks || c->join_pull || c->pull_ticks || c->target_scheme != SWIMSIM_TARGETS_RANDOM || c->n_shards > 1) {
-      snprintf(err, errn, "view_cap (bounded member maps) cannot be combined with gc_ticks, join_pull, pull_ticks, the robust target scheme or sharding"); return SWIMSIM_ERR_INVALID; }
+    if (c->gc_ticks || c->join_pull || c->pull_ticks || c->target_scheme != SWIMSIM_TARGETS_RANDOM) {
+      snprintf(err, errn, "view_cap (bounded member maps) cannot be combined with gc_ticks, join_pull, pull_ticks or the robust target scheme"); return SWIMSIM_ERR_INVALID; }
   }
   return SWIMSIM_OK;
 }

@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libswimsim.so")
 
 _cached = None
 
-KERNEL_SOURCES = ("swim_kernels.h", "swim_device.h", "swimsim.hip")
+KERNEL_SOURCES = ("swim_kernels.h", "swim_sparse.h", "swim_device.h", "swimsim.hip")
 
 
 def kernel_sources_sha():

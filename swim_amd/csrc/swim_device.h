@@ -196,6 +196,12 @@ struct DevState {
   uint2* sp_q;             // [2][N][8] queue lines {subject, key | tx << 24}; buffer (t & 1) is read in tick t, the other written
   uint32_t* sp_out;        // [N] probe -> merge: Pings sent | failed probes << 5 | own Ack sources << 10
   uint32_t sp_ack_cap;     // own Ack sources per member: P (1 + K), in ackfrom[N][sp_ack_cap]
+  // shards of a bounded cluster (swim_sparse.h): a replica of everybody's start-of-tick queue line (all-gathered with
+  // `mb` at the start of the tick), the tick's deliveries to members of other shards
+  uint2* sp_qall;          // [NT][8]
+  uint2* sp_ord;           // [64][sp_ord_cap] {dst, src} (global ids), unsorted; sp_ord_n[64 * 16] entries per list
+  uint32_t* sp_ord_n;
+  uint32_t sp_ord_cap;
 #ifdef SWIM_ABLATE
   uint32_t dbg;            // measurement build (scripts/ablate.py): memory operations the tick kernels leave out
 #endif

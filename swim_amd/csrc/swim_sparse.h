@@ -30,6 +30,11 @@ constexpr uint32_t SP_KEPT = 1u << 30;         // h0 bit (after the selection): 
 __device__ inline uint32_t* sp_row(const DevState& s, uint32_t li, uint32_t field) { return s.sp_tab + ((size_t)li * 3u + field) * s.C; }
 // queue lines sq[2][N][8] {subject, key | tx << 24}: buffer (t & 1) is read in tick t, the other one written
 __device__ inline uint2* sp_line(const DevState& s, uint32_t buf, uint32_t li) { return s.sp_q + ((size_t)buf * s.N + li) * PB_SLOTS; }
+// the queue line of member g (GLOBAL id) as the sources of tick t see it: on one handle the current buffer itself; on a shard the
+// replica sp_qall[NT][8] of everybody's start-of-tick line (own slice copied in by sp_publish_kernel, the others all-gathered)
+__device__ inline const uint2* sp_src_line(const DevState& s, uint32_t cur, uint32_t g) {
+  return s.n_shards > 1 ? s.sp_qall + (size_t)g * PB_SLOTS : s.sp_q + ((size_t)cur * s.N + g) * PB_SLOTS;
+}
 // sb[NT]: bit 0 up (ground truth), bits 1-4 queue length -- the one byte a prober gathers about a target (the `mb` table)
 __device__ inline uint32_t sb_up(uint32_t b) { return b & MB_UP; }
 __device__ inline uint32_t sb_qn(uint32_t b) { return (b >> MB_PBN_SHIFT) & 0xFu; }
@@ -56,17 +61,19 @@ __global__ __launch_bounds__(BLOCK) void sp_begin_kernel(DevState s, uint32_t t,
         s.mb[mbr] = 0;
         continue;
       }
+      if (!is_local(s, mbr)) { s.mb[mbr] = (uint8_t)(MB_UP | (1u << MB_PBN_SHIFT)); continue; }   // its owner does the rest (and publishes it)
       // (re)join: new incarnation, announce Alive: the queue holds exactly that rumour
-      const uint2 hot = s.hot[mbr];
+      const uint32_t ml = mbr - s.lo;
+      const uint2 hot = s.hot[ml];
       uint32_t ni = hot.x + 1;
       if (ni > INC_MAX) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_INC); ni = INC_MAX; }
       evd += h4(TAG_INC, ((uint64_t)t << 32) | mbr, ni, 0);
       const uint32_t akey = (ni << 2) | ST_ALIVE;
-      uint2* line = sp_line(s, cur, mbr);
+      uint2* line = sp_line(s, cur, ml);
       line[0] = make_uint2(mbr, pe_hi(akey, s.L));
       for (int q = 1; q < PB_SLOTS; ++q) line[q] = make_uint2(0u, 0u);
       s.mb[mbr] = (uint8_t)(MB_UP | (1u << MB_PBN_SHIFT));
-      s.hot[mbr] = make_uint2(ni, hot.y);
+      s.hot[ml] = make_uint2(ni, hot.y);
       if (s.event_mask & (1u << 4)) {
         const uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
         if (pos < s.event_cap) s.events[pos] = make_uint4(t, mbr, mbr, (akey << 8) | 4u);
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(BLOCK) void sp_probe_kernel(DevState s, uint32_t t,
   ctr_init(&sh);
   SECT_BEGIN(32);
   for (uint32_t li = blockIdx.x * SP_WAVES + wv; li < s.N; li += nwaves) {
-    const uint32_t i = li;
+    const uint32_t i = s.lo + li;                    // global id (hashes, targets, sources); li indexes what this handle owns
     // one round of loads: the member's byte, its map's length and the map itself (whatever its length: the loads do not wait for it)
     const uint32_t myb = s.mb[i];
     SpView<MT> v;
@@ -177,8 +184,25 @@ __global__ __launch_bounds__(BLOCK) void sp_probe_kernel(DevState s, uint32_t t,
     // in flight together.  Deliveries to the member itself (Acks, relayed Acks) go to its own list without atomics.
     uint32_t nd = 0, my_dst = NONE32, my_src = 0;     // my_*: this lane's delivery of the current round
     uint32_t nack = 0, nfail = 0;
+    // a destination on another shard: the delivery leaves as an 8-byte record {dst, src} in one of 64 unsorted lists (a
+    // counter each: one list would serialise the waves on one word), routed to its owner by sp_route_kernel
     auto flush = [&]() {
-      if (my_dst != NONE32) push(s, t, my_dst, my_src);
+      const bool remote = my_dst != NONE32 && !is_local(s, my_dst);
+      if (my_dst != NONE32 && !remote) push(s, t, my_dst - s.lo, my_src);
+      if (s.n_shards > 1) {
+        const unsigned long long rb = __ballot(remote);
+        if (rb) {
+          const uint32_t list = blockIdx.x & 63u;
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(&s.sp_ord_n[list * 16u], (uint32_t)__popcll(rb));
+          base = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
+          if (remote) {
+            const uint32_t pos = base + (uint32_t)__popcll(rb & ((1ull << lane) - 1ull));
+            if (pos < s.sp_ord_cap) s.sp_ord[(size_t)list * s.sp_ord_cap + pos] = make_uint2(my_dst, my_src);
+            else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG);
+          }
+        }
+      }
       my_dst = NONE32;
     };
     auto deliver = [&](uint32_t dst, uint32_t src, uint32_t srcb) {    // wave-uniform arguments
@@ -362,7 +386,7 @@ __global__ __launch_bounds__(64 * WAVES) void sp_merge_kernel(DevState s, uint32
   lds_wave_sync();
   const uint32_t cur = t & 1u;
   for (uint32_t li = blockIdx.x * WAVES + wv; li < s.N; li += nwaves) {
-    const uint32_t i = li;
+    const uint32_t i = s.lo + li;                    // global id
     // ---- ONE round of loads for everything the member's end of tick reads that depends on nothing else: its byte, counts,
     // the whole map (C entries whatever its length), the first 64 sources of either kind, its failed probes, its queue line.
     // (One member after the other with every load waiting for the one before was 20 round trips per member-tick.)
@@ -457,7 +481,7 @@ __global__ __launch_bounds__(64 * WAVES) void sp_merge_kernel(DevState s, uint32
           for (int r = 0; r < 4; ++r) {
             const uint32_t x = x0 + 8u * (uint32_t)r + (lane >> 3);
             en[r] = make_uint2(0u, 0u);
-            if (x < nsrc) en[r] = sp_line(s, cur, src_of(x))[lane & 7u];
+            if (x < nsrc) en[r] = sp_src_line(s, cur, src_of(x))[lane & 7u];
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) entry(en[r]);
@@ -472,7 +496,7 @@ __global__ __launch_bounds__(64 * WAVES) void sp_merge_kernel(DevState s, uint32
             for (; hits; hits &= hits - 1ull) {
               const int L = __ffsll((unsigned long long)hits) - 1;
               const uint32_t src = (uint32_t)__builtin_amdgcn_readlane((int)o.y, L);
-              if (lane < 8u) entry(sp_line(s, cur, src)[lane]);
+              if (lane < 8u) entry(sp_src_line(s, cur, src)[lane]);
             }
           }
         }
@@ -751,6 +775,61 @@ __global__ __launch_bounds__(64 * WAVES) void sp_merge_kernel(DevState s, uint32
 }
 
 // ================================================================================================
+// sharded clusters of bounded handles: one exchange of 8-byte delivery records per tick + an all-gather
+// ================================================================================================
+// Members shard by contiguous id range as on dense handles.  What a delivery "dst merges src's queue" needs from another shard is
+// (a) the receiver learning of it: an 8-byte record {dst, src} to dst's owner, which appends src to dst's inbox; (b) src's
+// start-of-tick queue line, 64 bytes: every shard holds a replica of everybody's line (sp_qall) and byte (mb), all-gathered at
+// the start of the tick -- after the scheduled changes, so that the bytes carry this tick's ground truth.  Probe outcomes need
+// nothing else (loss is a hash, selection reads the prober's own map).
+__global__ __launch_bounds__(BLOCK) void sp_publish_kernel(DevState s, uint32_t t) {
+  const uint32_t x = blockIdx.x * BLOCK + threadIdx.x;              // one 8-byte entry per thread: coalesced copy
+  if (x < s.N * (uint32_t)PB_SLOTS) s.sp_qall[(size_t)s.lo * PB_SLOTS + x] = s.sp_q[(size_t)(t & 1u) * s.N * PB_SLOTS + x];
+  if (x < 64u) s.sp_ord_n[x * 16u] = 0;                              // this tick's lists of remote deliveries
+  if (x < 3u * MAX_SHARDS) s.send_cnt[x] = 0;
+}
+// the tick's remote deliveries (64 unsorted lists) -> per-owner segments of 16-byte records {dst, src, -, -} (p_send): a block
+// counts its chunk per peer in LDS, reserves with one atomic per peer, writes
+__global__ __launch_bounds__(BLOCK) void sp_route_kernel(DevState s) {
+  __shared__ uint32_t cnt[MAX_SHARDS], base[MAX_SHARDS];
+  for (uint32_t list = 0; list < 64u; ++list) {
+    const uint32_t n = min(s.sp_ord_n[list * 16u], s.sp_ord_cap);
+    const uint32_t chunk = (n + gridDim.x - 1) / gridDim.x;
+    const uint32_t first = min(n, blockIdx.x * chunk), m = min(n - first, chunk);
+    if (!m) continue;                                // (block-uniform)
+    __syncthreads();
+    if (threadIdx.x < MAX_SHARDS) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint2* ord = s.sp_ord + (size_t)list * s.sp_ord_cap + first;
+    for (uint32_t k = threadIdx.x; k < m; k += BLOCK) atomicAdd(&cnt[owner_of(s, ord[k].x)], 1u);
+    __syncthreads();
+    if (threadIdx.x < MAX_SHARDS) {
+      const uint32_t c = cnt[threadIdx.x];
+      if (c) base[threadIdx.x] = atomicAdd(&s.send_cnt[1 * MAX_SHARDS + threadIdx.x], c);
+      cnt[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < m; k += BLOCK) {
+      const uint2 o = ord[k];
+      const uint32_t peer = owner_of(s, o.x);
+      const uint32_t pos = base[peer] + atomicAdd(&cnt[peer], 1u);
+      if (pos < s.p_cap) s.p_send[(size_t)peer * s.p_cap + pos] = make_uint4(o.x, o.y, 0u, 0u);
+      else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG);
+    }
+  }
+}
+// the records the peers sent: append src to my member's inbox
+__global__ __launch_bounds__(BLOCK) void sp_ingest_kernel(DevState s, uint32_t t, PeerCounts p_counts) {
+  for (uint32_t peer = 0; peer < s.n_shards; ++peer) {
+    const uint32_t np = min(p_counts.v[peer], s.p_cap);
+    for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < np; k += gridDim.x * BLOCK) {
+      const uint4 r = s.p_recv[(size_t)peer * s.p_cap + k];
+      if (is_local(s, r.x)) push(s, t, r.x - s.lo, r.y);
+    }
+  }
+}
+
+// ================================================================================================
 // observables
 // ================================================================================================
 __global__ __launch_bounds__(BLOCK) void sp_digest_kernel(DevState s, uint32_t t, unsigned long long* out) {
@@ -759,7 +838,7 @@ __global__ __launch_bounds__(BLOCK) void sp_digest_kernel(DevState s, uint32_t t
   __syncthreads();
   const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
   if (li < s.N) {
-    const uint32_t i = li, b = s.mb[i];
+    const uint32_t i = s.lo + li, b = s.mb[i];
     unsigned long long mh = h4(TAG_SELF, i, s.hot[li].x, sb_up(b) ? 1u : 0u);
     const uint32_t n = s.sp_tab_n[li];
     const uint32_t* rs = sp_row(s, li, 0); const uint32_t* rk = sp_row(s, li, 1); const uint32_t* rt = sp_row(s, li, 2);
@@ -784,7 +863,7 @@ __global__ __launch_bounds__(BLOCK) void sp_digest_kernel(DevState s, uint32_t t
 __global__ __launch_bounds__(BLOCK) void sp_coverage_kernel(DevState s, uint32_t subject, uint32_t key, unsigned long long* out) {
   const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
   uint32_t up = 0, hold = 0;
-  if (li < s.N && li != subject && sb_up(s.mb[li])) {
+  if (li < s.N && s.lo + li != subject && sb_up(s.mb[s.lo + li])) {
     up = 1;
     uint32_t k = 0;
     const uint32_t n = s.sp_tab_n[li];

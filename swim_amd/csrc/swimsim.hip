@@ -162,8 +162,8 @@ int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, std::string*
   if (c->view_cap) {
     if (c->view_cap < SWIMSIM_VIEW_CAP_MIN || c->view_cap > SWIMSIM_VIEW_CAP_MAX) {
       *err = "view_cap must be 0 (unbounded) or in [" + std::to_string(SWIMSIM_VIEW_CAP_MIN) + ", " + std::to_string(SWIMSIM_VIEW_CAP_MAX) + "]"; return SWIMSIM_ERR_INVALID; }
-    if (c->gc_ticks || c->join_pull || c->pull_ticks || c->target_scheme != SWIMSIM_TARGETS_RANDOM || c->n_shards > 1) {
-      *err = "view_cap (bounded member maps) cannot be combined with gc_ticks, join_pull, pull_ticks, the robust target scheme or sharding"; return SWIMSIM_ERR_INVALID; }
+    if (c->gc_ticks || c->join_pull || c->pull_ticks || c->target_scheme != SWIMSIM_TARGETS_RANDOM) {
+      *err = "view_cap (bounded member maps) cannot be combined with gc_ticks, join_pull, pull_ticks or the robust target scheme"; return SWIMSIM_ERR_INVALID; }
   }
   return SWIMSIM_OK;
 }
@@ -290,13 +290,14 @@ void size_sparse_grids(swimsim* h) {
     }
   }
 }
-void launch_sparse_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev) {
-  if (ev) (void)hipEventRecord(ev[0], h->stream);
-  const dim3 gp(h->sp_grid_probe), gm(h->sp_grid_merge);
+void launch_sparse_probe(swimsim* h, uint32_t t, uint32_t tk) {
+  const dim3 gp(h->sp_grid_probe);
   if (h->d.C <= 64) hipLaunchKernelGGL((sp_probe_kernel<1>), gp, dim3(BLOCK), 0, h->stream, h->d, t, tk);
   else if (h->d.C <= 128) hipLaunchKernelGGL((sp_probe_kernel<2>), gp, dim3(BLOCK), 0, h->stream, h->d, t, tk);
   else hipLaunchKernelGGL((sp_probe_kernel<4>), gp, dim3(BLOCK), 0, h->stream, h->d, t, tk);
-  if (ev) (void)hipEventRecord(ev[1], h->stream);
+}
+void launch_sparse_merge(swimsim* h, uint32_t t, uint32_t tk) {
+  const dim3 gm(h->sp_grid_merge);
   // the per-tick working set of a member: its map + the subjects it hears of for the first time = 4 x the capacity, a table in LDS
   // (256 / 512 / 1 024 slots; beyond it the rank floor of swim_sparse.h)
 #ifdef SWIM_SP_PHYS   // test builds: a tiny working set, so that ordinary ticks overflow it and take the rank-floor retries (view_cap <= SWIM_SP_PHYS / 4)
@@ -306,6 +307,12 @@ void launch_sparse_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev) {
   if (h->d.C <= 64) hipLaunchKernelGGL((sp_merge_kernel<256, 1, 4>), gm, dim3(256), 0, h->stream, h->d, t, tk);
   else if (h->d.C <= 128) hipLaunchKernelGGL((sp_merge_kernel<512, 2, 4>), gm, dim3(256), 0, h->stream, h->d, t, tk);
   else hipLaunchKernelGGL((sp_merge_kernel<1024, 4, 2>), gm, dim3(128), 0, h->stream, h->d, t, tk);
+}
+void launch_sparse_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev) {
+  if (ev) (void)hipEventRecord(ev[0], h->stream);
+  launch_sparse_probe(h, t, tk);
+  if (ev) (void)hipEventRecord(ev[1], h->stream);
+  launch_sparse_merge(h, t, tk);
   if (ev) (void)hipEventRecord(ev[2], h->stream);
 }
 
@@ -434,6 +441,20 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     CK(dev_alloc(h, &d.sp_tab, (size_t)N * 3 * d.C, 0));
     CK(dev_alloc(h, &d.sp_tab_n, N, 0));
     CK(dev_alloc(h, &d.sp_q, (size_t)2 * N * PB_SLOTS, 0));
+    if (d.n_shards > 1) {
+      // shards of a bounded cluster (swim_sparse.h): the replica of everybody's queue line, the lists of deliveries to members
+      // of other shards, the per-peer segments of 16-byte records {dst, src, -, -} they are routed into (kind 1)
+      const double l_ = c.loss_ppm / 1e6, pf_ = 1.0 - (1.0 - l_) * (1.0 - l_);
+      const double lam_ = 2.0 * c.probes_per_tick + 4.0 * c.probes_per_tick * c.indirect_k * pf_;   // deliveries per member-tick
+      const double remote = (double)N * lam_ * (d.n_shards - 1) / d.n_shards;
+      d.sp_ord_cap = (uint32_t)std::min<double>(4.0e8, remote * 1.5 / 64.0 + 8.0 * std::sqrt(remote) + 4096.0);
+      d.p_cap = (uint32_t)std::min<double>(4.0e8, remote / (d.n_shards - 1) * 1.5 + 8.0 * std::sqrt(remote) + 4096.0);
+      CK(dev_alloc(h, &d.sp_qall, (size_t)NT * PB_SLOTS, 0));
+      CK(dev_alloc(h, &d.sp_ord, (size_t)64 * d.sp_ord_cap, 0));
+      CK(dev_alloc(h, &d.sp_ord_n, (size_t)64 * 16, 0));
+      CK(dev_alloc(h, &d.p_send, (size_t)d.n_shards * d.p_cap, 0));
+      CK(dev_alloc(h, &d.p_recv, (size_t)d.n_shards * d.p_cap, 0));
+    }
     CK(dev_alloc(h, &d.sp_out, N, 0));
     CK(dev_alloc(h, &d.ackfrom, (size_t)N * d.sp_ack_cap, 0));
     CK(dev_alloc(h, &d.fail, (size_t)N * (d.P ? d.P : 1), 0));
@@ -759,8 +780,9 @@ static int read_column(swimsim_t* h, uint32_t observer, std::vector<uint2>* col,
 static int read_sparse_map(swimsim_t* h, uint32_t member, std::vector<uint32_t>* rows, uint32_t* n) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   rows->resize((size_t)3 * h->d.C);
-  HIPCHK(h, hipMemcpy(rows->data(), h->d.sp_tab + (size_t)member * 3 * h->d.C, rows->size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  HIPCHK(h, hipMemcpy(n, h->d.sp_tab_n + member, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  const uint32_t ml = member - h->d.lo;            // (the caller has checked that this handle owns the member)
+  HIPCHK(h, hipMemcpy(rows->data(), h->d.sp_tab + (size_t)ml * 3 * h->d.C, rows->size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(n, h->d.sp_tab_n + ml, sizeof(uint32_t), hipMemcpyDeviceToHost));
   if (*n > h->d.C) *n = h->d.C;
   return SWIMSIM_OK;
 }
@@ -1000,7 +1022,7 @@ int swimsim_shard_info(const swimsim_t* h, uint32_t* lo, uint32_t* n_local, uint
   if (!h) return SWIMSIM_ERR_INVALID;
   if (lo) *lo = h->d.lo;
   if (n_local) *n_local = h->d.N;
-  if (r_cap) *r_cap = DICT_RECS + h->d.r_cap;      // a segment starts with the tick's dictionary
+  if (r_cap) *r_cap = h->d.C ? 0u : DICT_RECS + h->d.r_cap;      // a segment starts with the tick's dictionary (bounded handles: no such records)
   if (p_cap) *p_cap = h->d.p_cap;
   if (x_cap) *x_cap = h->d.x_cap;
   return SWIMSIM_OK;
@@ -1102,6 +1124,22 @@ int swimsim_shard_phase1(swimsim_t* h, uint32_t* counts) {
   if (rc) return rc;
   if (!counts) return SWIMSIM_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
+  if (h->d.C) {
+    // a bounded shard (swim_sparse.h): the tick's scheduled changes, then its slice of the queue lines into the replica; round 1
+    // all-gathers the lines and the member bytes (no records of kind 0)
+    size_t fe = 0;
+    rc = upload_faults(h, 1, &fe);
+    if (rc) return rc;
+    const uint32_t t = (uint32_t)h->tick;
+    if (fe) hipLaunchKernelGGL(sp_begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, h->d_faults, (uint32_t)fe);
+    h->faults.erase(h->faults.begin(), h->faults.begin() + (long)fe);
+    hipLaunchKernelGGL(sp_publish_kernel, dim3((h->d.N * PB_SLOTS + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, h->d, t);
+    rc = finish_phase(h, nullptr);
+    if (rc) return rc;
+    for (uint32_t k = 0; k < 3 * h->d.n_shards; ++k) counts[k] = 0;
+    h->shard_phase = 1;
+    return SWIMSIM_OK;
+  }
   size_t fend = h->begun_fend;
   if (!h->begun) { rc = upload_faults(h, 1, &fend); if (rc) return rc; }
   if (h->timing && !h->tick_ev[0]) for (int k = 0; k < 3; ++k) HIPCHK(h, hipEventCreate(&h->tick_ev[k]));
@@ -1141,6 +1179,22 @@ int swimsim_shard_phase2(swimsim_t* h, const uint32_t* r_counts_in, uint32_t* co
   if (rc) return rc;
   if (!r_counts_in || !counts) return SWIMSIM_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
+  if (h->d.C) {
+    // a bounded shard: one period of failureDetector for its members against the gathered bytes; the deliveries to members of
+    // other shards routed into per-owner segments (kind 1: 16-byte records {dst, src, -, -}) for round 2
+    const uint32_t t = (uint32_t)h->tick, tk = tick_key(h->cfg.seed, t);
+    if (h->timing && !h->tick_ev[0]) for (int k = 0; k < 3; ++k) HIPCHK(h, hipEventCreate(&h->tick_ev[k]));
+    if (h->timing) (void)hipEventRecord(h->tick_ev[0], h->stream);
+    launch_sparse_probe(h, t, tk);
+    if (h->timing) (void)hipEventRecord(h->tick_ev[1], h->stream);
+    hipLaunchKernelGGL(sp_route_kernel, dim3(std::min<uint32_t>(1024u, (h->d.N + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, h->stream, h->d);
+    rc = finish_phase(h, counts);
+    if (rc) return rc;
+    for (uint32_t p = 0; p < h->d.n_shards; ++p) { counts[p] = 0; counts[2 * h->d.n_shards + p] = 0; }
+    if (h->timing) { float a = 0; HIPCHK(h, hipEventElapsedTime(&a, h->tick_ev[0], h->tick_ev[1])); h->probe_ms += a; }
+    h->shard_phase = 2;
+    return SWIMSIM_OK;
+  }
   const PeerCounts rc_in = peer_counts(h, r_counts_in);
   hipLaunchKernelGGL(xlat_kernel, dim3(h->d.n_shards), dim3(DICT_ENTRIES), 0, h->stream, h->d, rc_in);
   if (h->d.rm) hipLaunchKernelGGL(remote_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, (uint32_t)h->tick, tick_key(h->cfg.seed, (uint32_t)h->tick), robust_offsets(h, (uint32_t)h->tick));
@@ -1156,6 +1210,19 @@ int swimsim_shard_phase3(swimsim_t* h, const uint32_t* p_counts_in, const uint32
   if (rc) return rc;
   if (!p_counts_in || !x_counts_in) return SWIMSIM_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
+  if (h->d.C) {
+    const uint32_t t = (uint32_t)h->tick, tk = tick_key(h->cfg.seed, t);
+    hipLaunchKernelGGL(sp_ingest_kernel, dim3(std::min<uint32_t>(1024u, (h->d.N + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, h->stream, h->d, t, peer_counts(h, p_counts_in));
+    if (h->timing) (void)hipEventRecord(h->tick_ev[1], h->stream);
+    launch_sparse_merge(h, t, tk);
+    if (h->timing) (void)hipEventRecord(h->tick_ev[2], h->stream);
+    rc = finish_phase(h, nullptr);
+    if (rc) return rc;
+    if (h->timing) { float b = 0; HIPCHK(h, hipEventElapsedTime(&b, h->tick_ev[1], h->tick_ev[2])); h->merge_ms += b; h->timed_ticks++; }
+    h->tick++;
+    h->shard_phase = 0;
+    return SWIMSIM_OK;
+  }
   const uint32_t t = (uint32_t)h->tick;
   hipLaunchKernelGGL(ingest_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, peer_counts(h, p_counts_in), peer_counts(h, x_counts_in));
   if (h->timing) (void)hipEventRecord(h->tick_ev[1], h->stream);
@@ -1174,6 +1241,12 @@ int swimsim_shard_phase3(swimsim_t* h, const uint32_t* p_counts_in, const uint32
 
 int swimsim_shard_gather_buffers(swimsim_t* h, void** send /*[2]*/, void** recv /*[2]*/, uint32_t* n_local) {
   if (!h || !send || !recv) return SWIMSIM_ERR_INVALID;
+  if (h->d.C && h->d.n_shards > 1) {                // bounded handles: the queue lines (64-byte records) and the member bytes
+    if (n_local) *n_local = h->d.N;
+    send[0] = h->d.sp_qall + (size_t)h->d.lo * PB_SLOTS; send[1] = h->d.mb + h->d.lo;
+    recv[0] = h->d.sp_qall; recv[1] = h->d.mb;
+    return SWIMSIM_OK;
+  }
   if (n_local) *n_local = h->d.rm ? h->d.N : 0u;
   send[0] = h->d.rm ? (void*)(h->d.mask_all + h->d.lo) : nullptr; send[1] = h->d.rm ? (void*)(h->d.q_all + h->d.lo) : nullptr;
   recv[0] = h->d.mask_all; recv[1] = h->d.q_all;
@@ -1226,7 +1299,7 @@ int swimsim_shard_step(swimsim_t* h, uint32_t nticks, swimsim_exchange_fn xchg, 
     }
     rc = swimsim_shard_phase1(h, out.data());
     if (rc) return rc;
-    if (h->d.rm)                                    // round 1 also all-gathers the queue masks (kind 5) and queue bytes
+    if (h->d.rm || h->d.C)                          // round 1 also all-gathers the queue masks (kind 5) and queue bytes
       for (uint32_t p = 0; p < G; ++p) {            // (kind 6): N records to every peer, counted at [G + p] and [2G + p]
         out[G + p] = p == h->d.shard ? 0u : h->d.N;
         out[2 * G + p] = p == h->d.shard ? 0u : h->d.N;

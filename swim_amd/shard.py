@@ -51,14 +51,19 @@ class _Shard:
         self.index, self.n_shards = index, n_shards
         self.sim = Sim.create(abi, sim_config, shard_index=index, n_shards=n_shards)
         a, h, G = abi, self.sim._h, n_shards
+        # record sizes by kind; bounded handles (view_cap) all-gather whole 64-byte queue lines where dense ones gather 8-byte masks
+        self.rec_bytes = list(REC_BYTES)
+        if self.sim.resolved.view_cap:
+            self.rec_bytes[5] = 64
+        REC = self.rec_bytes
         vals = [C.c_uint32() for _ in range(5)]
         self.sim._check(a.shard_info(h, *[C.byref(v) for v in vals]))
         self.lo, self.n_local = vals[0].value, vals[1].value
         caps = [v.value for v in vals[2:]]
         sp, rp = (C.c_void_p * 3)(), (C.c_void_p * 3)()
         self.sim._check(a.shard_buffers(h, sp, rp))
-        self.send = [_wrap(sp[k], G * caps[k] * REC_BYTES[k], device).view(G, caps[k] * REC_BYTES[k]) for k in range(3)]
-        self.recv = [_wrap(rp[k], G * caps[k] * REC_BYTES[k], device).view(G, caps[k] * REC_BYTES[k]) for k in range(3)]
+        self.send = [_wrap(sp[k], G * caps[k] * REC[k], device).view(G, caps[k] * REC[k]) for k in range(3)]
+        self.recv = [_wrap(rp[k], G * caps[k] * REC[k], device).view(G, caps[k] * REC[k]) for k in range(3)]
         self.settling = self.sim.resolved.gc_ticks != 0
         self.join_pull = self.sim.resolved.join_pull != 0
         # kind 3: what every shard says about its rows (round 3, settling); kind 4: join-time pulls (round 0)
@@ -68,7 +73,7 @@ class _Shard:
                 continue
             sp_, rp_, cp_ = C.c_void_p(), C.c_void_p(), C.c_uint32()
             self.sim._check(fn(h, C.byref(sp_), C.byref(rp_), C.byref(cp_)))
-            nb = cp_.value * REC_BYTES[kind]
+            nb = cp_.value * REC[kind]
             self.send.append(_wrap(sp_.value, G * nb, device).view(G, nb))
             self.recv.append(_wrap(rp_.value, G * nb, device).view(G, nb))
 
@@ -81,7 +86,7 @@ class _Shard:
             if not self.replicated:
                 self.send.append(None); self.recv.append(None)
                 continue
-            nb = gn.value * REC_BYTES[5 + k]
+            nb = gn.value * REC[5 + k]
             self.send.append(_wrap(gs[k], nb, device).view(1, nb).expand(G, nb))
             self.recv.append(_wrap(gr[k], G * nb, device).view(G, nb))
 
@@ -138,7 +143,7 @@ class LocalFabric:
                     if n == 0:
                         continue
                     assert p != src.index, "a shard never sends to itself"
-                    nb = n * REC_BYTES[kind]
+                    nb = n * src.rec_bytes[kind]
                     shards[p].recv[kind][src.index, :nb].copy_(src.send[kind][p, :nb])
                     recv[p][j][src.index] = n
         if shards and shards[0].send[0].is_cuda:
@@ -246,7 +251,7 @@ class DistFabric:
             for j, kind in enumerate(kinds):
                 n_out, n_in = counts[0][j][p], recv[j][p]
                 if n_out:
-                    nb = n_out * REC_BYTES[kind]
+                    nb = n_out * sh.rec_bytes[kind]
                     row = 0 if kind in (5, 6) else p   # the same slice goes to every peer: staged once
                     out = stage[0][kind][row, :nb]
                     if (kind, row) not in staged:
@@ -254,7 +259,7 @@ class DistFabric:
                         staged.add((kind, row))
                     ops.append(dist.P2POp(dist.isend, out, p, group=grp))
                 if n_in:
-                    tmp = stage[1][kind][p, : n_in * REC_BYTES[kind]]
+                    tmp = stage[1][kind][p, : n_in * sh.rec_bytes[kind]]
                     landing.append((kind, p, tmp))
                     ops.append(dist.P2POp(dist.irecv, tmp, p, group=grp))
         if ops:

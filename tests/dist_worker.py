@@ -13,6 +13,7 @@ def main():
     n, p, loss, seed, ticks = (int(x) for x in sys.argv[1:6])
     mode = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     gc, pull = bool(mode & 1), bool(mode & 2)       # 1: settling, 2: join-time pull (round 0)
+    cap = mode >> 8                                 # bits 8..: bounded member maps with this view_cap (no other option)
     import torch.distributed as dist
     dist.init_process_group("gloo")
     rank = dist.get_rank()
@@ -25,6 +26,8 @@ def main():
         sc.suspicionTicks, sc.retransmitMult, sc.gcTicks = 5, 1, _abi.GC_AUTO
     if pull:
         sc.joinPull = 1
+    if cap:
+        sc.viewCap, sc.maxSubjects = cap, 0
     if os.environ.get("SWIM_DIST_DEVICE", "cpu") == "cuda":
         # all ranks share GPU 0 (RCCL refuses two ranks on one device): the real HIP library, device
         # buffers wrapped zero-copy, records staged through host memory over gloo

@@ -716,3 +716,32 @@ def test_full_event_stream_at_65536_members(oracle_abi, hip_abi):
     causes = {e[5] for e in ea}
     assert total > 1000000 and b.counters()["events_dropped"] == 0
     assert a.firstDetection() == b.firstDetection()
+
+
+@pytest.mark.parametrize("n,shards,cap,churn", [(4096, 4, 16, 10), (65536, 8, 64, 10), (262144, 4, 64, 1)])
+def test_sharded_cluster_of_bounded_handles_on_one_gpu(oracle_abi, hip_abi, n, shards, cap, churn):
+    """BASELINE config 5 is a CLUSTER: 16 M members over 8 GPUs at 30 % loss.  Bounded handles sharded by id range (DESIGN.md 7b:
+    one all-gather of queue lines + member bytes and one all-to-all-v of 8-byte delivery records per tick), here as several
+    handles on this GPU, against the unsharded oracle: digest, every counter, JOIN / REFUTE events, views and queues on
+    either side of the shard borders, first-detection ticks."""
+    from swim_amd.shard import LocalFabric, ShardedSim
+    ticks = 24
+    sc, crashes, faults = _config5_case(n, cap, churn, ticks)
+    a = Sim.create(oracle_abi, sc)
+    _oracle_threads(a)
+    b = ShardedSim(hip_abi, sc, LocalFabric(shards), device="cuda:0")
+    for s in (a, b):
+        workloads.apply_crashes(s, crashes)
+        for (t, m, up) in faults:
+            s.scheduleFault(t, m, up)
+    per, done = n // shards, 0
+    while done < ticks:
+        a.step(8); b.step(8); done += 8
+        assert a.counters() == b.counters(), "counters differ after %d ticks" % done
+        assert a.digest() == b.digest(), "digest differs after %d ticks" % done
+        assert a.drainEventsRaw() == b.drainEventsRaw()
+        for o in (0, per - 1, per, n - 1):
+            assert a.members(o) == b.members(o)
+            assert a.readMember(o) == b.readMember(o)
+    assert a.firstDetection() == b.firstDetection()
+    b.close()

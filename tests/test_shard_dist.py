@@ -42,3 +42,10 @@ def test_one_process_per_shard_gloo_with_replicated_masks():
     with loss, settling and the join-time pull on top."""
     run_world(4, (256, 3, 50000, 9, 60, 0), 29616, SWIMSIM_SHARD_REPLICATED_MASKS="1")
     run_world(2, (192, 3, 20000, 8, 130, 3), 29617, SWIMSIM_SHARD_REPLICATED_MASKS="1")
+
+
+def test_one_process_per_shard_gloo_with_bounded_member_maps():
+    """A cluster of bounded handles (view_cap = 16 / 64), one process per shard: the all-gather of queue lines
+    and member bytes and the 8-byte delivery records through swimsim_shard_step's callback, 30 % loss, a crash and a rejoin."""
+    run_world(2, (192, 3, 300000, 11, 40, 16 << 8), 29618)
+    run_world(4, (256, 3, 300000, 12, 30, 64 << 8), 29619)
