@@ -430,6 +430,12 @@ int swimsim_shard_phase3(swimsim_t* h, const uint32_t* p_counts_in, const uint32
  * step with SWIMSIM_ERR_STATE.  Every shard of the cluster must make the same call; this is what a host
  * without swim_amd/shard.py binds (haskell/Swim/Sim.hs: stepShard) -- MPI_Alltoallv, RCCL send/recv or, as
  * swim_amd/shard.py does, torch.distributed. */
+/* A cluster of BOUNDED handles (view_cap) that live in one process -- one per GPU, or several on one GPU: `nticks` periods with the
+ * tick loop AND the exchange inside the library.  The all-gather and the all-to-all-v of DESIGN.md 7b are device-to-device (peer)
+ * copies enqueued on the handles' streams and ordered by events; the receiving kernels read the record counts from device
+ * memory: no host synchronisation between the first tick and the last.  hs[k] = shard k of n handles of one configuration with
+ * one fault schedule.  (Multi-process clusters use swimsim_shard_step with the embedder's exchange.) */
+int swimsim_cluster_step(swimsim_t** hs, uint32_t n, uint32_t nticks);
 typedef int (*swimsim_exchange_fn)(void* ctx, int round, const uint32_t* counts_out /*[3*n_shards]*/,
                                    uint32_t* counts_in /*[3*n_shards]*/);
 int swimsim_shard_step(swimsim_t* h, uint32_t nticks, swimsim_exchange_fn xchg, void* ctx);

@@ -106,6 +106,7 @@ _PRODUCT_ONLY = {
     "shard_phase2": (C.c_int, [_H, _U32P, _U32P]),
     "shard_phase3": (C.c_int, [_H, _U32P, _U32P]),
     "shard_step": (C.c_int, [_H, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "cluster_step": (C.c_int, [C.POINTER(_H), C.c_uint32, C.c_uint32]),
     "shard_settle_buffers": (C.c_int, [_H, _VPP, _VPP, _U32P]),
     "shard_settle_counts": (C.c_int, [_H, _U32P]),
     "shard_settle_commit": (C.c_int, [_H, _U32P]),

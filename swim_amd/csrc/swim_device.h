@@ -202,6 +202,7 @@ struct DevState {
   uint2* sp_ord;           // [64][sp_ord_cap] {dst, src} (global ids), unsorted; sp_ord_n[64 * 16] entries per list
   uint32_t* sp_ord_n;
   uint32_t sp_ord_cap;
+  uint32_t* sp_pin;        // [MAX_SHARDS] records received from every peer this tick (swimsim_cluster_step: device-side counts)
 #ifdef SWIM_ABLATE
   uint32_t dbg;            // measurement build (scripts/ablate.py): memory operations the tick kernels leave out
 #endif

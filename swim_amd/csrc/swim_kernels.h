@@ -958,6 +958,9 @@ __global__ __launch_bounds__(BLOCK, 5) void records_kernel(DevState s, uint32_t 
 #ifndef SWIM_MERGE_WAVES         // measured with the todo batch (profiles/r03af_*; lossless / 1 % loss, us per merge): 4 waves x batch 2:
 #define SWIM_MERGE_WAVES 4       // 144 / 643; 5 x 2: 147 / 628; 4 x 4: 154 / 634; 5 x 4 (spills): 166 / 647
 #endif
+#ifndef SWIM_MERGE_SORT         // 1: a workgroup's members are dealt to its threads in descending order of work (merge_kernel)
+#define SWIM_MERGE_SORT 0
+#endif
 #ifndef SWIM_TODO_BATCH         // todo entries (explicit records' survivors) whose view cells merge_kernel loads together
 #define SWIM_TODO_BATCH 2
 #endif
@@ -992,9 +995,37 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
   __shared__ uint32_t wfl[BLOCK];
   __shared__ uint32_t wmax[BLOCK / 64];
   __shared__ uint4 ring_sh[KN_BITS];                    // this tick's ring (begin_kernel): position -> {slot, key, base, subject}
-  const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
-  const uint32_t i = s.lo + li;                    // global id
   const uint32_t tid = threadIdx.x;
+#if SWIM_MERGE_SORT
+  // Members to threads BY WORK: a wave executes the state rule as often as its busiest lane (the rumour loop runs max-over-lanes
+  // batches: ~4 for a mean of 1.3 per member), so the workgroup's 256 members are dealt to its threads in descending order of
+  // the rumours they have not seen yet (+ failed probes + explicit-record entries): the busiest 64 share a wave, the idle
+  // ones another.  Everything below addresses the member through li; its queue line is assembled in its thread's LDS
+  // columns as before.
+  __shared__ uint32_t sort_cnt[16], sort_base[16];
+  __shared__ uint32_t perm_sh[BLOCK];
+  uint32_t li;
+  {
+    const uint32_t li0 = blockIdx.x * BLOCK + tid;
+    uint32_t w = 0;
+    if (li0 < s.N && mi_up(s.minfo[s.lo + li0])) {
+      const unsigned long long f = (s.inmask[li0] | s.ackmask[li0]) & ~(s.pk[li0].y & ~stale_positions(s.g[G_PREV], s.g[G_HEAD]));
+      w = min(15u, 1u + (uint32_t)__popcll(f) + ((s.probe_out[li0] >> 5) & 31u) + min(s.inbox_cnt[li0], 6u));
+    }
+    if (tid < 16u) sort_cnt[tid] = 0;
+    __syncthreads();
+    const uint32_t r = atomicAdd(&sort_cnt[w], 1u);
+    __syncthreads();
+    if (tid == 0) { uint32_t b = 0; for (int k = 15; k >= 0; --k) { sort_base[k] = b; b += sort_cnt[k]; } }
+    __syncthreads();
+    perm_sh[sort_base[w] + r] = tid;
+    __syncthreads();
+    li = blockIdx.x * BLOCK + perm_sh[tid];
+  }
+#else
+  const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
+#endif
+  const uint32_t i = s.lo + li;                    // global id
   SECT_BEGIN(0);
   if (blockIdx.x == 0 && threadIdx.x == 0) s.g[G_OVF0 + ((t + 1) & 1u)] = 0;  // next tick's overflow list
   const uint32_t mi = li < s.N ? s.minfo[i] : 0u;
@@ -1452,7 +1483,11 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
       const uint32_t m = wbase + 16u * k + (lane >> 2);          // thread whose line this lane helps to store
       const uint32_t fl = wfl[m];
       if ((fl & 1u) && !ABL(ABL_LINE_STORE)) {
+#if SWIM_MERGE_SORT
+        const uint32_t gm = blockIdx.x * BLOCK + perm_sh[m];         // the member thread m stepped
+#else
         const uint32_t gm = blockIdx.x * BLOCK + m;
+#endif
         uint4* line = reinterpret_cast<uint4*>(s.pb + ((size_t)(fl >> 1) * s.N + gm) * PB_SLOTS);
         line[q] = make_uint4(asm_[4 * q][m], asm_[4 * q + 1][m], asm_[4 * q + 2][m], asm_[4 * q + 3][m]);
       }

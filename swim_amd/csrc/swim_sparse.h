@@ -818,10 +818,11 @@ __global__ __launch_bounds__(BLOCK) void sp_route_kernel(DevState s) {
     }
   }
 }
-// the records the peers sent: append src to my member's inbox
-__global__ __launch_bounds__(BLOCK) void sp_ingest_kernel(DevState s, uint32_t t, PeerCounts p_counts) {
+// the records the peers sent: append src to my member's inbox.  dev_counts: the number of records of every peer's segment comes
+// from sp_pin[] in device memory (swimsim_cluster_step copies the senders' counters there: no host in the loop)
+__global__ __launch_bounds__(BLOCK) void sp_ingest_kernel(DevState s, uint32_t t, PeerCounts p_counts, uint32_t dev_counts) {
   for (uint32_t peer = 0; peer < s.n_shards; ++peer) {
-    const uint32_t np = min(p_counts.v[peer], s.p_cap);
+    const uint32_t np = peer == s.shard ? 0u : min(dev_counts ? s.sp_pin[peer] : p_counts.v[peer], s.p_cap);
     for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < np; k += gridDim.x * BLOCK) {
       const uint4 r = s.p_recv[(size_t)peer * s.p_cap + k];
       if (is_local(s, r.x)) push(s, t, r.x - s.lo, r.y);

@@ -452,6 +452,7 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
       CK(dev_alloc(h, &d.sp_qall, (size_t)NT * PB_SLOTS, 0));
       CK(dev_alloc(h, &d.sp_ord, (size_t)64 * d.sp_ord_cap, 0));
       CK(dev_alloc(h, &d.sp_ord_n, (size_t)64 * 16, 0));
+      CK(dev_alloc(h, &d.sp_pin, (size_t)MAX_SHARDS, 0));
       CK(dev_alloc(h, &d.p_send, (size_t)d.n_shards * d.p_cap, 0));
       CK(dev_alloc(h, &d.p_recv, (size_t)d.n_shards * d.p_cap, 0));
     }
@@ -1212,7 +1213,7 @@ int swimsim_shard_phase3(swimsim_t* h, const uint32_t* p_counts_in, const uint32
   HIPCHK(h, hipSetDevice(h->device));
   if (h->d.C) {
     const uint32_t t = (uint32_t)h->tick, tk = tick_key(h->cfg.seed, t);
-    hipLaunchKernelGGL(sp_ingest_kernel, dim3(std::min<uint32_t>(1024u, (h->d.N + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, h->stream, h->d, t, peer_counts(h, p_counts_in));
+    hipLaunchKernelGGL(sp_ingest_kernel, dim3(std::min<uint32_t>(1024u, (h->d.N + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, h->stream, h->d, t, peer_counts(h, p_counts_in), 0u);
     if (h->timing) (void)hipEventRecord(h->tick_ev[1], h->stream);
     launch_sparse_merge(h, t, tk);
     if (h->timing) (void)hipEventRecord(h->tick_ev[2], h->stream);
@@ -1279,6 +1280,92 @@ int swimsim_shard_settle_commit(swimsim_t* h, const uint32_t* counts_in) {
   h->settled_alive_tick = ~0ull;                  // the bases just changed: a list read_view cached between phase 3 and now is stale
   h->shard_phase = 0;
   return SWIMSIM_OK;
+}
+
+/* A whole cluster of bounded handles in ONE process (one handle per GPU, or several on one GPU): the tick loop AND the exchange
+ * inside the library, enqueued on the handles' streams -- device-to-device (peer) copies ordered by events, the record counts
+ * read by the receiving kernels from device memory.  No host synchronisation between the first tick and the last: what a
+ * single-process host (a Haskell program with eight GPUs, tests/..., scripts/config5_cluster_one_gpu.py) calls instead of lending
+ * an exchange callback to swimsim_shard_step.  hs[k] must be shard k of n bounded (view_cap) handles of one configuration with the
+ * same fault schedule. */
+int swimsim_cluster_step(swimsim_t** hs, uint32_t n, uint32_t nticks) {
+  if (!hs || n < 2 || n > (uint32_t)MAX_SHARDS) return SWIMSIM_ERR_INVALID;
+  for (uint32_t k = 0; k < n; ++k) {
+    swimsim* h = hs[k];
+    if (!h) return SWIMSIM_ERR_INVALID;
+    if (h->poisoned) return set_err(h, SWIMSIM_ERR_STATE, "handle is poisoned by an earlier capacity error");
+    if (!h->d.C || h->d.n_shards != n || h->d.shard != k || h->shard_phase != 0 || h->tick != hs[0]->tick || h->d.NT != hs[0]->d.NT)
+      return set_err(h, SWIMSIM_ERR_INVALID, "cluster_step: hs[k] must be shard k of n bounded handles of one cluster, between ticks");
+  }
+  std::vector<size_t> fend(n, 0), fpos(n, 0);
+  std::vector<std::vector<hipEvent_t>> ev(n, std::vector<hipEvent_t>(2, nullptr));
+  auto cleanup = [&]() { for (auto& e : ev) for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); };
+  for (uint32_t k = 0; k < n; ++k) {
+    swimsim* h = hs[k];
+    HIPCHK(h, hipSetDevice(h->device));
+    { int rc_ = upload_faults(h, nticks, &fend[k]); if (rc_) { cleanup(); return rc_; } }
+    for (int e = 0; e < 2; ++e) HIPCHK(h, hipEventCreate(&ev[k][e]));
+  }
+  const uint32_t N = hs[0]->d.N;
+  auto peer_copy = [&](swimsim* dst, void* to, swimsim* src, const void* from, size_t bytes) -> hipError_t {
+    return dst->device == src->device ? hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToDevice, dst->stream)
+                                      : hipMemcpyPeerAsync(to, dst->device, from, src->device, bytes, dst->stream);
+  };
+  for (uint32_t tck = 0; tck < nticks; ++tck) {
+    const uint32_t t = (uint32_t)hs[0]->tick, tk = tick_key(hs[0]->cfg.seed, t);
+    // phase 1 on every shard: the tick's scheduled changes, its slice of the lines into its replica
+    for (uint32_t k = 0; k < n; ++k) {
+      swimsim* h = hs[k];
+      HIPCHK(h, hipSetDevice(h->device));
+      const size_t f0 = fpos[k];
+      while (fpos[k] < fend[k] && h->faults[fpos[k]].tick <= t) ++fpos[k];
+      if (fpos[k] > f0) hipLaunchKernelGGL(sp_begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, h->d_faults + f0, (uint32_t)(fpos[k] - f0));
+      hipLaunchKernelGGL(sp_publish_kernel, dim3((N * PB_SLOTS + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, h->d, t);
+      HIPCHK(h, hipEventRecord(ev[k][0], h->stream));
+    }
+    // round 1, the all-gather: every shard copies every peer's slice of the queue lines and member bytes, then probes
+    for (uint32_t k = 0; k < n; ++k) {
+      swimsim* h = hs[k];
+      HIPCHK(h, hipSetDevice(h->device));
+      for (uint32_t p = 0; p < n; ++p) {
+        if (p == k) continue;
+        swimsim* q = hs[p];
+        HIPCHK(h, hipStreamWaitEvent(h->stream, ev[p][0], 0));
+        HIPCHK(h, peer_copy(h, h->d.sp_qall + (size_t)q->d.lo * PB_SLOTS, q, q->d.sp_qall + (size_t)q->d.lo * PB_SLOTS, (size_t)N * PB_SLOTS * sizeof(uint2)));
+        HIPCHK(h, peer_copy(h, h->d.mb + q->d.lo, q, q->d.mb + q->d.lo, (size_t)N));
+      }
+      launch_sparse_probe(h, t, tk);
+      hipLaunchKernelGGL(sp_route_kernel, dim3(std::min<uint32_t>(1024u, (N + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, h->stream, h->d);
+      HIPCHK(h, hipEventRecord(ev[k][1], h->stream));
+    }
+    // round 2, the all-to-all-v: every peer's segment for me (its whole capacity: the true count travels as a word next to it)
+    for (uint32_t k = 0; k < n; ++k) {
+      swimsim* h = hs[k];
+      HIPCHK(h, hipSetDevice(h->device));
+      for (uint32_t p = 0; p < n; ++p) {
+        if (p == k) continue;
+        swimsim* q = hs[p];
+        HIPCHK(h, hipStreamWaitEvent(h->stream, ev[p][1], 0));
+        HIPCHK(h, peer_copy(h, h->d.sp_pin + p, q, q->d.send_cnt + 1 * MAX_SHARDS + k, sizeof(uint32_t)));
+        HIPCHK(h, peer_copy(h, h->d.p_recv + (size_t)p * h->d.p_cap, q, q->d.p_send + (size_t)k * q->d.p_cap, (size_t)q->d.p_cap * sizeof(uint4)));
+      }
+      hipLaunchKernelGGL(sp_ingest_kernel, dim3(std::min<uint32_t>(1024u, (N + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, h->stream, h->d, t, PeerCounts{}, 1u);
+      launch_sparse_merge(h, t, tk);
+    }
+    for (uint32_t k = 0; k < n; ++k) hs[k]->tick++;
+  }
+  int rc = SWIMSIM_OK;
+  for (uint32_t k = 0; k < n; ++k) {
+    swimsim* h = hs[k];
+    (void)hipSetDevice(h->device);
+    h->faults.erase(h->faults.begin(), h->faults.begin() + (long)fpos[k]);
+    hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(h->stream);
+    if (e1 != hipSuccess || e2 != hipSuccess) { rc = set_err(h, SWIMSIM_ERR_DEVICE, std::string("cluster_step: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2)); continue; }
+    const int rc_ = check_device_errors(h);
+    if (rc_ && !rc) rc = rc_;
+  }
+  cleanup();
+  return rc;
 }
 
 int swimsim_shard_step(swimsim_t* h, uint32_t nticks, swimsim_exchange_fn xchg, void* ctx) {

@@ -349,6 +349,20 @@ class ShardedSim:
         f, sh = self.fabric, self.shards
         if len(sh) == 1 and self.n_shards > 1:
             return self._step_by_library(nticks)
+        import os
+        if len(sh) == self.n_shards > 1 and self.resolved.view_cap and os.environ.get("SWIMSIM_CLUSTER_STEP", "1") != "0":
+            # every shard of a cluster of bounded handles lives in this process: the library steps the cluster itself, the
+            # exchange enqueued on the handles' streams (swimsim_cluster_step: no host in the loop)
+            import time
+            t0 = time.perf_counter()
+            arr = (C.c_void_p * self.n_shards)(*[s.sim._h for s in sh])
+            rc = sh[0].sim._abi.cluster_step(arr, self.n_shards, nticks)
+            if rc != _abi.OK:
+                bad = next((s for s in sh if (s.sim._abi.last_error(s.sim._h) or b"")), sh[0])
+                raise SwimError(rc, (bad.sim._abi.last_error(bad.sim._h) or b"").decode())
+            self.phase_seconds[4] += time.perf_counter() - t0
+            self.timed_ticks += nticks
+            return
         import time
         acc = self.phase_seconds
         for _ in range(nticks):

@@ -169,13 +169,17 @@ def test_waves_that_step_several_members(oracle_abi, emu_abi, monkeypatch):
 
 @pytest.mark.parametrize("n,shards,cap,p,loss,seed", [(128, 2, 16, 3, 0, 1), (256, 4, 8, 3, 300000, 2), (192, 3, 32, 2, 100000, 3), (512, 8, 64, 3, 300000, 4),
                                                       (240, 2, 200, 4, 250000, 5)])
-def test_a_sharded_cluster_of_bounded_handles_matches_the_oracle(oracle_abi, emu_abi, n, shards, cap, p, loss, seed):
+def test_a_sharded_cluster_of_bounded_handles_matches_the_oracle(oracle_abi, emu_abi, monkeypatch, n, shards, cap, p, loss, seed):
     """BASELINE config 5 is 16 M members over 8 GPUs: the population of bounded handles split by contiguous id range (DESIGN.md
     section 7b).  Per tick ONE all-gather (everybody's start-of-tick queue line and byte) and ONE all-to-all-v of 8-byte
     delivery records; every observable of the cluster equals the unsharded oracle's, with crashes and rejoins on either side
     of the shard borders."""
     from swim_amd.shard import LocalFabric, ShardedSim
     from tests.test_shard_hostemu import lockstep
+    # all shards in one process: by default the library steps the cluster itself (swimsim_cluster_step: the exchange as copies on
+    # the handles' streams, counts in device memory); odd seeds take the phase calls + the fabric's exchange instead -- the path
+    # a multi-process cluster takes (tests/test_shard_dist.py runs that one over gloo)
+    monkeypatch.setenv("SWIMSIM_CLUSTER_STEP", "0" if seed % 2 else "1")
     sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, eventMask=0x1F, suspicionTicks=6, viewCap=cap)
     a = Sim.create(oracle_abi, sc)
     b = ShardedSim(emu_abi, sc, LocalFabric(shards))

@@ -745,3 +745,28 @@ def test_sharded_cluster_of_bounded_handles_on_one_gpu(oracle_abi, hip_abi, n, s
             assert a.readMember(o) == b.readMember(o)
     assert a.firstDetection() == b.firstDetection()
     b.close()
+
+
+@pytest.mark.parametrize("block", range(2))
+def test_random_bounded_configurations_on_the_gpu(oracle_abi, hip_abi, block):
+    """The randomised sweep of tests/test_random_sweep.py for bounded member maps on the real thing (sizes up to 20 000, 1-8
+    shards on this GPU, capacities 4 ... 256, numToGossip up to 10, loss up to 50 %, churn)."""
+    import random
+    from swim_amd.shard import LocalFabric, ShardedSim
+    from tests.test_random_sweep import _random_bounded_case
+    rng = random.Random(9100 + block)
+    for _ in range(8):
+        sc, shards, faults, what = _random_bounded_case(rng, [8, 64, 300, 1024, 4096, 20000], 200)
+        sc.eventCap = 1 << 22
+        a = Sim.create(oracle_abi, sc)
+        _oracle_threads(a)
+        b = Sim.create(hip_abi, sc) if shards == 1 else ShardedSim(hip_abi, sc, LocalFabric(shards), device="cuda:0")
+        for (t, m, up) in faults:
+            a.scheduleFault(t, m, up); b.scheduleFault(t, m, up)
+        for _t in range(rng.choice([3, 5])):
+            a.step(5); b.step(5)
+            assert a.counters() == b.counters(), ("counters", what)
+            assert a.digest() == b.digest(), ("digest", what)
+            assert a.drainEventsRaw() == b.drainEventsRaw(), ("events", what)
+        assert a.firstDetection() == b.firstDetection(), ("first detection", what)
+        a.close(); b.close()
