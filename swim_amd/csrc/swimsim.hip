@@ -1298,13 +1298,15 @@ int swimsim_cluster_step(swimsim_t** hs, uint32_t n, uint32_t nticks) {
       return set_err(h, SWIMSIM_ERR_INVALID, "cluster_step: hs[k] must be shard k of n bounded handles of one cluster, between ticks");
   }
   std::vector<size_t> fend(n, 0), fpos(n, 0);
-  std::vector<std::vector<hipEvent_t>> ev(n, std::vector<hipEvent_t>(2, nullptr));
+  // per handle: [0] its slice of the replicas is published, [1] its records are routed, [2] it has copied what it needs from its
+  // peers' send buffers (a peer may then reuse them: the next tick's publish zeroes the counters, its route overwrites the segments)
+  std::vector<std::vector<hipEvent_t>> ev(n, std::vector<hipEvent_t>(3, nullptr));
   auto cleanup = [&]() { for (auto& e : ev) for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); };
   for (uint32_t k = 0; k < n; ++k) {
     swimsim* h = hs[k];
     HIPCHK(h, hipSetDevice(h->device));
     { int rc_ = upload_faults(h, nticks, &fend[k]); if (rc_) { cleanup(); return rc_; } }
-    for (int e = 0; e < 2; ++e) HIPCHK(h, hipEventCreate(&ev[k][e]));
+    for (int e = 0; e < 3; ++e) HIPCHK(h, hipEventCreate(&ev[k][e]));
   }
   const uint32_t N = hs[0]->d.N;
   auto peer_copy = [&](swimsim* dst, void* to, swimsim* src, const void* from, size_t bytes) -> hipError_t {
@@ -1319,6 +1321,7 @@ int swimsim_cluster_step(swimsim_t** hs, uint32_t n, uint32_t nticks) {
       HIPCHK(h, hipSetDevice(h->device));
       const size_t f0 = fpos[k];
       while (fpos[k] < fend[k] && h->faults[fpos[k]].tick <= t) ++fpos[k];
+      if (tck) for (uint32_t p = 0; p < n; ++p) if (p != k) HIPCHK(h, hipStreamWaitEvent(h->stream, ev[p][2], 0));   // the peers are done with my send buffers
       if (fpos[k] > f0) hipLaunchKernelGGL(sp_begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, h->d_faults + f0, (uint32_t)(fpos[k] - f0));
       hipLaunchKernelGGL(sp_publish_kernel, dim3((N * PB_SLOTS + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, h->d, t);
       HIPCHK(h, hipEventRecord(ev[k][0], h->stream));
@@ -1349,6 +1352,7 @@ int swimsim_cluster_step(swimsim_t** hs, uint32_t n, uint32_t nticks) {
         HIPCHK(h, peer_copy(h, h->d.sp_pin + p, q, q->d.send_cnt + 1 * MAX_SHARDS + k, sizeof(uint32_t)));
         HIPCHK(h, peer_copy(h, h->d.p_recv + (size_t)p * h->d.p_cap, q, q->d.p_send + (size_t)k * q->d.p_cap, (size_t)q->d.p_cap * sizeof(uint4)));
       }
+      HIPCHK(h, hipEventRecord(ev[k][2], h->stream));
       hipLaunchKernelGGL(sp_ingest_kernel, dim3(std::min<uint32_t>(1024u, (N + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, h->stream, h->d, t, PeerCounts{}, 1u);
       launch_sparse_merge(h, t, tk);
     }
