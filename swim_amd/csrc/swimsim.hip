@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -53,6 +54,7 @@ struct swimsim {
   bool timing = false;                         // HIP-event timing of the tick kernels
   std::vector<hipEvent_t> ev_pool;             // 3 events per tick: before probe, between, after merge
   double probe_ms = 0, merge_ms = 0; uint64_t timed_ticks = 0;
+  double graph_ms = 0;                      // SWIMSIM_GRAPH=1: launch-to-completion time of the last step's graph
   bool poisoned = false;
   std::string err;
   std::vector<InjectRec> injections;           // swimsim_inject_rumor: delivered in the next tick stepped
@@ -677,6 +679,11 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
     }
   }
   size_t fpos = 0;
+  // measurement knob: SWIMSIM_GRAPH=1 captures the call's launches into ONE HIP graph and launches that --
+  // what a graph does to the boundaries between the tick's kernels (scripts/graph_time.py)
+  static const bool want_graph = [] { const char* e = std::getenv("SWIMSIM_GRAPH"); return e && e[0] == '1'; }();
+  const bool graph = want_graph && !h->timing && h->injections.empty() && nticks > 0;
+  if (graph) HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
   for (uint32_t k = 0; k < nticks; ++k) {
     const uint32_t t = (uint32_t)h->tick;
     hipEvent_t* ev = h->timing ? &h->ev_pool[(size_t)k * 3] : nullptr;
@@ -725,6 +732,16 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
   h->faults.erase(h->faults.begin(), h->faults.begin() + (long)fpos);
   // the last tick's settling is committed before anybody reads state (between ticks begin_kernel does it)
   if (h->d.G && nticks) hipLaunchKernelGGL(settle_flush_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d);
+  if (graph) {
+    hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+    HIPCHK(h, hipStreamEndCapture(h->stream, &g));
+    HIPCHK(h, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    const auto w0 = std::chrono::steady_clock::now();
+    HIPCHK(h, hipGraphLaunch(ge, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->graph_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+    (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
+  }
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (h->timing) {
@@ -965,6 +982,7 @@ int swimsim_table_stats(swimsim_t* h, uint64_t* out, size_t n) {
   out[0] = g[G_NSLOTS]; out[1] = g[G_NLIVE]; out[2] = g[G_NFREE]; out[3] = g[G_NRUM]; out[4] = h->d.R_phys;   // (bounded member maps: all zero, no view rows)
   if (n >= 7) { out[5] = std::max(g[G_OVF0], g[G_OVF1]); out[6] = h->d.ovf_cap; }
   if (n >= 9 && h->d.C) { out[7] = h->sp_grid_probe; out[8] = h->sp_grid_merge; }   // bounded member maps: the persistent grids (workgroups)
+  if (n >= 10) out[9] = (uint64_t)(h->graph_ms * 1000.0);                           // SWIMSIM_GRAPH=1: the last step's graph, launch to completion, us
 #ifdef SWIM_REC_STATS
   if (n >= 10) { out[7] = g[90]; out[8] = g[91]; out[9] = g[92]; }
 #endif   // inbox overflow list: entries in the fuller of the two, room
