@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SWIMSIM_ABI_VERSION 5u
+#define SWIMSIM_ABI_VERSION 6u
 
 /* ---- status codes ------------------------------------------------------ */
 typedef enum swimsim_status {
@@ -121,7 +121,22 @@ typedef struct swimsim_config {
                                   from the default (`Map String Member`, src/Types.hs:55, with a capacity), in
                                   [SWIMSIM_VIEW_CAP_MIN, SWIMSIM_VIEW_CAP_MAX]; see "Bounded member maps" below.
                                   0: unbounded (a view row per subject in circulation, max_subjects)   */
+  uint32_t strict_reference_rules; /* 1: the LITERAL suspectOrDeadNode' (src/Core.hs:142-187) instead of the commutative
+                                  merge -- see "Strict reference rules" below.  0: the merge   */
 } swimsim_config_t;
+
+/* Strict reference rules (strict_reference_rules = 1; DESIGN.md sections 2.9 and 3, D13).  The reference's state rule is not the
+ * max-merge: beyond "an older incarnation is ignored" (src/Core.hs:151) it IGNORES a Suspect unless the entry is Alive (livenessCheck
+ * IsSuspect, :183) and a Dead when the entry is Dead already (IsDead, :184) -- at ANY incarnation, so a Suspect at a higher
+ * incarnation than a Suspect / Dead entry, or a Dead at a higher incarnation than a Dead entry, changes nothing there (the merge takes
+ * them).  That rule depends on the order in which a member's proposals of one period are applied, which the reference leaves to its
+ * scheduler; here the order is CANONICAL: the member's due suspicion deadlines, then its own failed probes, then the rumours delivered
+ * to it sorted by (subject, incarnation<<2|state) ascending, each applied to what the ones before it left.  (Alive rumours follow the
+ * merge in both modes: aliveNode is unwritten, src/Core.hs:197-218, D6; rumours about the member itself go to the refutation rule.)
+ * Because an ignored rumour may be accepted later -- after a refutation has made the entry Alive again -- no delivery may be filtered
+ * as "known already": every delivered queue entry is examined every time (the handle runs the exact record path in every tick), so a
+ * tick costs several times the default's.  Not combinable with view_cap, gc_ticks, join_pull, pull_ticks or sharding
+ * (SWIMSIM_ERR_INVALID). */
 
 /* Bounded member maps (view_cap = C > 0) -- what lets heavy message loss run at millions of members
  * per GPU (BASELINE config 5): there nearly every member is a subject of somebody's false suspicion all the time, and a

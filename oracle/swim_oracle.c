@@ -605,6 +605,12 @@ static int accept_key(octx_t* c, uint32_t i, uint32_t s, uint32_t key, uint8_t c
   return 1;
 }
 
+static int pend_cmp_subject_key(const void* a, const void* b) {
+  const opend_t* x = (const opend_t*)a; const opend_t* y = (const opend_t*)b;
+  if (x->subject != y->subject) return x->subject < y->subject ? -1 : 1;
+  return x->key < y->key ? -1 : x->key > y->key;
+}
+
 static void end_of_tick(octx_t* c, uint32_t i, const opend_t* pend, uint32_t npend,
                         const ofail_t* fails, uint32_t nfails) {
   swimoracle_t* o = c->o;
@@ -642,7 +648,16 @@ static void end_of_tick(octx_t* c, uint32_t i, const opend_t* pend, uint32_t npe
     accept_key(c, i, j, key, SWIMSIM_CAUSE_PROBE, &refute, &cand, self_inc_start);
   }
   /* phase 3: rumours received this tick (any order: the merge is commutative) */
-  if (o->shuffle_seed && npend > 1) {
+  if (o->literal_rule && npend > 1) {
+    /* the literal rule is not commutative: its order is CANONICAL (include/swimsim.h "Strict reference rules") -- by (subject,
+     * incarnation<<2|state) ascending, each rumour applied to what the ones before it left */
+    opend_t* srt = (opend_t*)malloc(npend * sizeof *srt);
+    memcpy(srt, pend, npend * sizeof *srt);
+    qsort(srt, npend, sizeof *srt, pend_cmp_subject_key);
+    for (uint32_t x = 0; x < npend; x++)
+      accept_key(c, i, srt[x].subject, srt[x].key, SWIMSIM_CAUSE_GOSSIP, &refute, &cand, self_inc_start);
+    free(srt);
+  } else if (o->shuffle_seed && npend > 1) {
     uint32_t* perm = (uint32_t*)malloc(npend * sizeof *perm);
     for (uint32_t x = 0; x < npend; x++) perm[x] = x;
     for (uint32_t x = npend - 1; x > 0; x--) {
@@ -1149,6 +1164,9 @@ static int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, char*
   if (c->target_scheme > SWIMSIM_TARGETS_ROBUST) { snprintf(err, errn, "unknown target_scheme"); return SWIMSIM_ERR_INVALID; }
   if (c->join_pull > 1) { snprintf(err, errn, "join_pull must be 0 or 1"); return SWIMSIM_ERR_INVALID; }
   if (c->pull_ticks == 1) { snprintf(err, errn, "pull_ticks must be 0 (off) or >= 2"); return SWIMSIM_ERR_INVALID; }
+  if (c->strict_reference_rules > 1) { snprintf(err, errn, "strict_reference_rules must be 0 or 1"); return SWIMSIM_ERR_INVALID; }
+  if (c->strict_reference_rules && (c->view_cap || c->gc_ticks || c->join_pull || c->pull_ticks)) {
+    snprintf(err, errn, "strict_reference_rules cannot be combined with view_cap, gc_ticks, join_pull or pull_ticks"); return SWIMSIM_ERR_INVALID; }
   if (c->view_cap) {
     if (c->view_cap < SWIMSIM_VIEW_CAP_MIN || c->view_cap > SWIMSIM_VIEW_CAP_MAX) { snprintf(err, errn, "view_cap must be 0 (unbounded) or in [%u, %u]", SWIMSIM_VIEW_CAP_MIN, SWIMSIM_VIEW_CAP_MAX); return SWIMSIM_ERR_INVALID; }
     if (c->gc_ticks || c->join_pull || c->pull_ticks || c->target_scheme != SWIMSIM_TARGETS_RANDOM) {
@@ -1169,6 +1187,7 @@ int swimoracle_create(const swimsim_config_t* cfg, swimoracle_t** out) {
   if (!o) return fail(NULL, SWIMSIM_ERR_NOMEM, "out of memory");
   o->cfg = c; o->N = c.n_members; o->P = (uint32_t)c.probes_per_tick; o->K = (uint32_t)c.indirect_k;
   o->S = c.suspicion_ticks; o->L = c.retransmit_mult * ceil_log2((uint64_t)c.n_members + 1);
+  o->literal_rule = c.strict_reference_rules != 0;   /* include/swimsim.h "Strict reference rules" (D13) */
   {
     uint64_t thr = ((uint64_t)c.loss_ppm << 32) / 1000000ull;
     o->loss_thr = thr > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)thr;
@@ -1455,7 +1474,7 @@ size_t swimoracle_remove_dead_nodes(swimsim_view_entry_t* entries, size_t n) {
  * commutative merge; *hits = proposals on which the two rules disagreed so far (D13).  While it stays 0 a
  * run is identical to the merge run -- which is how the tests narrow "parity unpinned". */
 int swimoracle_set_literal_rule(swimoracle_t* o, int on) {
-  if (!o || (on && o->C)) return SWIMSIM_ERR_INVALID;
+  if (!o || (on && (o->C || o->cfg.gc_ticks || o->cfg.join_pull || o->cfg.pull_ticks))) return SWIMSIM_ERR_INVALID;
   o->literal_rule = on != 0; return SWIMSIM_OK;
 }
 uint64_t swimoracle_d13_hits(const swimoracle_t* o) { return o ? o->d13_hits : 0; }

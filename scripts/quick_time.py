@@ -1,6 +1,6 @@
 """Quick per-kernel timing of the HIP tick at 1M members, saturated regime (not the bench contract).
 usage: quick_time.py [lib.so ...]   -- each library variant is timed with the library's own HIP events.
-env: WARM, TICKS, MEMBERS, REGIME (saturated|quiescent), SCHEME=robust, LOSS (ppm), GC=1"""
+env: WARM, TICKS, MEMBERS, REGIME (saturated|quiescent), SCHEME=robust, LOSS (ppm), GC=1, STRICT=1 (strict_reference_rules)"""
 import json, os, sys, time, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from swim_amd import Sim, workloads, _lib, _abi
@@ -14,6 +14,7 @@ for path in libs:
     if os.environ.get('GC'):
         sc.gcTicks = _abi.GC_AUTO
     sc.targetScheme = 1 if os.environ.get('SCHEME') == 'robust' else 0
+    sc.strictReferenceRules = bool(os.environ.get('STRICT'))
     s = Sim.create(abi, sc); workloads.apply_crashes(s, crashes)
     s.step(WARM)
     s.kernelTimingEnable(True)

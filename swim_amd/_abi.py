@@ -8,7 +8,7 @@ that loading happens in tests/ only, never in this package.
 """
 import ctypes as C
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 OK = 0
 ERR_INVALID, ERR_DEVICE, ERR_NOMEM, ERR_CAPACITY, ERR_STATE, ERR_BUFFER = -1, -2, -3, -4, -5, -6
@@ -41,7 +41,7 @@ class Config(C.Structure):
         ("inbox_cap", C.c_uint32),
         ("device", C.c_int32), ("shard_index", C.c_uint32), ("n_shards", C.c_uint32),
         ("target_scheme", C.c_uint32), ("join_pull", C.c_uint32), ("pull_ticks", C.c_uint32),
-        ("view_cap", C.c_uint32),
+        ("view_cap", C.c_uint32), ("strict_reference_rules", C.c_uint32),
     ]
 
 

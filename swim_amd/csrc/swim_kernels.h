@@ -240,7 +240,9 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
   const bool act = mi_up(mi);
   // masks are exact only if few rumour ids appeared since they were built (swim_device.h)
   const uint32_t Hprev = s.g[G_PREV], H = s.g[G_HEAD];
-  const bool use_mask = H - Hprev <= MASK_SLACK;
+  // (strict reference rules: never -- a rumour the literal rule ignored may be accepted later, so no delivery may be filtered as
+  // "known already": every delivery is an explicit record, every entry of its line is examined; include/swimsim.h)
+  const bool use_mask = H - Hprev <= MASK_SLACK && !s.strict;
   const unsigned long long stale = stale_positions(Hprev, H);   // ring positions nobody may trust this tick
   unsigned n_pings = 0;
   unsigned payloads = 0, rumors = 0, dfail = 0, preqs = 0, susp = 0, fsusp = 0;
@@ -1177,6 +1179,9 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
     if (!(have & HAVE_CELL) && !ABL(ABL_V_LOAD)) e = s.V[vidx(s, li, slot)];
     const uint32_t curk = e.x ? e.x : ((have & HAVE_BASE) ? sbase : s.slot_base[slot]);   // untouched cell: the settled base
     if (key <= curk) return;                     // old incarnation / weaker state: ignore (:151)
+    // strict reference rules: the literal livenessCheck (src/Core.hs:182-184) -- a Suspect only on an Alive entry, a Dead unless the
+    // entry is Dead already, whatever the incarnations (the merge above would take both at a higher incarnation: D13)
+    if (s.strict && (((key & 3u) == ST_SUSPECT && (curk & 3u) != ST_ALIVE) || ((key & 3u) == ST_DEAD && (curk & 3u) == ST_DEAD))) return;
     PSTAT(6); PSTAT(psite); SECT_COUNT(21);
     if (!ABL(ABL_V_STORE)) s.V[vidx(s, li, slot)] = make_uint2(key, t + 1);                    // memberLastChange = now (:176)
     if (s.G) s.slot_last[slot] = t;              // same value from every writer
@@ -1352,6 +1357,24 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
       kn |= s.kn_rec[li];                          // ring positions of the ids the records carried
       const uint4 sg = s.todo_seg[li];             // the list in two segments (records_kernel; one from the phase above)
       auto td = [&](uint32_t x) -> uint2 { return s.todo[x < sg.y ? (size_t)sg.x + x : (size_t)sg.z + (x - sg.y)]; };
+      if (s.strict) {
+        // strict reference rules: the literal rule is not commutative -- the delivered rumours are applied in the canonical order, by
+        // (subject, key) ascending (rows stand for subjects: by (row, key); the order ACROSS subjects changes nothing).  A selection
+        // sort over the list where it lies -- the smallest entry above the last one applied, again and again: duplicates cost one
+        // pass together; the mode is for checking runs against the reference's rule, not for speed.
+        unsigned long long last = 0;
+        for (;;) {
+          unsigned long long best = ~0ull; uint32_t brid = 0;
+          for (uint32_t x = 0; x < cnt; ++x) {
+            const uint2 e2 = td(x);
+            const unsigned long long k = (((unsigned long long)pe_slot(e2.x) << 32) | e2.y) + 1ull;
+            if (k > last && k < best) { best = k; brid = pe_rid(e2.x); }
+          }
+          if (best == ~0ull) break;
+          last = best;
+          examine((uint32_t)((best - 1ull) >> 32), (uint32_t)(best - 1ull), 2u, true, brid);
+        }
+      } else {
       constexpr int TB = SWIM_TODO_BATCH;
       uint2 en[TB];
 #pragma unroll
@@ -1381,6 +1404,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
           PSTAT(14);
           examine_with(pe_slot(e2.x), e2.y, 2u, true, pe_rid(e2.x), again ? (HAVE_BASE | HAVE_SUBJ) : EX_ALL, e, sb, sj);
         }
+      }
       }
     }
     // ---- refutation: bump own incarnation past the rumour's (src/Core.hs:155-166; D10); rumours at
@@ -2169,7 +2193,8 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
     // back INTO that zone for D > 2^RID_BITS - RID_NEAR - KW_BITS.  After such a tick (48 896 new rumours at once with
     // 16-bit ids: heavy message loss) every line of this tick is written without ids: masks and the known-ring
     // are out of the game anyway (explicit records), exactness does not depend on them
-    s.g[G_RIDS_OFF] = (s.g[G_HEAD] - s.g[G_PREV] > RID_MASK + 1u - RID_NEAR - KW_BITS) ? 1u : 0u;
+    // (strict reference rules: always -- no filter may drop a delivery, see probe_kernel)
+    s.g[G_RIDS_OFF] = (s.strict || s.g[G_HEAD] - s.g[G_PREV] > RID_MASK + 1u - RID_NEAR - KW_BITS) ? 1u : 0u;
   }
   for (uint32_t k = threadIdx.x; k <= TODO_REGIONS; k += blockDim.x) s.todo_n[k * 16u] = 0;   // the todo buffer's regions + the spill area
   if (t)                                                            // the deadline chains tick t-1 consumed

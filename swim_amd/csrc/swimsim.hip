@@ -161,6 +161,9 @@ int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, std::string*
   if (c->pull_ticks == 1) { *err = "pull_ticks must be 0 (off) or >= 2"; return SWIMSIM_ERR_INVALID; }
   if (c->pull_ticks && c->n_shards > 1) { *err = "pull_ticks (periodic state pull) is not available on sharded handles"; return SWIMSIM_ERR_INVALID; }
   if (c->n_shards > 1 && c->n_members > (1u << 27)) { *err = "sharded clusters: n_members must be <= 2^27"; return SWIMSIM_ERR_INVALID; }
+  if (c->strict_reference_rules > 1) { *err = "strict_reference_rules must be 0 or 1"; return SWIMSIM_ERR_INVALID; }
+  if (c->strict_reference_rules && (c->view_cap || c->gc_ticks || c->join_pull || c->pull_ticks || c->n_shards > 1)) {
+    *err = "strict_reference_rules cannot be combined with view_cap, gc_ticks, join_pull, pull_ticks or sharding"; return SWIMSIM_ERR_INVALID; }
   if (c->view_cap) {
     if (c->view_cap < SWIMSIM_VIEW_CAP_MIN || c->view_cap > SWIMSIM_VIEW_CAP_MAX) {
       *err = "view_cap must be 0 (unbounded) or in [" + std::to_string(SWIMSIM_VIEW_CAP_MIN) + ", " + std::to_string(SWIMSIM_VIEW_CAP_MAX) + "]"; return SWIMSIM_ERR_INVALID; }
@@ -260,7 +263,7 @@ Offsets robust_offsets(const swimsim* h, uint32_t t) {
 bool records_kernel_every_tick(const swimsim* h) {
   const char* force = std::getenv("SWIMSIM_RECORDS_KERNEL");             // test / measurement knob: 0 = never, 1 = always
   if (force && (force[0] == '0' || force[0] == '1')) return force[0] == '1';
-  return h->cfg.loss_ppm != 0 || h->d.n_shards > 1;
+  return h->cfg.loss_ppm != 0 || h->d.n_shards > 1 || h->d.strict;   // strict reference rules: every delivery is an explicit record
 }
 
 template <int PMAX>
@@ -374,6 +377,7 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   d.scheme = c.target_scheme;
   d.join_pull = c.join_pull;
   d.pull_T = c.pull_ticks;
+  d.strict = c.strict_reference_rules;
   d.P = (uint32_t)c.probes_per_tick; d.K = (uint32_t)c.indirect_k; d.S = c.suspicion_ticks;
   d.L = c.retransmit_mult * ceil_log2((uint64_t)NT + 1);
   {

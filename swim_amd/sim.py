@@ -45,6 +45,7 @@ def _to_c_config(sc: SimConfig, shard_index: int = 0, n_shards: int = 1) -> _abi
     c.join_pull = sc.joinPull
     c.pull_ticks = sc.pullTicks
     c.view_cap = sc.viewCap
+    c.strict_reference_rules = 1 if sc.strictReferenceRules else 0
     return c
 
 

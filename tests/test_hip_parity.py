@@ -317,6 +317,24 @@ def test_robust_target_scheme_parity(oracle_abi, hip_abi, n, p, loss, seed):
         assert all(fd[m] == t for (t, m) in crashes[1:])  # detected in the period of the crash (crashes[0] rejoined)
 
 
+@pytest.mark.parametrize("n,p,loss,seed,robust", [(777, 3, 300000, 1, 0), (4096, 3, 150000, 2, 0), (1000, 10, 200000, 3, 0), (65536, 3, 50000, 4, 0),
+                                                 (4096, 3, 150000, 5, 1), (2048, 3, 0, 6, 0)])
+def test_strict_reference_rules_on_the_gpu(oracle_abi, hip_abi, n, p, loss, seed, robust):
+    """the LITERAL suspectOrDeadNode' (/root/reference/src/Core.hs:151-152,182-184) under the canonical order
+    (include/swimsim.h "Strict reference rules") on the device, bit-exact against the oracle's literal mode -- on runs where the literal
+    rule and the merge do part (thousands of proposals decided differently), events record by record up to 4 096 members."""
+    sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, targetScheme=robust, eventMask=0x1F if n <= 4096 else 0,
+                   suspicionTicks=7, maxSubjects=n if n <= 4096 else 16384, strictReferenceRules=True)
+    crashes = workloads.hashed_crashes(n, seed, 1, 128, 3, 33)
+    a, b = make_pair(oracle_abi, hip_abi, sc, crashes, [(45, crashes[0][1], True)])
+    if n > 4096:
+        _oracle_threads(a)
+    run_lockstep(a, b, 70, 10, observers=(0, n - 1, crashes[0][1]), members=(0, n - 1, crashes[0][1]))
+    if loss:
+        assert oracle_abi.lib.swimoracle_d13_hits(a._h) > 0
+    a.close(); b.close()
+
+
 def _oracle_threads(sim):
     import os
     from tests import oracle_binding

@@ -1,0 +1,87 @@
+"""strict_reference_rules (include/swimsim.h "Strict reference rules"): the LITERAL suspectOrDeadNode'
+(/root/reference/src/Core.hs:142-187 -- a Suspect only on an Alive entry, a Dead unless the entry is Dead already, at any
+incarnation) under the canonical order timers -> own probes -> rumours by (subject, key), in the oracle and in the product's kernels
+(host emulation here, the gfx950 build in tests/test_hip_parity.py): bit-exact, on runs where the two rules do part."""
+import pytest
+
+from swim_amd import Config, Sim, SimConfig, SwimError, _abi
+from swim_amd import workloads
+from tests.helpers import make_pair, run_lockstep
+
+
+@pytest.fixture(scope="module")
+def emu_abi():
+    from tests import hostemu_binding
+    return hostemu_binding.load()
+
+
+def strict_config(n, p, loss, seed, susp=8, **kw):
+    return SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, eventMask=0x1F, suspicionTicks=susp,
+                     maxSubjects=min(n, 1024), strictReferenceRules=True, **kw)
+
+
+@pytest.mark.parametrize("n,p,loss,seed,chunk", [
+    (64, 2, 300000, 9, 1), (300, 3, 150000, 4, 5), (257, 10, 200000, 5, 5), (1000, 5, 50000, 3, 10), (129, 3, 0, 2, 1),
+    (500, 3, 250000, 11, 10),
+])
+def test_the_kernels_follow_the_oracle_under_the_literal_rule(oracle_abi, emu_abi, n, p, loss, seed, chunk):
+    sc = strict_config(n, p, loss, seed)
+    crashes = [(5, 7), (9, n // 2)]
+    faults = [(60, 7, True)]                       # ... and one comes back: its refutation races with the suspicions in flight
+    a, b = make_pair(oracle_abi, emu_abi, sc, crashes, faults)
+    run_lockstep(a, b, 100, chunk, observers=(0, 7, n - 1), members=(0, 7, n // 2))
+    hits = oracle_abi.lib.swimoracle_d13_hits(a._h)
+    if loss >= 150000:
+        # the run is one where the rules part: the same cluster under the merge ends elsewhere
+        assert hits > 0
+        sc.strictReferenceRules = False
+        m, _ = make_pair(oracle_abi, oracle_abi, sc, crashes, faults)
+        m.step(100)
+        assert m.digest() != a.digest()
+        _.close(); m.close()
+    a.close(); b.close()
+
+
+def test_the_canonical_order_makes_the_literal_rule_independent_of_arrival_order(oracle_abi):
+    """The oracle can shuffle the order in which a member's rumours of one tick arrive (swimoracle_set_shuffle): under the merge
+    nothing may change (commutative), under the literal rule nothing may change either BECAUSE of the canonical order."""
+    lib = oracle_abi.lib
+    runs = []
+    for shuffle in (0, 12345, 999):
+        s = Sim.create(oracle_abi, strict_config(300, 3, 200000, 4))
+        if shuffle:
+            lib.swimoracle_set_shuffle(s._h, shuffle)
+        s.crash(7, 5)
+        s.step(120)
+        runs.append((s.digest(), s.counters(), s.drainEventsRaw()))
+        assert lib.swimoracle_d13_hits(s._h) > 0
+        s.close()
+    assert runs[0] == runs[1] == runs[2]
+
+
+def test_without_loss_the_two_rules_give_the_same_run(oracle_abi, emu_abi):
+    """Nothing is suspected twice without loss: D13's difference set is never hit, strict and default handles agree in everything
+    (the strict one through the explicit-record path in every tick, the default one through the masks)."""
+    n = 2048
+    crashes = workloads.hashed_crashes(n, 5, 1, 8, 3, 43)
+    sc = strict_config(n, 3, 0, 5, susp=7)
+    a = Sim.create(emu_abi, sc)
+    sc.strictReferenceRules = False
+    b = Sim.create(emu_abi, sc)
+    for s in (a, b):
+        workloads.apply_crashes(s, crashes)
+    run_lockstep(a, b, 70, 10, observers=(0, n - 1), members=(0, 1))
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("kw", [dict(viewCap=16), dict(gcTicks=_abi.GC_AUTO), dict(joinPull=1), dict(pullTicks=5)])
+def test_strict_rules_refuse_the_options_they_cannot_carry(oracle_abi, emu_abi, kw):
+    for abi in (oracle_abi, emu_abi):
+        with pytest.raises(SwimError):
+            Sim.create(abi, strict_config(64, 3, 0, 1, **kw))
+
+
+def test_strict_rules_are_refused_on_shards(emu_abi):
+    from swim_amd.shard import LocalFabric, ShardedSim
+    with pytest.raises(SwimError):
+        ShardedSim(emu_abi, strict_config(64, 3, 0, 1), LocalFabric(2))
