@@ -70,6 +70,7 @@ data SimConfig = SimConfig
   , simPullTicks      :: Word32   -- T > 1 = every up member pulls a random up member's map once per T periods (the commented-out PushPullMsg, src/Types.hs:165,177); 0 = off
   , simViewCap        :: Word32   -- C > 0 = bounded member maps: at most C non-default entries per member, oldest evicted (`Map String Member`, src/Types.hs:55, with a capacity; include/swimsim.h); 0 = unbounded
   , simStrictReferenceRules :: Bool -- the literal suspectOrDeadNode' (src/Core.hs:142-187) under a canonical order instead of the commutative merge (D13; include/swimsim.h "Strict reference rules")
+  , simPushPull       :: Bool     -- with simPullTicks: the periodic pull is a push-pull (the host merges the puller's map too: the push half of PushPullMsg, src/Types.hs:165,177)
   , simShardIndex     :: Word32   -- this handle's shard of a cluster of simNShards handles (one per GPU); 0 of 1 = unsharded
   , simNShards        :: Word32   -- 0 or 1 = one handle steps the whole population (stepN); > 1 = stepShard
   }
@@ -107,7 +108,7 @@ foreign import ccall "wrapper" mkExchange :: ExchangeFn -> IO (FunPtr ExchangeFn
 foreign import ccall safe   "swimsim_shard_step"    c_shard_step    :: Ptr SwimsimT -> Word32 -> FunPtr ExchangeFn -> Ptr () -> IO CInt
 
 defaultSimConfig :: Config -> SimConfig
-defaultSimConfig c = SimConfig c 128 1 0 0 0 0 0 0 0 0 0 0 False 0 1
+defaultSimConfig c = SimConfig c 128 1 0 0 0 0 0 0 0 0 0 0 False False 0 1
 
 memberNameOf :: Word32 -> String
 memberNameOf i = 'm' : show i
@@ -132,6 +133,7 @@ configureSim SimConfig{..} =
     pokeByteOff p swimsimConfig_pull_ticks         simPullTicks
     pokeByteOff p swimsimConfig_view_cap           simViewCap
     pokeByteOff p swimsimConfig_strict_reference_rules (if simStrictReferenceRules then 1 else 0 :: Word32)
+    pokeByteOff p swimsimConfig_push_pull          (if simPushPull then 1 else 0 :: Word32)
     pokeByteOff p swimsimConfig_shard_index        simShardIndex
     pokeByteOff p swimsimConfig_n_shards           (max 1 simNShards)
     -- the failure text comes back through OUR buffer: the library's per-thread text could belong to another

@@ -123,6 +123,9 @@ typedef struct swimsim_config {
                                   0: unbounded (a view row per subject in circulation, max_subjects)   */
   uint32_t strict_reference_rules; /* 1: the LITERAL suspectOrDeadNode' (src/Core.hs:142-187) instead of the commutative
                                   merge -- see "Strict reference rules" below.  0: the merge   */
+  uint32_t push_pull;          /* 1 (needs pull_ticks): the periodic state pull is a PUSH-PULL -- the host merges the puller's
+                                  member map in the same exchange (the push half of the commented-out PushPullMsg,
+                                  src/Types.hs:165,177) -- see "Periodic state pull" below.  0: pull only               */
 } swimsim_config_t;
 
 /* Strict reference rules (strict_reference_rules = 1; DESIGN.md sections 2.9 and 3, D13).  The reference's state rule is not the
@@ -182,10 +185,15 @@ typedef struct swimsim_config {
  * does not depend on any order; none => no pull this period.  The merge is the join-time pull's: for every subject s != i
  * with a view row, i's entry becomes max(own entry, the host's entry), the host counting as Alive at its own incarnation;
  * lastChange = t, a pulled Suspect gets the deadline t + suspicion_ticks; a view change like any other (counters, digest),
- * not gossiped on, no event.  With pull_ticks on, a join host is not one of the tick's periodic pullers either.  (The push
- * half -- the host merging the puller's map in the same exchange -- would give one member map several writers per tick;
- * every member pulls once per T periods instead, so news travels both ways within two periods.)  Not available on sharded
- * handles (SWIMSIM_ERR_INVALID): a pull per member and period across shards is an exchange of its own. */
+ * not gossiped on, no event.  With pull_ticks on, a join host is not one of the tick's periodic pullers either.
+ * push_pull = 1 adds the PUSH half (memberlist's pushPull sends the local state and merges the remote one on both sides): after ALL
+ * of the tick's pulls, every puller's host merges the puller's member map the same way -- for every subject s != host with a view
+ * row, the host's entry becomes max(own entry, the puller's entry), the puller counting as Alive at its own incarnation; lastChange
+ * = t, deadline t + suspicion_ticks for a pushed Suspect, a view change like any other, not gossiped on, no event.  A host may have
+ * several pullers in one tick: the result is the max over all of them -- no order can matter, because hosts are never pullers (the
+ * pulls read maps nobody writes, the pushes write maps nobody reads), and pushing the map AFTER the pull gives the host exactly
+ * what the map before the pull would have (max is idempotent).  Not available on sharded handles (SWIMSIM_ERR_INVALID): a pull per
+ * member and period across shards is an exchange of its own. */
 
 #define SWIMSIM_GC_AUTO 0xFFFFFFFFu
 

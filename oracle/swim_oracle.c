@@ -823,7 +823,7 @@ static int fault_cmp(const void* a, const void* b) {
  * no change scheduled in this tick (faults[0..nf) are the tick's changes) and, with pull_ticks = T on, is not one of the
  * tick's periodic pullers (nobody reads a map that is being written).  purpose = P_JOIN: m just came up (`joinHosts`,
  * src/Types.hs:47); P_PULL: m's periodic pull (the commented-out PushPullMsg, src/Types.hs:165,177). */
-static void state_pull(swimoracle_t* o, uint32_t t, uint32_t m, size_t nf, uint32_t purpose) {
+static uint32_t pull_host_of(swimoracle_t* o, uint32_t t, uint32_t m, size_t nf, uint32_t purpose) {
   uint32_t tk = tick_key(o->cfg.seed, t), h = NONE32;
   const uint32_t T = o->cfg.pull_ticks;
   for (uint32_t a = 0; a < SEL_ATTEMPTS && h == NONE32; a++) {
@@ -832,7 +832,11 @@ static void state_pull(swimoracle_t* o, uint32_t t, uint32_t m, size_t nf, uint3
     for (size_t x = 0; x < nf && !busy; x++) busy = o->faults[x].member == c;
     if (!busy) h = c;
   }
-  if (h == NONE32) return;
+  return h;
+}
+/* m merges h's member map (`from` = h, a pull) -- or, push half of a push-pull (include/swimsim.h "Periodic state pull"): called with
+ * the roles swapped, the host merges its puller's map.  The sender counts as Alive at its own incarnation. */
+static void state_merge_from(swimoracle_t* o, uint32_t t, uint32_t m, uint32_t h) {
   for (uint32_t sl = 0; sl < o->nslots; sl++) {
     if (o->free_at[sl] != NONE32) continue;
     uint32_t s = o->subject_of[sl];
@@ -842,11 +846,15 @@ static void state_pull(swimoracle_t* o, uint32_t t, uint32_t m, size_t nf, uint3
     if (kh <= cur.key) continue;
     oentry_t* e = view_ref(o, m, s);
     o->counters[SWIMSIM_CTR_EVDIGEST] += ev_weight(t, m, s) * (uint64_t)(kh - cur.key);
-    o->counters[SWIMSIM_CTR_CHANGES]++;
+    if (e->since1 != t + 1) o->counters[SWIMSIM_CTR_CHANGES]++;   /* (a host raised by two pullers in one tick: one changed entry) */
     e->key = kh; e->since1 = t + 1;
     o->last_change[s] = t;
     if (key_state(kh) == SWIMSIM_SUSPECT) timer_push(o, m, s, t + o->S);
   }
+}
+static void state_pull(swimoracle_t* o, uint32_t t, uint32_t m, size_t nf, uint32_t purpose) {
+  const uint32_t h = pull_host_of(o, t, m, nf, purpose);
+  if (h != NONE32) state_merge_from(o, t, m, h);
 }
 
 static void apply_faults(swimoracle_t* o, uint32_t t) {
@@ -889,6 +897,16 @@ static void apply_faults(swimoracle_t* o, uint32_t t) {
       for (size_t x = 0; x < nf && !busy; x++) busy = o->faults[x].member == i;
       if (!busy) state_pull(o, t, i, nf, P_PULL);
     }
+    /* push_pull: after ALL pulls, every puller's host merges the puller's map (hosts are never pullers: the pulls above read maps
+     * nobody wrote, the pushes write maps nobody reads; several pullers of one host: max over all, any order) */
+    if (o->cfg.push_pull)
+      for (uint32_t i = t % T; i < o->N; i += T) {
+        int busy = !o->up[i];
+        for (size_t x = 0; x < nf && !busy; x++) busy = o->faults[x].member == i;
+        if (busy) continue;
+        const uint32_t h = pull_host_of(o, t, i, nf, P_PULL);
+        if (h != NONE32) state_merge_from(o, t, h, i);
+      }
   }
   if (k) { memmove(o->faults, o->faults + k, (o->nfaults - k) * sizeof *o->faults); o->nfaults -= k; }
 }
@@ -1164,6 +1182,7 @@ static int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, char*
   if (c->target_scheme > SWIMSIM_TARGETS_ROBUST) { snprintf(err, errn, "unknown target_scheme"); return SWIMSIM_ERR_INVALID; }
   if (c->join_pull > 1) { snprintf(err, errn, "join_pull must be 0 or 1"); return SWIMSIM_ERR_INVALID; }
   if (c->pull_ticks == 1) { snprintf(err, errn, "pull_ticks must be 0 (off) or >= 2"); return SWIMSIM_ERR_INVALID; }
+  if (c->push_pull > 1 || (c->push_pull && !c->pull_ticks)) { snprintf(err, errn, "push_pull must be 0 or 1 and needs pull_ticks"); return SWIMSIM_ERR_INVALID; }
   if (c->strict_reference_rules > 1) { snprintf(err, errn, "strict_reference_rules must be 0 or 1"); return SWIMSIM_ERR_INVALID; }
   if (c->strict_reference_rules && (c->view_cap || c->gc_ticks || c->join_pull || c->pull_ticks)) {
     snprintf(err, errn, "strict_reference_rules cannot be combined with view_cap, gc_ticks, join_pull or pull_ticks"); return SWIMSIM_ERR_INVALID; }

@@ -41,7 +41,7 @@ class Config(C.Structure):
         ("inbox_cap", C.c_uint32),
         ("device", C.c_int32), ("shard_index", C.c_uint32), ("n_shards", C.c_uint32),
         ("target_scheme", C.c_uint32), ("join_pull", C.c_uint32), ("pull_ticks", C.c_uint32),
-        ("view_cap", C.c_uint32), ("strict_reference_rules", C.c_uint32),
+        ("view_cap", C.c_uint32), ("strict_reference_rules", C.c_uint32), ("push_pull", C.c_uint32),
     ]
 
 

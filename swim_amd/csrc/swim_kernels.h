@@ -2314,6 +2314,72 @@ __global__ __launch_bounds__(BLOCK) void join_pull_kernel(DevState s, uint32_t t
   }
 }
 
+// The push half of a push-pull (push_pull = 1; include/swimsim.h "Periodic state pull"): after join_pull_kernel -- every pull has read
+// its host -- the host of every periodic puller merges the puller's map: one block per puller, the rows over its threads.  A host may
+// have several pullers (several blocks write its cells): the key is raised with atomicMax, whoever raises it accounts for the step it
+// made (the event digest is linear in the key: the steps telescope to final - initial whatever their order), the first to stamp
+// lastChange counts the change.  Hosts are never pullers: nobody reads a map that is written here.
+__global__ __launch_bounds__(BLOCK) void push_kernel(DevState s, uint32_t t, uint32_t tk, const FaultRec* faults, uint32_t nfaults) {
+  __shared__ unsigned long long evd_sh;
+  __shared__ unsigned pushed_sh, suspects_sh;
+  __shared__ uint32_t host_sh;
+  const uint32_t T = s.pull_T, first = t % T;
+  const uint32_t npp = first < s.N ? (s.N - first + T - 1u) / T : 0u;
+  const uint32_t nrows = min(s.g[G_NSLOTS], s.R_phys);
+  constexpr int U = 4;
+  for (uint32_t k = blockIdx.x; k < npp; k += gridDim.x) {
+    const uint32_t mbr = s.lo + first + k * T;
+    if (threadIdx.x == 0) {
+      evd_sh = 0; pushed_sh = 0; suspects_sh = 0;
+      host_sh = (mi_up(s.minfo[mbr]) && !changes_this_tick(faults, nfaults, mbr)) ? pull_host(s, t, tk, mbr, faults, nfaults, P_PULL) : NONE32;
+    }
+    __syncthreads();
+    const uint32_t host = host_sh;
+    if (host != NONE32) {
+      unsigned long long evd = 0; unsigned pushed = 0, suspects = 0;
+      const uint32_t ml = mbr - s.lo, hl = host - s.lo;
+      const uint32_t mkey = (s.hot[ml].x << 2) | ST_ALIVE;
+      const unsigned long long hw = mix64(mix64((uint64_t)TAG_EV) + (((uint64_t)t << 32) | host));
+      for (uint32_t r0 = threadIdx.x; r0 < nrows; r0 += BLOCK * U) {
+        uint32_t used[U], subj[U], vm[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t r = r0 + u * BLOCK;
+          used[u] = r < nrows ? s.slot_used[r] : 0u;
+          subj[u] = r < nrows ? s.subject_of[r] : 0u;
+          vm[u] = r < nrows ? s.V[vidx(s, ml, r)].x : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (!used[u] || subj[u] == host) continue;
+          const uint32_t r = r0 + u * BLOCK;
+          const uint32_t km = subj[u] == mbr ? mkey : vm[u];     // an untouched cell is the base: no news
+          if (!km || km <= s.slot_base[r]) continue;              // (an untouched cell of the host reads 0: never raise it to below the base)
+          uint32_t* cell = reinterpret_cast<uint32_t*>(&s.V[vidx(s, hl, r)]);
+          const uint32_t old = atomicMax(&cell[0], km);
+          const uint32_t curk = old ? old : s.slot_base[r];
+          if (km <= curk) continue;
+          evd += (mix64(hw + subj[u]) | 1ull) * (unsigned long long)(km - curk);
+          if (atomicMax(&cell[1], t + 1u) != t + 1u) pushed++;
+          if (s.G) s.slot_last[r] = t;
+          suspects += (km & 3u) == ST_SUSPECT ? 1u : 0u;
+        }
+      }
+      if (evd) atomicAdd(&evd_sh, evd);
+      if (pushed) atomicAdd(&pushed_sh, pushed);
+      if (suspects) atomicAdd(&suspects_sh, suspects);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (evd_sh) atomicAdd(reinterpret_cast<unsigned long long*>(&s.blk[(size_t)s.nblocks * C_COUNT + C_EVDIGEST]), evd_sh);
+      if (pushed_sh) atomicAdd(reinterpret_cast<unsigned long long*>(&s.blk[(size_t)s.nblocks * C_COUNT + C_CHANGES]), (unsigned long long)pushed_sh);
+      // a host that took a Suspect over: merge_kernel rebuilds its deadline cells from its view cells (as for a puller)
+      if (suspects_sh) atomicOr(&s.hot[host - s.lo].y, 1u);
+    }
+    __syncthreads();
+  }
+}
+
 // Sharded clusters with join_pull: between the two parts of begin_kernel the owner of a join host sends what the host
 // knows to the joiner's owner -- one record {joiner, subject, entry} per entry that differs from the base (the host
 // itself as Alive at its own incarnation) -- exchange round 0.  One thread per member that came up this tick.

@@ -161,6 +161,7 @@ int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, std::string*
   if (c->pull_ticks == 1) { *err = "pull_ticks must be 0 (off) or >= 2"; return SWIMSIM_ERR_INVALID; }
   if (c->pull_ticks && c->n_shards > 1) { *err = "pull_ticks (periodic state pull) is not available on sharded handles"; return SWIMSIM_ERR_INVALID; }
   if (c->n_shards > 1 && c->n_members > (1u << 27)) { *err = "sharded clusters: n_members must be <= 2^27"; return SWIMSIM_ERR_INVALID; }
+  if (c->push_pull > 1 || (c->push_pull && !c->pull_ticks)) { *err = "push_pull must be 0 or 1 and needs pull_ticks"; return SWIMSIM_ERR_INVALID; }
   if (c->strict_reference_rules > 1) { *err = "strict_reference_rules must be 0 or 1"; return SWIMSIM_ERR_INVALID; }
   if (c->strict_reference_rules && (c->view_cap || c->gc_ticks || c->join_pull || c->pull_ticks || c->n_shards > 1)) {
     *err = "strict_reference_rules cannot be combined with view_cap, gc_ticks, join_pull, pull_ticks or sharding"; return SWIMSIM_ERR_INVALID; }
@@ -378,6 +379,7 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   d.join_pull = c.join_pull;
   d.pull_T = c.pull_ticks;
   d.strict = c.strict_reference_rules;
+  d.push_pull = c.push_pull;
   d.P = (uint32_t)c.probes_per_tick; d.K = (uint32_t)c.indirect_k; d.S = c.suspicion_ticks;
   d.L = c.retransmit_mult * ceil_log2((uint64_t)NT + 1);
   {
@@ -722,6 +724,8 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
                          h->d_joined, 1u, PeerCounts{});
       hipLaunchKernelGGL(join_pull_kernel, dim3(std::min(nup + npp, 16384u)), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0,
                          (uint32_t)(fpos - f0), h->d_joined, nup);
+      // push-pull: once every pull has read its host, the hosts merge their pullers' maps
+      if (h->d.push_pull && npp) hipLaunchKernelGGL(push_kernel, dim3(std::min(npp, 16384u)), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, (uint32_t)(fpos - f0));
       part = (part & ~1u) | 8u;
     }
     hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, (uint32_t)(fpos - f0),

@@ -46,6 +46,7 @@ def _to_c_config(sc: SimConfig, shard_index: int = 0, n_shards: int = 1) -> _abi
     c.pull_ticks = sc.pullTicks
     c.view_cap = sc.viewCap
     c.strict_reference_rules = 1 if sc.strictReferenceRules else 0
+    c.push_pull = 1 if sc.pushPull else 0
     return c
 
 

@@ -63,6 +63,7 @@ class SimConfig:
     joinPull: int = 0             # 1 = a member that comes up pulls a join host's member map (joinHosts, src/Types.hs:47)
     viewCap: int = 0              # C > 0 = bounded member maps: at most C non-default entries per member, the oldest evicted (include/swimsim.h "Bounded member maps"; `Map String Member`, src/Types.hs:55, with a capacity)
     strictReferenceRules: bool = False   # the LITERAL suspectOrDeadNode' (src/Core.hs:142-187: a Suspect is ignored unless the entry is Alive, a Dead when it is Dead already, at any incarnation) under the canonical order of include/swimsim.h "Strict reference rules" instead of the merge (D13)
+    pushPull: bool = False        # with pullTicks: the host of a periodic pull merges the puller's map too (the push half of the commented-out PushPullMsg, src/Types.hs:165,177)
     pullTicks: int = 0            # T > 1 = every up member pulls a random up member's map once per T periods (the commented-out PushPullMsg, src/Types.hs:165,177)
 
 

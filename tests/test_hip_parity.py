@@ -390,6 +390,7 @@ def test_random_configurations_on_the_gpu(oracle_abi, hip_abi, block):
                        targetScheme=scheme, inboxCap=rng.choice([0, 0, 1, 2]) if n <= 4096 else 0, gcTicks=gc,
                        joinPull=1 if shards == 1 and seed % 2 else 0,
                        pullTicks=(0, 0, 2, 5, 17)[(seed >> 3) % 5] if shards == 1 else 0)
+        sc.pushPull = bool(sc.pullTicks) and (seed >> 7) % 2 == 1
         a = Sim.create(oracle_abi, sc)
         _oracle_threads(a)
         b = Sim.create(hip_abi, sc) if shards == 1 else ShardedSim(hip_abi, sc, LocalFabric(shards), device="cuda:0")
@@ -613,13 +614,15 @@ def test_config5_metrics_on_the_gpu(oracle_abi, hip_abi, loss):
     assert a[0] > 0 and a[2][3] == (0, 4095)
 
 
-@pytest.mark.parametrize("T,gc,loss,n", [(2, 0, 0, 3000), (7, 1, 50000, 3000), (40, 1, 10000, 65536)])
-def test_periodic_state_pull_on_the_gpu(oracle_abi, hip_abi, T, gc, loss, n):
+@pytest.mark.parametrize("T,gc,loss,n,push", [(2, 0, 0, 3000, 0), (7, 1, 50000, 3000, 0), (40, 1, 10000, 65536, 0),
+                                              (2, 0, 0, 3000, 1), (3, 1, 50000, 3000, 1), (40, 1, 10000, 65536, 1)])
+def test_periodic_state_pull_on_the_gpu(oracle_abi, hip_abi, T, gc, loss, n, push):
     """pull_ticks = T (the periodic state pull between up members; include/swimsim.h): join_pull_kernel's second kind of
-    work item -- one block per puller of the tick --, with crashes, rejoins, join pulls, loss and settling: MI355X = oracle."""
+    work item -- one block per puller of the tick --, with crashes, rejoins, join pulls, loss and settling: MI355X = oracle.
+    push = 1: push_pull (push_kernel: every puller's host merges the puller's map, concurrent pullers of one host by atomics)."""
     from swim_amd import _abi
     sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=31 + T, lossPpm=loss, eventMask=0x1F if n <= 4096 else 0,
-                   suspicionTicks=6, maxSubjects=min(n, 4096), gcTicks=_abi.GC_AUTO if gc else 0, joinPull=1, pullTicks=T)
+                   suspicionTicks=6, maxSubjects=min(n, 4096), gcTicks=_abi.GC_AUTO if gc else 0, joinPull=1, pullTicks=T, pushPull=bool(push))
     crashes = [(3 + 2 * k, (37 * k + 11) % n) for k in range(40)]
     faults = [(t + 9 + (m % 13), m, True) for (t, m) in crashes[::2]]
     a, b = make_pair(oracle_abi, hip_abi, sc, crashes, faults)

@@ -303,15 +303,17 @@ def test_config5_metrics_false_dead_count_and_ticks_to_all(oracle_abi, emu_abi, 
         assert to_all is None and curve[-1][0] > 450
 
 
-@pytest.mark.parametrize("T,gc,loss", [(2, 0, 0), (7, 1, 50000), (30, 1, 150000), (5, 0, 300000)])
-def test_periodic_state_pull_parity(oracle_abi, emu_abi, T, gc, loss):
+@pytest.mark.parametrize("T,gc,loss,push", [(2, 0, 0, 0), (7, 1, 50000, 0), (30, 1, 150000, 0), (5, 0, 300000, 0),
+                                            (2, 0, 0, 1), (7, 1, 50000, 1), (3, 1, 150000, 1), (5, 0, 300000, 1)])
+def test_periodic_state_pull_parity(oracle_abi, emu_abi, T, gc, loss, push):
     """pull_ticks = T: every up member merges a random up member's map once per T periods (the commented-out PushPullMsg,
     src/Types.hs:165,177), with crashes, rejoins (join pull on: a join host is never one of the tick's pullers), loss and
-    settling; compared every few ticks -- counters, digest, views, queues, timers (via the digest) and events."""
+    settling; compared every few ticks -- counters, digest, views, queues, timers (via the digest) and events.  push = 1: a push-pull --
+    the host merges the puller's map too (push_kernel: several pullers of one host raise its cells with atomics)."""
     from swim_amd import _abi
     n = 700 if loss < 300000 else 300                # (30 % loss: every member a subject, the emulation is slow)
     sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=31 + T, lossPpm=loss, eventMask=0x1F, suspicionTicks=6,
-                   maxSubjects=n, gcTicks=_abi.GC_AUTO if gc else 0, joinPull=1, pullTicks=T)
+                   maxSubjects=n, gcTicks=_abi.GC_AUTO if gc else 0, joinPull=1, pullTicks=T, pushPull=bool(push))
     crashes = [(3 + 2 * k, (37 * k + 11) % n) for k in range(40)]
     faults = [(t + 9 + (m % 13), m, True) for (t, m) in crashes[::2]]
     a, b = make_pair(oracle_abi, emu_abi, sc, crashes, faults)
@@ -334,11 +336,30 @@ def test_periodic_state_pull_spreads_what_gossip_lost(oracle_abi):
     assert left_behind(8) == 0
 
 
+def test_push_pull_moves_news_both_ways_in_one_exchange(oracle_abi):
+    """The push half (the commented-out PushPullMsg, src/Types.hs:165,177: memberlist's pushPull merges on both sides): with a pull
+    only, what a PULLER knows reaches its host only when the host's own turn to pull comes; with push_pull the host has it in the
+    same tick.  One member is told of a crash nobody else will hear of (no gossip budget), and pulls."""
+    def holders_after(push, ticks):
+        sc = SimConfig(cfg=Config(numToGossip=1), nMembers=64, seed=3, lossPpm=1000000, eventMask=0, suspicionTicks=60,
+                       retransmitMult=1, maxSubjects=64, pullTicks=64, pushPull=push)   # every message lost: only the pulls move anything
+        s = Sim.create(oracle_abi, sc)
+        s.setView(observer=5, subject=9, state=2, incarnation=0)      # member 5 alone holds "9 is Dead"
+        s.step(ticks)
+        return s.coverage(9, 2, 0)[0]
+    # member 5 pulls in tick 5 (5 mod 64): pull-only leaves the news with 5 (nobody has pulled FROM 5 yet, or at most a few have) ...
+    assert holders_after(False, 6) == 1
+    # ... the push-pull hands it to 5's host in that very tick
+    assert holders_after(True, 6) == 2
+
+
 def test_pull_ticks_validation(oracle_abi, emu_abi):
     from swim_amd.sim import SwimError
     for abi in (oracle_abi, emu_abi):
         with pytest.raises(SwimError):
             Sim.create(abi, SimConfig(cfg=Config(numToGossip=3), nMembers=64, pullTicks=1))
+        with pytest.raises(SwimError):
+            Sim.create(abi, SimConfig(cfg=Config(numToGossip=3), nMembers=64, pushPull=True))     # needs pull_ticks
 
 
 def test_pull_ticks_is_refused_on_sharded_handles(emu_abi):
