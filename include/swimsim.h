@@ -401,7 +401,8 @@ int swimsim_get_config(const swimsim_t* h, swimsim_config_t* out);
  * to `observer` in the next tick that is stepped, next to the rumours the tick's Pings and Acks carry (same state
  * rule, same events, re-gossiped if accepted) -- if `observer` is up when that tick starts and stays up through the
  * tick's scheduled changes; nobody listens otherwise.  The subject gets a view row like any subject somebody states a
- * rumour about.  Unsharded handles only. */
+ * rumour about.  On a sharded cluster the message goes to the handle that owns `observer` (SWIMSIM_ERR_INVALID on the others).  Not
+ * available with bounded member maps. */
 int swimsim_inject_rumor(swimsim_t* h, uint32_t observer, uint32_t subject, uint8_t state, uint32_t incarnation);
 
 /* ---- sharded clusters (one handle per GPU / process) -------------------------------

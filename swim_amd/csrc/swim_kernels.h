@@ -2419,11 +2419,11 @@ __global__ void inject_kernel(DevState s, uint32_t t, const InjectRec* recs, uin
   uint32_t num = 0;
   (void)num;
   const uint32_t rid = find_rid(s, slot, r.key, &num);      // handed out before the tick's window head is taken: an id like any of the tick before
-  uint4* line = s.fl + (size_t)k * 4;
+  uint4* line = s.fl + ((size_t)s.fl_inj_base + k) * 4;
   line[0] = make_uint4(pe_lo(slot, rid), pe_hi(r.key, 1u), 0u, 0u);
   line[1] = make_uint4(0u, 0u, 0u, 0u); line[2] = make_uint4(0u, 0u, 0u, 0u); line[3] = make_uint4(0u, 0u, 0u, 0u);
   __threadfence();
-  push(s, t, r.observer - s.lo, SRC_FOREIGN | k);
+  push(s, t, r.observer - s.lo, SRC_FOREIGN | (s.fl_inj_base + k));
 }
 
 // full-state digest: Sum_i mix64(member_hash(i) + mix64(TAG_MEMBER + i)) + first-detection terms

@@ -267,6 +267,21 @@ bool records_kernel_every_tick(const swimsim* h) {
   return h->cfg.loss_ppm != 0 || h->d.n_shards > 1 || h->d.strict;   // strict reference rules: every delivery is an explicit record
 }
 
+// messages from outside the simulation (swimsim_inject_rumor) go into this tick's inboxes BEFORE the start of the tick: the rows they
+// open count as stated in this tick (a row nobody holds anything in settles at the end of it, as in the oracle), the ids they take
+// are older than the tick's window head.  *any = explicit records exist already (begin_kernel's part bit 2)
+int flush_injections(swimsim* h, uint32_t t, bool* any) {
+  *any = false;
+  if (h->injections.empty()) return SWIMSIM_OK;
+  const uint32_t ni = (uint32_t)h->injections.size();
+  HIPCHK(h, hipMemcpyAsync(h->d_inject, h->injections.data(), ni * sizeof(InjectRec), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(inject_kernel, dim3((ni + 63) / 64), dim3(64), 0, h->stream, h->d, t, h->d_inject, ni);
+  HIPCHK(h, hipStreamSynchronize(h->stream));   // the host list is reused
+  h->injections.clear();
+  *any = true;
+  return SWIMSIM_OK;
+}
+
 template <int PMAX>
 void launch_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev) {
   if (ev) (void)hipEventRecord(ev[0], h->stream);
@@ -569,7 +584,10 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     // foreign lines of remote_kernel: normally a handful per tick (a rumour's first tick abroad), but in a tick without
     // masks HERE every payload that arrives becomes one: a Ping and an Ack per probe
     d.fl_dyn_cap = d.rm ? 2u * N * std::max(1u, d.P) + 4096u : 0u;
-    CK(dev_alloc(h, &d.fl, ((size_t)d.n_shards * ((size_t)d.x_cap + d.p_cap + d.r_cap) + d.fl_dyn_cap) * 4, 0));
+    // (+ the foreign lines of injected rumours, swimsim_inject_rumor, behind the exchange's)
+    d.fl_inj_base = (uint32_t)((size_t)d.n_shards * ((size_t)d.x_cap + d.p_cap + d.r_cap) + d.fl_dyn_cap);
+    CK(dev_alloc(h, &d.fl, ((size_t)d.fl_inj_base + INJECT_CAP) * 4, 0));
+    CK(dev_alloc(h, &h->d_inject, (size_t)INJECT_CAP, 0));
     if (d.rm) {
       CK(dev_alloc(h, &d.mask_all, (size_t)NT, 0));
       CK(dev_alloc(h, &d.q_all, ((size_t)NT + 15) & ~(size_t)15, 0));
@@ -613,7 +631,7 @@ int swimsim_inject_rumor(swimsim_t* h, uint32_t observer, uint32_t subject, uint
   if (!h) return SWIMSIM_ERR_INVALID;
   if (observer >= h->d.NT || subject >= h->d.NT || state > 2 || incarnation > INC_MAX)
     return set_err(h, SWIMSIM_ERR_INVALID, "inject_rumor: bad member / state / incarnation");
-  if (h->d.n_shards > 1) return set_err(h, SWIMSIM_ERR_STATE, "inject_rumor: unsharded handles only");
+  if (observer - h->d.lo >= h->d.N) return set_err(h, SWIMSIM_ERR_INVALID, "inject_rumor: the observer is a member of another shard (its owner takes the message)");
   if (h->d.C) return set_err(h, SWIMSIM_ERR_INVALID, "inject_rumor: not available with bounded member maps (view_cap)");
   if (h->injections.size() >= INJECT_CAP) return set_err(h, SWIMSIM_ERR_BUFFER, "inject_rumor: more than 4096 rumours before the next tick");
   h->injections.push_back(InjectRec{observer, subject, (incarnation << 2) | state, 0u});
@@ -702,18 +720,8 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
       h->tick++;
       continue;
     }
-    // messages from outside the simulation go into this tick's inboxes BEFORE the start of the tick: the rows they open
-    // count as stated in this tick (a row nobody holds anything in settles at the end of it, as in the oracle), the ids
-    // they take are older than the tick's window head
     uint32_t part = 3u;
-    if (!h->injections.empty()) {
-      const uint32_t ni = (uint32_t)h->injections.size();
-      HIPCHK(h, hipMemcpyAsync(h->d_inject, h->injections.data(), ni * sizeof(InjectRec), hipMemcpyHostToDevice, h->stream));
-      hipLaunchKernelGGL(inject_kernel, dim3((ni + 63) / 64), dim3(64), 0, h->stream, h->d, t, h->d_inject, ni);
-      HIPCHK(h, hipStreamSynchronize(h->stream));   // the host list is reused
-      h->injections.clear();
-      part |= 4u;                                   // begin_kernel: explicit records exist already
-    }
+    { bool inj = false; const int rc_ = flush_injections(h, t, &inj); if (rc_) return rc_; if (inj) part |= 4u; }   // begin_kernel: explicit records exist already
     uint32_t nup = 0;                               // upper bound of this tick's joins
     if (h->d.join_pull) for (size_t f = f0; f < fpos; ++f) nup += h->faults[f].up != 0;
     const uint32_t T = h->d.pull_T, first = T ? t % T : 0u;
@@ -1120,6 +1128,7 @@ int swimsim_shard_phase0(swimsim_t* h, uint32_t* counts, int* round_needed) {
   if (rc) return rc;
   const uint32_t t = (uint32_t)h->tick;
   const uint32_t tk = tick_key(h->cfg.seed, t);
+  { bool inj = false; rc = flush_injections(h, t, &inj); if (rc) return rc; }   // before the tick's scheduled changes (swimsim_step does the same)
   hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults, (uint32_t)fend, h->d_joined, 1u, PeerCounts{});
   hipLaunchKernelGGL(pull_send_kernel, dim3(std::min<uint32_t>(64u, (uint32_t)(fend + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, h->stream,
                      h->d, tk, h->d_faults, (uint32_t)fend, h->d_joined);
@@ -1174,6 +1183,7 @@ int swimsim_shard_phase1(swimsim_t* h, uint32_t* counts) {
   const uint32_t tk = tick_key(h->cfg.seed, t);
   // one launch does the whole start of the tick, unless swimsim_shard_phase0 ran its first part already (join-time
   // pulls to exchange in between)
+  if (!h->begun) { bool inj = false; rc = flush_injections(h, t, &inj); if (rc) return rc; }
   if (h->begun) {                                   // the pulls from hosts on this shard: a block per joiner (the ones the peers
     uint32_t nup = 0;                               // sent are merged by begin_kernel: other joiners, rows no local host holds)
     for (size_t f = 0; f < fend; ++f) nup += h->faults[f].up != 0;

@@ -310,6 +310,13 @@ class ShardedSim:
     def crash(self, member: int, tick: int):
         self.scheduleFault(tick, member, False)
 
+    def injectRumor(self, observer: int, subject: int, state: int, incarnation: int = 0):
+        """A message from outside the simulation (swimsim_inject_rumor) goes to the shard that owns the observer; in a cluster of one
+        process per shard every rank makes the call, the owner's takes it."""
+        s = self._owner(observer)
+        if s is not None:
+            s.sim.injectRumor(observer, subject, state, incarnation)
+
     # -- the hot path ------------------------------------------------------------------------------------
     def _step_by_library(self, nticks: int):
         """One shard per process: the tick loop runs inside libswimsim.so (swimsim_shard_step); this
