@@ -328,6 +328,17 @@ def main():
                                         "frac_traffic_of_wall": (tr_tot / (dt / args.steps) / 1e9 / HBM_PEAK_GBS) if tr_tot else None},
                          "kernels": per_kernel},
         }
+        if not args.view_cap:
+            # what the 8 TB/s yardstick hides ("Round 4: merge_kernel against the chip's RANDOM-access rate"): both
+            # tick kernels are made of scattered 8-byte accesses, which the chip serves at fixed RATES (microbenchmarks under profiles/)
+            chg = rt["r"] * n
+            png = (c1["pings"] - c0["pings"]) / float(args.steps) / world
+            out["roofline"]["scattered_access"] = {
+                "merge_kernel": {"view_cells_changed_per_launch": chg, "chip_rate_load_then_store_back_G_per_s": 19.8,
+                                 "us_at_that_rate_if_no_two_cells_shared_a_sector": chg / 19.8e9 * 1e6},
+                "probe_kernel": {"ping_pushes_per_launch_upper_bound": png, "chip_rate_scattered_atomics_G_per_s": 26.7,
+                                 "us_at_that_rate": png / 26.7e9 * 1e6},
+                "source": "profiles/r04o_microbench_random_access.txt, profiles/r01_microbench_gather_rate.txt"}
         if world > 1:
             out["shard_tick_breakdown_us_rank0"] = sim.phaseBreakdown()      # where a sharded tick goes (host view)
         if not args.no_cpu_baseline and world == 1:

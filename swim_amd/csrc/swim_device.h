@@ -88,6 +88,8 @@ struct DevState {
   uint32_t scheme;         // SWIMSIM_TARGETS_*: how the direct probes of a period pick their targets
   uint32_t join_pull;      // a member that comes up merges a join host's member map (include/swimsim.h)
   uint32_t pull_T;         // periodic state pull: member i pulls in the ticks t = i (mod pull_T); 0 = off (include/swimsim.h)
+  uint32_t* sp_bloom;      // bounded member maps: [N][2^(sp_bloom_log2 - 5)] "not Alive in my view" filters (swim_sparse.h)
+  uint32_t sp_bloom_log2;  // bits per filter, log2
   uint32_t fl_inj_base;    // first foreign line of the injected rumours (0 on unsharded handles: they are the only foreign lines)
   uint32_t push_pull;      // the periodic pull's host merges the puller's map too (include/swimsim.h "Periodic state pull")
   uint32_t strict;         // strict_reference_rules: the literal suspectOrDeadNode' under the canonical order (include/swimsim.h; D13)

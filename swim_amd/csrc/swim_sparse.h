@@ -4,12 +4,13 @@
 // (swim_kernels.h) cannot exist.
 //
 // A member's map is `Map String Member` (src/Types.hs:55) with a capacity: <= C exceptions {subject, key, lastChange} to the
-// default "Alive at incarnation 0", C x 12 bytes per member in HBM.  ONE WAVE steps one member -- the 64-wide wavefront is the
-// unit of work here, not the thread:
-//   * sp_probe_kernel : the member's map sits in the wave's registers (C / 64 entries per lane); "is c Alive in my view"
-//     (kRandomMembers, src/Core.hs:72-74) is one compare per lane and a ballot; the period's deliveries are dealt to the
-//     lanes, one inbox append (an atomic with a returned position) per lane, all in flight together;
-//   * sp_merge_kernel : the member's map is rebuilt in LDS as a hash table; the lanes are the RUMOURS of the tick (8 sources x
+// default "Alive at incarnation 0", C x 12 bytes per member in HBM.
+//   * sp_probe_lane_kernel : one member per LANE; "is c Alive in my view" (kRandomMembers, src/Core.hs:72-74) is one bit of the
+//     member's filter (written with the map) and, for the few set bits, a look into the map by the whole wave; every delivery an
+//     inbox append (an atomic with a returned position).  (sp_probe_kernel, the first form -- one WAVE per member, the map in the
+//     wave's registers -- stays for A/B: SWIMSIM_SP_PROBE=wave; it was bound by its wave-uniform instructions, 3.2 against 1.2 ms);
+//   * sp_merge_kernel : ONE WAVE steps one member's end of tick -- the 64-wide wavefront is the unit of work there, not the
+//     thread: the member's map is rebuilt in LDS as a hash table; the lanes are the RUMOURS of the tick (8 sources x
 //     8 queue entries per round of loads) and the state rule suspectOrDeadNode' / aliveNode (src/Core.hs:142-218) is an LDS
 //     atomicMax on the packed (incarnation, state) key -- the commutative merge of H3 / D13 in one instruction; who stays
 //     when the map is over capacity is a radix select over (lastChange, rank) in LDS; the map streams back coalesced.
@@ -24,6 +25,12 @@ namespace swim {
 constexpr uint32_t SP_WAVES = BLOCK / 64;      // members a workgroup steps at a time
 constexpr uint32_t SP_PRIO_TIMER = 2u, SP_PRIO_PROBE = 1u, SP_PRIO_GOSSIP = 0u;   // who states a key first (phase order)
 constexpr uint32_t SP_KEPT = 1u << 30;         // h0 bit (after the selection): the entry stays in the map
+// A member's "who is NOT Alive in my view" filter: 16 bits per map entry of the capacity (1 024 bits for C <= 64, 2 048 for C <= 128,
+// 4 096 beyond: s.sp_bloom_log2 = 10 / 11 / 12), one hash; rewritten by sp_merge_kernel with the map, read by sp_probe_lane_kernel (a
+// set bit = look the subject up in the map; a clear one = Alive for sure: no entry, or an Alive one)
+constexpr uint32_t SP_BLOOM_WORDS_MAX = 128u;
+__device__ inline uint32_t sp_bloom_words(const DevState& s) { return 1u << (s.sp_bloom_log2 - 5u); }
+__device__ inline uint32_t sp_bloom_bit(const DevState& s, uint32_t subject) { return (subject * 0x9E3779B1u) >> (32u - s.sp_bloom_log2); }
 
 // ---- layout helpers ----------------------------------------------------------------------------------
 // tab[N][3][C]: subjects, keys, lastChange + 1 of member li, entry e -- three coalesced runs per member
@@ -303,6 +310,200 @@ __global__ __launch_bounds__(BLOCK) void sp_probe_kernel(DevState s, uint32_t t,
   ctr_flush(s, &sh, blockIdx.x);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The same period with one member per LANE (the default; sp_probe_kernel above stays for A/B: SWIMSIM_SP_PROBE=wave).  With a
+// wave per member nearly every instruction of the period is wave-uniform -- 64 lanes compute one member's hashes and tests -- and
+// the kernel was bound by exactly those instructions (3.2 ms per launch at 2 M members, profiles/r04h_*).  What made the wave
+// necessary was "is c Alive in my view": a search of the member's map.  But a draw is a uniform pick among ALL members and the map
+// holds <= C of them: the answer is almost always "no entry".  So sp_merge_kernel leaves a filter of 16 bits per map entry next to
+// every member's map (sp_bloom: the non-Alive subjects, one hash) and a lane tests ONE BIT per draw (a 4-byte load from the member's
+// own 128-byte filter: staging the tile's filters in LDS cost occupancy and lost, 1 340 against 1 160 us); for the few set bits (6 %
+// at a full map, nearly all false positives) the WAVE looks the subject up in that member's map -- 64 entries per step, one ballot.  Control flow is wave-uniform throughout (loops over probes, proxies and
+// attempts run while any lane needs them, lanes are predicated): every __ballot sees the whole wave.
+// Draws, hashes, loss, deliveries: sp_probe_kernel's, line by line; only the order of a member's inbox / Ack-list entries differs
+// (nothing depends on it: the end of the tick is stated over sets).
+template <int PMAX>
+__global__ __launch_bounds__(BLOCK) void sp_probe_lane_kernel(DevState s, uint32_t t, uint32_t tk) {
+  __shared__ BlockCounters sh;
+  __shared__ uint32_t pick_sh[PMAX][BLOCK];          // this period's targets / the current probe's proxies, per lane
+  __shared__ uint32_t prox_sh[PMAX][BLOCK];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  unsigned c_pings = 0, c_active = 0, c_payloads = 0, c_rumors = 0, c_dfail = 0, c_preqs = 0, c_susp = 0, c_fsusp = 0;
+  ctr_init(&sh);
+  const uint32_t N = s.NT;
+  for (uint32_t base = blockIdx.x * BLOCK; base < s.N; base += gridDim.x * BLOCK) {
+    const uint32_t li = base + tid;
+    const bool valid = li < s.N;
+    const uint32_t i = s.lo + li;
+    // the tile's filters, coalesced: word w of member m at [m * WORDS + w]
+    const uint32_t myb = valid ? s.mb[i] : 0u;
+    const bool act = valid && sb_up(myb);
+    const uint32_t mk = mix32(tk ^ i);
+    __syncthreads();
+    // "c is not Alive in li's view": the filter bit first ...
+    auto filter_hit = [&](uint32_t c) -> bool {
+      const uint32_t b = sp_bloom_bit(s, c);
+      return valid && ((s.sp_bloom[(size_t)li * sp_bloom_words(s) + (b >> 5)] >> (b & 31u)) & 1u);
+    };
+    // ... then, for the lanes whose bit is set, the wave walks that member's map: 64 entries per step (called by the whole wave)
+    auto confirm = [&](bool need, uint32_t c) -> bool {
+      bool dead = false;
+      for (unsigned long long m = __ballot(need); m; m &= m - 1ull) {
+        const int L = __ffsll((unsigned long long)m) - 1;
+        const uint32_t liL = (uint32_t)__builtin_amdgcn_readlane((int)li, L), cL = (uint32_t)__builtin_amdgcn_readlane((int)c, L);
+        const uint32_t nL = s.sp_tab_n[liL];
+        const uint32_t* rs = sp_row(s, liL, 0); const uint32_t* rk = sp_row(s, liL, 1);
+        bool hit = false;
+        for (uint32_t e0 = 0; e0 < nL; e0 += 64u) {
+          const uint32_t e = e0 + lane;
+          if (e < nL && rs[e] == cL) hit = (rk[e] & 3u) != ST_ALIVE;
+        }
+        const bool any = __ballot(hit) != 0ull;
+        if ((int)lane == L) dead = any;
+      }
+      return dead;
+    };
+    // one lane alone (the cyclic scan behind eight failed draws: tiny clusters only)
+    auto dead_scan = [&](uint32_t c) -> bool {
+      if (!filter_hit(c)) return false;
+      const uint32_t n = s.sp_tab_n[li];
+      const uint32_t* rs = sp_row(s, li, 0); const uint32_t* rk = sp_row(s, li, 1);
+      for (uint32_t e = 0; e < n; ++e) if (rs[e] == c) return (rk[e] & 3u) != ST_ALIVE;
+      return false;
+    };
+    // kRandomMembers (src/Core.hs:69-74): pick number p of a selection -- the draws of sp_select, one lane one member.  `want`: this lane
+    // is selecting; earlier picks of the selection in tab[0..cnt); returns found (the pick in c).
+    auto select_one = [&](bool want, uint32_t (*tab)[BLOCK], uint32_t cnt, uint32_t p, uint32_t purpose, uint32_t hi_idx, uint32_t excl, uint32_t& c) -> bool {
+      const uint32_t hb = (purpose << 24) | (purpose == P_SELECT ? (p << 8) : ((hi_idx << 16) | (p << 8)));
+      bool found = false;
+      c = 0;
+      auto fresh = [&](uint32_t d) -> bool {
+        if (d == i || d == excl) return false;        // D15; D7: the target is no proxy of itself
+        for (uint32_t q = 0; q < cnt; ++q) if (tab[q][tid] == d) return false;
+        return true;
+      };
+      for (uint32_t a = 0; a < (uint32_t)SEL_ATTEMPTS; ++a) {
+        const bool trying = want && !found;
+        if (!__ballot(trying)) break;
+        const uint32_t d = __umulhi(hash_mk(mk, hb | a, 0), N);
+        if (trying) c = d;
+        const bool ok = trying && fresh(d);
+        const bool dead = confirm(ok && filter_hit(d), d);
+        if (ok && !dead) found = true;
+      }
+      if (want && !found) {                           // fewer candidates than draws hit: the cyclic scan (test/Spec.hs:117-128)
+        const uint32_t cs = (c + 1 == N) ? 0 : c + 1;
+        for (uint32_t d = 0; d < N; ++d) {
+          uint32_t x = cs + d; if (x >= N) x -= N;
+          if (fresh(x) && !dead_scan(x)) { c = x; found = true; break; }
+        }
+      }
+      return found;
+    };
+    uint32_t nack = 0, nfail = 0;
+    uint32_t ncall = blockIdx.x * SP_WAVES + (tid >> 6);   // (wave-uniform) which of the 64 remote lists the next call appends to
+    // "dst merges src's start-of-tick queue" (called by the whole wave, `on` = this lane has one)
+    auto deliver = [&](bool on, uint32_t dst, uint32_t src, uint32_t srcb) {
+      const uint32_t cnt = sb_qn(srcb);
+      on = on && cnt != 0u;                           // empty payload: nothing travels
+      if (on) { c_payloads++; c_rumors += cnt; }
+      const bool self = on && dst == i;
+      if (self) { s.ackfrom[(size_t)li * s.sp_ack_cap + nack] = src; nack++; }
+      const bool local = on && !self && is_local(s, dst);
+      if (local) push(s, t, dst - s.lo, src);
+      if (s.n_shards > 1) {
+        // a destination on another shard: an 8-byte record {dst, src} in one of 64 unsorted lists, one atomic per wave and call; the
+        // calls of a wave go round the lists (their capacity is a 64th of a tick's records + slack: a small shard has few waves)
+        const bool remote = on && !self && !local;
+        const unsigned long long rb = __ballot(remote);
+        if (rb) {
+          const uint32_t list = ncall++ & 63u;
+          const int L0 = __ffsll((unsigned long long)rb) - 1;
+          uint32_t b0 = 0;
+          if ((int)lane == L0) b0 = atomicAdd(&s.sp_ord_n[list * 16u], (uint32_t)__popcll(rb));
+          b0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, L0);
+          if (remote) {
+            const uint32_t pos = b0 + (uint32_t)__popcll(rb & ((1ull << lane) - 1ull));
+            if (pos < s.sp_ord_cap) s.sp_ord[(size_t)list * s.sp_ord_cap + pos] = make_uint2(dst, src);
+            else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG);
+          }
+        }
+      }
+    };
+    // ms <- kRandomMembers store (numToGossip cfg) []        (src/Core.hs:239)
+    uint32_t np = 0;
+    {
+      bool going = act;
+      for (uint32_t p = 0; p < s.P; ++p) {
+        if (!__ballot(going)) break;
+        uint32_t c;
+        const bool f = select_one(going, pick_sh, np, p, P_SELECT, 0u, NONE32, c);
+        if (going && f) { pick_sh[np][tid] = c; np++; }
+        else going = false;                           // no candidate left: the selection ends (`return np`)
+      }
+    }
+    if (act) { c_pings += np; c_active++; }
+    for (uint32_t p = 0; p < s.P; ++p) {
+      const bool on = act && p < np;
+      if (!__ballot(on)) break;
+      const uint32_t j = on ? pick_sh[p][tid] : 0u;
+      const uint32_t bj = on ? s.mb[j] : 0u;
+      // Direct (Ping seq j) is delivered iff not lost and j is up (src/Core.hs:246); j answers Ack (:97-99), which may be lost too
+      const bool ping_ok = on && sb_up(bj) && !lost(s, tk, P_L_PING, i, j, p);
+      const bool ack_ok = ping_ok && !lost(s, tk, P_L_ACK, j, i, p);
+      deliver(ping_ok, j, i, myb);
+      deliver(ack_ok, i, j, bj);
+      // unlessAck (D2, D3): K proxies, not the target (src/Core.hs:249; D7)
+      const bool failed = on && !ack_ok;
+      if (!__ballot(failed)) continue;
+      if (failed) c_dfail++;
+      const bool jup = sb_up(bj) != 0u;
+      bool acked = false, going = failed;
+      uint32_t nq = 0;
+      for (uint32_t k = 0; k < s.K; ++k) {
+        if (!__ballot(going)) break;
+        uint32_t q;
+        const bool f = select_one(going, prox_sh, nq, k, P_PROXY, p, j, q);
+        const bool have = going && f;
+        if (!have) going = false;
+        // the chain i -> q -> j -> q -> i of proxy number nq (src/Core.hs:250, 262-269, 105-108; D8, D9, D12)
+        const uint32_t idx = (p << 8) | nq;
+        const uint32_t bq = have ? s.mb[q] : 0u;
+        const bool h0 = have && sb_up(bq) && !lost(s, tk, P_L_REQ, i, q, idx);
+        const bool h1 = h0 && jup && !lost(s, tk, P_L_FWD, q, j, idx);
+        const bool h2 = h1 && !lost(s, tk, P_L_BACK, j, q, idx);
+        const bool h3 = h2 && !lost(s, tk, P_L_RELAY, q, i, idx);
+        deliver(h0, q, i, myb);
+        deliver(h1, j, q, bq);
+        deliver(h2, q, j, bj);
+        deliver(h3, i, q, bq);
+        acked |= h3;
+        if (have) { prox_sh[nq][tid] = q; nq++; }
+      }
+      if (failed) c_preqs += nq;
+      if (failed && !acked) {                         // second unlessAck (src/Core.hs:251): suspectNode (:253) lands in merge
+        s.fail[(size_t)li * s.P + nfail] = j;
+        nfail++;
+        c_susp++;
+        if (jup) c_fsusp++;
+        else atomicMin(&s.first_suspect[j], t);
+      }
+    }
+    if (act) s.sp_out[li] = np | (nfail << 5) | (nack << 10);
+    __syncthreads();                                   // the tile's filters and picks are done with
+  }
+  ctr_add_wave(&sh, C_PINGS, c_pings);
+  ctr_add_wave(&sh, C_ACTIVE, c_active);
+  ctr_add_wave(&sh, C_PAYLOADS, c_payloads);
+  ctr_add_wave(&sh, C_RUMORS_SEEN, c_rumors);
+  ctr_add_wave(&sh, C_DIRECT_FAILED, c_dfail);
+  ctr_add_wave(&sh, C_PING_REQS, c_preqs);
+  ctr_add_wave(&sh, C_SUSPECTS, c_susp);
+  ctr_add_wave(&sh, C_FALSE_SUSPECTS, c_fsusp);
+  ctr_flush(s, &sh, blockIdx.x);
+}
+
 // ================================================================================================
 // merge kernel: one member's end of tick per WAVE, its map as a hash table in LDS
 // ================================================================================================
@@ -319,6 +520,7 @@ struct SpTable {
   uint32_t srcs[128];       // the first 64 own-Ack sources and the first 64 inbox sources of the member, staged for the lanes
   uint32_t nnew, refute1, full, sel_b, sel_need, sel_cnt;
   uint2 qnew[PB_SLOTS];     // the head of the next queue line: this tick's rumours, by subject
+  uint32_t bloom[SP_BLOOM_WORDS_MAX];      // the member's next "not Alive in my view" filter (sp_bloom_bit), written back with the map
 };
 template <uint32_t CPHYS>
 __device__ inline uint32_t sp_hash(uint32_t subject) {
@@ -731,12 +933,20 @@ __global__ __launch_bounds__(64 * WAVES) void sp_merge_kernel(DevState s, uint32
     {
       uint32_t* rs = sp_row(s, li, 0); uint32_t* rk = sp_row(s, li, 1); uint32_t* rt = sp_row(s, li, 2);
       uint32_t base = 0;
+      const uint32_t bw = sp_bloom_words(s);
+      for (uint32_t w = lane; w < bw; w += 64u) T.bloom[w] = 0u;
+      lds_wave_sync();
+      auto bloom_put = [&](uint32_t subject, uint32_t key) {    // sp_probe_lane_kernel's filter: the subjects that are not Alive here
+        if ((key & 3u) != ST_ALIVE) { const uint32_t b = sp_bloom_bit(s, subject); atomicOr(&T.bloom[b >> 5], 1u << (b & 31u)); }
+      };
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         uint32_t tot = 0;
         const uint32_t r = sp_rank_of(mkeep[m], lane, &tot);
         if (mkeep[m]) {
-          rs[base + r] = msub[m]; rk[base + r] = T.hk[mslot[m]] >> 2; rt[base + r] = mch[m] ? t + 1u : msince[m];
+          const uint32_t kf = T.hk[mslot[m]] >> 2;
+          rs[base + r] = msub[m]; rk[base + r] = kf; rt[base + r] = mch[m] ? t + 1u : msince[m];
+          bloom_put(msub[m], kf);
         }
         base += tot;
       }
@@ -746,10 +956,12 @@ __global__ __launch_bounds__(64 * WAVES) void sp_merge_kernel(DevState s, uint32
         if (x < nnew) { sl = T.newl[x]; keep = (T.h0[sl] & SP_KEPT) != 0u; }
         uint32_t tot = 0;
         const uint32_t r = sp_rank_of(keep, lane, &tot);
-        if (keep) { rs[base + r] = T.hs[sl]; rk[base + r] = T.hk[sl] >> 2; rt[base + r] = t + 1u; }
+        if (keep) { rs[base + r] = T.hs[sl]; rk[base + r] = T.hk[sl] >> 2; rt[base + r] = t + 1u; bloom_put(T.hs[sl], T.hk[sl] >> 2); }
         base += tot;
       }
       if (lane == 0) s.sp_tab_n[li] = base;
+      lds_wave_sync();
+      for (uint32_t w = lane; w < bw; w += 64u) s.sp_bloom[(size_t)li * bw + w] = T.bloom[w];
       (void)nkept_old;
       lds_wave_sync();                                // every lane has read what it needs of the table
 #pragma unroll

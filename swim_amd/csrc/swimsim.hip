@@ -312,6 +312,16 @@ void size_sparse_grids(swimsim* h) {
   }
 }
 void launch_sparse_probe(swimsim* h, uint32_t t, uint32_t tk) {
+  // one member per lane (swim_sparse.h sp_probe_lane_kernel); SWIMSIM_SP_PROBE=wave: the wave-per-member kernel, for A/B
+  static const bool by_wave = [] { const char* e = std::getenv("SWIMSIM_SP_PROBE"); return e && e[0] == 'w'; }();
+  if (!by_wave) {
+    const dim3 g(std::min<uint32_t>((h->d.N + BLOCK - 1) / BLOCK, h->d.nblocks));   // (a counter row per workgroup: the rest by grid stride)
+    const uint32_t pk = std::max(h->d.P, h->d.K);
+    if (pk <= 4) hipLaunchKernelGGL((sp_probe_lane_kernel<4>), g, dim3(BLOCK), 0, h->stream, h->d, t, tk);
+    else if (pk <= 8) hipLaunchKernelGGL((sp_probe_lane_kernel<8>), g, dim3(BLOCK), 0, h->stream, h->d, t, tk);
+    else hipLaunchKernelGGL((sp_probe_lane_kernel<16>), g, dim3(BLOCK), 0, h->stream, h->d, t, tk);
+    return;
+  }
   const dim3 gp(h->sp_grid_probe);
   if (h->d.C <= 64) hipLaunchKernelGGL((sp_probe_kernel<1>), gp, dim3(BLOCK), 0, h->stream, h->d, t, tk);
   else if (h->d.C <= 128) hipLaunchKernelGGL((sp_probe_kernel<2>), gp, dim3(BLOCK), 0, h->stream, h->d, t, tk);
@@ -463,6 +473,8 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     CK(dev_alloc(h, &d.hot, N, 0));
     CK(dev_alloc(h, &d.sp_tab, (size_t)N * 3 * d.C, 0));
     CK(dev_alloc(h, &d.sp_tab_n, N, 0));
+    d.sp_bloom_log2 = d.C <= 64 ? 10u : d.C <= 128 ? 11u : 12u;
+    CK(dev_alloc(h, &d.sp_bloom, (size_t)N << (d.sp_bloom_log2 - 5u), 0));
     CK(dev_alloc(h, &d.sp_q, (size_t)2 * N * PB_SLOTS, 0));
     if (d.n_shards > 1) {
       // shards of a bounded cluster (swim_sparse.h): the replica of everybody's queue line, the lists of deliveries to members
