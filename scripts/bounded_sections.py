@@ -18,7 +18,7 @@ s.kernelTimingEnable(True); s.step(ticks); kt = s.kernelTiming()
 lib.swimsim_debug_sections(s._h, out)
 MERGE = ["inputs (one round of loads)", "map -> hash table", "failed probes + rumours", "what changed, how many", "radix select", "who stays",
          "accounting", "rumours by subject (wave minima)", "queue line + state stores", "map write-back + clear"]
-PROBE = ["own byte + map", "target selection", "outcomes, proxies, chains", "inbox appends"]
+PROBE = ["own byte", "target selection (filter bits, map look-ups by the wave)", "outcomes, proxies, chains, inbox appends", "outputs"]   # sp_probe_lane_kernel (SWIMSIM_SP_PROBE=wave: own byte + map | target selection | outcomes, proxies, chains | inbox appends)
 res = {"members": n, "view_cap": cap, "probe_us": kt["probe_ms"] * 1e3 / kt["ticks"], "merge_us": kt["merge_ms"] * 1e3 / kt["ticks"]}
 for name, base, labels in (("sp_merge_kernel", 0, MERGE), ("sp_probe_kernel", 32, PROBE)):
     waves = out[base + 15]

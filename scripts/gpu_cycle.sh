@@ -1,6 +1,6 @@
 #!/bin/bash
 # one GPU iteration: parity tests, bench lines, kernel-trace stats, PMC passes.
-# usage: gpu_cycle.sh <tag> [what...]   what = tests bench extra variants shard prof pmc churn config5 bounded (default: all but churn, config5, bounded)   -> gpurun_out/<tag>_*
+# usage: gpu_cycle.sh <tag> [what...]   what = tests bench extra variants shard prof pmc churn config5 bounded cluster strict (default: all but churn, config5, bounded, cluster, strict)   -> gpurun_out/<tag>_*
 TAG=$1; shift; WHAT="${*:-tests bench extra variants shard prof pmc}"
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out; mkdir -p $O
 cd $R
@@ -37,9 +37,16 @@ if has bounded; then
   b config5_2m_cap64 --steps 20 --warmup 5 --members 2097152 --loss-ppm 300000 --view-cap 64
   b config5_2m_cap64_churn1pct --steps 20 --warmup 5 --members 2097152 --loss-ppm 300000 --view-cap 64 --churn 10
   b config5_1m_cap256 --steps 20 --warmup 5 --members 1048576 --loss-ppm 300000 --view-cap 256
-  timeout 600 python scripts/bounded_time.py 65536 64 262144 64 1048576 64 2097152 64 2097152 128 2097152 256 4194304 64 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_bounded_time.txt
+  (timeout 600 python scripts/bounded_time.py 65536 64 262144 64 1048576 64 2097152 64 2097152 128 2097152 256 4194304 64; echo '# sp_probe_kernel (one wave per member), SWIMSIM_SP_PROBE=wave:'; SWIMSIM_SP_PROBE=wave timeout 300 python scripts/bounded_time.py 2097152 64) 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_bounded_time.txt
   (CAP=64 TICKS=160 T0=60 timeout 600 python scripts/config5.py 2097152; CAP=256 TICKS=200 T0=60 timeout 900 python scripts/config5.py 2097152; echo '# oracle-checked at 262 144 members:'; CAP=64 TICKS=80 T0=30 ORACLE=1 timeout 900 python scripts/config5.py 262144) 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_config5_bounded.txt
   timeout 300 python scripts/bounded_sections.py 2097152 64 2>&1 | grep -v amdgpu.ids > $O/${TAG}_bounded_sections_2m_cap64.json
+fi
+if has cluster; then   # BASELINE config 5 at FULL size as 8 handles on this GPU: the exchange on the handles' streams, then through the host
+  (echo "# swimsim_cluster_step (exchange on the handles' streams):"; MEMBERS=4194304 SHARDS=4 timeout 600 python scripts/config5_cluster_one_gpu.py; timeout 900 python scripts/config5_cluster_one_gpu.py;
+   echo "# phase calls + LocalFabric (host in the loop: SWIMSIM_CLUSTER_STEP=0):"; SWIMSIM_CLUSTER_STEP=0 timeout 900 python scripts/config5_cluster_one_gpu.py) 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_config5_cluster_one_gpu.txt
+fi
+if has strict; then    # strict_reference_rules: what the literal rule costs
+  (echo "# strict_reference_rules, 1 M members, saturated regime:"; STRICT=1 TICKS=50 timeout 600 python scripts/quick_time.py; echo "# the default (merge) on the same cluster:"; TICKS=50 timeout 300 python scripts/quick_time.py; echo "# 1 % loss, strict / default:"; STRICT=1 LOSS=10000 TICKS=30 timeout 600 python scripts/quick_time.py; LOSS=10000 TICKS=30 timeout 600 python scripts/quick_time.py) 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_strict_time.txt
 fi
 cd /tmp && export TMPDIR=/tmp
 if has prof; then

@@ -331,16 +331,16 @@ __global__ __launch_bounds__(BLOCK) void sp_probe_lane_kernel(DevState s, uint32
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   unsigned c_pings = 0, c_active = 0, c_payloads = 0, c_rumors = 0, c_dfail = 0, c_preqs = 0, c_susp = 0, c_fsusp = 0;
   ctr_init(&sh);
+  SECT_BEGIN(32);
   const uint32_t N = s.NT;
   for (uint32_t base = blockIdx.x * BLOCK; base < s.N; base += gridDim.x * BLOCK) {
     const uint32_t li = base + tid;
     const bool valid = li < s.N;
     const uint32_t i = s.lo + li;
-    // the tile's filters, coalesced: word w of member m at [m * WORDS + w]
     const uint32_t myb = valid ? s.mb[i] : 0u;
     const bool act = valid && sb_up(myb);
     const uint32_t mk = mix32(tk ^ i);
-    __syncthreads();
+    SECT(32);                                         // own byte
     // "c is not Alive in li's view": the filter bit first ...
     auto filter_hit = [&](uint32_t c) -> bool {
       const uint32_t b = sp_bloom_bit(s, c);
@@ -444,6 +444,7 @@ __global__ __launch_bounds__(BLOCK) void sp_probe_lane_kernel(DevState s, uint32
       }
     }
     if (act) { c_pings += np; c_active++; }
+    SECT(33);                                         // target selection
     for (uint32_t p = 0; p < s.P; ++p) {
       const bool on = act && p < np;
       if (!__ballot(on)) break;
@@ -490,8 +491,9 @@ __global__ __launch_bounds__(BLOCK) void sp_probe_lane_kernel(DevState s, uint32
         else atomicMin(&s.first_suspect[j], t);
       }
     }
+    SECT(34);                                         // outcomes, proxies, chains, inbox appends
     if (act) s.sp_out[li] = np | (nfail << 5) | (nack << 10);
-    __syncthreads();                                   // the tile's filters and picks are done with
+    SECT(35);                                         // (the picks in LDS are per-lane columns: nothing to wait for between tiles)                                   // the tile's filters and picks are done with
   }
   ctr_add_wave(&sh, C_PINGS, c_pings);
   ctr_add_wave(&sh, C_ACTIVE, c_active);
