@@ -516,13 +516,12 @@ struct SpTable {
   uint32_t h0[CPHYS];       // the entry's key at the start of the tick (0: no entry = the default) | SP_KEPT
   uint32_t newl[CPHYS];     // slots of the subjects that got an entry in this tick, in the order their creators came
   uint32_t newr[CPHYS];     // ... and their ranks (filled when the capacity needs them)
-  uint32_t hist[256];       // radix select
+  uint32_t hist[256];       // radix select; then (write-back) the member's next "not Alive in my view" filter, <= SP_BLOOM_WORDS_MAX words
   uint32_t cl[CPHYS / 4u + 8u];            // slots of the entries that changed and stayed (<= C <= CPHYS / 4)
   uint32_t cs[CPHYS / 4u + 8u];            // ... and their subjects
   uint32_t srcs[128];       // the first 64 own-Ack sources and the first 64 inbox sources of the member, staged for the lanes
   uint32_t nnew, refute1, full, sel_b, sel_need, sel_cnt;
   uint2 qnew[PB_SLOTS];     // the head of the next queue line: this tick's rumours, by subject
-  uint32_t bloom[SP_BLOOM_WORDS_MAX];      // the member's next "not Alive in my view" filter (sp_bloom_bit), written back with the map
 };
 template <uint32_t CPHYS>
 __device__ inline uint32_t sp_hash(uint32_t subject) {
@@ -936,10 +935,10 @@ __global__ __launch_bounds__(64 * WAVES) void sp_merge_kernel(DevState s, uint32
       uint32_t* rs = sp_row(s, li, 0); uint32_t* rk = sp_row(s, li, 1); uint32_t* rt = sp_row(s, li, 2);
       uint32_t base = 0;
       const uint32_t bw = sp_bloom_words(s);
-      for (uint32_t w = lane; w < bw; w += 64u) T.bloom[w] = 0u;
+      for (uint32_t w = lane; w < bw; w += 64u) T.hist[w] = 0u;
       lds_wave_sync();
       auto bloom_put = [&](uint32_t subject, uint32_t key) {    // sp_probe_lane_kernel's filter: the subjects that are not Alive here
-        if ((key & 3u) != ST_ALIVE) { const uint32_t b = sp_bloom_bit(s, subject); atomicOr(&T.bloom[b >> 5], 1u << (b & 31u)); }
+        if ((key & 3u) != ST_ALIVE) { const uint32_t b = sp_bloom_bit(s, subject); atomicOr(&T.hist[b >> 5], 1u << (b & 31u)); }
       };
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
@@ -963,7 +962,7 @@ __global__ __launch_bounds__(64 * WAVES) void sp_merge_kernel(DevState s, uint32
       }
       if (lane == 0) s.sp_tab_n[li] = base;
       lds_wave_sync();
-      for (uint32_t w = lane; w < bw; w += 64u) s.sp_bloom[(size_t)li * bw + w] = T.bloom[w];
+      for (uint32_t w = lane; w < bw; w += 64u) s.sp_bloom[(size_t)li * bw + w] = T.hist[w];
       (void)nkept_old;
       lds_wave_sync();                                // every lane has read what it needs of the table
 #pragma unroll
