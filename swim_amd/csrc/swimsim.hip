@@ -69,6 +69,7 @@ struct swimsim {
   uint32_t* h_sync = nullptr;                  // pinned host copy of the globals (flags + send counts)
   hipEvent_t tick_ev[3] = {nullptr, nullptr, nullptr};
   uint32_t sp_grid_probe = 0, sp_grid_merge = 0;   // bounded member maps: workgroups of the two tick kernels
+  bool sp_probe_by_wave = false;                   // SWIMSIM_SP_PROBE=wave at create: the wave-per-member probe kernel (A/B, tests)
 };
 
 // the tick kernels' state argument: by value, or (-DSWIM_STATE_BY_POINTER, measurement knob) a pointer to a device copy
@@ -302,6 +303,7 @@ void size_sparse_grids(swimsim* h) {
   h->sp_grid_probe = std::max(1u, std::min<uint32_t>((N + SP_WAVES - 1) / SP_WAVES, 16384u));
   const uint32_t mw = h->d.C <= 128 ? 4u : 2u;      // members per workgroup of the merge kernel (its LDS tables)
   h->sp_grid_merge = std::max(1u, std::min<uint32_t>((N + mw - 1) / mw, 16384u));
+  { const char* e = std::getenv("SWIMSIM_SP_PROBE"); h->sp_probe_by_wave = e && e[0] == 'w'; }
   // measurement knob: SWIMSIM_SP_GRID="<probe workgroups>,<merge workgroups>" (0 = keep)
   if (const char* e = std::getenv("SWIMSIM_SP_GRID")) {
     unsigned a = 0, b = 0;
@@ -312,9 +314,8 @@ void size_sparse_grids(swimsim* h) {
   }
 }
 void launch_sparse_probe(swimsim* h, uint32_t t, uint32_t tk) {
-  // one member per lane (swim_sparse.h sp_probe_lane_kernel); SWIMSIM_SP_PROBE=wave: the wave-per-member kernel, for A/B
-  static const bool by_wave = [] { const char* e = std::getenv("SWIMSIM_SP_PROBE"); return e && e[0] == 'w'; }();
-  if (!by_wave) {
+  // one member per lane (swim_sparse.h sp_probe_lane_kernel); SWIMSIM_SP_PROBE=wave (read at create): the wave-per-member kernel, for A/B
+  if (!h->sp_probe_by_wave) {
     const dim3 g(std::min<uint32_t>((h->d.N + BLOCK - 1) / BLOCK, h->d.nblocks));   // (a counter row per workgroup: the rest by grid stride)
     const uint32_t pk = std::max(h->d.P, h->d.K);
     if (pk <= 4) hipLaunchKernelGGL((sp_probe_lane_kernel<4>), g, dim3(BLOCK), 0, h->stream, h->d, t, tk);
@@ -1350,11 +1351,19 @@ int swimsim_cluster_step(swimsim_t** hs, uint32_t n, uint32_t nticks) {
   // peers' send buffers (a peer may then reuse them: the next tick's publish zeroes the counters, its route overwrites the segments)
   std::vector<std::vector<hipEvent_t>> ev(n, std::vector<hipEvent_t>(3, nullptr));
   auto cleanup = [&]() { for (auto& e : ev) for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); };
+  // a HIP call that fails once the ticks are under way leaves every handle of the cluster half-stepped: all of them are poisoned
+  // (SWIMSIM_ERR_STATE from then on), the streams drained, the events freed
+  auto broken = [&](swimsim* h, hipError_t e, const char* what) -> int {
+    for (uint32_t k = 0; k < n; ++k) { hs[k]->poisoned = true; (void)hipSetDevice(hs[k]->device); (void)hipStreamSynchronize(hs[k]->stream); }
+    cleanup();
+    return set_err(h, SWIMSIM_ERR_DEVICE, std::string("cluster_step: ") + what + ": " + hipGetErrorString(e) + " (the cluster's handles are poisoned)");
+  };
+#define CCHK(h, call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return broken((h), e_, #call); } while (0)
   for (uint32_t k = 0; k < n; ++k) {
     swimsim* h = hs[k];
-    HIPCHK(h, hipSetDevice(h->device));
+    { const hipError_t e_ = hipSetDevice(h->device); if (e_ != hipSuccess) { cleanup(); return set_err(h, SWIMSIM_ERR_DEVICE, hipGetErrorString(e_)); } }
     { int rc_ = upload_faults(h, nticks, &fend[k]); if (rc_) { cleanup(); return rc_; } }
-    for (int e = 0; e < 3; ++e) HIPCHK(h, hipEventCreate(&ev[k][e]));
+    for (int e = 0; e < 3; ++e) { const hipError_t e_ = hipEventCreate(&ev[k][e]); if (e_ != hipSuccess) { cleanup(); return set_err(h, SWIMSIM_ERR_DEVICE, hipGetErrorString(e_)); } }
   }
   const uint32_t N = hs[0]->d.N;
   auto peer_copy = [&](swimsim* dst, void* to, swimsim* src, const void* from, size_t bytes) -> hipError_t {
@@ -1366,41 +1375,41 @@ int swimsim_cluster_step(swimsim_t** hs, uint32_t n, uint32_t nticks) {
     // phase 1 on every shard: the tick's scheduled changes, its slice of the lines into its replica
     for (uint32_t k = 0; k < n; ++k) {
       swimsim* h = hs[k];
-      HIPCHK(h, hipSetDevice(h->device));
+      CCHK(h, hipSetDevice(h->device));
       const size_t f0 = fpos[k];
       while (fpos[k] < fend[k] && h->faults[fpos[k]].tick <= t) ++fpos[k];
-      if (tck) for (uint32_t p = 0; p < n; ++p) if (p != k) HIPCHK(h, hipStreamWaitEvent(h->stream, ev[p][2], 0));   // the peers are done with my send buffers
+      if (tck) for (uint32_t p = 0; p < n; ++p) if (p != k) CCHK(h, hipStreamWaitEvent(h->stream, ev[p][2], 0));   // the peers are done with my send buffers
       if (fpos[k] > f0) hipLaunchKernelGGL(sp_begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, h->d_faults + f0, (uint32_t)(fpos[k] - f0));
       hipLaunchKernelGGL(sp_publish_kernel, dim3((N * PB_SLOTS + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream, h->d, t);
-      HIPCHK(h, hipEventRecord(ev[k][0], h->stream));
+      CCHK(h, hipEventRecord(ev[k][0], h->stream));
     }
     // round 1, the all-gather: every shard copies every peer's slice of the queue lines and member bytes, then probes
     for (uint32_t k = 0; k < n; ++k) {
       swimsim* h = hs[k];
-      HIPCHK(h, hipSetDevice(h->device));
+      CCHK(h, hipSetDevice(h->device));
       for (uint32_t p = 0; p < n; ++p) {
         if (p == k) continue;
         swimsim* q = hs[p];
-        HIPCHK(h, hipStreamWaitEvent(h->stream, ev[p][0], 0));
-        HIPCHK(h, peer_copy(h, h->d.sp_qall + (size_t)q->d.lo * PB_SLOTS, q, q->d.sp_qall + (size_t)q->d.lo * PB_SLOTS, (size_t)N * PB_SLOTS * sizeof(uint2)));
-        HIPCHK(h, peer_copy(h, h->d.mb + q->d.lo, q, q->d.mb + q->d.lo, (size_t)N));
+        CCHK(h, hipStreamWaitEvent(h->stream, ev[p][0], 0));
+        CCHK(h, peer_copy(h, h->d.sp_qall + (size_t)q->d.lo * PB_SLOTS, q, q->d.sp_qall + (size_t)q->d.lo * PB_SLOTS, (size_t)N * PB_SLOTS * sizeof(uint2)));
+        CCHK(h, peer_copy(h, h->d.mb + q->d.lo, q, q->d.mb + q->d.lo, (size_t)N));
       }
       launch_sparse_probe(h, t, tk);
       hipLaunchKernelGGL(sp_route_kernel, dim3(std::min<uint32_t>(1024u, (N + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, h->stream, h->d);
-      HIPCHK(h, hipEventRecord(ev[k][1], h->stream));
+      CCHK(h, hipEventRecord(ev[k][1], h->stream));
     }
     // round 2, the all-to-all-v: every peer's segment for me (its whole capacity: the true count travels as a word next to it)
     for (uint32_t k = 0; k < n; ++k) {
       swimsim* h = hs[k];
-      HIPCHK(h, hipSetDevice(h->device));
+      CCHK(h, hipSetDevice(h->device));
       for (uint32_t p = 0; p < n; ++p) {
         if (p == k) continue;
         swimsim* q = hs[p];
-        HIPCHK(h, hipStreamWaitEvent(h->stream, ev[p][1], 0));
-        HIPCHK(h, peer_copy(h, h->d.sp_pin + p, q, q->d.send_cnt + 1 * MAX_SHARDS + k, sizeof(uint32_t)));
-        HIPCHK(h, peer_copy(h, h->d.p_recv + (size_t)p * h->d.p_cap, q, q->d.p_send + (size_t)k * q->d.p_cap, (size_t)q->d.p_cap * sizeof(uint4)));
+        CCHK(h, hipStreamWaitEvent(h->stream, ev[p][1], 0));
+        CCHK(h, peer_copy(h, h->d.sp_pin + p, q, q->d.send_cnt + 1 * MAX_SHARDS + k, sizeof(uint32_t)));
+        CCHK(h, peer_copy(h, h->d.p_recv + (size_t)p * h->d.p_cap, q, q->d.p_send + (size_t)k * q->d.p_cap, (size_t)q->d.p_cap * sizeof(uint4)));
       }
-      HIPCHK(h, hipEventRecord(ev[k][2], h->stream));
+      CCHK(h, hipEventRecord(ev[k][2], h->stream));
       hipLaunchKernelGGL(sp_ingest_kernel, dim3(std::min<uint32_t>(1024u, (N + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, h->stream, h->d, t, PeerCounts{}, 1u);
       launch_sparse_merge(h, t, tk);
     }
@@ -1419,6 +1428,7 @@ int swimsim_cluster_step(swimsim_t** hs, uint32_t n, uint32_t nticks) {
   cleanup();
   return rc;
 }
+#undef CCHK
 
 int swimsim_shard_step(swimsim_t* h, uint32_t nticks, swimsim_exchange_fn xchg, void* ctx) {
   if (!h || !xchg) return SWIMSIM_ERR_INVALID;

@@ -190,3 +190,24 @@ def test_a_sharded_cluster_of_bounded_handles_matches_the_oracle(oracle_abi, emu
     lockstep(a, b, 30, 3, observers=(0, per - 1, per, n - 1), members=(0, per, n // 2, n - 1))
     assert b.counters()["changes"] > 0
     b.close(); a.close()
+
+
+@pytest.mark.parametrize("n,cap,p,loss,shards", [(150, 16, 3, 300000, 1), (64, 64, 10, 200000, 1), (192, 64, 3, 300000, 4)])
+def test_the_wave_per_member_probe_kernel_still_matches(oracle_abi, monkeypatch, n, cap, p, loss, shards):
+    """sp_probe_kernel (one WAVE per member, the first form; SWIMSIM_SP_PROBE=wave, read when a handle is created) stays in the library
+    for A/B measurements against sp_probe_lane_kernel (the default everywhere else in this file): it must stay exact."""
+    from swim_amd.shard import LocalFabric, ShardedSim
+    from tests import hostemu_binding
+    emu = hostemu_binding.load()
+    sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=17, lossPpm=loss, eventMask=0x1F, suspicionTicks=5, viewCap=cap)
+    monkeypatch.setenv("SWIMSIM_SP_PROBE", "wave")
+    a = Sim.create(oracle_abi, sc)
+    b = Sim.create(emu, sc) if shards == 1 else ShardedSim(emu, sc, LocalFabric(shards))
+    monkeypatch.delenv("SWIMSIM_SP_PROBE")
+    for s in (a, b):
+        s.scheduleFault(3, 7, False); s.scheduleFault(20, 7, True)
+    for _ in range(8):
+        a.step(5); b.step(5)
+        assert a.counters() == b.counters() and a.digest() == b.digest()
+        assert a.drainEventsRaw() == b.drainEventsRaw()
+    a.close(); b.close()
