@@ -192,8 +192,10 @@ typedef struct swimsim_config {
  * = t, deadline t + suspicion_ticks for a pushed Suspect, a view change like any other, not gossiped on, no event.  A host may have
  * several pullers in one tick: the result is the max over all of them -- no order can matter, because hosts are never pullers (the
  * pulls read maps nobody writes, the pushes write maps nobody reads), and pushing the map AFTER the pull gives the host exactly
- * what the map before the pull would have (max is idempotent).  Not available on sharded handles (SWIMSIM_ERR_INVALID): a pull per
- * member and period across shards is an exchange of its own. */
+ * what the map before the pull would have (max is idempotent).
+ * On sharded handles the periodic pull works as the join-time pull does: a puller whose host lives on another shard receives the host's
+ * map as kind-4 records in exchange round 0, so a shard with pull_ticks starts EVERY tick with swimsim_shard_phase0 (swimsim_shard_step
+ * does).  push_pull is not available on sharded handles (SWIMSIM_ERR_INVALID). */
 
 #define SWIMSIM_GC_AUTO 0xFFFFFFFFu
 

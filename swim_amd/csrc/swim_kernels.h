@@ -2044,8 +2044,8 @@ __device__ inline uint32_t pull_host(const DevState& s, uint32_t t, uint32_t tk,
   }
   return NONE32;
 }
-__device__ inline uint32_t join_host(const DevState& s, uint32_t tk, uint32_t m, const FaultRec* faults, uint32_t nfaults) {
-  return pull_host(s, 0u, tk, m, faults, nfaults, P_JOIN);     // (sharded handles: no periodic pulls, t is not looked at)
+__device__ inline uint32_t join_host(const DevState& s, uint32_t t, uint32_t tk, uint32_t m, const FaultRec* faults, uint32_t nfaults) {
+  return pull_host(s, t, tk, m, faults, nfaults, P_JOIN);
 }
 
 // one pulled entry: joiner ml's cell of `slot` becomes kh if that is news to it
@@ -2141,7 +2141,7 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
     }
     return;
   }
-  if (s.join_pull) {
+  if (s.join_pull || (s.pull_T && s.n_shards > 1)) {
     // Join-time state pull (`joinHosts`, src/Types.hs:47; include/swimsim.h), behind the barrier: every row this
     // tick's joins opened is complete, and nothing else in this kernel writes view cells.  A member that came up
     // during the tick merges its host's member map: (i) hosts on other shards sent theirs as records {joiner,
@@ -2153,6 +2153,9 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
         if (!is_local(s, r.x) || r.y >= s.NT) continue;
         unsigned long long evd = 0; unsigned pulled = 0;
         pull_entry(s, t, r.x, get_slot(s, r.y), r.y, r.z, &evd, &pulled);
+        // (a periodic puller that took a Suspect over: merge_kernel rebuilds its deadline cells, as join_pull_kernel arranges for
+        // the pulls from local hosts; a joiner carries the flag already)
+        if (pulled && (r.z & 3u) == ST_SUSPECT) atomicOr(&s.hot[r.x - s.lo].y, 1u);
         if (evd) atomicAdd(&evd_sh, evd);
         if (pulled) atomicAdd(&changes_sh, pulled);
       }
@@ -2258,7 +2261,7 @@ __global__ __launch_bounds__(BLOCK) void join_pull_kernel(DevState s, uint32_t t
   __shared__ unsigned pulled_sh, suspects_sh;
   __shared__ uint32_t host_sh;
   const uint32_t nj = s.join_pull ? min(s.g[G_NJOINED], nj_bound) : 0u;
-  const uint32_t T = s.pull_T, first = T ? t % T : 0u;
+  const uint32_t T = s.pull_T, first = T ? (t % T + T - s.lo % T) % T : 0u;   // my first periodic puller (local index; a shard starts at lo)
   const uint32_t npp = (T && first < s.N) ? (s.N - first + T - 1u) / T : 0u;
   const uint32_t nrows = min(s.g[G_NSLOTS], s.R_phys);
   constexpr int U = 4;
@@ -2383,13 +2386,19 @@ __global__ __launch_bounds__(BLOCK) void push_kernel(DevState s, uint32_t t, uin
 // Sharded clusters with join_pull: between the two parts of begin_kernel the owner of a join host sends what the host
 // knows to the joiner's owner -- one record {joiner, subject, entry} per entry that differs from the base (the host
 // itself as Alive at its own incarnation) -- exchange round 0.  One thread per member that came up this tick.
-__global__ __launch_bounds__(BLOCK) void pull_send_kernel(DevState s, uint32_t tk, const FaultRec* faults, uint32_t nfaults,
+__global__ __launch_bounds__(BLOCK) void pull_send_kernel(DevState s, uint32_t t, uint32_t tk, const FaultRec* faults, uint32_t nfaults,
                                                            const uint32_t* joined) {
-  const uint32_t nj = s.g[G_NJOINED];
-  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nj; k += gridDim.x * blockDim.x) {
-    const uint32_t mbr = joined[k];
+  // work items: the members that came up in this tick (join_pull), then -- pull_ticks = T -- the periodic pullers of the WHOLE population,
+  // t mod T, t mod T + T, ...: every shard looks at all of them and serves those whose host it owns and whose puller it does not
+  const uint32_t nj = s.join_pull ? s.g[G_NJOINED] : 0u;
+  const uint32_t T = s.pull_T, first = T ? t % T : 0u;
+  const uint32_t npp = (T && first < s.NT) ? (s.NT - first + T - 1u) / T : 0u;
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nj + npp; k += gridDim.x * blockDim.x) {
+    const bool joiner = k < nj;
+    const uint32_t mbr = joiner ? joined[k] : first + (k - nj) * T;
     if (is_local(s, mbr)) continue;
-    const uint32_t host = join_host(s, tk, mbr, faults, nfaults);
+    if (!joiner && (!mi_up(s.minfo[mbr]) || changes_this_tick(faults, nfaults, mbr))) continue;   // (a puller is up and has no change in this tick)
+    const uint32_t host = joiner ? join_host(s, t, tk, mbr, faults, nfaults) : pull_host(s, t, tk, mbr, faults, nfaults, P_PULL);
     if (host == NONE32 || !is_local(s, host)) continue;
     const uint32_t peer = owner_of(s, mbr), nrows = min(s.g[G_NSLOTS], s.R_phys), hl = host - s.lo;
     for (uint32_t r = 0; r < nrows; ++r) {

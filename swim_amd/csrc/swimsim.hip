@@ -160,7 +160,7 @@ int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, std::string*
   if (c->target_scheme > SWIMSIM_TARGETS_ROBUST) { *err = "unknown target_scheme"; return SWIMSIM_ERR_INVALID; }
   if (c->join_pull > 1) { *err = "join_pull must be 0 or 1"; return SWIMSIM_ERR_INVALID; }
   if (c->pull_ticks == 1) { *err = "pull_ticks must be 0 (off) or >= 2"; return SWIMSIM_ERR_INVALID; }
-  if (c->pull_ticks && c->n_shards > 1) { *err = "pull_ticks (periodic state pull) is not available on sharded handles"; return SWIMSIM_ERR_INVALID; }
+  if (c->push_pull && c->n_shards > 1) { *err = "push_pull (the push half of the periodic state exchange) is not available on sharded handles"; return SWIMSIM_ERR_INVALID; }
   if (c->n_shards > 1 && c->n_members > (1u << 27)) { *err = "sharded clusters: n_members must be <= 2^27"; return SWIMSIM_ERR_INVALID; }
   if (c->push_pull > 1 || (c->push_pull && !c->pull_ticks)) { *err = "push_pull must be 0 or 1 and needs pull_ticks"; return SWIMSIM_ERR_INVALID; }
   if (c->strict_reference_rules > 1) { *err = "strict_reference_rules must be 0 or 1"; return SWIMSIM_ERR_INVALID; }
@@ -612,8 +612,11 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
       CK(dev_alloc(h, &d.s_recv, (size_t)d.n_shards * d.s_cap, 0));
       CK(dev_alloc(h, &d.settle_acc, (size_t)NT, 0));
     }
-    if (d.join_pull) {                           // join-time pulls from hosts on other shards (round 0): a mass restart
+    if (d.join_pull || d.pull_T) {               // state pulls from hosts on other shards (round 0): a mass restart
       d.j_cap = std::max<uint32_t>(1u << 16, 16u * d.R_phys);   // of J members costs J x (entries a host holds) records
+      // periodic pulls (pull_ticks = T): NT / T pullers per tick, a shard's share of their hosts sends what each host holds -- room for
+      // 64 entries per pull and twice the share, at most 4 M records per peer (a loud capacity error beyond: SWIMSIM_ERR_CAPACITY)
+      if (d.pull_T) d.j_cap = (uint32_t)std::min<double>(4194304.0, std::max<double>(d.j_cap, 2.0 * 64.0 * ((double)NT / d.pull_T / d.n_shards + 64.0)));
       CK(dev_alloc(h, &d.j_send, (size_t)d.n_shards * d.j_cap, 0));
       CK(dev_alloc(h, &d.j_recv, (size_t)d.n_shards * d.j_cap, 0));
     }
@@ -1131,10 +1134,12 @@ int swimsim_shard_phase0(swimsim_t* h, uint32_t* counts, int* round_needed) {
   const uint32_t G = h->d.n_shards;
   for (uint32_t p = 0; p < G; ++p) counts[p] = 0;
   *round_needed = 0;
-  if (!h->d.join_pull || h->begun) return SWIMSIM_OK;
+  if ((!h->d.join_pull && !h->d.pull_T) || h->begun) return SWIMSIM_OK;
   bool joins = false;
-  for (const Fault& f : h->faults) { if (f.tick > h->tick) break; joins |= f.up != 0; }
-  if (!joins) return SWIMSIM_OK;
+  if (h->d.join_pull) for (const Fault& f : h->faults) { if (f.tick > h->tick) break; joins |= f.up != 0; }
+  // periodic pulls (pull_ticks = T): the members t mod T, t mod T + T, ... of the whole population pull in this tick -- every tick has some
+  const bool pulls = h->d.pull_T != 0 && (uint32_t)(h->tick % h->d.pull_T) < h->d.NT;
+  if (!joins && !pulls) return SWIMSIM_OK;
   HIPCHK(h, hipSetDevice(h->device));
   size_t fend = 0;
   rc = upload_faults(h, 1, &fend);
@@ -1143,8 +1148,12 @@ int swimsim_shard_phase0(swimsim_t* h, uint32_t* counts, int* round_needed) {
   const uint32_t tk = tick_key(h->cfg.seed, t);
   { bool inj = false; rc = flush_injections(h, t, &inj); if (rc) return rc; }   // before the tick's scheduled changes (swimsim_step does the same)
   hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults, (uint32_t)fend, h->d_joined, 1u, PeerCounts{});
-  hipLaunchKernelGGL(pull_send_kernel, dim3(std::min<uint32_t>(64u, (uint32_t)(fend + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, h->stream,
-                     h->d, tk, h->d_faults, (uint32_t)fend, h->d_joined);
+  {
+    const uint32_t T = h->d.pull_T, first = T ? t % T : 0u;
+    const uint32_t items = (uint32_t)fend + ((T && first < h->d.NT) ? (h->d.NT - first + T - 1u) / T : 0u);   // joiners (at most) + the tick's periodic pullers, everywhere
+    hipLaunchKernelGGL(pull_send_kernel, dim3(std::max(1u, std::min<uint32_t>(1024u, (items + BLOCK - 1) / BLOCK))), dim3(BLOCK), 0, h->stream,
+                       h->d, t, tk, h->d_faults, (uint32_t)fend, h->d_joined);
+  }
   rc = finish_phase(h, nullptr);
   if (rc) return rc;
   for (uint32_t p = 0; p < G; ++p) counts[p] = p == h->d.shard ? 0u : std::min(h->h_sync[G_JSEND + p], h->d.j_cap);
@@ -1197,11 +1206,14 @@ int swimsim_shard_phase1(swimsim_t* h, uint32_t* counts) {
   // one launch does the whole start of the tick, unless swimsim_shard_phase0 ran its first part already (join-time
   // pulls to exchange in between)
   if (!h->begun) { bool inj = false; rc = flush_injections(h, t, &inj); if (rc) return rc; }
-  if (h->begun) {                                   // the pulls from hosts on this shard: a block per joiner (the ones the peers
-    uint32_t nup = 0;                               // sent are merged by begin_kernel: other joiners, rows no local host holds)
-    for (size_t f = 0; f < fend; ++f) nup += h->faults[f].up != 0;
-    if (nup) hipLaunchKernelGGL(join_pull_kernel, dim3(std::min(nup, 4096u)), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults,
-                                (uint32_t)fend, h->d_joined, nup);
+  if (h->d.pull_T && !h->begun) return set_err(h, SWIMSIM_ERR_STATE, "a shard with pull_ticks starts every tick with swimsim_shard_phase0 (its periodic pulls are exchange round 0)");
+  if (h->begun) {                                   // the pulls from hosts on this shard: a block per puller (the ones the peers
+    uint32_t nup = 0;                               // sent are merged by begin_kernel: other pullers, rows no local host holds)
+    if (h->d.join_pull) for (size_t f = 0; f < fend; ++f) nup += h->faults[f].up != 0;
+    const uint32_t T = h->d.pull_T, first = T ? (t % T + T - h->d.lo % T) % T : 0u;       // my first periodic puller, as a local index
+    const uint32_t npp = (T && first < h->d.N) ? (h->d.N - first + T - 1u) / T : 0u;
+    if (nup + npp) hipLaunchKernelGGL(join_pull_kernel, dim3(std::min(nup + npp, 4096u)), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults,
+                                      (uint32_t)fend, h->d_joined, nup);
   }
   hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults, (uint32_t)fend,
                      h->d_joined, h->begun ? (2u | 8u) : 3u, peer_counts(h, h->j_in));
@@ -1436,7 +1448,7 @@ int swimsim_shard_step(swimsim_t* h, uint32_t nticks, swimsim_exchange_fn xchg, 
   std::vector<uint32_t> out(3 * MAX_SHARDS), in(3 * MAX_SHARDS);
   for (uint32_t k = 0; k < nticks; ++k) {
     int rc, need = 0;
-    if (h->d.join_pull) {
+    if (h->d.join_pull || h->d.pull_T) {
       rc = swimsim_shard_phase0(h, out.data(), &need);
       if (rc) return rc;
       if (need) {

@@ -65,7 +65,7 @@ class _Shard:
         self.send = [_wrap(sp[k], G * caps[k] * REC[k], device).view(G, caps[k] * REC[k]) for k in range(3)]
         self.recv = [_wrap(rp[k], G * caps[k] * REC[k], device).view(G, caps[k] * REC[k]) for k in range(3)]
         self.settling = self.sim.resolved.gc_ticks != 0
-        self.join_pull = self.sim.resolved.join_pull != 0
+        self.join_pull = self.sim.resolved.join_pull != 0 or self.sim.resolved.pull_ticks != 0   # state pulls: exchange round 0 (kind 4)
         # kind 3: what every shard says about its rows (round 3, settling); kind 4: join-time pulls (round 0)
         for kind, on, fn in ((3, self.settling, a.shard_settle_buffers), (4, self.join_pull, a.shard_join_buffers)):
             if not on:
@@ -374,7 +374,7 @@ class ShardedSim:
         acc = self.phase_seconds
         for _ in range(nticks):
             t0 = time.perf_counter()
-            if sh[0].join_pull:                                                     # round 0: join-time pulls
+            if sh[0].join_pull:                                                     # round 0: state pulls (join-time, periodic)
                 c0 = [s.phase0() for s in sh]
                 if c0[0][1]:
                     j_in = f.exchange(sh, (4,), [[c[0]] for c in c0])

@@ -389,8 +389,8 @@ def test_random_configurations_on_the_gpu(oracle_abi, hip_abi, block):
                        suspicionTicks=rng.choice([3, 6, 12]), retransmitMult=rng.choice([1, 3]), maxSubjects=min(n, 4096),
                        targetScheme=scheme, inboxCap=rng.choice([0, 0, 1, 2]) if n <= 4096 else 0, gcTicks=gc,
                        joinPull=1 if shards == 1 and seed % 2 else 0,
-                       pullTicks=(0, 0, 2, 5, 17)[(seed >> 3) % 5] if shards == 1 else 0)
-        sc.pushPull = bool(sc.pullTicks) and (seed >> 7) % 2 == 1
+                       pullTicks=(0, 0, 2, 5, 17)[(seed >> 3) % 5])
+        sc.pushPull = bool(sc.pullTicks) and shards == 1 and (seed >> 7) % 2 == 1
         a = Sim.create(oracle_abi, sc)
         _oracle_threads(a)
         b = Sim.create(hip_abi, sc) if shards == 1 else ShardedSim(hip_abi, sc, LocalFabric(shards), device="cuda:0")
@@ -629,6 +629,32 @@ def test_periodic_state_pull_on_the_gpu(oracle_abi, hip_abi, T, gc, loss, n, pus
     _oracle_threads(a)
     run_lockstep(a, b, 120, 6, observers=(0, 11, n - 1, n // 2), members=(0, 11, n - 1), check_events=n <= 4096)
     assert b.counters()["changes"] > 0
+
+
+@pytest.mark.parametrize("n,loss,T,gc,join,shards", [(4096, 50000, 5, 1, 1, 4), (65536, 10000, 64, 0, 1, 8), (3000, 150000, 3, 0, 0, 2)])
+def test_periodic_state_pull_on_sharded_clusters_on_one_gpu(oracle_abi, hip_abi, n, loss, T, gc, join, shards):
+    """pull_ticks on a cluster of dense shards (several handles on this GPU, the exchange as device-to-device copies): pullers whose
+    hosts live on other shards are served in exchange round 0 (pull_send_kernel / begin_kernel's record merge).  MI355X = the
+    unsharded oracle."""
+    from swim_amd import _abi
+    from swim_amd.shard import LocalFabric, ShardedSim
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=41 + T, lossPpm=loss, eventMask=0x1F if n <= 4096 else 0, suspicionTicks=6,
+                   maxSubjects=min(n, 4096), pullTicks=T, gcTicks=_abi.GC_AUTO if gc else 0, joinPull=join)
+    a, b = Sim.create(oracle_abi, sc), ShardedSim(hip_abi, sc, LocalFabric(shards), device="cuda:0")
+    _oracle_threads(a)
+    crashes = [(3 + 2 * k, (37 * k + 11) % n) for k in range(40)]
+    for s in (a, b):
+        for t, m in crashes:
+            s.crash(m, t)
+        for t, m in crashes[::2]:
+            s.scheduleFault(t + 9 + (m % 13), m, True)
+    for _ in range(15):
+        a.step(6); b.step(6)
+        assert a.counters() == b.counters() and a.digest() == b.digest(), "tick %d" % a.tick
+        if n <= 4096:
+            assert a.drainEventsRaw() == b.drainEventsRaw()
+    assert a.firstDetection() == b.firstDetection()
+    a.close(); b.close()
 
 
 # ---- bounded member maps (view_cap; swim_sparse.h): BASELINE config 5 at the sizes a dense view cannot reach --------------------

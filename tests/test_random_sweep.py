@@ -29,8 +29,8 @@ def test_random_configurations(oracle_abi, block):
         sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, eventMask=0x1F,
                        suspicionTicks=rng.choice([3, 6, 12]), retransmitMult=rng.choice([1, 1, 3]), maxSubjects=min(n, 1024),
                        targetScheme=scheme, inboxCap=rng.choice([0, 0, 1, 2]), gcTicks=gc,
-                       joinPull=seed % 2, pullTicks=(0, 0, 2, 5, 17)[(seed >> 3) % 5] if shards == 1 else 0)
-        sc.pushPull = bool(sc.pullTicks) and (seed >> 7) % 2 == 1
+                       joinPull=seed % 2, pullTicks=(0, 0, 2, 5, 17)[(seed >> 3) % 5])
+        sc.pushPull = bool(sc.pullTicks) and shards == 1 and (seed >> 7) % 2 == 1
         a = Sim.create(oracle_abi, sc)
         rm = shards > 1 and rng.random() < 0.5       # replicated queue masks instead of probe records (read at create)
         os.environ["SWIMSIM_SHARD_REPLICATED_MASKS"] = "1" if rm else "0"
