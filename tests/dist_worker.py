@@ -1,7 +1,8 @@
 """Worker for tests/test_shard_dist.py: one process = one shard (torch.distributed, gloo on CPU).
 Every rank drives its shard through the host emulation of the product kernels; rank 0 also runs the
 oracle and compares every observable.  usage: dist_worker.py <n_members> <p> <loss_ppm> <seed> <ticks> [mode]
-(mode bit 0: settling on, suspicion 5 ticks, retransmit x1, and the member that went down comes back twice)"""
+(mode bit 0: settling on, suspicion 5 ticks, retransmit x1, and the member that went down comes back twice; bit 1: join pull;
+bit 2: periodic state pull every 5 periods; bits 8..: view_cap)"""
 import os
 import sys
 
@@ -12,7 +13,7 @@ sys.path.insert(0, ROOT)
 def main():
     n, p, loss, seed, ticks = (int(x) for x in sys.argv[1:6])
     mode = int(sys.argv[6]) if len(sys.argv) > 6 else 0
-    gc, pull = bool(mode & 1), bool(mode & 2)       # 1: settling, 2: join-time pull (round 0)
+    gc, pull, ppull = bool(mode & 1), bool(mode & 2), bool(mode & 4)       # 1: settling, 2: join-time pull (round 0), 4: periodic pull (round 0 in every tick)
     cap = mode >> 8                                 # bits 8..: bounded member maps with this view_cap (no other option)
     import torch.distributed as dist
     dist.init_process_group("gloo")
@@ -26,6 +27,8 @@ def main():
         sc.suspicionTicks, sc.retransmitMult, sc.gcTicks = 5, 1, _abi.GC_AUTO
     if pull:
         sc.joinPull = 1
+    if ppull:
+        sc.pullTicks = 5
     if cap:
         sc.viewCap, sc.maxSubjects = cap, 0
     if os.environ.get("SWIM_DIST_DEVICE", "cpu") == "cuda":

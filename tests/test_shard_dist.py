@@ -37,6 +37,13 @@ def test_one_process_per_shard_gloo_with_join_pull_and_settling():
     run_world(2, (192, 3, 20000, 8, 130, 3), 29615)
 
 
+def test_one_process_per_shard_gloo_with_periodic_state_pulls():
+    """pull_ticks on a sharded cluster: round 0 in EVERY tick (the periodic pullers whose hosts live on the other shard) through
+    swimsim_shard_step's callback, with join pulls and settling on top."""
+    run_world(2, (192, 3, 20000, 13, 60, 4), 29620)
+    run_world(4, (256, 3, 100000, 14, 60, 7), 29621)
+
+
 def test_one_process_per_shard_gloo_with_replicated_masks():
     """SWIMSIM_SHARD_REPLICATED_MASKS=1: the all-gather of queue masks (round 4) through swimsim_shard_step's callback,
     with loss, settling and the join-time pull on top."""
