@@ -614,9 +614,11 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     }
     if (d.join_pull || d.pull_T) {               // state pulls from hosts on other shards (round 0): a mass restart
       d.j_cap = std::max<uint32_t>(1u << 16, 16u * d.R_phys);   // of J members costs J x (entries a host holds) records
-      // periodic pulls (pull_ticks = T): NT / T pullers per tick, a shard's share of their hosts sends what each host holds -- room for
-      // 64 entries per pull and twice the share, at most 4 M records per peer (a loud capacity error beyond: SWIMSIM_ERR_CAPACITY)
-      if (d.pull_T) d.j_cap = (uint32_t)std::min<double>(4194304.0, std::max<double>(d.j_cap, 2.0 * 64.0 * ((double)NT / d.pull_T / d.n_shards + 64.0)));
+      // periodic pulls (pull_ticks = T): NT / T pullers per tick, a shard's share of their hosts sends what each host holds -- under
+      // loss that is every row in use (3 000 members at 15 % loss, T = 3: 250 pulls x 1 500 entries to one peer per tick, the GPU
+      // test that found the first sizing too small): room for min(rows, 2 048) entries per pull and twice the share, at most 8 M
+      // records per peer (a loud capacity error beyond: SWIMSIM_ERR_CAPACITY)
+      if (d.pull_T) d.j_cap = (uint32_t)std::min<double>(8388608.0, std::max<double>(d.j_cap, 2.0 * std::min<double>(d.R_phys, 2048.0) * ((double)NT / d.pull_T / d.n_shards + 64.0)));
       CK(dev_alloc(h, &d.j_send, (size_t)d.n_shards * d.j_cap, 0));
       CK(dev_alloc(h, &d.j_recv, (size_t)d.n_shards * d.j_cap, 0));
     }

@@ -631,14 +631,15 @@ def test_periodic_state_pull_on_the_gpu(oracle_abi, hip_abi, T, gc, loss, n, pus
     assert b.counters()["changes"] > 0
 
 
-@pytest.mark.parametrize("n,loss,T,gc,join,shards", [(4096, 50000, 5, 1, 1, 4), (65536, 10000, 64, 0, 1, 8), (3000, 150000, 3, 0, 0, 2)])
+@pytest.mark.parametrize("n,loss,T,gc,join,shards", [(4096, 50000, 5, 1, 1, 4), (65536, 10000, 64, 0, 1, 8), (1500, 150000, 3, 0, 0, 2), (3000, 150000, 3, 0, 0, 2)])
 def test_periodic_state_pull_on_sharded_clusters_on_one_gpu(oracle_abi, hip_abi, n, loss, T, gc, join, shards):
     """pull_ticks on a cluster of dense shards (several handles on this GPU, the exchange as device-to-device copies): pullers whose
     hosts live on other shards are served in exchange round 0 (pull_send_kernel / begin_kernel's record merge).  MI355X = the
     unsharded oracle."""
     from swim_amd import _abi
     from swim_amd.shard import LocalFabric, ShardedSim
-    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=41 + T, lossPpm=loss, eventMask=0x1F if n <= 4096 else 0, suspicionTicks=6,
+    events = n <= 4096 and not (n >= 3000 and loss >= 100000)      # (3 000 members at 15 % loss fill the event ring within 6 ticks: what is dropped then is implementation-defined)
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=41 + T, lossPpm=loss, eventMask=0x1F if events else 0, suspicionTicks=6,
                    maxSubjects=min(n, 4096), pullTicks=T, gcTicks=_abi.GC_AUTO if gc else 0, joinPull=join)
     a, b = Sim.create(oracle_abi, sc), ShardedSim(hip_abi, sc, LocalFabric(shards), device="cuda:0")
     _oracle_threads(a)
@@ -651,7 +652,7 @@ def test_periodic_state_pull_on_sharded_clusters_on_one_gpu(oracle_abi, hip_abi,
     for _ in range(15):
         a.step(6); b.step(6)
         assert a.counters() == b.counters() and a.digest() == b.digest(), "tick %d" % a.tick
-        if n <= 4096:
+        if events:
             assert a.drainEventsRaw() == b.drainEventsRaw()
     assert a.firstDetection() == b.firstDetection()
     a.close(); b.close()
