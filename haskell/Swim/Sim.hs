@@ -24,7 +24,7 @@ module Swim.Sim
   , defaultSimConfig, configureSim, stepN, scheduleFault
   , drainEvents, simulate, memberView, firstDetection, digest
   , encodeEnvelope, decodeEnvelope
-  , stepShard
+  , stepShard, stepCluster
   ) where
 
 import           Control.Concurrent.MVar (MVar, newMVar, withMVar)
@@ -106,6 +106,8 @@ foreign import ccall safe   "swimsim_shard_phase3"  c_shard_phase3  :: Ptr Swims
 type ExchangeFn = Ptr () -> CInt -> Ptr Word32 -> Ptr Word32 -> IO CInt
 foreign import ccall "wrapper" mkExchange :: ExchangeFn -> IO (FunPtr ExchangeFn)
 foreign import ccall safe   "swimsim_shard_step"    c_shard_step    :: Ptr SwimsimT -> Word32 -> FunPtr ExchangeFn -> Ptr () -> IO CInt
+-- a whole cluster of BOUNDED handles (simViewCap > 0) owned by this process, the exchange inside the library (include/swimsim.h)
+foreign import ccall safe   "swimsim_cluster_step"  c_cluster_step  :: Ptr (Ptr SwimsimT) -> Word32 -> Word32 -> IO CInt
 
 defaultSimConfig :: Config -> SimConfig
 defaultSimConfig c = SimConfig c 128 1 0 0 0 0 0 0 0 0 0 0 False False 0 1
@@ -348,3 +350,20 @@ stepShard s nticks nShards exchange = withSim s $ \h -> do
           Left e   -> writeIORef failure (Just e) >> return 1
   rc <- bracket (mkExchange body) freeHaskellFunPtr $ \cb -> c_shard_step h nticks cb nullPtr
   readIORef failure >>= maybe (check h rc) throwIO
+
+-- | All shards of a cluster of bounded handles (simViewCap > 0) in ONE process -- one GPU, or the GPUs of a node with peer access --
+-- stepped together: the two exchange rounds of a tick run as copies on the handles' own streams, nothing comes back to the host
+-- between the phases (`swimsim_cluster_step`; DESIGN.md section 7b).  `sims` = shard 0, 1, ... of the cluster, in that order.
+stepCluster :: [Sim] -> Word32 -> IO ()
+stepCluster sims nticks = go sims []
+  where
+    go (s : rest) hs = withSim s $ \h -> go rest (h : hs)       -- every handle's lock is held for the call
+    go [] hs = allocaArray (length hs) $ \arr -> do
+      let ordered = reverse hs
+      pokeArray arr ordered
+      rc <- c_cluster_step arr (fromIntegral (length ordered)) nticks
+      unless (rc == 0) $ firstError ordered rc
+    firstError (h : rest) rc = do
+      msg <- c_last_error h >>= peekCString
+      if null msg && not (null rest) then firstError rest rc else ioError (userError (if null msg then "swimsim_cluster_step: status " ++ show rc else msg))
+    firstError [] rc = ioError (userError ("swimsim_cluster_step: status " ++ show rc))
