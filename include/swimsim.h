@@ -34,6 +34,9 @@
 extern "C" {
 #endif
 
+/* 6: config fields strict_reference_rules, push_pull (round 4); 5: view_cap, counter EVICTED, swimsim_cluster_step, the wire codec's
+ * bare form (round 4); 4: pull_ticks, swimsim_inject_rumor, the bridge (round 3).  A handle is refused unless struct_size and
+ * abi_version match the library's. */
 #define SWIMSIM_ABI_VERSION 6u
 
 /* ---- status codes ------------------------------------------------------ */
