@@ -36,7 +36,9 @@ enum { G_NSLOTS = 0 /* view rows ever handed out (high-water mark) */, G_ERR = 1
        G_NJOINED = 64 /* members that came up in this tick (begin_kernel part A) */,
        G_JSEND = 65 /* [16] join-pull records appended per peer (exchange round 0) */,
        G_FLDYN = 81 /* foreign lines handed out by remote_kernel this tick */,
-       G_ANYREC = 83 /* somebody wrote an explicit record this tick */,
+       G_ANYREC = 83 /* = t + 1: somebody wrote an explicit record in tick t */,
+       G_HEAD_NEW = 84, G_PREV_NEW = 85 /* a tick WITHOUT begin_kernel (swimsim_step's plain ticks): the tick's window head / the one before,
+                                           left by probe_kernel's workgroup 0 for merge_kernel, whose workgroup 0 commits them to G_HEAD / G_PREV */,
        G_WORDS = 96 };
 // the todo buffer (explicit records' survivors) is cut into TODO_REGIONS regions with a counter each, on 64-byte lines of
 // their own (todo_n[region * 16]): workgroup b reserves from region b mod TODO_REGIONS -- every wave of the grid bumping

@@ -222,7 +222,7 @@ __device__ inline void deliver_local(const DevState& s, uint32_t t, bool use_mas
 #endif
 constexpr int PX_KG = 4;        // proxy indices per round of the wave's indirect-probe pass (probe_kernel pass 5)
 template <int PMAX>
-__global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? SWIM_PROBE_WAVES8 : PMAX <= 12 ? SWIM_PROBE_WAVES12 : SWIM_PROBE_WAVES16) void probe_kernel(SWIM_STATE_PARAM, uint32_t t, uint32_t tk, Offsets off) {
+__global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? SWIM_PROBE_WAVES8 : PMAX <= 12 ? SWIM_PROBE_WAVES12 : SWIM_PROBE_WAVES16) void probe_kernel(SWIM_STATE_PARAM, uint32_t t, uint32_t tk, Offsets off, uint32_t fold) {
   SWIM_STATE_BIND
   __shared__ BlockCounters sh;
   __shared__ uint32_t ordn;                        // deliveries left to the exchange (sharded runs)
@@ -239,7 +239,28 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
   const uint32_t mi = li < s.N ? s.minfo[i] : 0u;
   const bool act = mi_up(mi);
   // masks are exact only if few rumour ids appeared since they were built (swim_device.h)
-  const uint32_t Hprev = s.g[G_PREV], H = s.g[G_HEAD];
+  // `fold` (swimsim_step, a PLAIN tick: no scheduled change, no message from outside, no pull, no settling, one handle): there is
+  // NO begin_kernel launch -- the tick's window head is the rumour-id counter as it stands (nothing allocates ids between the ticks'
+  // merge kernels), the head before it is what the last tick left in G_HEAD, and workgroup 0 leaves what merge_kernel needs of the
+  // start of the tick (below): a launch and a kernel boundary less per tick (~ 11 us; profiles/r03i_*: a boundary is ~ 6 us)
+  const uint32_t Hprev = fold ? s.g[G_HEAD] : s.g[G_PREV], H = fold ? s.g[G_NRUM] : s.g[G_HEAD];
+  if (fold && blockIdx.x == 0) {
+    // begin_kernel's part B for a plain tick, by the one workgroup: nothing of it is read by this kernel's other workgroups
+    // (they took H and Hprev from words nobody writes during this launch), all of it by merge_kernel behind the kernel boundary
+    if (threadIdx.x == 0) {
+      s.g[G_PREV_NEW] = Hprev; s.g[G_HEAD_NEW] = H;
+      s.g[G_RIDS_OFF] = (H - Hprev > RID_MASK + 1u - RID_NEAR - KW_BITS) ? 1u : 0u;
+    }
+    for (uint32_t k = threadIdx.x; k <= TODO_REGIONS; k += blockDim.x) s.todo_n[k * 16u] = 0;
+    if (t)
+      for (uint32_t k = threadIdx.x; k < s.tovf_nsub; k += blockDim.x)
+        s.tovf_n[((((t - 1u) % s.S) * 2u + ((((t - 1u) / s.S) & 1u) ^ 1u)) * s.tovf_nsub + k) * 16u] = 0;
+    if (threadIdx.x < KN_BITS) {
+      const uint2 r = s.rum[rid_at(threadIdx.x, H) & RID_MASK];
+      const uint32_t row = r.x < s.R_phys ? r.x : 0u;
+      s.ring[threadIdx.x] = make_uint4(r.x, r.y, s.slot_base[row], s.subject_of[row]);
+    }
+  }
   // (strict reference rules: never -- a rumour the literal rule ignored may be accepted later, so no delivery may be filtered as
   // "known already": every delivery is an explicit record, every entry of its line is examined; include/swimsim.h)
   const bool use_mask = H - Hprev <= MASK_SLACK && !s.strict;
@@ -525,7 +546,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
     pubq = mycnt | (((mi & MI_OOW) || !use_mask) ? Q_OOW : 0u) | (clean ? 0u : Q_EXC);   // a tick without masks: no queue travels as one
   }
   if (li < s.N && !ABL(ABL_ACKMASK_STORE)) s.ackmask[li] = ackacc;
-  if (__ballot(wrote_rec) && (threadIdx.x & 63u) == 0u) s.g[G_ANYREC] = 1u;   // one plain store per wave that wrote any
+  if (__ballot(wrote_rec) && (threadIdx.x & 63u) == 0u) s.g[G_ANYREC] = t + 1u;   // one plain store per wave that wrote any (tagged with the tick: nobody has to reset it)
   if (s.rm && li < s.N) { s.mask_all[i] = pubmask; s.q_all[i] = (uint8_t)pubq; }
   ctr_add_wave(&sh, C_PINGS, n_pings);
   ctr_add_wave(&sh, C_ACTIVE, act ? 1u : 0u);
@@ -719,7 +740,7 @@ __device__ inline uint32_t records_serial(const DevState& s, uint32_t t, uint32_
   return nout;
 }
 
-__device__ __forceinline__ void records_phase(const DevState& s, uint32_t t, uint32_t li, uint32_t mi, unsigned long long got SECT_PARAM) {
+__device__ __forceinline__ void records_phase(const DevState& s, uint32_t t, uint32_t li, uint32_t mi, unsigned long long got, uint32_t H, uint32_t Hprev SECT_PARAM) {
   const bool up = mi_up(mi);
   uint32_t cnt = 0, nack = 0;
   if (up) { cnt = s.inbox_cnt[li]; nack = s.probe_out[li] >> 10; }
@@ -728,7 +749,6 @@ __device__ __forceinline__ void records_phase(const DevState& s, uint32_t t, uin
 #ifdef SWIM_REC_STATS
   { const unsigned long long b = __ballot(has); if ((threadIdx.x & 63u) == 0u) { atomicAdd(&s.g[90], (uint32_t)__popcll(b)); atomicAdd(&s.g[91], 1u); } }
 #endif
-  const uint32_t H = s.g[G_HEAD];
   const uint32_t nin = cnt < s.inbox_cap ? cnt : s.inbox_cap;
   const uint32_t novf = cnt > s.inbox_cap ? min(s.g[G_OVF0 + (t & 1u)], s.ovf_cap) : 0u;
   // room for 8 survivors per source; the overflow list is shared: count my entries first
@@ -745,7 +765,7 @@ __device__ __forceinline__ void records_phase(const DevState& s, uint32_t t, uin
   const uint32_t off = base + incl - ub;
   // my 64-position ring as the rest of the kernel will hold it when it comes to the records: last tick's new ids
   // forgotten, this tick's mask deliveries (got: pushed to me and pulled by me) learnt
-  const unsigned long long kn = (s.pk[li].y & ~stale_positions(s.g[G_PREV], H)) | got;
+  const unsigned long long kn = (s.pk[li].y & ~stale_positions(Hprev, H)) | got;
   unsigned long long learnt = 0;                   // ring positions of the ids the records carry: ORed into the ring later
   Ring256 kw = load_wide_ring(s, li, H, kn);
   const uint32_t nout = records_serial(s, t, li, H, s.g[G_RIDS_OFF] != 0u, kw, learnt, nack, nin, novf, 0u, s.todo + off SECT_ARG);
@@ -789,7 +809,7 @@ __device__ inline uint32_t block_prefix_excl(uint32_t x, uint32_t* wsum /* LDS, 
   return before + incl - x;
 }
 __global__ __launch_bounds__(BLOCK, 5) void records_kernel(DevState s, uint32_t t) {
-  if (!s.g[G_ANYREC]) return;                      // uniform: nobody wrote a record this tick
+  if (s.g[G_ANYREC] != t + 1u) return;             // uniform: nobody wrote a record this tick
   __shared__ unsigned long long kw_sh[4][BLOCK];   // the members' wide rings
   __shared__ unsigned long long learnt_sh[BLOCK];
   __shared__ uint32_t pref[BLOCK + 1];             // exclusive prefix of the members' dealt sources (acks + inbox)
@@ -989,7 +1009,7 @@ __device__ inline void settle_pass(const DevState& s, uint32_t li, bool up, uint
     for (uint32_t k = 0; k < nz; ++k) s.V[vidx(s, li, s.zero_slots[k])] = make_uint2(0u, 0u);
 }
 
-__global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STATE_PARAM, uint32_t t, uint32_t rec_inline) {
+__global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STATE_PARAM, uint32_t t, uint32_t rec_inline, uint32_t folded) {
   SWIM_STATE_BIND
   __shared__ BlockCounters sh;
   __shared__ uint32_t asm_[PB_SLOTS * 2][ASM_STRIDE];   // the outgoing line is assembled here: [2 entry + word][thread]
@@ -1011,7 +1031,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
     const uint32_t li0 = blockIdx.x * BLOCK + tid;
     uint32_t w = 0;
     if (li0 < s.N && mi_up(s.minfo[s.lo + li0])) {
-      const unsigned long long f = (s.inmask[li0] | s.ackmask[li0]) & ~(s.pk[li0].y & ~stale_positions(s.g[G_PREV], s.g[G_HEAD]));
+      const unsigned long long f = (s.inmask[li0] | s.ackmask[li0]) & ~(s.pk[li0].y & ~stale_positions(s.g[folded ? G_PREV_NEW : G_PREV], s.g[folded ? G_HEAD_NEW : G_HEAD]));
       w = min(15u, 1u + (uint32_t)__popcll(f) + ((s.probe_out[li0] >> 5) & 31u) + min(s.inbox_cnt[li0], 6u));
     }
     if (tid < 16u) sort_cnt[tid] = 0;
@@ -1032,8 +1052,12 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
   if (blockIdx.x == 0 && threadIdx.x == 0) s.g[G_OVF0 + ((t + 1) & 1u)] = 0;  // next tick's overflow list
   const uint32_t mi = li < s.N ? s.minfo[i] : 0u;
   const bool up = mi_up(mi);
-  const uint32_t H = s.g[G_HEAD];
-  const unsigned long long stale = stale_positions(s.g[G_PREV], H);
+  // (`folded`: a tick without begin_kernel -- probe_kernel's workgroup 0 left the window heads in the _NEW words; my workgroup 0
+  // commits them, so that whatever comes next -- a begin_kernel, a reader on the host -- finds G_HEAD / G_PREV as always.  No
+  // workgroup of this launch reads those two.)
+  const uint32_t H = s.g[folded ? G_HEAD_NEW : G_HEAD], Hprev = s.g[folded ? G_PREV_NEW : G_PREV];
+  if (folded && blockIdx.x == 0 && threadIdx.x == 0) { s.g[G_PREV] = Hprev; s.g[G_HEAD] = H; }
+  const unsigned long long stale = stale_positions(Hprev, H);
 
   // ---- this member's inputs of the tick (coalesced)
   uint32_t nsent = 0, nfail = 0, cnt = 0;
@@ -1059,7 +1083,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
   }
   // the records phase, behind the loads above (the wait for its flag -- a scalar load at the cold start of the kernel --
   // used to stand in front of them: 7 500 clocks per wave in a tick without records, profiles/r03r_*)
-  if (rec_inline && s.g[G_ANYREC]) records_phase(s, t, li, mi, pushed | pulled SECT_ARG);   // wave-uniform: somebody wrote an explicit record this tick
+  if (rec_inline && s.g[G_ANYREC] == t + 1u) records_phase(s, t, li, mi, pushed | pulled, H, Hprev SECT_ARG);   // wave-uniform: somebody wrote an explicit record this tick
   SECT(14);                                         // records phase
   if (up) cnt = s.inbox_cnt[li];                    // entries of my todo list
   if (s.G) settle_pass(s, li, up, wmax);
@@ -2189,7 +2213,7 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
     if (changes_sh) s.blk[(size_t)s.nblocks * C_COUNT + C_CHANGES] += changes_sh;
     s.g[G_PREV] = s.g[G_HEAD];
     s.g[G_HEAD] = s.g[G_NRUM];
-    s.g[G_ANYREC] = (s.n_shards > 1 || (part & 4u)) ? 1u : 0u;   // set by whoever writes an explicit record (the exchange kernels may;
+    s.g[G_ANYREC] = (s.n_shards > 1 || (part & 4u)) ? t + 1u : 0u;   // = t + 1, set by whoever writes an explicit record (the exchange kernels may;
                                                                   // part bit 2: inject_kernel already has)
     // a line is rewritten every tick and replaces ids outside [H - KW_BITS, H + RID_NEAR) by "no id"; an id born at
     // distance r < RID_NEAR above the head sits at r - D one tick later (D = ids of the tick) and would wrap

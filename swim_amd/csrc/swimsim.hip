@@ -69,6 +69,7 @@ struct swimsim {
   uint32_t* h_sync = nullptr;                  // pinned host copy of the globals (flags + send counts)
   hipEvent_t tick_ev[3] = {nullptr, nullptr, nullptr};
   uint32_t sp_grid_probe = 0, sp_grid_merge = 0;   // bounded member maps: workgroups of the two tick kernels
+  bool fold_begin = true;                          // plain ticks run without begin_kernel (SWIMSIM_FOLD_BEGIN=0 at create: never)
   bool sp_probe_by_wave = false;                   // SWIMSIM_SP_PROBE=wave at create: the wave-per-member probe kernel (A/B, tests)
 };
 
@@ -284,13 +285,13 @@ int flush_injections(swimsim* h, uint32_t t, bool* any) {
 }
 
 template <int PMAX>
-void launch_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev) {
+void launch_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev, uint32_t fold) {
   if (ev) (void)hipEventRecord(ev[0], h->stream);
-  hipLaunchKernelGGL((probe_kernel<PMAX>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, tk, robust_offsets(h, t));
+  hipLaunchKernelGGL((probe_kernel<PMAX>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, tk, robust_offsets(h, t), fold);
   if (ev) (void)hipEventRecord(ev[1], h->stream);
   const bool rk = records_kernel_every_tick(h);
   if (rk) hipLaunchKernelGGL(records_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
-  hipLaunchKernelGGL(merge_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, rk ? 0u : 1u);
+  hipLaunchKernelGGL(merge_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, rk ? 0u : 1u, fold);
   if (ev) (void)hipEventRecord(ev[2], h->stream);
 }
 
@@ -393,6 +394,7 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   swimsim* h = new (std::nothrow) swimsim();
   if (!h) return set_err(nullptr, SWIMSIM_ERR_NOMEM, "out of host memory");
   h->cfg = c; h->device = c.device;
+  { const char* e = std::getenv("SWIMSIM_FOLD_BEGIN"); h->fold_begin = !(e && e[0] == '0'); }
   auto bail = [&](int code) { g_create_err = h->err; swimsim_destroy(h); return code; };
 #define CK(expr) do { int rc_ = (expr); if (rc_) return bail(rc_); } while (0)
 #define HK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { h->err = std::string(#expr) + ": " + hipGetErrorString(e_); return bail(e_ == hipErrorOutOfMemory ? SWIMSIM_ERR_NOMEM : SWIMSIM_ERR_DEVICE); } } while (0)
@@ -754,13 +756,18 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
       if (h->d.push_pull && npp) hipLaunchKernelGGL(push_kernel, dim3(std::min(npp, 16384u)), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, (uint32_t)(fpos - f0));
       part = (part & ~1u) | 8u;
     }
-    hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, (uint32_t)(fpos - f0),
-                       h->d_joined, part, PeerCounts{});
+    // A PLAIN tick -- no scheduled change, no message from outside, no state pull, no settling, no explicit-record kernel -- needs
+    // nothing of begin_kernel but the window heads, the tick's ring and three resets: probe_kernel's workgroup 0 does that on the
+    // side (`fold`), the launch and its kernel boundary are saved (SWIMSIM_FOLD_BEGIN=0 at create: always launch it; A/B, tests)
+    const uint32_t fold = (h->fold_begin && part == 3u && fpos == f0 && !(nup + npp) && !h->d.G && !records_kernel_every_tick(h)) ? 1u : 0u;
+    if (!fold)
+      hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, (uint32_t)(fpos - f0),
+                         h->d_joined, part, PeerCounts{});
     const uint32_t pk = std::max(h->d.P, h->d.K);   // registers follow the probe / proxy arrays: four sizes
-    if (pk <= 4) launch_tick<4>(h, t, tk, ev);
-    else if (pk <= 8) launch_tick<8>(h, t, tk, ev);
-    else if (pk <= 12) launch_tick<12>(h, t, tk, ev);   // the reference's default numToGossip = 10 (src/Util.hs:48)
-    else launch_tick<16>(h, t, tk, ev);
+    if (pk <= 4) launch_tick<4>(h, t, tk, ev, fold);
+    else if (pk <= 8) launch_tick<8>(h, t, tk, ev, fold);
+    else if (pk <= 12) launch_tick<12>(h, t, tk, ev, fold);   // the reference's default numToGossip = 10 (src/Util.hs:48)
+    else launch_tick<16>(h, t, tk, ev, fold);
     h->tick++;
   }
   h->faults.erase(h->faults.begin(), h->faults.begin() + (long)fpos);
@@ -1225,10 +1232,10 @@ int swimsim_shard_phase1(swimsim_t* h, uint32_t* counts) {
   if (h->timing) (void)hipEventRecord(h->tick_ev[0], h->stream);
   const uint32_t pk = std::max(h->d.P, h->d.K);
   const Offsets off = robust_offsets(h, t);
-  if (pk <= 4) hipLaunchKernelGGL((probe_kernel<4>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, tk, off);
-  else if (pk <= 8) hipLaunchKernelGGL((probe_kernel<8>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, tk, off);
-  else if (pk <= 12) hipLaunchKernelGGL((probe_kernel<12>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, tk, off);
-  else hipLaunchKernelGGL((probe_kernel<16>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, tk, off);
+  if (pk <= 4) hipLaunchKernelGGL((probe_kernel<4>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, tk, off, 0u);
+  else if (pk <= 8) hipLaunchKernelGGL((probe_kernel<8>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, tk, off, 0u);
+  else if (pk <= 12) hipLaunchKernelGGL((probe_kernel<12>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, tk, off, 0u);
+  else hipLaunchKernelGGL((probe_kernel<16>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, tk, off, 0u);
   if (h->timing) (void)hipEventRecord(h->tick_ev[1], h->stream);
   hipLaunchKernelGGL(split_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
   rc = finish_phase(h, counts);
@@ -1292,7 +1299,7 @@ int swimsim_shard_phase3(swimsim_t* h, const uint32_t* p_counts_in, const uint32
   if (h->timing) (void)hipEventRecord(h->tick_ev[1], h->stream);
   const bool rk = records_kernel_every_tick(h);
   if (rk) hipLaunchKernelGGL(records_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
-  hipLaunchKernelGGL(merge_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, rk ? 0u : 1u);
+  hipLaunchKernelGGL(merge_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, rk ? 0u : 1u, 0u);
   if (h->timing) (void)hipEventRecord(h->tick_ev[2], h->stream);
   if (h->d.G) hipLaunchKernelGGL(settle_publish_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t);
   rc = finish_phase(h, nullptr);

@@ -335,6 +335,33 @@ def test_strict_reference_rules_on_the_gpu(oracle_abi, hip_abi, n, p, loss, seed
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("fold,n", [("0", 4096), ("1", 4096), ("1", 65536)])
+def test_plain_ticks_with_and_without_begin_kernel_on_the_gpu(oracle_abi, hip_abi, monkeypatch, fold, n):
+    """Ticks without scheduled changes run without begin_kernel (probe_kernel's workgroup 0 does its part on the side, merge_kernel's
+    commits the window heads; SWIMSIM_FOLD_BEGIN=0 at create: never): both forms on MI355X against the oracle, plain ticks and ticks
+    with crashes, rejoins, set_view and messages from outside interleaved -- here the probe's other workgroups really run next to
+    workgroup 0."""
+    monkeypatch.setenv("SWIMSIM_FOLD_BEGIN", fold)
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=77, eventMask=0x1F if n <= 4096 else 0, suspicionTicks=6, maxSubjects=2048)
+    a, b = make_pair(oracle_abi, hip_abi, sc, [(3, 11), (4, 12), (9, 300), (30, 301)], [(20, 11, True), (41, 300, True)])
+    monkeypatch.delenv("SWIMSIM_FOLD_BEGIN")
+    if n > 4096:
+        _oracle_threads(a)
+    for k in range(30):
+        if k == 12:
+            for s in (a, b):
+                s.injectRumor(5, 40, 1, 0); s.injectRumor(6, 41, 2, 0)
+        if k == 16:
+            for s in (a, b):
+                s.setView(observer=8, subject=9, state=1, incarnation=0)
+        a.step(2); b.step(2)
+        assert a.counters() == b.counters() and a.digest() == b.digest(), "tick %d" % a.tick
+        if n <= 4096:
+            assert a.drainEventsRaw() == b.drainEventsRaw()
+    assert a.firstDetection() == b.firstDetection()
+    a.close(); b.close()
+
+
 def _oracle_threads(sim):
     import os
     from tests import oracle_binding

@@ -406,3 +406,28 @@ def test_a_shard_with_pull_ticks_must_start_the_tick_with_phase0(emu_abi):
     counts = (C.c_uint32 * 6)()
     assert emu_abi.shard_phase1(s._h, counts) != 0
     s.close()
+
+
+@pytest.mark.parametrize("fold", ["0", "1"])
+def test_plain_ticks_with_and_without_begin_kernel(oracle_abi, emu_abi, monkeypatch, fold):
+    """A tick without scheduled changes, messages from outside, pulls or settling runs WITHOUT begin_kernel (probe_kernel's workgroup 0
+    leaves the window heads, the ring and the resets for merge_kernel) unless SWIMSIM_FOLD_BEGIN=0 at create.  Both forms,
+    with ticks of both kinds interleaved (crashes and rejoins in some ticks, set_view and injected rumours between others), against
+    the oracle every tick."""
+    monkeypatch.setenv("SWIMSIM_FOLD_BEGIN", fold)
+    n = 700
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=77, eventMask=0x1F, suspicionTicks=6, maxSubjects=n)
+    a, b = make_pair(oracle_abi, emu_abi, sc, [(3, 11), (4, 12), (9, 300), (30, 301)], [(20, 11, True), (41, 300, True)])
+    monkeypatch.delenv("SWIMSIM_FOLD_BEGIN")
+    for k in range(60):
+        if k == 25:
+            for s in (a, b):
+                s.injectRumor(5, 40, 1, 0); s.injectRumor(6, 41, 2, 0)
+        if k == 33:
+            for s in (a, b):
+                s.setView(observer=8, subject=9, state=1, incarnation=0)
+        a.step(1); b.step(1)
+        assert a.counters() == b.counters() and a.digest() == b.digest(), "tick %d" % a.tick
+        assert a.drainEventsRaw() == b.drainEventsRaw()
+    assert a.firstDetection() == b.firstDetection()
+    a.close(); b.close()
