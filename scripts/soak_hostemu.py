@@ -1,5 +1,6 @@
 """Randomised long-run soak of the product's kernels in the host emulation against the oracle (CPU only): random
-populations (130-3000) on 1-8 shards, both target schemes, fan-outs, loss rates up to 20 %, settling, join pull, tiny inboxes, hundreds of crashes and
+populations (130-3000) on 1-8 shards, both target schemes, fan-outs, loss rates up to 20 %, settling, join pull, periodic pulls (push-pull on one
+handle), strict reference rules, messages from outside, plain ticks with and without begin_kernel, tiny inboxes, hundreds of crashes and
 rejoins over 200-800 ticks, on the normal build and the knob-shrunk ones (8- and 10-bit rumour ids, 4-id mask
 window).  Every 20 ticks: counters (the dropped-event count aside: implementation-defined once the ring overflows),
 state digest, events (while nothing was dropped), first-detection ticks at the end.
@@ -28,19 +29,23 @@ while time.time() < t_end:
     gc = rng.random() < 0.6
     jp = rng.random() < 0.5
     S = rng.choice([4, 7, 12])
-    pt = rng.choice([0, 0, 2, 3, 9, 40]) if shards == 1 else 0   # periodic state pull (unsharded handles)
+    pt = rng.choice([0, 0, 2, 3, 9, 40])                          # periodic state pull (on shards: exchange round 0 in every tick)
+    pp = bool(pt) and shards == 1 and rng.random() < 0.5         # ... as a push-pull (one handle only)
+    strict = shards == 1 and not gc and not jp and not pt and rng.random() < 0.5   # the literal suspectOrDeadNode' (no other option with it)
+    fold = rng.choice(["0", "1"])                                # plain ticks with / without begin_kernel
     ticks = rng.choice([200, 400, 800])
     sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=rng.randrange(1, 1 << 30), lossPpm=loss, eventMask=0x1F,
                    suspicionTicks=S, retransmitMult=rng.choice([1, 2, 3]), maxSubjects=n, gcTicks=_abi.GC_AUTO if gc else 0,
                    joinPull=1 if jp else 0, inboxCap=rng.choice([0, 0, 2]), targetScheme=scheme,
-                   pullTicks=pt)
+                   pullTicks=pt, pushPull=pp, strictReferenceRules=strict)
+    os.environ["SWIMSIM_FOLD_BEGIN"] = fold
     a = Sim.create(orc, sc)
     rm = shards > 1 and rng.random() < 0.5                       # replicated queue masks (read from the environment at create)
     os.environ["SWIMSIM_SHARD_REPLICATED_MASKS"] = "1" if rm else "0"
     rk = rng.choice(["", "0", "1"])                              # explicit records: the handle's own choice / phase in merge_kernel / records_kernel
     if rk: os.environ["SWIMSIM_RECORDS_KERNEL"] = rk
     else: os.environ.pop("SWIMSIM_RECORDS_KERNEL", None)
-    inject = shards == 1 and rng.random() < 0.4                   # rumours from outside the simulation (swimsim_inject_rumor)
+    inject = rng.random() < 0.4                                  # rumours from outside the simulation (swimsim_inject_rumor; on shards: to the observer's owner)
     b = Sim.create(variants[vname], sc) if shards == 1 else ShardedSim(variants[vname], sc, LocalFabric(shards))
     nf = rng.randrange(0, n // 4)
     for _ in range(nf):
@@ -49,7 +54,7 @@ while time.time() < t_end:
         if rng.random() < 0.7:
             t2 = t + rng.randrange(1, 150)
             for s in (a, b): s.scheduleFault(t2, m, True)
-    what = (vname, n, p, loss, gc, jp, S, ticks, sc.seed, nf, shards, scheme, rm, "rk" + rk, inject, "pull%d" % pt)
+    what = (vname, n, p, loss, gc, jp, S, ticks, sc.seed, nf, shards, scheme, rm, "rk" + rk, inject, "pull%d" % pt, "push" if pp else "", "strict" if strict else "", "fold" + fold)
     ok = True
     try:
         for _ in range(ticks // 20):
