@@ -25,6 +25,12 @@ SPECS = {
     # bounded member maps (view_cap = 8) under 30 % loss: evictions every tick, a crash and a rejoin
     "bounded_n96_cap8": {"n": 96, "k": 3, "seed": 13, "loss_ppm": 300000, "suspicion": 6, "ticks": 60, "every": 5, "view_cap": 8,
                          "faults": [[4, 10, 0], [9, 50, 0], [30, 10, 1]]},
+    # strict_reference_rules (the literal suspectOrDeadNode' under the canonical order) where the rules part: 20 % loss, a rejoin
+    "strict_n96_k3": {"n": 96, "k": 3, "seed": 17, "loss_ppm": 200000, "suspicion": 6, "ticks": 100, "every": 10, "strict": 1,
+                      "faults": [[4, 10, 0], [9, 50, 0], [40, 10, 1]]},
+    # a push-pull every 5 periods (the periodic state exchange, both halves)
+    "pushpull_n96_k3": {"n": 96, "k": 3, "seed": 19, "loss_ppm": 100000, "suspicion": 6, "ticks": 100, "every": 10, "pull_ticks": 5, "push_pull": 1,
+                        "faults": [[4, 10, 0], [9, 50, 0], [40, 10, 1]]},
 }
 
 if __name__ == "__main__":

@@ -44,7 +44,7 @@ def test_many_crashes_saturated_queue(oracle_abi, emu_abi):
     run_lockstep(a, b, 70, 5, observers=(0, 1, n - 1), members=(0, 1, n - 1))
 
 
-@pytest.mark.parametrize("name", ["config1_n128_k3", "lossy_n96_k3", "churn_n64_k2", "robust_n96_k3", "bounded_n96_cap8"])
+@pytest.mark.parametrize("name", ["config1_n128_k3", "lossy_n96_k3", "churn_n64_k2", "robust_n96_k3", "bounded_n96_cap8", "strict_n96_k3", "pushpull_n96_k3"])
 def test_matches_committed_golden_fixtures(emu_abi, name):
     import json, os
     from tests.test_oracle_semantics import GOLDEN, run_fixture

@@ -13,7 +13,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def run_fixture(abi, spec):
     sc = SimConfig(cfg=Config(numToGossip=spec["k"]), nMembers=spec["n"], seed=spec["seed"], lossPpm=spec["loss_ppm"],
-                   eventMask=0x1F, suspicionTicks=spec["suspicion"], targetScheme=spec.get("scheme", 0), viewCap=spec.get("view_cap", 0))
+                   eventMask=0x1F, suspicionTicks=spec["suspicion"], targetScheme=spec.get("scheme", 0), viewCap=spec.get("view_cap", 0),
+                   strictReferenceRules=bool(spec.get("strict", 0)), pullTicks=spec.get("pull_ticks", 0), pushPull=bool(spec.get("push_pull", 0)))
     s = Sim.create(abi, sc)
     for (tick, member, up) in spec["faults"]:
         s.scheduleFault(tick, member, bool(up))
@@ -28,7 +29,7 @@ def run_fixture(abi, spec):
             "counters": {k: v for k, v in s.counters().items()}}
 
 
-@pytest.mark.parametrize("name", ["config1_n128_k3", "lossy_n96_k3", "churn_n64_k2", "robust_n96_k3", "bounded_n96_cap8"])
+@pytest.mark.parametrize("name", ["config1_n128_k3", "lossy_n96_k3", "churn_n64_k2", "robust_n96_k3", "bounded_n96_cap8", "strict_n96_k3", "pushpull_n96_k3"])
 def test_golden_fixture(oracle_abi, name):
     """Regression pin: the committed fixtures were produced by the oracle itself
     (tests/golden/make_golden.py); the GPU tests check the HIP path against the same files."""
