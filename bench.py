@@ -128,6 +128,10 @@ def main():
     ap.add_argument("--loss-ppm", type=int, default=0, help="per-message loss (BASELINE config 5 uses 300000)")
     ap.add_argument("--num-to-gossip", type=int, default=3, help="P = k (the reference's default config has 10)")
     ap.add_argument("--gc", action="store_true", help="settling on (gc_ticks = auto): view rows are reclaimed")
+    ap.add_argument("--crashes-per-tick", type=float, default=1.0,
+                    help="saturated regime: crashes per tick cluster-wide (default 1; BASELINE.md section 3 row 3(s) as written -- 1 %% of "
+                         "1 048 576 members over 1 100 ticks -- is 9.5, with --gc --max-subjects 8192 --steps 1000 --warmup 100)")
+    ap.add_argument("--max-subjects", type=int, default=0, help="view rows (0 = sized by the workload)")
     ap.add_argument("--view-cap", type=int, default=0,
                     help="bounded member maps (view_cap = C; include/swimsim.h): BASELINE config 5's regime at its per-GPU size, e.g. "
                          "--members 2097152 --loss-ppm 300000 --view-cap 64 [--churn 10]; no crash schedule of its own, no pre-roll")
@@ -165,7 +169,8 @@ def main():
     # the same global failure rate at every size (~1 crash per tick from tick 0 on): per-member rumour load,
     # and so the per-GPU work, stays what it is on one GPU
     if saturated:
-        sc, crashes, _ = workloads.saturated(nt, horizon, seed=1, t0=0, loss_ppm=args.loss_ppm, num_to_gossip=args.num_to_gossip)
+        sc, crashes, _ = workloads.saturated(nt, horizon, seed=1, t0=0, loss_ppm=args.loss_ppm, num_to_gossip=args.num_to_gossip,
+                                              crashes_per_tick=args.crashes_per_tick)
     elif args.view_cap:
         from swim_amd import Config, SimConfig
         sc = SimConfig(cfg=Config(numToGossip=args.num_to_gossip), nMembers=nt, seed=1, lossPpm=args.loss_ppm, eventMask=0x10, viewCap=args.view_cap)
@@ -178,6 +183,8 @@ def main():
     sc.targetScheme = 1 if args.scheme == "robust" else 0
     if args.gc:
         sc.gcTicks = _abi.GC_AUTO
+    if args.max_subjects:
+        sc.maxSubjects = args.max_subjects
     exchange = "none (one shard)"
     if args.replicated_masks:
         os.environ["SWIMSIM_SHARD_REPLICATED_MASKS"] = "1"      # read by swimsim_create
@@ -248,7 +255,7 @@ def main():
         # regime, recorded by scripts/pmc_passes.sh -- a rocprof run cannot nest in here
         tj, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and saturated and not args.loss_ppm and args.num_to_gossip == 3 and args.scheme == "random":
+        if os.path.exists(tpath) and saturated and not args.loss_ppm and args.num_to_gossip == 3 and args.scheme == "random" and args.crashes_per_tick == 1.0:
             tj = json.load(open(tpath))
             # keyed by the sha of the kernel sources the counters were collected on: never quoted for other kernels
             if tj.get("regime") == args.regime and tj.get("members") == n and tj.get("kernels_sha") == _lib.kernel_sources_sha():
@@ -297,7 +304,7 @@ def main():
             "config": {"workload": "%s: %d members/GPU, k=%d, %s, loss %d ppm, suspicion %d ticks, retransmit %dx log2 N%s" % (
                            ("config5(bounded member maps, view_cap %d, churn %d per mille / 100 ticks)" % (args.view_cap, args.churn)) if args.view_cap else "config3(%s)" % args.regime,
                            n, args.num_to_gossip,
-                           "~1 crash per tick from tick 0 (hashed schedule); untimed pre-roll of %d ticks until d >= %.1f and "
+                           ("~%g crashes per tick" % args.crashes_per_tick) + " from tick 0 (hashed schedule); untimed pre-roll of %d ticks until d >= %.1f and "
                            "the suspicion timeout has passed, then the warm-up" % (preroll, SATURATED_D) if saturated else ("message loss is the load: no pre-roll" if args.view_cap else "one crash at tick 2"),
                            args.loss_ppm, sim.resolved.suspicion_ticks, sim.resolved.retransmit_mult,
                            ", settling every %d quiet ticks" % sim.resolved.gc_ticks if sim.resolved.gc_ticks else ""),

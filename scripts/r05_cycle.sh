@@ -1,0 +1,12 @@
+#!/bin/bash
+# round-5 GPU cycles (one gpurun call each): r05_cycle.sh <name>; output under gpurun_out/r05<name>_*
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out; mkdir -p $O; cd $R
+C=swim_amd/csrc
+case "$1" in
+a)  # view-cell layout A/B (SWIM_VSPLIT), random-sector rate by table size, BASELINE.md's config 3(s) as written
+  (cd scripts/microbench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o random_access random_access.hip && for lg in 24 27 28 30; do ./random_access $lg; done) 2>&1 | tee $O/r05a_microbench_random_access_by_size.txt
+  (ROUNDS=7 timeout 600 python scripts/ab_time.py $C/libswimsim.so $C/libswimsim_x_vsplit.so; echo '# 1 % loss:'; LOSS=10000 ROUNDS=5 CHUNK=20 timeout 600 python scripts/ab_time.py $C/libswimsim.so $C/libswimsim_x_vsplit.so) 2>&1 | grep -v amdgpu.ids | tee $O/r05a_ab_vsplit.txt
+  timeout 900 python bench.py --crashes-per-tick 9.5 --gc --max-subjects 8192 --steps 300 --warmup 100 2>&1 | grep -v amdgpu.ids | tee $O/r05a_bench_config3s_as_written.json
+  timeout 300 python -m pytest tests/test_hip_parity.py -m gpu -x -q -k "golden or config1 or small_populations" 2>&1 | tail -3 | tee $O/r05a_pytest_subset.log
+  ;;
+esac

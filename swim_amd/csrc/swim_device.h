@@ -147,6 +147,11 @@ struct DevState {
                            // tick under message loss, and one counter serialises them (same-address atomics)
   uint32_t tovf_cap, tovf_nsub, tovf_sub_cap;   // cells per (row, parity); sub-pools (power of two); cells per sub-pool
   uint2* V;                // [R_phys][N] {key = inc<<2|state, lastChange+1}; key 0 = default = slot_base[slot]
+  // SWIM_VSPLIT (round 5): the same cells as two 4-byte planes -- Vk[row][member] = key << 8 | (lastChange + 1) & 0xFF, the
+  // only word the hot path LOADS (16 members per 64-byte sector instead of 8: merge_kernel runs at the chip's random-SECTOR
+  // rate), Vs[row][member] = lastChange + 1 in full: stored with every change, loaded by the cold paths
+  // (digest, views, the walk of a member that woke up) and where the low byte cannot decide (below)
+  uint32_t* Vk; uint32_t* Vs;
   // ---- settling (gc_ticks; include/swimsim.h): removeDeadNodes (src/Core.hs:65-67)
   uint32_t* slot_last;     // [R_phys] last tick any entry of the row changed / its subject announced itself
   uint32_t* slot_base;     // [R_phys] base key of the row's subject (what a cell with key 0 means)
@@ -261,6 +266,103 @@ __host__ __device__ inline size_t vidx_of(uint32_t N, uint32_t R_phys, uint32_t 
   return ((size_t)(li / (VTILE ? VTILE : 1u)) * R_phys + slot) * (VTILE ? VTILE : 1u) + (li % (VTILE ? VTILE : 1u));
 }
 __device__ inline size_t vidx(const DevState& s, uint32_t li, uint32_t slot) { return vidx_of(s.N, s.R_phys, li, slot); }
+// ---- view cells: every access goes through these (two layouts, one compile-time switch) -------------------------
+// SWIM_VSPLIT = 0: one 8-byte cell {key, lastChange + 1}.  SWIM_VSPLIT = 1: two planes (DevState::Vk / Vs).  The hot
+// path (merge_kernel's state rule, the probe's "Alive in my view") sees a cell as VCell {key, tag}: tag = lastChange + 1 in
+// full (unsplit) or its low byte (split).  What the rule needs of lastChange, and how the low byte serves it:
+//   * "did this entry change in THIS tick already" (CHANGES counts an entry once per tick): tag != (t + 1) & 0xFF says no at
+//     once; on a match the full word decides (one more load for a repeated change, or one entry in 256 that last changed a
+//     multiple of 256 ticks ago);
+//   * a due deadline: the cell of row t mod S names an entry that is Suspect since a tick = t (mod S); for a member that
+//     was up all along that tick lies in (t - 256, t] whenever S <= 255, so the low byte names it exactly; S > 255 (a
+//     configuration knob nobody uses at these sizes: 3 log2 N = 60 at a million members) loads the full word.
+#ifndef SWIM_VSPLIT
+#define SWIM_VSPLIT 0
+#endif
+struct VCell { uint32_t key, tag; };
+__device__ inline VCell v_hot(const DevState& s, size_t ix) {
+#if SWIM_VSPLIT
+  const uint32_t w = s.Vk[ix];
+  return VCell{w >> 8, w & 0xFFu};
+#else
+  const uint2 e = s.V[ix];
+  return VCell{e.x, e.y};
+#endif
+}
+__device__ inline uint32_t v_key(const DevState& s, size_t ix) {
+#if SWIM_VSPLIT
+  return s.Vk[ix] >> 8;
+#else
+  return s.V[ix].x;
+#endif
+}
+// the full cell {key, lastChange + 1} (cold paths)
+__device__ inline uint2 v_full(const DevState& s, size_t ix) {
+#if SWIM_VSPLIT
+  return make_uint2(s.Vk[ix] >> 8, s.Vs[ix]);
+#else
+  return s.V[ix];
+#endif
+}
+__device__ inline void v_put(const DevState& s, size_t ix, uint32_t key, uint32_t since1) {
+#if SWIM_VSPLIT
+  s.Vk[ix] = (key << 8) | (since1 & 0xFFu);
+  s.Vs[ix] = since1;
+#else
+  s.V[ix] = make_uint2(key, since1);
+#endif
+}
+// has the entry changed in tick t already?  (c = v_hot of the same cell, loaded before)
+__device__ inline bool v_changed_in(const DevState& s, size_t ix, const VCell& c, uint32_t t) {
+#if SWIM_VSPLIT
+  return c.tag == ((t + 1u) & 0xFFu) && s.Vs[ix] == t + 1u;
+#else
+  (void)s; (void)ix;
+  return c.tag == t + 1u;
+#endif
+}
+// a full cell as the hot path sees it
+__device__ inline VCell v_cell_of(uint2 e) {
+#if SWIM_VSPLIT
+  return VCell{e.x, e.y & 0xFFu};
+#else
+  return VCell{e.x, e.y};
+#endif
+}
+// several writers raise one cell's key (push_kernel: a host with several pullers): returns the key before; the caller that
+// raised it stamps lastChange (v_stamp returns the stamp before: the first to stamp counts the change)
+__device__ inline uint32_t v_raise_key(const DevState& s, size_t ix, uint32_t km, uint32_t t) {
+#if SWIM_VSPLIT
+  uint32_t* w = &s.Vk[ix];
+  uint32_t cur = atomicOr(w, 0u), old;
+  do {
+    old = cur;
+    if ((old >> 8) >= km) break;
+    cur = atomicCAS(w, old, (km << 8) | ((t + 1u) & 0xFFu));
+  } while (cur != old);
+  return old >> 8;
+#else
+  (void)t;
+  return atomicMax(&reinterpret_cast<uint32_t*>(&s.V[ix])[0], km);
+#endif
+}
+__device__ inline uint32_t v_stamp(const DevState& s, size_t ix, uint32_t t) {
+#if SWIM_VSPLIT
+  return atomicMax(&s.Vs[ix], t + 1u);
+#else
+  return atomicMax(&reinterpret_cast<uint32_t*>(&s.V[ix])[1], t + 1u);
+#endif
+}
+// lastChange + 1 of a cell a deadline names (see above)
+__device__ inline uint32_t v_since1(const DevState& s, size_t ix, const VCell& c, uint32_t t) {
+#if SWIM_VSPLIT
+  if (s.S > 255u) return s.Vs[ix];
+  return (t + 1u) - (((t + 1u) - c.tag) & 0xFFu);
+#else
+  (void)s; (void)ix; (void)t;
+  return c.tag;
+#endif
+}
 __device__ inline size_t ridx(const DevState& s, uint32_t li, uint32_t pos) {
   return (size_t)pos * s.N + li;
 }
@@ -422,7 +524,7 @@ __device__ inline uint32_t mi_src(uint32_t id, uint32_t mi) { return id | (mi_bu
 __device__ inline bool view_alive(const DevState& s, uint32_t li, uint32_t mc) {
   const uint32_t sl = mc & MI_SLOT;
   if (sl == 0 || sl == MI_SLOT) return ((mc >> MI_BASE_SHIFT) & 3u) == ST_ALIVE;   // no row: the settled base (Alive@0 at first)
-  const uint32_t k = s.V[vidx(s, li, sl - 1)].x;
+  const uint32_t k = v_key(s, vidx(s, li, sl - 1));
   return ((k ? k : s.slot_base[sl - 1]) & 3u) == ST_ALIVE;
 }
 

@@ -994,7 +994,7 @@ constexpr int ASM_STRIDE = BLOCK + 2;   // words per LDS column: keeps the trans
 __device__ inline void settle_pass(const DevState& s, uint32_t li, bool up, uint32_t* wmax /* LDS, one word per wave */) {
   const uint32_t ns = s.g[G_SETTLE_N], nz = s.g[G_ZERO_N];
   for (uint32_t k = 0; k < ns; ++k) {
-    const uint32_t key = up ? s.V[vidx(s, li, s.settle_slots[k])].x : 0u;
+    const uint32_t key = up ? v_key(s, vidx(s, li, s.settle_slots[k])) : 0u;
     const uint32_t m = wave_max(key);
     if ((threadIdx.x & 63u) == 0u) wmax[threadIdx.x >> 6] = m;
     __syncthreads();
@@ -1006,7 +1006,7 @@ __device__ inline void settle_pass(const DevState& s, uint32_t li, bool up, uint
     __syncthreads();
   }
   if (li < s.N)
-    for (uint32_t k = 0; k < nz; ++k) s.V[vidx(s, li, s.zero_slots[k])] = make_uint2(0u, 0u);
+    for (uint32_t k = 0; k < nz; ++k) v_put(s, vidx(s, li, s.zero_slots[k]), 0u, 0u);
 }
 
 __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STATE_PARAM, uint32_t t, uint32_t rec_inline, uint32_t folded) {
@@ -1119,9 +1119,9 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
   // DB deadlines of this tick's cell (the kernel spends its time waiting on such round trips, one after the
   // other: profiles/r02u_section_clocks_before.txt)
   constexpr int DB = 4;
-  uint32_t dsl[DB]; uint2 dcell[DB];
+  uint32_t dsl[DB]; VCell dcell[DB];
 #pragma unroll
-  for (int k = 0; k < DB; ++k) { dsl[k] = 0; dcell[k] = make_uint2(0u, 0u); }
+  for (int k = 0; k < DB; ++k) { dsl[k] = 0; dcell[k] = VCell{0u, 0u}; }
   const bool plain_due = timer_due && !woke && (uint32_t)(due.w >> 16) != TR_FULL;
   if (act) {
     PSTAT(0);
@@ -1136,7 +1136,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
 #pragma unroll
       for (int k = 0; k < DB; ++k) {
         dsl[k] = tc_get(due, k);
-        if (dsl[k] && !ABL(ABL_V_LOAD)) dcell[k] = s.V[vidx(s, li, dsl[k] - 1)];
+        if (dsl[k] && !ABL(ABL_V_LOAD)) dcell[k] = v_hot(s, vidx(s, li, dsl[k] - 1));
       }
     }
     kn = known0 & ~stale;
@@ -1192,7 +1192,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
   // row's base, its subject
   enum { HAVE_CELL = 1, HAVE_BASE = 2, HAVE_SUBJ = 4, EX_LOAD = 0, EX_ALL = HAVE_CELL | HAVE_BASE | HAVE_SUBJ };
   int psite = 47; (void)psite;     // PSITE/PSTAT: path statistics of the host emulation, nothing in the product
-  auto examine_with = [&](uint32_t slot, uint32_t key, uint32_t cause, bool hasrid, uint32_t rid_in, int have, uint2 e,
+  auto examine_with = [&](uint32_t slot, uint32_t key, uint32_t cause, bool hasrid, uint32_t rid_in, int have, VCell e,
                           uint32_t sbase, uint32_t subject) {
     if (slot + 1 == my_slot1) {
       // about self -> refute (src/Core.hs:155-166): remember the largest non-Alive incarnation
@@ -1200,21 +1200,22 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
       return;
     }
     PSTAT(5); SECT_COUNT(20);
-    if (!(have & HAVE_CELL) && !ABL(ABL_V_LOAD)) e = s.V[vidx(s, li, slot)];
-    const uint32_t curk = e.x ? e.x : ((have & HAVE_BASE) ? sbase : s.slot_base[slot]);   // untouched cell: the settled base
+    if (!(have & HAVE_CELL) && !ABL(ABL_V_LOAD)) e = v_hot(s, vidx(s, li, slot));
+    const uint32_t curk = e.key ? e.key : ((have & HAVE_BASE) ? sbase : s.slot_base[slot]);   // untouched cell: the settled base
     if (key <= curk) return;                     // old incarnation / weaker state: ignore (:151)
     // strict reference rules: the literal livenessCheck (src/Core.hs:182-184) -- a Suspect only on an Alive entry, a Dead unless the
     // entry is Dead already, whatever the incarnations (the merge above would take both at a higher incarnation: D13)
     if (s.strict && (((key & 3u) == ST_SUSPECT && (curk & 3u) != ST_ALIVE) || ((key & 3u) == ST_DEAD && (curk & 3u) == ST_DEAD))) return;
     PSTAT(6); PSTAT(psite); SECT_COUNT(21);
-    if (!ABL(ABL_V_STORE)) s.V[vidx(s, li, slot)] = make_uint2(key, t + 1);                    // memberLastChange = now (:176)
+    const bool again_ = v_changed_in(s, vidx(s, li, slot), e, t);     // (before the store below)
+    if (!ABL(ABL_V_STORE)) v_put(s, vidx(s, li, slot), key, t + 1);                    // memberLastChange = now (:176)
     if (s.G) s.slot_last[slot] = t;              // same value from every writer
     if (!(have & HAVE_SUBJ)) subject = s.subject_of[slot];
     if (!ha) ha = mix64(mix64((uint64_t)TAG_EV) + (((uint64_t)t << 32) | i));
     // the running event digest moves by E(t, i, subject) * (key - old key): linear in the key, so the changes of one
     // entry in one tick telescope whatever their order -- one hash per change (three before: 6 % of the kernel)
     if (!ABL(ABL_EVD)) evd += (mix64(ha + subject) | 1ull) * (unsigned long long)(key - curk);
-    changes += (e.y != t + 1) ? 1u : 0u;
+    changes += again_ ? 0u : 1u;
     // Suspect -> Dead by timeout; ... of a member that is up all the same (a false positive: ground truth, replicated)
     if (cause == 1u) timers_fired += 1u + ((uint32_t)mi_up(s.minfo[subject]) << 16);
     if ((key & 3u) == ST_SUSPECT) tput(slot + 1);                     // deadline t + S (D4)
@@ -1230,16 +1231,17 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
     }
   };
   auto examine = [&](uint32_t slot, uint32_t key, uint32_t cause, bool hasrid, uint32_t rid_in) {
-    examine_with(slot, key, cause, hasrid, rid_in, EX_LOAD, make_uint2(0u, 0u), 0u, 0u);
+    examine_with(slot, key, cause, hasrid, rid_in, EX_LOAD, VCell{0u, 0u}, 0u, 0u);
   };
   // one entry of this tick's deadline cell: Suspect since t' with t' + S <= t => Dead at the same incarnation
   // (D4); a deadline still ahead that belongs to this row goes back into the cell (a fixture of
   // swimsim_set_view); anything else (refuted, already Dead, reclaimed, superseded by a later suspicion with
   // its own cell) is dropped
-  auto deadline = [&](uint32_t slot, uint2 e) {
-    if ((e.x & 3u) != ST_SUSPECT) return;
-    if (e.y - 1 + s.S <= t) examine_with(slot, (e.x & ~3u) | ST_DEAD, 1u, false, 0u, HAVE_CELL, e, 0u, 0u);
-    else if ((e.y - 1 + s.S) % s.S == row_now) tput(slot + 1);
+  auto deadline = [&](uint32_t slot, VCell e) {
+    if ((e.key & 3u) != ST_SUSPECT) return;
+    const uint32_t since1 = v_since1(s, vidx(s, li, slot), e, t);
+    if (since1 - 1 + s.S <= t) examine_with(slot, (e.key & ~3u) | ST_DEAD, 1u, false, 0u, HAVE_CELL, e, 0u, 0u);
+    else if ((since1 - 1 + s.S) % s.S == row_now) tput(slot + 1);
   };
   SECT(1);                                          // own line
   // phase 1: suspicion deadlines, evaluated on the start-of-tick view
@@ -1264,7 +1266,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
         for (uint32_t r0 = 0; r0 < ns; r0 += 64u) {
           const uint32_t r = r0 + lane;
           uint2 e = make_uint2(0u, 0u);
-          if (r < ns) e = s.V[vidx(s, li_L, r)];
+          if (r < ns) e = v_full(s, vidx(s, li_L, r));
           unsigned long long hits = __ballot(r < ns && (e.x & 3u) == ST_SUSPECT && s.slot_used[r < ns ? r : 0u]);
           for (; hits; hits &= hits - 1ull) {
             const int src = __ffsll((unsigned long long)hits) - 1;
@@ -1272,7 +1274,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
             const uint2 eh = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)e.x, src), (uint32_t)__builtin_amdgcn_readlane((int)e.y, src));
             if ((int)lane != L) continue;            // the member's own lane rules on what the wave found
             const uint32_t dl = eh.y - 1 + s.S;
-            if (dl <= t) { if (woke || dl == t) examine_with(rh, (eh.x & ~3u) | ST_DEAD, 1u, false, 0u, HAVE_CELL, eh, 0u, 0u); }
+            if (dl <= t) { if (woke || dl == t) examine_with(rh, (eh.x & ~3u) | ST_DEAD, 1u, false, 0u, HAVE_CELL, v_cell_of(eh), 0u, 0u); }
             else if (woke && dl % s.S == row_now) tput(rh + 1);     // a pulled Suspect (since = t): this tick's own cell
             else if (woke) {
               const size_t ix = (size_t)(dl % s.S) * s.N + li;
@@ -1301,12 +1303,12 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
           const uint32_t v = tc_get(cell, k);
           if (!v) break;
           bool have = first && k < (uint32_t)DB;
-          uint2 e = dcell[0];
+          VCell e = dcell[0];
 #pragma unroll
           for (int j = 1; j < DB; ++j) if (k == (uint32_t)j) e = dcell[j];
 #pragma unroll
           for (int j = 0; j < DB - 1; ++j) have &= !((uint32_t)j < k && dsl[j] == v);
-          if (!have && !ABL(ABL_V_LOAD)) e = s.V[vidx(s, li, v - 1)];
+          if (!have && !ABL(ABL_V_LOAD)) e = v_hot(s, vidx(s, li, v - 1));
           if (!ABL(ABL_DEADLINES)) deadline(v - 1, e);
         }
         if (!tc_linked(cell.w)) break;
@@ -1321,8 +1323,8 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
       PSTAT(9);
       const uint32_t j = s.fail[(size_t)li * s.P + f];
       const uint32_t sl = (s.minfo[j] & MI_SLOT) - 1;
-      const uint2 e = s.V[vidx(s, li, sl)];
-      const uint32_t curk = e.x ? e.x : s.slot_base[sl];
+      const uint32_t ek = v_key(s, vidx(s, li, sl));
+      const uint32_t curk = ek ? ek : s.slot_base[sl];
       const uint32_t key = (curk & ~3u) | ST_SUSPECT;
       if (key > curk) examine(sl, key, 0u, false, 0u);
     }
@@ -1342,11 +1344,11 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
     if (ABL(ABL_RUMOURS)) fresh = 0;
     while (fresh) {
       PSTAT(10);
-      uint32_t rid[GB]; uint4 r[GB]; uint2 e[GB];
+      uint32_t rid[GB]; uint4 r[GB]; VCell e[GB];
       uint32_t n = 0;
 #pragma unroll
       for (int k = 0; k < GB; ++k) {
-        rid[k] = 0; r[k] = make_uint4(0u, 0u, 0u, 0u); e[k] = make_uint2(0u, 0u);
+        rid[k] = 0; r[k] = make_uint4(0u, 0u, 0u, 0u); e[k] = VCell{0u, 0u};
         if (fresh) {
           const uint32_t p = (uint32_t)__ffsll((unsigned long long)fresh) - 1u;
           fresh &= fresh - 1ull;
@@ -1357,7 +1359,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
       }
 #pragma unroll
       for (int k = 0; k < GB; ++k)
-        if ((uint32_t)k < n && r[k].x + 1 != my_slot1 && !ABL(ABL_V_LOAD)) e[k] = s.V[vidx(s, li, r[k].x)];
+        if ((uint32_t)k < n && r[k].x + 1 != my_slot1 && !ABL(ABL_V_LOAD)) e[k] = v_hot(s, vidx(s, li, r[k].x));
 #pragma unroll
       for (int k = 0; k < GB; ++k) {
         if ((uint32_t)k >= n) continue;
@@ -1404,22 +1406,22 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
 #pragma unroll
       for (int k = 0; k < TB; ++k) { en[k] = make_uint2(0u, 0u); if ((uint32_t)k < cnt) en[k] = td((uint32_t)k); }
       for (uint32_t x0 = 0; x0 < cnt; x0 += TB) {
-        uint2 ce[TB]; uint32_t cb[TB], cs[TB];
+        VCell ce[TB]; uint32_t cb[TB], cs[TB];
         uint2 cur_en[TB];
 #pragma unroll
         for (int k = 0; k < TB; ++k) {
           cur_en[k] = en[k];
-          ce[k] = make_uint2(0u, 0u); cb[k] = 0u; cs[k] = 0u;
+          ce[k] = VCell{0u, 0u}; cb[k] = 0u; cs[k] = 0u;
           const uint32_t slot = pe_slot(en[k].x);
           if (x0 + k < cnt && slot + 1 != my_slot1) {
-            if (!ABL(ABL_V_LOAD)) ce[k] = s.V[vidx(s, li, slot)];
+            if (!ABL(ABL_V_LOAD)) ce[k] = v_hot(s, vidx(s, li, slot));
             cb[k] = s.slot_base[slot]; cs[k] = s.subject_of[slot];
           }
         }
 #pragma unroll
         for (int k = 0; k < TB; ++k) { en[k] = make_uint2(0u, 0u); if (x0 + TB + k < cnt) en[k] = td(x0 + TB + k); }   // the next batch's entries travel meanwhile
         for (uint32_t k = 0; k < (uint32_t)TB && x0 + k < cnt; ++k) {
-          uint2 e2 = cur_en[0], e = ce[0]; uint32_t sb = cb[0], sj = cs[0];
+          uint2 e2 = cur_en[0]; VCell e = ce[0]; uint32_t sb = cb[0], sj = cs[0];
           bool again = false;                      // an earlier entry of the batch is about the same subject: look again
 #pragma unroll
           for (int j = 1; j < TB; ++j) if (k == (uint32_t)j) { e2 = cur_en[j]; e = ce[j]; sb = cb[j]; sj = cs[j]; }
@@ -2076,9 +2078,9 @@ __device__ inline uint32_t join_host(const DevState& s, uint32_t t, uint32_t tk,
 __device__ inline void pull_entry(const DevState& s, uint32_t t, uint32_t mbr, uint32_t slot, uint32_t subject, uint32_t kh,
                                   unsigned long long* evd, unsigned* pulled) {
   const size_t ix = vidx(s, mbr - s.lo, slot);
-  const uint32_t vm = s.V[ix].x, curk = vm ? vm : s.slot_base[slot];
+  const uint32_t vm = v_key(s, ix), curk = vm ? vm : s.slot_base[slot];
   if (kh <= curk) return;
-  s.V[ix] = make_uint2(kh, t + 1);                             // its deadline, if Suspect: the cells are rebuilt by merge_kernel
+  v_put(s, ix, kh, t + 1);                             // its deadline, if Suspect: the cells are rebuilt by merge_kernel
   if (s.G) s.slot_last[slot] = t;
   *evd += (mix64(mix64(mix64((uint64_t)TAG_EV) + (((uint64_t)t << 32) | mbr)) + subject) | 1ull) * (unsigned long long)(kh - curk);
   (*pulled)++;
@@ -2198,7 +2200,7 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
         if (!s.slot_used[r]) continue;
         const uint32_t subject = s.subject_of[r];
         if (subject == mbr) continue;
-        const uint32_t vh = s.V[vidx(s, hl, r)].x;
+        const uint32_t vh = v_key(s, vidx(s, hl, r));
         const uint32_t kh = subject == host ? ((s.hot[hl].x << 2) | ST_ALIVE) : vh;   // an untouched cell is the base: no news
         if (kh) pull_entry(s, t, mbr, r, subject, kh, &evd, &pulled);
       }
@@ -2313,7 +2315,7 @@ __global__ __launch_bounds__(BLOCK) void join_pull_kernel(DevState s, uint32_t t
           const uint32_t r = r0 + u * BLOCK;
           used[u] = r < nrows ? s.slot_used[r] : 0u;
           subj[u] = r < nrows ? s.subject_of[r] : 0u;
-          vh[u] = r < nrows ? s.V[vidx(s, hl, r)].x : 0u;
+          vh[u] = r < nrows ? v_key(s, vidx(s, hl, r)) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -2374,7 +2376,7 @@ __global__ __launch_bounds__(BLOCK) void push_kernel(DevState s, uint32_t t, uin
           const uint32_t r = r0 + u * BLOCK;
           used[u] = r < nrows ? s.slot_used[r] : 0u;
           subj[u] = r < nrows ? s.subject_of[r] : 0u;
-          vm[u] = r < nrows ? s.V[vidx(s, ml, r)].x : 0u;
+          vm[u] = r < nrows ? v_key(s, vidx(s, ml, r)) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -2382,12 +2384,12 @@ __global__ __launch_bounds__(BLOCK) void push_kernel(DevState s, uint32_t t, uin
           const uint32_t r = r0 + u * BLOCK;
           const uint32_t km = subj[u] == mbr ? mkey : vm[u];     // an untouched cell is the base: no news
           if (!km || km <= s.slot_base[r]) continue;              // (an untouched cell of the host reads 0: never raise it to below the base)
-          uint32_t* cell = reinterpret_cast<uint32_t*>(&s.V[vidx(s, hl, r)]);
-          const uint32_t old = atomicMax(&cell[0], km);
+          const size_t ix = vidx(s, hl, r);
+          const uint32_t old = v_raise_key(s, ix, km, t);
           const uint32_t curk = old ? old : s.slot_base[r];
           if (km <= curk) continue;
           evd += (mix64(hw + subj[u]) | 1ull) * (unsigned long long)(km - curk);
-          if (atomicMax(&cell[1], t + 1u) != t + 1u) pushed++;
+          if (v_stamp(s, ix, t) != t + 1u) pushed++;
           if (s.G) s.slot_last[r] = t;
           suspects += (km & 3u) == ST_SUSPECT ? 1u : 0u;
         }
@@ -2429,7 +2431,7 @@ __global__ __launch_bounds__(BLOCK) void pull_send_kernel(DevState s, uint32_t t
       if (!s.slot_used[r]) continue;
       const uint32_t subject = s.subject_of[r];
       if (subject == mbr) continue;
-      const uint32_t kh = subject == host ? ((s.hot[hl].x << 2) | ST_ALIVE) : s.V[vidx(s, hl, r)].x;
+      const uint32_t kh = subject == host ? ((s.hot[hl].x << 2) | ST_ALIVE) : v_key(s, vidx(s, hl, r));
       if (!kh) continue;
       const uint32_t pos = atomicAdd(&s.g[G_JSEND + peer], 1u);
       if (pos < s.j_cap) s.j_send[(size_t)peer * s.j_cap + pos] = make_uint4(mbr, subject, kh, 0u);
@@ -2469,7 +2471,7 @@ __global__ __launch_bounds__(BLOCK) void coverage_kernel(DevState s, uint32_t su
   uint32_t up = 0, hold = 0;
   if (li < s.N && s.lo + li != subject && mi_up(s.minfo[s.lo + li])) {
     up = 1;
-    const uint32_t k = sl1 ? s.V[vidx(s, li, sl1 - 1u)].x : 0u;
+    const uint32_t k = sl1 ? v_key(s, vidx(s, li, sl1 - 1u)) : 0u;
     hold = (k ? k : base) >= key ? 1u : 0u;                   // an untouched cell is the settled base
   }
   const unsigned long long bh = __ballot(hold != 0u), bu = __ballot(up != 0u);
@@ -2492,7 +2494,7 @@ __global__ __launch_bounds__(BLOCK) void digest_kernel(DevState s, unsigned long
     const uint32_t ns = min(s.g[G_NSLOTS], s.R_phys);
     for (uint32_t r = 0; r < ns; ++r) {
       if (!s.slot_used[r]) continue;                 // reclaimed (its cells are cleared by the next merge)
-      const uint2 e = s.V[vidx(s, li, r)];
+      const uint2 e = v_full(s, vidx(s, li, r));
       if (e.x == 0) continue;
       const uint32_t subject = s.subject_of[r];
       if (subject == i) continue;
@@ -2533,7 +2535,7 @@ __global__ void set_view_kernel(DevState s, uint32_t t, uint32_t observer, uint3
   ensure_slot(s, subject);
   const uint32_t sl = (s.minfo[subject] & MI_SLOT) - 1;
   const uint32_t ol = observer - s.lo;
-  s.V[vidx(s, ol, sl)] = make_uint2(key, t + 1);
+  v_put(s, vidx(s, ol, sl), key, t + 1);
   if ((key & 3u) == ST_SUSPECT) {                   // deadline t + S: row t mod S (merge_kernel carries it over)
     const size_t ix = (size_t)(t % s.S) * s.N + ol;
     const uint4 cell = s.trow[ix];

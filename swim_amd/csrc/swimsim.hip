@@ -546,7 +546,15 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   d.tovf_cap = d.tovf_sub_cap * d.tovf_nsub;
   CK(dev_alloc(h, &d.tovf, (size_t)d.S * 2 * d.tovf_cap, 0));
   CK(dev_alloc(h, &d.tovf_n, (size_t)d.S * 2 * d.tovf_nsub * 16, 0));
-  CK(dev_alloc(h, &d.V, (size_t)(VTILE ? (N + VTILE - 1) / VTILE * VTILE : N) * d.R_phys, 0));
+  {
+    const size_t cells = (size_t)(VTILE ? (N + VTILE - 1) / VTILE * VTILE : N) * d.R_phys;
+#if SWIM_VSPLIT
+    CK(dev_alloc(h, &d.Vk, cells, 0));
+    CK(dev_alloc(h, &d.Vs, cells, 0));
+#else
+    CK(dev_alloc(h, &d.V, cells, 0));
+#endif
+  }
   CK(dev_alloc(h, &d.slot_last, (size_t)d.R_phys, 0xFF));
   CK(dev_alloc(h, &d.slot_base, (size_t)d.R_phys, 0));
   CK(dev_alloc(h, &d.slot_used, (size_t)d.R_phys, 0));
@@ -825,8 +833,19 @@ static int read_column(swimsim_t* h, uint32_t observer, std::vector<uint2>* col,
   col->resize(ns); subj->resize(ns);
   if (!ns) return SWIMSIM_OK;
   // one observer's entries are a strided column of V (stride = one row of its tile)
+#if SWIM_VSPLIT
+  {
+    // the two planes of the column (swim_device.h: key << 8 | low byte of lastChange + 1; lastChange + 1)
+    std::vector<uint32_t> wk(ns), ws(ns);
+    const size_t at = vidx_of(h->d.N, h->d.R_phys, observer, 0), pitch = (VTILE ? (size_t)VTILE : (size_t)h->d.N) * sizeof(uint32_t);
+    HIPCHK(h, hipMemcpy2D(wk.data(), sizeof(uint32_t), h->d.Vk + at, pitch, sizeof(uint32_t), ns, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy2D(ws.data(), sizeof(uint32_t), h->d.Vs + at, pitch, sizeof(uint32_t), ns, hipMemcpyDeviceToHost));
+    for (uint32_t r = 0; r < ns; ++r) (*col)[r] = make_uint2(wk[r] >> 8, ws[r]);
+  }
+#else
   HIPCHK(h, hipMemcpy2D(col->data(), sizeof(uint2), h->d.V + vidx_of(h->d.N, h->d.R_phys, observer, 0),
                         (VTILE ? (size_t)VTILE : (size_t)h->d.N) * sizeof(uint2), sizeof(uint2), ns, hipMemcpyDeviceToHost));
+#endif
   HIPCHK(h, hipMemcpy(subj->data(), h->d.subject_of, (size_t)ns * sizeof(uint32_t), hipMemcpyDeviceToHost));
   std::vector<uint8_t> used(ns);
   HIPCHK(h, hipMemcpy(used.data(), h->d.slot_used, ns, hipMemcpyDeviceToHost));

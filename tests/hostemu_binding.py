@@ -15,6 +15,10 @@ CSRC = os.path.join(ROOT, "swim_amd", "csrc")
 LIB = os.path.join(EMU, "_build", "libswimsim_hostemu.so")
 
 _cached = None
+# SWIM_EMU_EXTRA="tag:DEF1=1,DEF2" (test knob): EVERY emulation build of the session gets these defines on top of its own, under
+# library names of their own -- the whole CPU suite against an A/B build of the kernels (e.g. the other view-cell layout)
+_EXTRA = os.environ.get("SWIM_EMU_EXTRA", "")
+_XTAG, _XDEFS = (_EXTRA.split(":", 1)[0], _EXTRA.split(":", 1)[1].split(",")) if ":" in _EXTRA else ("", [])
 
 
 def build(lib=None, defines=()):
@@ -41,14 +45,15 @@ def build(lib=None, defines=()):
 def load():
     global _cached
     if _cached is None:
-        build()
-        _cached = _abi.bind(C.CDLL(LIB), "swimsim_")
+        lib = LIB if not _XTAG else os.path.join(EMU, "_build", "libswimsim_hostemu_x%s.so" % _XTAG)
+        build(lib, _XDEFS)
+        _cached = _abi.bind(C.CDLL(lib), "swimsim_")
     return _cached
 
 
 def load_variant(tag, defines):
     """A second build of the same sources with compile-time knobs changed (e.g. a tiny examination
     list so that the overflow path runs), for stress tests."""
-    lib = os.path.join(EMU, "_build", "libswimsim_hostemu_%s.so" % tag)
-    build(lib, defines)
+    lib = os.path.join(EMU, "_build", "libswimsim_hostemu_%s%s.so" % (tag, ("_x" + _XTAG) if _XTAG else ""))
+    build(lib, list(defines) + _XDEFS)
     return _abi.bind(C.CDLL(lib), "swimsim_")

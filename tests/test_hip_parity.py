@@ -80,7 +80,7 @@ def test_million_members_digest(oracle_abi, hip_abi):
     run_lockstep(a, b, 12, 4, observers=(0, 1 << 19), members=(7,), check_events=True)
 
 
-@pytest.mark.parametrize("name", ["config1_n128_k3", "lossy_n96_k3", "churn_n64_k2", "robust_n96_k3", "bounded_n96_cap8"])
+@pytest.mark.parametrize("name", ["config1_n128_k3", "lossy_n96_k3", "churn_n64_k2", "robust_n96_k3", "bounded_n96_cap8", "strict_n96_k3", "pushpull_n96_k3"])
 def test_hip_matches_committed_golden_fixtures(hip_abi, name):
     """The HIP path against the committed golden vectors (tests/golden/*.json)."""
     import json, os
