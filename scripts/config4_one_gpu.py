@@ -1,5 +1,5 @@
 """BASELINE config 4 -- 4 194 304 members over 4 shards of 1 048 576 -- as far as ONE GPU can show it: the sharded cluster
-(4 handles on one device, LocalFabric: the exchange is device-to-device copies), the same population on one unsharded
+(4 handles on one device stepped by swimsim_cluster_step: the exchange inside the library), the same population on one unsharded
 handle, and the CPU oracle (32 threads) step the same saturated workload; digests and counters must agree.  Timing on one
 GPU says what the sharded path COSTS (the shards run one after the other), not how it scales: no multi-GPU number here.
 usage (GPU box): config4_one_gpu.py        env: MEMBERS (default 4194304), SHARDS (4), WARM (100), TICKS (40), ORACLE=0 to skip"""
@@ -11,7 +11,6 @@ from swim_amd.shard import LocalFabric, ShardedSim
 abi = _lib.load()
 N = int(os.environ.get("MEMBERS", 1 << 22)); G = int(os.environ.get("SHARDS", 4))
 WARM = int(os.environ.get("WARM", 100)); TICKS = int(os.environ.get("TICKS", 40))
-os.environ["SWIMSIM_SHARD_REPLICATED_MASKS"] = "0"
 
 
 def run(make, name):

@@ -41,7 +41,7 @@ while time.time() < t_end:
     os.environ["SWIMSIM_FOLD_BEGIN"] = fold
     a = Sim.create(orc, sc)
     rm = shards > 1 and rng.random() < 0.5                       # replicated queue masks (read from the environment at create)
-    os.environ["SWIMSIM_SHARD_REPLICATED_MASKS"] = "1" if rm else "0"
+    os.environ["SWIMSIM_CLUSTER_STEP"] = "0" if rm else "1"
     rk = rng.choice(["", "0", "1"])                              # explicit records: the handle's own choice / phase in merge_kernel / records_kernel
     if rk: os.environ["SWIMSIM_RECORDS_KERNEL"] = rk
     else: os.environ.pop("SWIMSIM_RECORDS_KERNEL", None)

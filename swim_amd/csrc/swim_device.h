@@ -35,7 +35,8 @@ enum { G_NSLOTS = 0 /* view rows ever handed out (high-water mark) */, G_ERR = 1
        G_SEND = 16 /* [3][16] exchange records appended per peer (send_cnt) */,
        G_NJOINED = 64 /* members that came up in this tick (begin_kernel part A) */,
        G_JSEND = 65 /* [16] join-pull records appended per peer (exchange round 0) */,
-       G_FLDYN = 81 /* foreign lines handed out by remote_kernel this tick */,
+       G_FLDYN = 81 /* foreign lines handed out by this tick's deliveries from other shards */,
+       G_XLINES = 82 /* queues published as lists this tick (publish_kernel) */,
        G_ANYREC = 83 /* = t + 1: somebody wrote an explicit record in tick t */,
        G_HEAD_NEW = 84, G_PREV_NEW = 85 /* a tick WITHOUT begin_kernel (swimsim_step's plain ticks): the tick's window head / the one before,
                                            left by probe_kernel's workgroup 0 for merge_kernel, whose workgroup 0 commits them to G_HEAD / G_PREV */,
@@ -172,20 +173,30 @@ struct DevState {
   uint2* ovf;              // [2][ovf_cap] inbox overflow (dst, src)
   uint4* events;           // {tick, observer, subject, key<<8|cause}
   uint64_t* blk;           // [nblocks+1][C_COUNT] per-block counter rows (no atomics)
-  // ---- cross-shard exchange (n_shards > 1) --------------------------------------
-  uint4* ord;              // [nblocks][ord_cap] deliveries the probe could not do locally (order format below)
-  uint32_t* ord_cnt;       // [nblocks]
+  // ---- cross-shard exchange (n_shards > 1) ------------------------------
+  // Slots (view rows) and rumour ids are per-shard numberings; what crosses shards is named by (subject, key).  Every shard
+  // holds a REPLICA of what a delivery "dst merges src's queue" reads about src -- its start-of-tick queue mask (over its
+  // OWNER's ring of the tick) and a queue byte -- all-gathered at the start of the tick together with every shard's ring
+  // dictionary (position -> {subject, key}) and the queues a mask cannot express as lists of (subject, key).  A delivery to a
+  // member of another shard is then ONE 8-byte record {dst, src} to the owner of dst; everything else -- outcomes, the
+  // Acks' payloads, every filter -- is a local read.  Nothing is requested, nothing is answered.
+  uint2* ord;              // [nblocks][ord_cap] {dst, src} (global ids): deliveries a probe block hands to a shard's ingest
+                           //   (the owner of dst -- possibly this shard itself: a remote source whose queue needs more than a
+                           //   mask translation); routed into q_send by the block itself at the end of probe_kernel
   uint32_t ord_cap;
-  uint4* r_send; uint4* r_recv;         // [n_shards][DICT_RECS + r_cap]: this tick's id dictionary (64 x {subject,
-                                        //   key}, one per mask position), then round-1 records (order format)
-  uint4* p_send; uint4* p_recv;         // [n_shards][p_cap] mask payloads {dst | tag<<27, -, mask over MY dictionary}
-  uint32_t* x_send; uint32_t* x_recv;   // [n_shards][x_cap][XREC_WORDS] explicit payload records (exact fallback)
+  uint4* r_send; uint4* r_recv;         // round 1, 16-byte records: [DICT_RECS + r_cap] / [n_shards][DICT_RECS + r_cap]: this
+                                        //   tick's ring dictionary (64 x {subject, key}), then the queues that travel as lists
+                                        //   (XLINE_RECS records each: {member, n, tick, -} + 8 x {subject, key}); ONE segment
+                                        //   goes to every peer
+  uint4* p_send; uint4* p_recv;         // bounded handles (swim_sparse.h): [n_shards][p_cap] {dst, src, -, -}
+  uint2* q_send; uint2* q_recv;         // round 2: [n_shards][p_cap] {dst, src}; segment [shard] of q_send stays here
   uint32_t r_cap, p_cap, x_cap;
-  uint32_t* send_cnt;      // = g + G_SEND: [3][MAX_SHARDS] records appended per peer: requests, mask payloads,
-                           //   explicit payloads (inside g so that ONE small copy brings flags and counts to the host)
-  uint2* xl;               // [n_shards][64] a peer's dictionary in MY numbering {slot | rid<<16, key}
-  uint4* fl;               // [n_shards * (x_cap + p_cap + r_cap)][4] "foreign lines": received entries my masks cannot carry
-  unsigned long long* ackslot;  // [N][P] Ack payloads pulled from remote targets: one slot per probe, plain stores
+  uint32_t* send_cnt;      // = g + G_SEND: [3][MAX_SHARDS] records appended per peer ([0][0]: round-1 records, [1][p]: round-2
+                           //   records for peer p) -- inside g so that ONE small copy brings flags and counts to the host
+  uint2* xl;               // [n_shards][64] a peer's ring dictionary in MY numbering {slot | rid<<16, key | my ring position<<24
+                           //   (0xFF: my masks cannot carry it this tick)}; NONE32 = the peer's position is empty
+  uint32_t* xidx;          // [NT] where a remote member's list (r_recv) lies, as of the list's own tick stamp
+  uint4* fl;               // "foreign lines": received entries my masks cannot carry, read through explicit records
   // sharded settling: what every shard says about its rows at the end of a tick, all-gathered
   uint2* s_send; uint2* s_recv;         // [n_shards][s_cap] {subject | SR_CAND / SR_VETO, largest entry among my up members}
   uint32_t s_cap;
@@ -193,14 +204,10 @@ struct DevState {
   // join-time pulls whose host lives on another shard (round 0): {joiner, subject, the host's entry, -}
   uint4* j_send; uint4* j_recv;         // [n_shards][j_cap]
   uint32_t j_cap;
-  // replicated queue masks (rm = 1; DESIGN.md section 7, "replicated masks"): every shard holds every member's
-  // start-of-tick queue mask and a byte about its queue (global index; the own slice is written by probe_kernel, the
-  // others arrive by all-gather), so that the direct probes between shards need no records
-  uint32_t rm;
-  unsigned long long* mask_all;  // [NT] queue mask over the OWNER's dictionary of the tick
-  uint8_t* q_all;                // [NT] bits 0-3 queue length, 4 = the mask cannot express the queue (MI_OOW), 5 = the member
-                                 //   handles its direct probes of remote targets by records this tick (Q_EXC)
-  uint32_t fl_dyn_base, fl_dyn_cap;   // region of `fl` for foreign lines that belong to no record (remote_kernel)
+  unsigned long long* mask_all;  // [NT] start-of-tick queue mask over the OWNER's ring of the tick (own slice: publish_kernel)
+  uint8_t* q_all;                // [NT] bits 0-3 queue length, 4 = the queue travels as a list this tick (Q_OOW: an entry the mask
+                                 //   cannot express, or a tick in which the owner's masks are off)
+  uint32_t fl_dyn_base, fl_dyn_cap;   // region of `fl` handed out by the tick's deliveries (G_FLDYN)
   // ---- bounded member maps (view_cap = C > 0; swim_sparse.h): none of the view / mask / deadline tables above
   uint32_t C;              // entries a member's map holds at most; 0 = the unbounded layout above
   uint32_t* sp_tab;        // [N][3][C] the maps: subjects, keys, lastChange + 1 (three coalesced runs per member)
@@ -229,25 +236,34 @@ struct DevState {
 enum { ABL_PUSH_ATOMIC = 1, ABL_PK_GATHER = 2, ABL_MB_GATHER = 4, ABL_ACKMASK_STORE = 8, ABL_V_STORE = 16, ABL_V_LOAD = 32,
        ABL_OWN_LINE = 64, ABL_LINE_STORE = 128, ABL_EVD = 256, ABL_FIND_RID = 512, ABL_GROUP = 1024, ABL_STATE_STORES = 2048,
        ABL_INPUTS = 4096, ABL_DEADLINES = 8192, ABL_RUMOURS = 16384 };
-constexpr uint32_t Q_PBN = 0xFu, Q_OOW = 1u << 4, Q_EXC = 1u << 5;
+constexpr uint32_t Q_PBN = 0xFu, Q_OOW = 1u << 4;
 // settle records: a shard lists a row as a CANDIDATE (quiet here for G ticks; y = the largest entry among its members
 // that are up) or as a VETO (an entry changed / the subject announced itself within the last G ticks)
 constexpr uint32_t SR_CAND = 1u << 30, SR_VETO = 1u << 31, SR_KEY = 0xFFFFFFu;
 constexpr uint32_t DICT_ENTRIES = 64;   // one dictionary entry per ring position ...
 constexpr uint32_t DICT_RECS = 32;      // ... = 32 sixteen-byte records at the head of every round-1 segment
-// Orders and round-1 records, 16 bytes: {x = dst | tag<<27, y = src | flags<<27, z/w = 64-bit mask}.
-//   tag = 0 : "dst merges src's queue", src on another shard than this record's reader: a pull request.
-//   tag = p+1: the direct probe p of member src at REMOTE target dst, fused: flags bit 0 = the mask is src's
-//             queue (deliver it to dst), bit 1 = dst's Ack arrived: send its queue back into src's slot p.
+constexpr uint32_t XLINE_RECS = 5;      // a queue as a list: {member, n, tick, -} + PB_SLOTS x {subject, key} = 80 bytes
 constexpr uint32_t ID_BITS = 27, ID_MASK = (1u << ID_BITS) - 1u;   // sharded runs: n_members <= 2^27
-constexpr uint32_t OF_PAYLOAD = 1u, OF_WANTS_ACK = 2u;
 constexpr int MAX_SHARDS = 16;
 struct PeerCounts { uint32_t v[MAX_SHARDS]; };   // received records per peer, passed to kernels by value
+// How a shard's kernels find what its peers published (passed by value).  direct = 0: the embedder's exchange has copied it
+// into this shard's receive buffers (r_recv, q_recv, the replicas), the counts come by value (swimsim_shard_phase*).
+// direct = 1 (swimsim_cluster_step: every shard of the cluster is a handle of this process): the kernels read the peers'
+// SEND buffers where they lie -- same device, or a peer device over xGMI -- and the counts from the peers' own words:
+// nothing is copied but the replicas, nothing comes back to the host.
+struct PeerView {
+  uint32_t direct;
+  const uint4* r[MAX_SHARDS];                 // peer p's round-1 segment (dictionary + lists)
+  const uint32_t* rn[MAX_SHARDS];             //   its number of lists (g + G_XLINES)
+  const uint2* q[MAX_SHARDS];                 // peer p's round-2 segment for ME
+  const uint32_t* qn[MAX_SHARDS];             //   its record count (send_cnt[1][me])
+  const unsigned long long* mask[MAX_SHARDS]; // peer p's replica of the queue masks (its own slice is the fresh one)
+  const uint8_t* qb[MAX_SHARDS];              //   ... of the queue bytes
+  const uint2* st[MAX_SHARDS];                // settling: peer p's list for me, its length (g + G_SETTLE_SEND)
+  const uint32_t* stn[MAX_SHARDS];
+};
 struct Offsets { uint32_t o[16]; };              // robust scheme: this period's rotation per probe index (0 = none)
 
-// payload record on the wire: {dst (global id), n, n x {subject, key}} -- ids, not slots: every shard
-// has its own slot and rumour-id numbering
-constexpr int XREC_WORDS = 2 + 2 * PB_SLOTS;
 constexpr uint32_t SRC_FOREIGN = 1u << 30;      // explicit-record source word: index into fl, not a member
 
 __device__ inline bool is_local(const DevState& s, uint32_t g) { return g - s.lo < s.N; }

@@ -221,11 +221,20 @@ __device__ inline void deliver_local(const DevState& s, uint32_t t, bool use_mas
 #define SWIM_PROBE_WAVES16 2
 #endif
 constexpr int PX_KG = 4;        // proxy indices per round of the wave's indirect-probe pass (probe_kernel pass 5)
-template <int PMAX>
+// SH: the handle is a shard of a cluster (n_shards > 1) -- targets, proxies and sources may live on other shards; what the
+// kernel needs of them comes from the replicas all-gathered at the start of the tick (swim_device.h, "cross-shard exchange"):
+// ground truth (minfo / mb), queue byte (q_all), queue mask (mask_all, through the owner's ring dictionary xl).  A delivery to
+// a member of another shard is an 8-byte record {dst, src} for the owner of dst.  The unsharded instantiation has none of it.
+template <int PMAX, bool SH>
 __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? SWIM_PROBE_WAVES8 : PMAX <= 12 ? SWIM_PROBE_WAVES12 : SWIM_PROBE_WAVES16) void probe_kernel(SWIM_STATE_PARAM, uint32_t t, uint32_t tk, Offsets off, uint32_t fold) {
   SWIM_STATE_BIND
   __shared__ BlockCounters sh;
-  __shared__ uint32_t ordn;                        // deliveries left to the exchange (sharded runs)
+  __shared__ uint32_t ordn;                        // deliveries handed to a shard's ingest (sharded runs)
+  // the peers' ring dictionaries as far as this kernel needs them (xlat_kernel): a peer's ring position -> mine; 0xFF: my masks
+  // cannot carry that rumour this tick, 0xFE: the position is empty
+  __shared__ uint8_t xpos[SH ? MAX_SHARDS * DICT_ENTRIES : 1];
+  __shared__ uint32_t rt_cnt[MAX_SHARDS], rt_base[MAX_SHARDS];
+  if (SH) for (uint32_t k = threadIdx.x; k < s.n_shards * DICT_ENTRIES; k += BLOCK) { const uint2 e = s.xl[k]; xpos[k] = e.x == NONE32 ? (uint8_t)0xFEu : (uint8_t)(e.y >> 24); }   // (ctr_init's barrier publishes it)
   // pass 5, per wave: the (prober, proxy) pairs of a round, the probers' context, the chains' outcomes
   __shared__ uint4 px_item[BLOCK / 64][64 * PX_KG];      // {proxy, its minfo, prober lane | proxy index << 8, -}
   __shared__ uint4 px_ctx[BLOCK / 64][64];               // {prober's minfo, target, its minfo, -}
@@ -268,7 +277,6 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
   unsigned n_pings = 0;
   unsigned payloads = 0, rumors = 0, dfail = 0, preqs = 0, susp = 0, fsusp = 0;
   unsigned long long ackacc = 0;                  // masks this member pulls in with its Acks
-  unsigned long long pubmask = 0; uint32_t pubq = 0;   // replicated masks (sharded, s.rm): what the peers learn about my queue
   bool wrote_rec = false;                          // this member left an explicit record somewhere: the records phase of merge_kernel has work
   SECT_BEGIN(32);
   // what passes 1-4 leave for the wave's pass 5 (indirect probes) and for the outputs
@@ -278,16 +286,34 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
   uint32_t picks[PMAX], pinfo[PMAX];
   uint32_t failmask = 0;                           // probe indices that ended without an Ack (unlessAck; D2, D3)
   uint32_t nfail = 0, nack = 0;
-  bool clean = false;
 #pragma unroll
   for (int p = 0; p < PMAX; ++p) { picks[p] = 0; pinfo[p] = 0; }
-  // a delivery this shard cannot complete alone: the exchange routes it
-  auto emit_raw = [&](uint32_t x, uint32_t y, unsigned long long m) {
+  // "dst merges src's start-of-tick queue", left to the ingest of dst's owner: dst on another shard,
+  // or a remote src whose queue takes more than a mask translation (then the owner may be this very shard)
+  auto emit_order = [&](uint32_t dst, uint32_t src) {
     const uint32_t pos = atomicAdd(&ordn, 1u);
-    if (pos < s.ord_cap) s.ord[(size_t)blockIdx.x * s.ord_cap + pos] = make_uint4(x, y, (uint32_t)m, (uint32_t)(m >> 32));
+    if (pos < s.ord_cap) s.ord[(size_t)blockIdx.x * s.ord_cap + pos] = make_uint2(dst, src);
     else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG);
   };
-  auto emit_order = [&](uint32_t dst, uint32_t src) { emit_raw(dst, src, 0ull); };
+  // the queue of REMOTE member src as a mask over MY ring: its replicated mask through its owner's dictionary.  false: the
+  // queue travels as a list this tick, or holds an entry my masks cannot carry (an id younger than my head) -- then the
+  // delivery goes to ingest_kernel, which has the machinery (foreign lines, explicit records)
+  auto pull_remote = [&](uint32_t src, uint32_t qsrc, unsigned long long* bits) -> bool {
+    if (!SH) return false;
+    if ((qsrc & Q_OOW) || !use_mask) return false;
+    unsigned long long m = s.mask_all[src], acc = 0;
+    const uint8_t* d = xpos + owner_of(s, src) * DICT_ENTRIES;
+    while (m) {
+      const uint32_t q = (uint32_t)__ffsll((unsigned long long)m) - 1u;
+      m &= m - 1ull;
+      const uint32_t at = d[q];
+      if (at == 0xFEu) continue;
+      if (at == 0xFFu) return false;
+      acc |= 1ull << at;
+    }
+    *bits |= acc;
+    return true;
+  };
   if (act) {
     mymask = (mycnt && use_mask) ? s.pk[li].x : 0ull;
     bool valid[PMAX];                               // probe index p is in use this period
@@ -296,14 +322,9 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
     // a sharded cluster the pinger may live elsewhere, and the payloads are pushed like the random scheme's
     const bool pull = robust && s.n_shards == 1u;
     uint32_t np;                                    // probe indices in play
-    // replicated masks: a prober whose targets are simply its first draws, with a queue its mask expresses in full,
-    // leaves its direct probes of REMOTE targets to remote_kernel on both sides (no records); anybody else says so
-    // in its queue byte (Q_EXC) and sends records as before
     if (!robust) {
       // ms <- kRandomMembers store (numToGossip cfg) []        (src/Core.hs:239)
-      bool all_first = false;
-      np = select_members<PMAX>(s, mk, i, s.P, P_SELECT, 0, nullptr, 0, picks, pinfo, use_mask, &all_first);
-      clean = s.rm && use_mask && !(mi & MI_OOW) && all_first;
+      np = select_members<PMAX>(s, mk, i, s.P, P_SELECT, 0, nullptr, 0, picks, pinfo, use_mask);
       n_pings = np;
 #pragma unroll
       for (int p = 0; p < PMAX; ++p) valid[p] = (uint32_t)p < np;
@@ -322,10 +343,6 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
           n_pings += valid[p] ? 1u : 0u;
         }
       }
-      // replicated masks: clean = no target of this period's rotation was skipped
-      clean = s.rm && use_mask && !(mi & MI_OOW);
-#pragma unroll
-      for (int p = 0; p < PMAX; ++p) if ((uint32_t)p < np && off.o[p] && !valid[p]) clean = false;
     }
     SECT(32);                                       // target selection
     // Passes 1-4 run over the probe indices CH at a time: what a pass keeps per probe -- outcomes, the 16-byte `pk` of the
@@ -354,7 +371,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
     for (int q = 0; q < CH; ++q) {
       const int p = c0 + q;
       tk2[q] = make_ulonglong2(0ull, 0ull);
-      if (use_mask && ping_ok[q] && is_local(s, picks[p]) && (mymask || (ack_ok[q] && mi_pbn(pinfo[p]))) && !ABL(ABL_PK_GATHER))
+      if (use_mask && ping_ok[q] && (!SH || is_local(s, picks[p])) && (mymask || (ack_ok[q] && mi_pbn(pinfo[p]))) && !ABL(ABL_PK_GATHER))
         tk2[q] = s.pk[picks[p] - s.lo];
     }
     SECT(33);                                       // outcomes + the targets' pk gathers issued
@@ -369,20 +386,20 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
         if (ping_ok[q]) {
           payloads++; rumors += mycnt;
           if (pull) continue;                        // the target pulls it (below): its pingers are computable
-          if (is_local(s, picks[p])) {
+          if (!SH || is_local(s, picks[p])) {
             const uint32_t dl = picks[p] - s.lo;
             const unsigned long long m = mymask & ~(tk2[q].y & ~stale);   // only what the target does not know
             if (m && !ABL(ABL_PUSH_ATOMIC)) atomicOr(&s.inmask[dl], m);
             if (expl) { pos[q] = atomicAdd(&s.inbox_cnt[dl], 1u); wrote_rec = true; }
-          } else if (expl) {
-            emit_order(picks[p], i);                 // my queue as an explicit payload record
+          } else if (SH) {
+            emit_order(picks[p], i);                 // the target's owner delivers it (from its replica of my queue)
           }
         }
       }
       if (expl && !pull) {
 #pragma unroll
         for (int q = 0; q < CH; ++q)
-          if (ping_ok[q] && is_local(s, picks[c0 + q])) push_commit(s, t, picks[c0 + q] - s.lo, mi_src(li, mi), pos[q]);
+          if (ping_ok[q] && (!SH || is_local(s, picks[c0 + q]))) push_commit(s, t, picks[c0 + q] - s.lo, mi_src(li, mi), pos[q]);
       }
     }
     SECT(34);                                       // pushes
@@ -400,21 +417,20 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
         if (!use_mask || (mq & MI_OOW)) { push(s, t, li, mi_src(q - s.lo, mq)); wrote_rec = true; }
       }
     }
-    // remote targets: ONE record per probe carries my queue's mask (if it says everything) and the request
-    // for the target's queue (if its Ack arrived); the answer lands in my slot p without an atomic
-#pragma unroll
-    for (int q = 0; q < CH; ++q) {
-      const int p = c0 + q;
-      if (pull || clean || !ping_ok[q] || is_local(s, picks[p])) continue;
-      const uint32_t fl = ((mymask && !(mi & MI_OOW)) ? OF_PAYLOAD : 0u) | (ack_ok[q] ? OF_WANTS_ACK : 0u);
-      if (fl) emit_raw(picks[p] | ((uint32_t)(p + 1) << ID_BITS), i | (fl << ID_BITS), (fl & OF_PAYLOAD) ? mymask : 0ull);
-    }
     // pass 4: the Acks' payloads, pulled by the prober itself
 #pragma unroll
     for (int q = 0; q < CH; ++q) {
       const int p = c0 + q;
       if (!ack_ok[q]) continue;
-      if (!is_local(s, picks[p])) continue;          // asked for above
+      if (SH && !is_local(s, picks[p])) {
+        // a remote target's queue comes from the replicas: translated here, or handed to my own ingest
+        const uint32_t qc = s.q_all[picks[p]];
+        if (qc & Q_PBN) {
+          payloads++; rumors += qc & Q_PBN;
+          if (!pull_remote(picks[p], qc, &ackacc)) emit_order(i, picks[p]);
+        }
+        continue;
+      }
       const uint32_t pj = mi_pbn(pinfo[p]);
       if (pj) {
         ackacc |= tk2[q].x;
@@ -442,15 +458,21 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
     // any dst / src (global ids); msrc = minfo[src]; what the prober itself pulls is ORed into *got
     auto deliver_for = [&](uint32_t pi, uint32_t pli, unsigned long long pmask, uint32_t dst, uint32_t src, uint32_t msrc,
                            unsigned long long* got) {
-      if (!is_local(s, src)) { emit_order(dst, src); return; }       // the owner of src knows its queue
-      const uint32_t cnt = mi_pbn(msrc);
+      const bool src_here = !SH || is_local(s, src);
+      const uint32_t qsrc = src_here ? 0u : (uint32_t)s.q_all[src];   // a remote member's queue: its replicated byte
+      const uint32_t cnt = src_here ? mi_pbn(msrc) : (qsrc & Q_PBN);
       if (!cnt) return;                                             // empty payload
       payloads++; rumors += cnt;
+      if (!src_here) {
+        if (dst == pi && pull_remote(src, qsrc, got)) return;       // pulled by the prober itself
+        emit_order(dst, src);                                       // dst's owner (maybe this shard) delivers it
+        return;
+      }
       if (dst == pi) {
         // pulled by the prober itself: no atomics on the mask path, (rarely) an explicit record of its own
         if (use_mask) *got |= src == pi ? pmask : s.pk[src - s.lo].x;
         if (!use_mask || (msrc & MI_OOW)) { push(s, t, pli, mi_src(src - s.lo, msrc)); wrote_rec = true; }
-      } else if (is_local(s, dst)) {
+      } else if (!SH || is_local(s, dst)) {
         deliver_local(s, t, use_mask, stale, dst - s.lo, src - s.lo, msrc, src == pi ? pmask : (use_mask ? s.pk[src - s.lo].x : 0ull));
         wrote_rec |= !use_mask || (msrc & MI_OOW);
       } else {
@@ -542,12 +564,9 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
   SECT(36);                                         // indirect probes
   if (act) {
     s.probe_out[li] = (uint16_t)(n_pings | (nfail << 5) | (nack << 10));
-    pubmask = mymask;
-    pubq = mycnt | (((mi & MI_OOW) || !use_mask) ? Q_OOW : 0u) | (clean ? 0u : Q_EXC);   // a tick without masks: no queue travels as one
   }
   if (li < s.N && !ABL(ABL_ACKMASK_STORE)) s.ackmask[li] = ackacc;
   if (__ballot(wrote_rec) && (threadIdx.x & 63u) == 0u) s.g[G_ANYREC] = t + 1u;   // one plain store per wave that wrote any (tagged with the tick: nobody has to reset it)
-  if (s.rm && li < s.N) { s.mask_all[i] = pubmask; s.q_all[i] = (uint8_t)pubq; }
   ctr_add_wave(&sh, C_PINGS, n_pings);
   ctr_add_wave(&sh, C_ACTIVE, act ? 1u : 0u);
   ctr_add_wave(&sh, C_PAYLOADS, payloads);
@@ -562,7 +581,28 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
   SECT(37);                                         // outputs, counters
   ctr_flush(s, &sh, blockIdx.x);
   SECT(38);
-  if (s.n_shards > 1 && threadIdx.x == 0) s.ord_cnt[blockIdx.x] = ordn < s.ord_cap ? ordn : s.ord_cap;
+  if (SH) {
+    // the block routes its own records into the per-owner segments of q_send: count (LDS), one reservation per owner and
+    // block, write -- the list is this block's own (written above, visible behind the barrier)
+    if (threadIdx.x < (uint32_t)MAX_SHARDS) rt_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t n = ordn < s.ord_cap ? ordn : s.ord_cap;
+    const uint2* list = s.ord + (size_t)blockIdx.x * s.ord_cap;
+    for (uint32_t k = threadIdx.x; k < n; k += BLOCK) atomicAdd(&rt_cnt[owner_of(s, list[k].x)], 1u);
+    __syncthreads();
+    if (threadIdx.x < s.n_shards) {
+      const uint32_t c = rt_cnt[threadIdx.x];
+      rt_base[threadIdx.x] = c ? atomicAdd(&s.send_cnt[MAX_SHARDS + threadIdx.x], c) : 0u;
+      rt_cnt[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n; k += BLOCK) {
+      const uint2 o = list[k];
+      const uint32_t peer = owner_of(s, o.x), pos = rt_base[peer] + atomicAdd(&rt_cnt[peer], 1u);
+      if (pos < s.p_cap) s.q_send[(size_t)peer * s.p_cap + pos] = o;
+      else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG);
+    }
+  }
 }
 
 // ================================================================================================
@@ -830,8 +870,7 @@ __global__ __launch_bounds__(BLOCK, 5) void records_kernel(DevState s, uint32_t 
   const uint32_t novf = cnt > s.inbox_cap ? min(s.g[G_OVF0 + (t & 1u)], s.ovf_cap) : 0u;
   const bool dealt = has && nack + nin <= REC_CHUNK;   // else: all of it in the serial pass
   if (has) {
-    unsigned long long got = s.inmask[li] | s.ackmask[li];
-    if (s.n_shards > 1) for (uint32_t p = 0; p < s.P; ++p) got |= s.ackslot[(size_t)li * s.P + p];
+    const unsigned long long got = s.inmask[li] | s.ackmask[li];
     const unsigned long long kn = (s.pk[li].y & ~stale_positions(s.g[G_PREV], H)) | got;
     const Ring256 kw = load_wide_ring(s, li, H, kn);
     kw_sh[0][tid] = kw.w0; kw_sh[1][tid] = kw.w1; kw_sh[2][tid] = kw.w2; kw_sh[3][tid] = kw.w3;
@@ -1073,11 +1112,6 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
     nsent = po & 31u; nfail = (po >> 5) & 31u;
     pushed = s.inmask[li];
     pulled = s.ackmask[li];
-    if (s.n_shards > 1)                              // Ack payloads of remote targets: one slot per probe
-      for (uint32_t p = 0; p < s.P; ++p) {
-        const unsigned long long v = s.ackslot[(size_t)li * s.P + p];
-        if (v) { pulled |= v; s.ackslot[(size_t)li * s.P + p] = 0; }
-      }
     hot0 = s.hot[li];
     due = trow_now[li];
   }
@@ -1549,181 +1583,113 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
 }
 
 // ================================================================================================
-// cross-shard exchange kernels (n_shards > 1; DESIGN.md section 7)
+// cross-shard exchange kernels (n_shards > 1; DESIGN.md section 7, round 5)
 // ================================================================================================
-// Records are appended to per-peer send buffers with ONE global atomic per (block, kind, peer): a block
-// first counts what its orders need (LDS), reserves the ranges, then writes -- two passes over its own
-// chunk of orders, so contended same-address atomics stay in the low thousands per tick.
-struct AppendCtx { uint32_t cnt[3][MAX_SHARDS]; uint32_t base[3][MAX_SHARDS]; };
+// One tick of a shard:  begin_kernel (faults, window head, ring, ring dictionary) -> publish_kernel (my slice of the
+// replicas) -> ROUND 1: all-gather of dictionary + lists (r), queue masks, queue bytes -> xlat_kernel -> probe_kernel<.., true>
+// (routes its own records) -> ROUND 2: all-to-all-v of {dst, src} records (q) -> ingest_kernel -> merge_kernel.
 
-// the payload record of local member src_li for destination dst: ids instead of slots
-__device__ inline void write_xrec(const DevState& s, uint32_t* rec, uint32_t dst, uint32_t src_li, uint32_t msrc) {
-  const uint2* line = reinterpret_cast<const uint2*>(line_ptr(s, mi_buf(msrc), src_li));
-  uint32_t n = 0;
-  for (int k = 0; k < PB_SLOTS; ++k) {
-    const uint2 e = line[k];
-    if (!pe_tx(e.y)) break;
-    rec[2 + 2 * n] = s.subject_of[pe_slot(e.x)];
-    rec[3 + 2 * n] = pe_key(e.y);
-    n++;
-  }
-  rec[0] = dst; rec[1] = n;
-}
-
-// translate a mask over a PEER's dictionary (xls = that dictionary in my numbering, LDS) into my ring
-// positions; entries my masks cannot carry this tick (ids younger than the head) go to a foreign line
-__device__ inline void translate_mask(const uint2* xls, unsigned long long m, bool use_mask, uint32_t H,
-                                      unsigned long long* bits, uint32_t* fl, uint32_t* nf) {
-  while (m) {
-    const uint32_t p = (uint32_t)__ffsll((unsigned long long)m) - 1u;
-    m &= m - 1ull;
-    const uint2 e = xls[p];                          // {slot | rid<<16, key} in my numbering
-    if (e.x == NONE32) continue;                     // cannot happen: the sender set the bit from an entry
-    const uint32_t rid = pe_rid(e.x);
-    if (use_mask && rid_in_ring(rid, H)) *bits |= rid_bit(rid);
-    else if (*nf < (uint32_t)PB_SLOTS) { fl[2 * *nf] = e.x; fl[2 * *nf + 1] = pe_hi(e.y, 1u); (*nf)++; }
-  }
-}
-
-// hand a received payload to local member dst_li: what my masks can carry goes in as a mask -- into the
-// member's Ack slot `tag-1` with a plain store when it answers its own probe, else by atomicOr --, the
-// rest becomes a "foreign line" read through an explicit record
-__device__ inline void ingest_finish(const DevState& s, uint32_t t, unsigned long long stale, uint32_t dst_li, uint32_t tag,
-                                     unsigned long long bits, uint32_t* fl, uint32_t nf, uint32_t fl_index) {
-  if (tag) {
-    if (bits) s.ackslot[(size_t)dst_li * s.P + (tag - 1u)] = bits;
-  } else if (bits) {
-    const unsigned long long m = bits & ~(s.pk[dst_li].y & ~stale);
-    if (m) atomicOr(&s.inmask[dst_li], m);
-  }
-  if (nf) {
-    for (uint32_t e = nf; e < (uint32_t)PB_SLOTS; ++e) { fl[2 * e] = 0; fl[2 * e + 1] = 0; }
-    push(s, t, dst_li, SRC_FOREIGN | fl_index);
-  }
-}
-
-// What one order / round-1 record needs (format: swim_device.h).  kind 0: round-1 record (a pull request
-// to the owner of src, or a fused probe record to the owner of dst); 1: mask payload / 2: explicit payload
-// to `peer` about local member `who`; -1: nothing to send.  local: deliver who's queue to local dst here.
-struct OrderPlan { int kind; uint32_t peer, who, out_dst; bool local, fused_in; uint32_t mwho; };
-__device__ inline OrderPlan plan_order(const DevState& s, bool use_mask, uint4 o) {
-  OrderPlan pl{-1, 0u, 0u, 0u, false, false, 0u};
-  const uint32_t tag = o.x >> ID_BITS, dst = o.x & ID_MASK, src = o.y & ID_MASK, fl = o.y >> ID_BITS;
-  if (tag) {
-    if (is_local(s, src)) { pl.kind = 0; pl.peer = owner_of(s, dst); return pl; }   // my probe of a remote target
-    // a peer's probe of MY member dst: its payload is delivered by the caller; the Ack's payload goes back
-    pl.fused_in = true;
-    if (!(fl & OF_WANTS_ACK)) return pl;
-    pl.who = dst; pl.mwho = s.minfo[dst];
-    if (!mi_pbn(pl.mwho)) return pl;
-    pl.kind = (use_mask && !(pl.mwho & MI_OOW)) ? 1 : 2;
-    pl.peer = owner_of(s, src);
-    pl.out_dst = src | (tag << ID_BITS);
-    return pl;
-  }
-  if (!is_local(s, src)) { pl.kind = 0; pl.peer = owner_of(s, src); return pl; }
-  pl.who = src; pl.mwho = s.minfo[src];
-  if (!mi_pbn(pl.mwho)) return pl;                  // empty payload: nothing travels
-  if (is_local(s, dst)) { pl.local = true; return pl; }
-  pl.kind = (use_mask && !(pl.mwho & MI_OOW)) ? 1 : 2;
-  pl.peer = owner_of(s, dst);
-  pl.out_dst = dst;
-  return pl;
-}
-
-// One block routes the records [0, n) of `list`: pass 1 counts, pass 2 writes.  served = the list came in
-// from peer `from` (round 1): this shard accounts for the payloads it serves, and xls holds that peer's
-// dictionary for the masks of fused records.
-__device__ inline void route_block(const DevState& s, uint32_t t, AppendCtx* a, BlockCounters* sh, const uint4* list,
-                                   uint32_t n, bool served, uint32_t from, size_t list_index0, const uint2* xls) {
+// my slice of the replicas, as the peers' probes of this tick will read it: every member's queue mask (over MY ring of the
+// tick: the dictionary begin_kernel wrote) and queue byte; a queue that cannot travel as a mask -- an entry outside the mask
+// window, or a tick in which my masks are off (a burst of rumour ids: swim_device.h) -- is published as a LIST of (subject,
+// key) behind the dictionary, the same list for every peer.  One thread per member, one list reservation per wave.
+__global__ __launch_bounds__(BLOCK) void publish_kernel(DevState s, uint32_t t) {
   const uint32_t Hprev = s.g[G_PREV], H = s.g[G_HEAD];
   const bool use_mask = H - Hprev <= MASK_SLACK;
-  const unsigned long long stale = stale_positions(Hprev, H);
-  const size_t rstride = DICT_RECS + s.r_cap;
-  __syncthreads();                                  // the previous call's ranks are done with the counters
-  if (threadIdx.x < 3 * MAX_SHARDS) a->cnt[threadIdx.x / MAX_SHARDS][threadIdx.x % MAX_SHARDS] = 0;
-  __syncthreads();
-  for (uint32_t k = threadIdx.x; k < n; k += BLOCK) {
-    const OrderPlan pl = plan_order(s, use_mask, list[k]);
-    if (pl.kind >= 0) atomicAdd(&a->cnt[pl.kind][pl.peer], 1u);
-  }
-  __syncthreads();
-  if (threadIdx.x < 3 * MAX_SHARDS) {
-    const uint32_t kind = threadIdx.x / MAX_SHARDS, peer = threadIdx.x % MAX_SHARDS, c = a->cnt[kind][peer];
-    if (c) a->base[kind][peer] = atomicAdd(&s.send_cnt[kind * MAX_SHARDS + peer], c);
-    a->cnt[kind][peer] = 0;
-  }
-  __syncthreads();
-  for (uint32_t k = threadIdx.x; k < n; k += BLOCK) {
-    const uint4 o = list[k];
-    const OrderPlan pl = plan_order(s, use_mask, o);
-    if (pl.fused_in && ((o.y >> ID_BITS) & OF_PAYLOAD)) {
-      // the Ping's payload of a peer's probe, as a mask over ITS dictionary
-      const size_t fi = (size_t)s.n_shards * ((size_t)s.x_cap + s.p_cap) + (size_t)from * s.r_cap + list_index0 + k;
-      uint32_t* fl = reinterpret_cast<uint32_t*>(s.fl + fi * 4);
-      unsigned long long bits = 0; uint32_t nf = 0;
-      translate_mask(xls, ((unsigned long long)o.w << 32) | o.z, use_mask, H, &bits, fl, &nf);
-      ingest_finish(s, t, stale, (o.x & ID_MASK) - s.lo, 0u, bits, fl, nf, (uint32_t)fi);
+  for (uint32_t l0 = blockIdx.x * BLOCK; l0 < s.N; l0 += gridDim.x * BLOCK) {      // (wave-uniform trip count)
+    const uint32_t li = l0 + threadIdx.x, i = s.lo + li;
+    uint32_t mi = 0;
+    bool list = false;
+    if (li < s.N) {
+      mi = s.minfo[i];
+      const uint32_t n = mi_up(mi) ? mi_pbn(mi) : 0u;
+      list = n != 0u && (!use_mask || (mi & MI_OOW));
+      s.mask_all[i] = (n && !list) ? s.pk[li].x : 0ull;
+      s.q_all[i] = (uint8_t)(n | (list ? Q_OOW : 0u));
     }
-    const uint32_t who_li = pl.who - s.lo;
-    if (served && mi_pbn(pl.mwho)) { ctr_add(sh, C_PAYLOADS, 1u); ctr_add(sh, C_RUMORS_SEEN, mi_pbn(pl.mwho)); }
-    if (pl.local) deliver_local(s, t, use_mask, stale, (o.x & ID_MASK) - s.lo, who_li, pl.mwho, use_mask ? s.pk[who_li].x : 0ull);
-    if (pl.kind < 0) continue;
-    const uint32_t pos = a->base[pl.kind][pl.peer] + atomicAdd(&a->cnt[pl.kind][pl.peer], 1u);
-    if (pl.kind == 0) {
-      if (pos < s.r_cap) s.r_send[(size_t)pl.peer * rstride + DICT_RECS + pos] = o;
-      else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG);
-    } else if (pl.kind == 1) {
-      if (pos < s.p_cap) {
-        const unsigned long long m = s.pk[who_li].x;
-        s.p_send[(size_t)pl.peer * s.p_cap + pos] = make_uint4(pl.out_dst, 0u, (uint32_t)m, (uint32_t)(m >> 32));
-      } else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG);
-    } else {
-      if (pos < s.x_cap) write_xrec(s, s.x_send + ((size_t)pl.peer * s.x_cap + pos) * XREC_WORDS, pl.out_dst, who_li, pl.mwho);
-      else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG);
+    const unsigned long long b = __ballot(list);
+    if (!b) continue;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == 0u) base = atomicAdd(&s.g[G_XLINES], (uint32_t)__popcll(b));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
+    if (!list) continue;
+    const uint32_t pos = base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+    if ((pos + 1u) * XLINE_RECS > s.r_cap) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG); continue; }
+    uint4* rec = s.r_send + DICT_RECS + (size_t)pos * XLINE_RECS;
+    const uint2* line = reinterpret_cast<const uint2*>(line_ptr(s, mi_buf(mi), li));
+    uint32_t w[2 * PB_SLOTS];
+    uint32_t n = 0;
+#pragma unroll
+    for (int k = 0; k < PB_SLOTS; ++k) {
+      const uint2 e = line[k];
+      const bool v = pe_tx(e.y) != 0u;
+      w[2 * k] = v ? s.subject_of[pe_slot(e.x)] : 0u;
+      w[2 * k + 1] = v ? pe_key(e.y) : 0u;
+      n += v ? 1u : 0u;                              // (a line holds its valid entries first)
     }
+    rec[0] = make_uint4(i, n, t, 0u);
+#pragma unroll
+    for (int k = 0; k < PB_SLOTS / 2; ++k) rec[1 + k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
   }
 }
 
-// after probe_kernel: the orders it left.  Fused probe records and pull requests go out in round 1,
-// payloads of local sources for remote members in round 2.  One block per probe block (its own region).
-__global__ __launch_bounds__(BLOCK) void split_kernel(DevState s, uint32_t t) {
-  __shared__ BlockCounters sh;
-  __shared__ AppendCtx a;
-  ctr_init(&sh);
-  route_block(s, t, &a, &sh, s.ord + (size_t)blockIdx.x * s.ord_cap, s.ord_cnt[blockIdx.x], false, 0u, 0, nullptr);
-  ctr_flush(s, &sh, blockIdx.x);
+// the round-1 segment of peer `peer` (dictionary, then lists) and its number of lists, wherever they lie (PeerView)
+__device__ inline const uint4* r_list_of(const DevState& s, const PeerView& pv, const PeerCounts& rc, uint32_t peer, uint32_t* nlists) {
+  if (pv.direct) { *nlists = min(*pv.rn[peer], s.r_cap / XLINE_RECS); return pv.r[peer]; }
+  const uint32_t got = rc.v[peer];
+  *nlists = got > DICT_RECS ? min(got - DICT_RECS, s.r_cap) / XLINE_RECS : 0u;
+  return got >= DICT_RECS ? s.r_recv + (size_t)peer * (DICT_RECS + s.r_cap) : nullptr;
 }
 
-// after round 1: the records other shards sent me.  Fixed grid (= nblocks) so that every block owns a
-// counter row; each block takes one contiguous chunk of each peer's list.
-__global__ __launch_bounds__(BLOCK) void serve_kernel(DevState s, uint32_t t, PeerCounts r_counts) {
-  __shared__ BlockCounters sh;
-  __shared__ AppendCtx a;
-  __shared__ uint2 xls[DICT_ENTRIES];
-  ctr_init(&sh);
-  const size_t rstride = DICT_RECS + s.r_cap;
-  for (uint32_t peer = 0; peer < s.n_shards; ++peer) {
-    const uint32_t got = r_counts.v[peer];          // dictionary + records
-    const uint32_t n = got > DICT_RECS ? min(got - DICT_RECS, s.r_cap) : 0u;
-    const uint32_t chunk = (n + gridDim.x - 1) / gridDim.x;
-    const uint32_t first = min(n, blockIdx.x * chunk), cnt = min(n - first, chunk);
-    __syncthreads();
-    if (threadIdx.x < DICT_ENTRIES) xls[threadIdx.x] = s.xl[(size_t)peer * DICT_ENTRIES + threadIdx.x];
-    route_block(s, t, &a, &sh, s.r_recv + (size_t)peer * rstride + DICT_RECS + first, cnt, true, peer, first, xls);
+// before the probes, one launch of 256-thread blocks:
+//   blocks [0, n_shards): every peer's ring dictionary of the tick in MY numbering (slots and rumour ids are per shard).
+//     Rumours this shard never heard of get their slot and id here; such ids are younger than this tick's head: my masks
+//     cannot carry them until the next tick (position 0xFF: the delivery goes through a foreign line);
+//   blocks [n_shards, n_shards + XLAT_INDEX_BLOCKS): where each received list lies (xidx), for the lookups of ingest_kernel;
+//   the rest (direct mode only): the peers' slices of the replicas -- queue masks and queue bytes -- copied over.
+constexpr uint32_t XLAT_INDEX_BLOCKS = 32;
+__global__ __launch_bounds__(BLOCK) void xlat_kernel(DevState s, uint32_t t, PeerCounts r_counts, PeerView pv) {
+  const uint32_t H = s.g[G_HEAD];
+  const bool use_mask = H - s.g[G_PREV] <= MASK_SLACK;
+  if (blockIdx.x >= s.n_shards + XLAT_INDEX_BLOCKS) {
+    // the replicas: everybody else's slice from its owner (8 + 1 bytes per member, coalesced)
+    const uint32_t nb = gridDim.x - s.n_shards - XLAT_INDEX_BLOCKS, b = blockIdx.x - s.n_shards - XLAT_INDEX_BLOCKS;
+    for (uint32_t peer = 0; peer < s.n_shards; ++peer) {
+      if (peer == s.shard) continue;
+      const unsigned long long* m = pv.mask[peer]; const uint8_t* q = pv.qb[peer];
+      const uint32_t lo = peer * s.N;
+      for (uint32_t k = b * BLOCK + threadIdx.x; k < s.N; k += nb * BLOCK) s.mask_all[lo + k] = m[lo + k];
+      const uint32_t* q4 = reinterpret_cast<const uint32_t*>(q + lo);       // (N is a multiple of 4 here, or the tail goes bytewise)
+      uint32_t* d4 = reinterpret_cast<uint32_t*>(s.q_all + lo);
+      if ((lo & 3u) == 0u) {
+        for (uint32_t k = b * BLOCK + threadIdx.x; k < s.N / 4u; k += nb * BLOCK) d4[k] = q4[k];
+        for (uint32_t k = (s.N & ~3u) + b * BLOCK + threadIdx.x; k < s.N; k += nb * BLOCK) s.q_all[lo + k] = q[lo + k];
+      } else {
+        for (uint32_t k = b * BLOCK + threadIdx.x; k < s.N; k += nb * BLOCK) s.q_all[lo + k] = q[lo + k];
+      }
+    }
+    return;
   }
-  ctr_flush(s, &sh, blockIdx.x);
-}
-
-// after round 1: every peer's dictionary of the tick in MY numbering (slots and rumour ids are per shard).
-// Rumours this shard never heard of get their slot and id here; such ids are younger than this tick's
-// head, so ingest hands them over through foreign lines until the next tick.
-__global__ void xlat_kernel(DevState s, PeerCounts r_counts) {
+  if (blockIdx.x >= s.n_shards) {
+    for (uint32_t peer = 0; peer < s.n_shards; ++peer) {
+      if (peer == s.shard) continue;
+      uint32_t nl = 0;
+      const uint4* seg = r_list_of(s, pv, r_counts, peer, &nl);
+      for (uint32_t k = (blockIdx.x - s.n_shards) * BLOCK + threadIdx.x; k < nl; k += XLAT_INDEX_BLOCKS * BLOCK) {
+        const uint4 hd = seg[DICT_RECS + (size_t)k * XLINE_RECS];
+        if (hd.x < s.NT && hd.z == t) s.xidx[hd.x] = k;
+      }
+    }
+    return;
+  }
   const uint32_t peer = blockIdx.x, p = threadIdx.x;
   if (p >= DICT_ENTRIES) return;
   uint2 out = make_uint2(NONE32, 0u);
-  if (peer != s.shard && r_counts.v[peer] >= DICT_RECS) {
-    const uint2 e = reinterpret_cast<const uint2*>(s.r_recv + (size_t)peer * (DICT_RECS + s.r_cap))[p];   // {subject, key}
+  uint32_t nl = 0;
+  const uint4* seg = peer != s.shard ? r_list_of(s, pv, r_counts, peer, &nl) : nullptr;
+  if (seg) {
+    const uint2 e = reinterpret_cast<const uint2*>(seg)[p];   // {subject, key}
     if (e.x != NONE32) {
       const uint32_t slot = get_slot(s, e.x);
       // a dictionary changes by a few entries per tick: keep last tick's translation of this position while it
@@ -1732,159 +1698,98 @@ __global__ void xlat_kernel(DevState s, PeerCounts r_counts) {
       const uint2 prev = s.xl[(size_t)peer * DICT_ENTRIES + p];
       const uint32_t prid = pe_rid(prev.x);
       const uint2 pr = s.rum[prid & RID_MASK];
-      if (prev.x != NONE32 && prev.y == e.y && pe_slot(prev.x) == slot && prid != RID_PARKED && pr.x == slot && pr.y == e.y &&
+      uint2 o;
+      if (prev.x != NONE32 && pe_key(prev.y) == e.y && pe_slot(prev.x) == slot && prid != RID_PARKED && pr.x == slot && pr.y == e.y &&
           ((s.g[G_NRUM] - prid) & RID_MASK) < RID_FAR)
-        out = prev;
-      else
-      {
+        o = make_uint2(prev.x, e.y);
+      else {
         uint32_t num = 0;
         const uint32_t nrid = find_rid(s, slot, e.y, &num);
-        out = make_uint2(pe_lo(slot, young_rid(nrid, num, s.g[G_HEAD])), e.y);
+        o = make_uint2(pe_lo(slot, young_rid(nrid, num, H)), e.y);
       }
+      const uint32_t rid = pe_rid(o.x);
+      out = make_uint2(o.x, o.y | ((use_mask && rid_in_ring(rid, H)) ? ((rid & 63u) << 24) : (0xFFu << 24)));
     }
   }
   s.xl[(size_t)peer * DICT_ENTRIES + p] = out;
 }
 
-// Replicated masks (s.rm).  After round 1 every shard holds every member's start-of-tick queue
-// mask (over its owner's dictionary) and queue byte.  The direct probes between shards of "clean" probers -- targets
-// = first draws, queue fully expressed by its mask -- then need no records at all: both ends recompute the probe
-// from the hashes (pure functions of seed, tick, prober, probe index) and replicated ground truth.
-//   part (a), one thread per LOCAL member i: the Acks of its remote targets -- i pulls the target's replicated mask;
-//   part (b), one thread per REMOTE member g: the Pings of g that hit my members -- the target's shard delivers g's
-//     replicated mask itself; and where my member's queue cannot travel as a mask, its Ack goes out as the explicit
-//     record serve_kernel would have written.
-// Masks are translated through the owner's dictionary (xl, xlat_kernel) like any mask record; entries my masks
-// cannot carry this tick become foreign lines (fl) read through an explicit record.
-__device__ inline void rm_deliver(const DevState& s, uint32_t t, bool use_mask, uint32_t H, unsigned long long stale, const uint2* xls,
-                                  unsigned long long m, uint32_t dst_li, unsigned long long* pulled /* non-null: dst pulls it itself */) {
-  unsigned long long bits = 0; uint32_t nf = 0;
-  uint32_t tmp[2 * PB_SLOTS];
-  translate_mask(xls, m, use_mask, H, &bits, tmp, &nf);
-  if (pulled) *pulled |= bits;
-  else if (bits) {
-    const unsigned long long mm = bits & ~(s.pk[dst_li].y & ~stale);
-    if (mm) atomicOr(&s.inmask[dst_li], mm);
-  }
-  if (nf) {
-    const uint32_t k = atomicAdd(&s.g[G_FLDYN], 1u);
-    if (k >= s.fl_dyn_cap) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG); return; }
-    uint32_t* fl = reinterpret_cast<uint32_t*>(s.fl + ((size_t)s.fl_dyn_base + k) * 4);
-    for (uint32_t e = 0; e < (uint32_t)PB_SLOTS; ++e) { fl[2 * e] = e < nf ? tmp[2 * e] : 0u; fl[2 * e + 1] = e < nf ? tmp[2 * e + 1] : 0u; }
-    __threadfence();
-    push(s, t, dst_li, SRC_FOREIGN | (s.fl_dyn_base + k));
-  }
+// a foreign line for local member dst_li: `nf` entries {slot | rid << 16, key | tx = 1 << 24} my masks cannot carry, read
+// through an explicit record (the exact path behind the masks: records phase / records_kernel)
+__device__ inline void push_foreign(const DevState& s, uint32_t t, uint32_t dst_li, const uint32_t* ent, uint32_t nf) {
+  const uint32_t k = atomicAdd(&s.g[G_FLDYN], 1u);
+  if (k >= s.fl_dyn_cap) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG); return; }
+  uint32_t* fl = reinterpret_cast<uint32_t*>(s.fl + ((size_t)s.fl_dyn_base + k) * 4);
+  for (uint32_t e = 0; e < (uint32_t)PB_SLOTS; ++e) { fl[2 * e] = e < nf ? ent[2 * e] : 0u; fl[2 * e + 1] = e < nf ? ent[2 * e + 1] : 0u; }
+  __threadfence();
+  push(s, t, dst_li, SRC_FOREIGN | (s.fl_dyn_base + k));
+  s.g[G_ANYREC] = t + 1u;                            // same value from every writer: the records phase has work
 }
 
-// probe p of member i in a clean period: its first draw (random scheme) or its rotation target (robust scheme; NONE32:
-// the rotation has no target at this index)
-__device__ inline uint32_t clean_target(const DevState& s, uint32_t mk, uint32_t i, uint32_t p, const Offsets& off) {
-  if (s.scheme == 1u) {
-    if (!off.o[p]) return NONE32;
-    const uint32_t c = i + off.o[p];
-    return c >= s.NT ? c - s.NT : c;
-  }
-  return __umulhi(hash_mk(mk, ((uint32_t)P_SELECT << 24) | (p << 8), 0), s.NT);
-}
-
-__global__ __launch_bounds__(BLOCK) void remote_kernel(DevState s, uint32_t t, uint32_t tk, Offsets off) {
-  __shared__ BlockCounters sh;
+// after round 2: the records {dst, src} for my members -- "dst merges src's start-of-tick queue" -- from every shard's
+// probes (mine included: segment [shard] of q_send never left).  src local: its queue mask as any local delivery.  src
+// remote: its replicated mask through its owner's dictionary; entries my masks cannot carry this tick, and queues that
+// travel as lists, become foreign lines.
+__global__ __launch_bounds__(BLOCK) void ingest_kernel(DevState s, uint32_t t, PeerCounts q_counts, PeerView pv) {
   __shared__ uint2 xls[MAX_SHARDS * DICT_ENTRIES];
-  ctr_init(&sh);
   for (uint32_t k = threadIdx.x; k < s.n_shards * DICT_ENTRIES; k += BLOCK) xls[k] = s.xl[k];
   __syncthreads();
   const uint32_t Hprev = s.g[G_PREV], H = s.g[G_HEAD];
   const bool use_mask = H - Hprev <= MASK_SLACK;
   const unsigned long long stale = stale_positions(Hprev, H);
-  unsigned payloads = 0, rumors = 0;
-  {                                                 // (a tick without masks HERE: my probers are all exceptions, my
-    const uint32_t NR = s.NT - s.N;                 //  members' queues travel as explicit records, what arrives becomes foreign lines)
-    for (uint32_t x = blockIdx.x * BLOCK + threadIdx.x; x < s.N + NR; x += gridDim.x * BLOCK) {
-      if (x < s.N) {
-        // ---- (a) my member i = lo + x: Acks of its remote targets
-        const uint32_t i = s.lo + x;
-        if (!(s.mb[i] & MB_UP) || (s.q_all[i] & Q_EXC)) continue;
-        const uint32_t mk = mix32(tk ^ i);
-        unsigned long long acc = 0;
-        for (uint32_t p = 0; p < s.P; ++p) {
-          const uint32_t c = clean_target(s, mk, i, p, off);
-          if (c == NONE32 || is_local(s, c) || !(s.mb[c] & MB_UP)) continue;
-          if (lost(s, tk, P_L_PING, i, c, p) || lost(s, tk, P_L_ACK, c, i, p)) continue;
-          const uint32_t qc = s.q_all[c], pj = qc & Q_PBN;
-          if (!pj) continue;
-          payloads++; rumors += pj;
-          if (!(qc & Q_OOW)) rm_deliver(s, t, use_mask, H, stale, xls + owner_of(s, c) * DICT_ENTRIES, s.mask_all[c], x, &acc);
-          // else: the target's owner sends the queue as an explicit record (part (b) over there)
-        }
-        if (acc) s.ackmask[x] |= acc;               // probe_kernel stored it; this thread is its only writer now
-      } else {
-        // ---- (b) a remote member g: its Pings that reach my members
-        const uint32_t r = x - s.N, g = r < s.lo ? r : r + s.N;
-        if (!(s.mb[g] & MB_UP)) continue;
-        const uint32_t qg = s.q_all[g];
-        if (qg & Q_EXC) continue;
-        const uint32_t mk = mix32(tk ^ g);
-        for (uint32_t p = 0; p < s.P; ++p) {
-          const uint32_t c = clean_target(s, mk, g, p, off);
-          if (c == NONE32 || !is_local(s, c)) continue;
-          const uint32_t mc = s.minfo[c];
-          if (!mi_up(mc) || lost(s, tk, P_L_PING, g, c, p)) continue;
-          if (qg & Q_PBN) rm_deliver(s, t, use_mask, H, stale, xls + owner_of(s, g) * DICT_ENTRIES, s.mask_all[g], c - s.lo, nullptr);
-          if (((mc & MI_OOW) || !use_mask) && mi_pbn(mc) && !lost(s, tk, P_L_ACK, c, g, p)) {
-            // my member's queue cannot travel as a mask: its Ack's payload as an explicit record into g's slot p
-            const uint32_t peer = owner_of(s, g);
-            const uint32_t pos = atomicAdd(&s.send_cnt[2 * MAX_SHARDS + peer], 1u);
-            if (pos < s.x_cap) write_xrec(s, s.x_send + ((size_t)peer * s.x_cap + pos) * XREC_WORDS, g | ((p + 1u) << ID_BITS), c - s.lo, mc);
-            else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG);
-          }
-        }
-      }
-    }
-  }
-  ctr_add(&sh, C_PAYLOADS, payloads);
-  ctr_add(&sh, C_RUMORS_SEEN, rumors);
-  ctr_flush(s, &sh, blockIdx.x);
-}
-
-// after round 2: payload records for my members, as masks over the sender's dictionary or as explicit ids
-__global__ __launch_bounds__(BLOCK) void ingest_kernel(DevState s, uint32_t t, PeerCounts p_counts, PeerCounts x_counts) {
-  __shared__ uint2 xls[DICT_ENTRIES];
-  const uint32_t Hprev = s.g[G_PREV], H = s.g[G_HEAD];
-  const bool use_mask = H - Hprev <= MASK_SLACK;
-  const unsigned long long stale = stale_positions(Hprev, H);
-  const size_t fl_x = (size_t)s.n_shards * s.x_cap;            // foreign lines of mask records come after these
   for (uint32_t peer = 0; peer < s.n_shards; ++peer) {
-    // ---- mask records
-    const uint32_t np = min(p_counts.v[peer], s.p_cap);
-    __syncthreads();
-    if (threadIdx.x < DICT_ENTRIES) xls[threadIdx.x] = s.xl[(size_t)peer * DICT_ENTRIES + threadIdx.x];
-    __syncthreads();
-    for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < np; k += gridDim.x * BLOCK) {
-      const size_t ri = (size_t)peer * s.p_cap + k;
-      const uint4 rec = s.p_recv[ri];
-      uint32_t* fl = reinterpret_cast<uint32_t*>(s.fl + (fl_x + ri) * 4);
-      unsigned long long bits = 0; uint32_t nf = 0;
-      translate_mask(xls, ((unsigned long long)rec.w << 32) | rec.z, use_mask, H, &bits, fl, &nf);
-      ingest_finish(s, t, stale, (rec.x & ID_MASK) - s.lo, rec.x >> ID_BITS, bits, fl, nf, (uint32_t)(fl_x + ri));
-    }
-    // ---- explicit records
-    const uint32_t nx = min(x_counts.v[peer], s.x_cap);
-    for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < nx; k += gridDim.x * BLOCK) {
-      const size_t ri = (size_t)peer * s.x_cap + k;
-      const uint32_t* rec = s.x_recv + ri * XREC_WORDS;
-      const uint32_t ne = min(rec[1], (uint32_t)PB_SLOTS);
-      unsigned long long bits = 0;
-      uint32_t nf = 0;
-      uint32_t* fl = reinterpret_cast<uint32_t*>(s.fl + ri * 4);
-      for (uint32_t e = 0; e < ne; ++e) {
-        const uint32_t subject = rec[2 + 2 * e], key = rec[3 + 2 * e];
-        const uint32_t slot = get_slot(s, subject);
-        uint32_t num = 0;
-        const uint32_t rid0 = find_rid(s, slot, key, &num), rid = young_rid(rid0, num, H);
-        if (use_mask && rid_in_ring(rid, H)) bits |= rid_bit(rid);     // an id of an earlier tick
-        else { fl[2 * nf] = pe_lo(slot, rid); fl[2 * nf + 1] = pe_hi(key, 1u); nf++; }
+    const uint32_t n = min(peer == s.shard ? s.send_cnt[MAX_SHARDS + peer] : (pv.direct ? *pv.qn[peer] : q_counts.v[peer]), s.p_cap);
+    const uint2* list = peer == s.shard ? s.q_send + (size_t)peer * s.p_cap : (pv.direct ? pv.q[peer] : s.q_recv + (size_t)peer * s.p_cap);
+    for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < n; k += gridDim.x * BLOCK) {
+      const uint2 o = list[k];
+      const uint32_t dst = o.x, src = o.y;
+      if (!is_local(s, dst) || src >= s.NT) continue;
+      const uint32_t dl = dst - s.lo;
+      if (is_local(s, src)) {                        // a peer's prober walked a chain through two of my members
+        const uint32_t ms = s.minfo[src];
+        if (!mi_pbn(ms)) continue;
+        deliver_local(s, t, use_mask, stale, dl, src - s.lo, ms, use_mask ? s.pk[src - s.lo].x : 0ull);
+        if (!use_mask || (ms & MI_OOW)) s.g[G_ANYREC] = t + 1u;
+        continue;
       }
-      ingest_finish(s, t, stale, (rec[0] & ID_MASK) - s.lo, 0u, bits, fl, nf, (uint32_t)ri);
+      const uint32_t qs = s.q_all[src];
+      if (!(qs & Q_PBN)) continue;
+      unsigned long long bits = 0;
+      uint32_t ent[2 * PB_SLOTS], nf = 0;
+      if (!(qs & Q_OOW)) {
+        unsigned long long m = s.mask_all[src];
+        const uint2* d = xls + owner_of(s, src) * DICT_ENTRIES;
+        while (m) {
+          const uint32_t q = (uint32_t)__ffsll((unsigned long long)m) - 1u;
+          m &= m - 1ull;
+          const uint2 e = d[q];
+          if (e.x == NONE32) continue;               // cannot happen: the owner set the bit from an entry of its ring
+          if ((e.y >> 24) != 0xFFu) bits |= 1ull << (e.y >> 24);
+          else if (nf < (uint32_t)PB_SLOTS) { ent[2 * nf] = e.x; ent[2 * nf + 1] = pe_hi(pe_key(e.y), 1u); nf++; }
+        }
+      } else {
+        // the queue as a list of (subject, key): where it lies was noted by xlat_kernel; the list carries its member and tick
+        const uint32_t at = s.xidx[src], own = owner_of(s, src);
+        const uint4* seg = pv.direct ? pv.r[own] : s.r_recv + (size_t)own * (DICT_RECS + s.r_cap);
+        const uint4* rec = seg + DICT_RECS + (size_t)at * XLINE_RECS;
+        const uint4 hd = at < s.r_cap / XLINE_RECS ? rec[0] : make_uint4(NONE32, 0u, 0u, 0u);
+        if (hd.x != src || hd.z != t) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG); continue; }
+        const uint32_t ne = min(hd.y, (uint32_t)PB_SLOTS);
+        const uint2* pe = reinterpret_cast<const uint2*>(rec + 1);
+        for (uint32_t e = 0; e < ne; ++e) {
+          const uint2 sk = pe[e];
+          const uint32_t slot = get_slot(s, sk.x);
+          uint32_t num = 0;
+          const uint32_t rid0 = find_rid(s, slot, sk.y, &num), rid = young_rid(rid0, num, H);
+          if (use_mask && rid_in_ring(rid, H)) bits |= rid_bit(rid);     // an id of an earlier tick
+          else { ent[2 * nf] = pe_lo(slot, rid); ent[2 * nf + 1] = pe_hi(sk.y, 1u); nf++; }
+        }
+      }
+      if (bits) {
+        const unsigned long long mm = bits & ~(s.pk[dl].y & ~stale);
+        if (mm) atomicOr(&s.inmask[dl], mm);
+      }
+      if (nf) push_foreign(s, t, dl, ent, nf);
     }
   }
 }
@@ -1998,11 +1903,12 @@ __global__ __launch_bounds__(BLOCK) void settle_publish_kernel(DevState s, uint3
 // after round 3: every shard's list (mine in s_send, the peers' in s_recv).  One u32 per subject collects the
 // lists with atomicMax: a veto outranks everything, candidates combine to the largest entry; the thread that
 // takes the word back (atomicExch) commits the subject -- once per shard, the same decision everywhere.
-__global__ __launch_bounds__(BLOCK) void settle_commit_kernel(DevState s, uint32_t u, PeerCounts counts) {
+__global__ __launch_bounds__(BLOCK) void settle_commit_kernel(DevState s, uint32_t u, PeerCounts counts, PeerView pv) {
   __shared__ uint32_t nz_new;
   if (threadIdx.x == 0) nz_new = 0;
   auto list_of = [&](uint32_t p, uint32_t* n) -> const uint2* {
     if (p == s.shard) { *n = s.g[G_SETTLE_SEND]; return s.s_send + (size_t)p * s.s_cap; }
+    if (pv.direct) { *n = min(*pv.stn[p], s.s_cap); return pv.st[p]; }      // the peer's list where it lies (swimsim_cluster_step)
     *n = min(counts.v[p], s.s_cap);
     return s.s_recv + (size_t)p * s.s_cap;
   };
@@ -2215,8 +2121,7 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
     if (changes_sh) s.blk[(size_t)s.nblocks * C_COUNT + C_CHANGES] += changes_sh;
     s.g[G_PREV] = s.g[G_HEAD];
     s.g[G_HEAD] = s.g[G_NRUM];
-    s.g[G_ANYREC] = (s.n_shards > 1 || (part & 4u)) ? t + 1u : 0u;   // = t + 1, set by whoever writes an explicit record (the exchange kernels may;
-                                                                  // part bit 2: inject_kernel already has)
+    s.g[G_ANYREC] = (part & 4u) ? t + 1u : 0u;   // = t + 1, set by whoever writes an explicit record (part bit 2: inject_kernel already has)
     // a line is rewritten every tick and replaces ids outside [H - KW_BITS, H + RID_NEAR) by "no id"; an id born at
     // distance r < RID_NEAR above the head sits at r - D one tick later (D = ids of the tick) and would wrap
     // back INTO that zone for D > 2^RID_BITS - RID_NEAR - KW_BITS.  After such a tick (48 896 new rumours at once with
@@ -2254,9 +2159,8 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
   if (s.n_shards > 1 && threadIdx.x == 0) {
     const uint32_t H = s.g[G_NRUM];
     for (int k = 0; k < 3 * MAX_SHARDS; ++k) s.send_cnt[k] = 0;
-    s.g[G_FLDYN] = 0;
+    s.g[G_FLDYN] = 0; s.g[G_XLINES] = 0;
     // this tick's dictionary for the peers: ring position -> {subject, key} of the id that owns it
-    const size_t rstride = DICT_RECS + s.r_cap;
     for (uint32_t p = 0; p < DICT_ENTRIES; ++p) {
       const uint32_t rid = rid_at(p, H);
       uint2 e = make_uint2(NONE32, 0u);
@@ -2268,8 +2172,7 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
         const bool live = !s.G || (r.x < s.R_phys && s.slot_used[r.x] && (int32_t)(rid - s.slot_born[r.x]) >= 0);
         if (live) e = make_uint2(s.subject_of[r.x], r.y);
       }
-      for (uint32_t g = 0; g < s.n_shards; ++g)
-        if (g != s.shard) reinterpret_cast<uint2*>(s.r_send + (size_t)g * rstride)[p] = e;
+      reinterpret_cast<uint2*>(s.r_send)[p] = e;     // one segment, the same for every peer
     }
   }
 }

@@ -65,6 +65,7 @@ struct swimsim {
   int shard_phase = 0;
   bool begun = false;                          // swimsim_shard_phase0 applied this tick's faults already (part A of begin_kernel)
   size_t begun_fend = 0;
+  bool tick_inj = false;                       // messages from outside went into this tick's inboxes (begin_kernel's part bit 2)
   uint32_t j_in[MAX_SHARDS] = {};              // join-pull records received in round 0
   uint32_t* h_sync = nullptr;                  // pinned host copy of the globals (flags + send counts)
   hipEvent_t tick_ev[3] = {nullptr, nullptr, nullptr};
@@ -261,12 +262,12 @@ Offsets robust_offsets(const swimsim* h, uint32_t t) {
 
 // Explicit records are read by records_kernel (its own launch: a kernel boundary costs ~10 us on this chip, profiles/r03i_*)
 // on handles whose every tick has them for every member -- message loss (after a burst of rumour ids no queue travels
-// as a mask), shards (the exchange kernels push records); a lossless handle meets them in a few ticks per hundred and
+// as a mask); a lossless handle meets them in a few ticks per hundred and
 // reads them in a phase at the start of merge_kernel instead.  Same result either way (tests run both on both).
 bool records_kernel_every_tick(const swimsim* h) {
   const char* force = std::getenv("SWIMSIM_RECORDS_KERNEL");             // test / measurement knob: 0 = never, 1 = always
   if (force && (force[0] == '0' || force[0] == '1')) return force[0] == '1';
-  return h->cfg.loss_ppm != 0 || h->d.n_shards > 1 || h->d.strict;   // strict reference rules: every delivery is an explicit record
+  return h->cfg.loss_ppm != 0 || h->d.strict;   // strict reference rules: every delivery is an explicit record
 }
 
 // messages from outside the simulation (swimsim_inject_rumor) go into this tick's inboxes BEFORE the start of the tick: the rows they
@@ -284,10 +285,28 @@ int flush_injections(swimsim* h, uint32_t t, bool* any) {
   return SWIMSIM_OK;
 }
 
-template <int PMAX>
+// one period of failureDetector for the handle's members; registers follow the probe / proxy arrays: four sizes (12: the
+// reference's default numToGossip = 10, src/Util.hs:48); a shard of a cluster runs the instantiation that knows about remote members
+void launch_probe(swimsim* h, uint32_t t, uint32_t tk, uint32_t fold) {
+  const uint32_t pk = std::max(h->d.P, h->d.K);
+  const Offsets off = robust_offsets(h, t);
+  const dim3 g(h->d.nblocks), b(BLOCK);
+#define SWIM_LAUNCH_PROBE(PM) do { if (h->d.n_shards > 1) hipLaunchKernelGGL((probe_kernel<PM, true>), g, b, 0, h->stream, SWIM_STATE_ARG(h), t, tk, off, fold); \
+                                   else hipLaunchKernelGGL((probe_kernel<PM, false>), g, b, 0, h->stream, SWIM_STATE_ARG(h), t, tk, off, fold); } while (0)
+  if (pk <= 4) SWIM_LAUNCH_PROBE(4);
+  else if (pk <= 8) SWIM_LAUNCH_PROBE(8);
+  else if (pk <= 12) SWIM_LAUNCH_PROBE(12);
+  else SWIM_LAUNCH_PROBE(16);
+#undef SWIM_LAUNCH_PROBE
+}
+
+// sharded dense handles (swim_kernels.h "cross-shard exchange kernels"): grids of the small kernels around the two rounds
+uint32_t publish_grid(const swimsim* h) { return std::max(1u, std::min<uint32_t>(h->d.nblocks, 2048u)); }
+uint32_t ingest_grid(const swimsim* h) { return std::max(1u, std::min<uint32_t>(h->d.nblocks, 2048u)); }
+
 void launch_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev, uint32_t fold) {
   if (ev) (void)hipEventRecord(ev[0], h->stream);
-  hipLaunchKernelGGL((probe_kernel<PMAX>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, tk, robust_offsets(h, t), fold);
+  launch_probe(h, t, tk, fold);
   if (ev) (void)hipEventRecord(ev[1], h->stream);
   const bool rk = records_kernel_every_tick(h);
   if (rk) hipLaunchKernelGGL(records_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
@@ -577,45 +596,38 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
   CK(dev_alloc(h, &d.blk, ((size_t)d.nblocks + 1) * C_COUNT + 4096, 0));   // + the section-clock table of the measurement build
   CK(dev_alloc(h, &h->d_scratch64, (size_t)2, 0));
   if (d.n_shards > 1) {
-    // exchange buffers, sized from the expected traffic (2P deliveries per member, spread over the shards)
-    // with headroom; overruns are loud (SWIMSIM_ERR_CAPACITY), never silent drops
-    const double per_peer = (double)N * std::max(1u, d.P) / d.n_shards;
-    const double lossf = 1.0 + 8.0 * c.loss_ppm / 1e6 * std::max(1u, d.K);
-    // orders a probe block leaves: one per direct probe of a remote target, and up to four hops per proxy of every
-    // direct probe that fails (P x K x 4 x P[fail]); the old bound of 64 per member overflowed at P = K = 10 with 20 %
-    // loss (found by the sharded soak: a loud capacity error)
+    // exchange buffers (swim_device.h "cross-shard exchange"), sized from the expected traffic with headroom; overruns are
+    // loud (SWIMSIM_ERR_CAPACITY), never silent drops
     const double l_ = c.loss_ppm / 1e6, pfail = 1.0 - (1.0 - l_) * (1.0 - l_);
-    const double per_member = std::max(1u, d.P) * (1.0 + 4.0 * std::max(1u, d.K) * pfail);
+    // records a probe block hands to the ingests: one per direct probe (a Ping's payload for a remote target; an Ack's that
+    // needs more than a mask translation), and up to four hops per proxy of every direct probe that fails
+    const double per_member = std::max(1u, d.P) * (2.0 + 4.0 * std::max(1u, d.K) * pfail);
     d.ord_cap = (uint32_t)std::min<double>(BLOCK * 2048.0, BLOCK * (1.5 * per_member + 6.0 * std::sqrt(per_member) + 4.0));
-    d.r_cap = (uint32_t)(per_peer * 1.5 * lossf) + 4096;
-    d.p_cap = (uint32_t)(per_peer * 3.0 * lossf) + 4096;
-    d.x_cap = d.p_cap;                           // a tick after a burst of rumour ids sends everything explicitly
+    // round 2: records per owner -- my members' deliveries spread over the shards; a degraded cluster under heavy loss sends
+    // everything to the few members it still holds Alive (they may all sit on one shard): up to 65 536 members the hard bound
+    const double per_peer = (double)N * per_member / d.n_shards;
+    d.p_cap = (uint32_t)std::min<double>(4.0e8, std::max(per_peer * 2.0 + 8.0 * std::sqrt(per_peer) + 4096.0,
+                                                            N <= 65536u ? (double)N * std::max(1u, d.P) * (2.0 + 4.0 * std::max(1u, d.K)) : 0.0));
+    d.x_cap = 0;
+    // round 1: the queues that travel as lists -- in a tick without masks every member's
+    d.r_cap = XLINE_RECS * (N + 64u);
     CK(dev_alloc(h, &d.ord, (size_t)d.nblocks * d.ord_cap, 0));
-    CK(dev_alloc(h, &d.ord_cnt, (size_t)d.nblocks, 0));
-    CK(dev_alloc(h, &d.r_send, (size_t)d.n_shards * (DICT_RECS + d.r_cap), 0));
+    CK(dev_alloc(h, &d.r_send, (size_t)DICT_RECS + d.r_cap, 0));
     CK(dev_alloc(h, &d.r_recv, (size_t)d.n_shards * (DICT_RECS + d.r_cap), 0));
-    CK(dev_alloc(h, &d.p_send, (size_t)d.n_shards * d.p_cap, 0));
-    CK(dev_alloc(h, &d.p_recv, (size_t)d.n_shards * d.p_cap, 0));
-    CK(dev_alloc(h, &d.x_send, (size_t)d.n_shards * d.x_cap * XREC_WORDS, 0));
-    CK(dev_alloc(h, &d.x_recv, (size_t)d.n_shards * d.x_cap * XREC_WORDS, 0));
+    CK(dev_alloc(h, &d.q_send, (size_t)d.n_shards * d.p_cap, 0));
+    CK(dev_alloc(h, &d.q_recv, (size_t)d.n_shards * d.p_cap, 0));
     CK(dev_alloc(h, &d.xl, (size_t)d.n_shards * DICT_ENTRIES, 0xFF));
-    // SWIMSIM_SHARD_REPLICATED_MASKS=1: the direct probes between shards through all-gathered queue masks instead of
-    // records (off by default until it has been timed on the GPU)
-    const char* rm_env = std::getenv("SWIMSIM_SHARD_REPLICATED_MASKS");
-    d.rm = (rm_env && rm_env[0] == '1') ? 1u : 0u;
-    d.fl_dyn_base = (uint32_t)std::min<size_t>((size_t)d.n_shards * ((size_t)d.x_cap + d.p_cap + d.r_cap), (size_t)1 << 29);
-    // foreign lines of remote_kernel: normally a handful per tick (a rumour's first tick abroad), but in a tick without
-    // masks HERE every payload that arrives becomes one: a Ping and an Ack per probe
-    d.fl_dyn_cap = d.rm ? 2u * N * std::max(1u, d.P) + 4096u : 0u;
+    CK(dev_alloc(h, &d.xidx, (size_t)NT, 0xFF));
+    // foreign lines: normally a handful per tick (a rumour's first tick abroad), but in a tick without masks every
+    // delivery from another shard becomes one
+    d.fl_dyn_base = 0;
+    d.fl_dyn_cap = (uint32_t)std::min<double>(4.0e8, (double)N * per_member * 1.5 + 65536.0);
     // (+ the foreign lines of injected rumours, swimsim_inject_rumor, behind the exchange's)
-    d.fl_inj_base = (uint32_t)((size_t)d.n_shards * ((size_t)d.x_cap + d.p_cap + d.r_cap) + d.fl_dyn_cap);
+    d.fl_inj_base = d.fl_dyn_cap;
     CK(dev_alloc(h, &d.fl, ((size_t)d.fl_inj_base + INJECT_CAP) * 4, 0));
     CK(dev_alloc(h, &h->d_inject, (size_t)INJECT_CAP, 0));
-    if (d.rm) {
-      CK(dev_alloc(h, &d.mask_all, (size_t)NT, 0));
-      CK(dev_alloc(h, &d.q_all, ((size_t)NT + 15) & ~(size_t)15, 0));
-    }
-    CK(dev_alloc(h, &d.ackslot, (size_t)N * std::max(1u, d.P), 0));
+    CK(dev_alloc(h, &d.mask_all, (size_t)NT, 0));
+    CK(dev_alloc(h, &d.q_all, ((size_t)NT + 15) & ~(size_t)15, 0));
     if (d.G) {                                   // settling: every shard's word about its rows, all-gathered per tick
       d.s_cap = d.R_phys;
       CK(dev_alloc(h, &d.s_send, (size_t)d.n_shards * d.s_cap, 0));
@@ -771,11 +783,7 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
     if (!fold)
       hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, (uint32_t)(fpos - f0),
                          h->d_joined, part, PeerCounts{});
-    const uint32_t pk = std::max(h->d.P, h->d.K);   // registers follow the probe / proxy arrays: four sizes
-    if (pk <= 4) launch_tick<4>(h, t, tk, ev, fold);
-    else if (pk <= 8) launch_tick<8>(h, t, tk, ev, fold);
-    else if (pk <= 12) launch_tick<12>(h, t, tk, ev, fold);   // the reference's default numToGossip = 10 (src/Util.hs:48)
-    else launch_tick<16>(h, t, tk, ev, fold);
+    launch_tick(h, t, tk, ev, fold);
     h->tick++;
   }
   h->faults.erase(h->faults.begin(), h->faults.begin() + (long)fpos);
@@ -1101,7 +1109,7 @@ int swimsim_shard_info(const swimsim_t* h, uint32_t* lo, uint32_t* n_local, uint
   if (!h) return SWIMSIM_ERR_INVALID;
   if (lo) *lo = h->d.lo;
   if (n_local) *n_local = h->d.N;
-  if (r_cap) *r_cap = h->d.C ? 0u : DICT_RECS + h->d.r_cap;      // a segment starts with the tick's dictionary (bounded handles: no such records)
+  if (r_cap) *r_cap = h->d.C ? 0u : DICT_RECS + h->d.r_cap;      // the tick's dictionary, then the queues that travel as lists (bounded handles: no such records)
   if (p_cap) *p_cap = h->d.p_cap;
   if (x_cap) *x_cap = h->d.x_cap;
   return SWIMSIM_OK;
@@ -1109,8 +1117,10 @@ int swimsim_shard_info(const swimsim_t* h, uint32_t* lo, uint32_t* n_local, uint
 
 int swimsim_shard_buffers(swimsim_t* h, void** send /*[3]*/, void** recv /*[3]*/) {
   if (!h || !send || !recv) return SWIMSIM_ERR_INVALID;
-  send[0] = h->d.r_send; send[1] = h->d.p_send; send[2] = h->d.x_send;
-  recv[0] = h->d.r_recv; recv[1] = h->d.p_recv; recv[2] = h->d.x_recv;
+  // dense handles: kind 0 = ONE segment for every peer (dictionary + lists), kind 1 = 8-byte records {dst, src}; bounded
+  // handles: kind 1 = 16-byte records {dst, src, -, -}; kind 2: nothing any more
+  send[0] = h->d.r_send; send[1] = h->d.C ? (void*)h->d.p_send : (void*)h->d.q_send; send[2] = nullptr;
+  recv[0] = h->d.r_recv; recv[1] = h->d.C ? (void*)h->d.p_recv : (void*)h->d.q_recv; recv[2] = nullptr;
   return SWIMSIM_OK;
 }
 
@@ -1123,8 +1133,8 @@ static int shard_check(swimsim* h, int phase) {
 }
 
 // End of a phase: ONE small pinned copy brings the capacity flags and the per-peer send counts to the
-// host, one stream synchronisation.  counts[k * n_shards + g], k = 0 requests (dictionary included),
-// 1 mask payloads, 2 explicit payloads.
+// host, one stream synchronisation.  counts[k * n_shards + g], k = 0 round-1 records (dictionary + lists: the
+// same segment for every peer), 1 round-2 records {dst, src}, 2 nothing any more.
 static int finish_phase(swimsim* h, uint32_t* counts) {
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemcpyAsync(h->h_sync, h->d.g, G_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
@@ -1135,9 +1145,9 @@ static int finish_phase(swimsim* h, uint32_t* counts) {
     const uint32_t G = h->d.n_shards;
     const uint32_t* c = g + G_SEND;
     for (uint32_t p = 0; p < G; ++p) {
-      counts[p] = p == h->d.shard ? 0u : DICT_RECS + std::min(c[p], h->d.r_cap);
-      counts[G + p] = std::min(c[MAX_SHARDS + p], h->d.p_cap);
-      counts[2 * G + p] = std::min(c[2 * MAX_SHARDS + p], h->d.x_cap);
+      counts[p] = p == h->d.shard ? 0u : DICT_RECS + std::min(g[G_XLINES] * XLINE_RECS, h->d.r_cap);   // the same segment for every peer
+      counts[G + p] = p == h->d.shard ? 0u : std::min(c[MAX_SHARDS + p], h->d.p_cap);
+      counts[2 * G + p] = 0u;
     }
   }
   return SWIMSIM_OK;
@@ -1174,7 +1184,7 @@ int swimsim_shard_phase0(swimsim_t* h, uint32_t* counts, int* round_needed) {
   if (rc) return rc;
   const uint32_t t = (uint32_t)h->tick;
   const uint32_t tk = tick_key(h->cfg.seed, t);
-  { bool inj = false; rc = flush_injections(h, t, &inj); if (rc) return rc; }   // before the tick's scheduled changes (swimsim_step does the same)
+  { bool inj = false; rc = flush_injections(h, t, &inj); if (rc) return rc; h->tick_inj = inj; }   // before the tick's scheduled changes (swimsim_step does the same)
   hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults, (uint32_t)fend, h->d_joined, 1u, PeerCounts{});
   {
     const uint32_t T = h->d.pull_T, first = T ? t % T : 0u;
@@ -1233,7 +1243,7 @@ int swimsim_shard_phase1(swimsim_t* h, uint32_t* counts) {
   const uint32_t tk = tick_key(h->cfg.seed, t);
   // one launch does the whole start of the tick, unless swimsim_shard_phase0 ran its first part already (join-time
   // pulls to exchange in between)
-  if (!h->begun) { bool inj = false; rc = flush_injections(h, t, &inj); if (rc) return rc; }
+  if (!h->begun) { bool inj = false; rc = flush_injections(h, t, &inj); if (rc) return rc; h->tick_inj = inj; }
   if (h->d.pull_T && !h->begun) return set_err(h, SWIMSIM_ERR_STATE, "a shard with pull_ticks starts every tick with swimsim_shard_phase0 (its periodic pulls are exchange round 0)");
   if (h->begun) {                                   // the pulls from hosts on this shard: a block per puller (the ones the peers
     uint32_t nup = 0;                               // sent are merged by begin_kernel: other pullers, rows no local host holds)
@@ -1244,22 +1254,15 @@ int swimsim_shard_phase1(swimsim_t* h, uint32_t* counts) {
                                       (uint32_t)fend, h->d_joined, nup);
   }
   hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults, (uint32_t)fend,
-                     h->d_joined, h->begun ? (2u | 8u) : 3u, peer_counts(h, h->j_in));
-  h->begun = false;
+                     h->d_joined, (h->begun ? (2u | 8u) : 3u) | (h->tick_inj ? 4u : 0u), peer_counts(h, h->j_in));
+  h->begun = false; h->tick_inj = false;
   std::fill(h->j_in, h->j_in + MAX_SHARDS, 0u);
   h->faults.erase(h->faults.begin(), h->faults.begin() + (long)fend);
-  if (h->timing) (void)hipEventRecord(h->tick_ev[0], h->stream);
-  const uint32_t pk = std::max(h->d.P, h->d.K);
-  const Offsets off = robust_offsets(h, t);
-  if (pk <= 4) hipLaunchKernelGGL((probe_kernel<4>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, tk, off, 0u);
-  else if (pk <= 8) hipLaunchKernelGGL((probe_kernel<8>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, tk, off, 0u);
-  else if (pk <= 12) hipLaunchKernelGGL((probe_kernel<12>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, tk, off, 0u);
-  else hipLaunchKernelGGL((probe_kernel<16>), dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, tk, off, 0u);
-  if (h->timing) (void)hipEventRecord(h->tick_ev[1], h->stream);
-  hipLaunchKernelGGL(split_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
+  // my slice of the replicas (queue masks, queue bytes) and, behind the dictionary, the queues that travel as lists: round 1
+  hipLaunchKernelGGL(publish_kernel, dim3(publish_grid(h)), dim3(BLOCK), 0, h->stream, h->d, t);
   rc = finish_phase(h, counts);
   if (rc) return rc;
-  if (h->timing) { float a = 0; HIPCHK(h, hipEventElapsedTime(&a, h->tick_ev[0], h->tick_ev[1])); h->probe_ms += a; }
+  for (uint32_t p = 0; p < h->d.n_shards; ++p) counts[h->d.n_shards + p] = 0;     // (round 2's counts: phase 2)
   h->shard_phase = 1;
   return SWIMSIM_OK;
 }
@@ -1285,12 +1288,18 @@ int swimsim_shard_phase2(swimsim_t* h, const uint32_t* r_counts_in, uint32_t* co
     h->shard_phase = 2;
     return SWIMSIM_OK;
   }
-  const PeerCounts rc_in = peer_counts(h, r_counts_in);
-  hipLaunchKernelGGL(xlat_kernel, dim3(h->d.n_shards), dim3(DICT_ENTRIES), 0, h->stream, h->d, rc_in);
-  if (h->d.rm) hipLaunchKernelGGL(remote_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, (uint32_t)h->tick, tick_key(h->cfg.seed, (uint32_t)h->tick), robust_offsets(h, (uint32_t)h->tick));
-  hipLaunchKernelGGL(serve_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, (uint32_t)h->tick, rc_in);
+  // the peers' dictionaries into my numbering, then one period of failureDetector for my members against the replicas; the
+  // deliveries for members of other shards leave the kernel routed by owner (kind 1: 8-byte records {dst, src}) for round 2
+  const uint32_t t = (uint32_t)h->tick, tk = tick_key(h->cfg.seed, t);
+  if (h->timing && !h->tick_ev[0]) for (int k = 0; k < 3; ++k) HIPCHK(h, hipEventCreate(&h->tick_ev[k]));
+  hipLaunchKernelGGL(xlat_kernel, dim3(h->d.n_shards + XLAT_INDEX_BLOCKS), dim3(BLOCK), 0, h->stream, h->d, t, peer_counts(h, r_counts_in), PeerView{});
+  if (h->timing) (void)hipEventRecord(h->tick_ev[0], h->stream);
+  launch_probe(h, t, tk, 0u);
+  if (h->timing) (void)hipEventRecord(h->tick_ev[1], h->stream);
   rc = finish_phase(h, counts);
   if (rc) return rc;
+  for (uint32_t p = 0; p < h->d.n_shards; ++p) counts[p] = 0;                       // (round 1 is over)
+  if (h->timing) { float a = 0; HIPCHK(h, hipEventElapsedTime(&a, h->tick_ev[0], h->tick_ev[1])); h->probe_ms += a; }
   h->shard_phase = 2;
   return SWIMSIM_OK;
 }
@@ -1314,7 +1323,7 @@ int swimsim_shard_phase3(swimsim_t* h, const uint32_t* p_counts_in, const uint32
     return SWIMSIM_OK;
   }
   const uint32_t t = (uint32_t)h->tick;
-  hipLaunchKernelGGL(ingest_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t, peer_counts(h, p_counts_in), peer_counts(h, x_counts_in));
+  hipLaunchKernelGGL(ingest_kernel, dim3(ingest_grid(h)), dim3(BLOCK), 0, h->stream, h->d, t, peer_counts(h, p_counts_in), PeerView{});
   if (h->timing) (void)hipEventRecord(h->tick_ev[1], h->stream);
   const bool rk = records_kernel_every_tick(h);
   if (rk) hipLaunchKernelGGL(records_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
@@ -1337,8 +1346,9 @@ int swimsim_shard_gather_buffers(swimsim_t* h, void** send /*[2]*/, void** recv 
     recv[0] = h->d.sp_qall; recv[1] = h->d.mb;
     return SWIMSIM_OK;
   }
-  if (n_local) *n_local = h->d.rm ? h->d.N : 0u;
-  send[0] = h->d.rm ? (void*)(h->d.mask_all + h->d.lo) : nullptr; send[1] = h->d.rm ? (void*)(h->d.q_all + h->d.lo) : nullptr;
+  const bool sh = h->d.n_shards > 1;               // dense shards: the queue masks (8 bytes) and the queue bytes
+  if (n_local) *n_local = sh ? h->d.N : 0u;
+  send[0] = sh ? (void*)(h->d.mask_all + h->d.lo) : nullptr; send[1] = sh ? (void*)(h->d.q_all + h->d.lo) : nullptr;
   recv[0] = h->d.mask_all; recv[1] = h->d.q_all;
   return SWIMSIM_OK;
 }
@@ -1364,7 +1374,7 @@ int swimsim_shard_settle_commit(swimsim_t* h, const uint32_t* counts_in) {
   if (rc) return rc;
   if (!counts_in) return SWIMSIM_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
-  hipLaunchKernelGGL(settle_commit_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, (uint32_t)(h->tick - 1), peer_counts(h, counts_in));
+  hipLaunchKernelGGL(settle_commit_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, (uint32_t)(h->tick - 1), peer_counts(h, counts_in), PeerView{});
   HIPCHK(h, hipGetLastError());
   h->settled_alive_tick = ~0ull;                  // the bases just changed: a list read_view cached between phase 3 and now is stale
   h->shard_phase = 0;
@@ -1377,15 +1387,151 @@ int swimsim_shard_settle_commit(swimsim_t* h, const uint32_t* counts_in) {
  * single-process host (a Haskell program with eight GPUs, tests/..., scripts/config5_cluster_one_gpu.py) calls instead of lending
  * an exchange callback to swimsim_shard_step.  hs[k] must be shard k of n bounded (view_cap) handles of one configuration with the
  * same fault schedule. */
+// what must be equal across the handles of a cluster: the resolved configuration apart from the shard index and the device
+static bool same_cluster_config(const swimsim_config_t& a, const swimsim_config_t& b) {
+  swimsim_config_t x = a, y = b;
+  x.shard_index = y.shard_index = 0; x.device = y.device = 0;
+  return std::memcmp(&x, &y, sizeof x) == 0;
+}
+
+/* The same for DENSE handles.  Per tick and handle, on the handle's own stream:
+ *   begin_kernel + publish_kernel -> e0 | wait every peer's e0; xlat_kernel (dictionaries, list index, the peers' slices of the
+ *   replicas pulled over) + probe_kernel -> e1 | wait every peer's e1; ingest_kernel reads the peers' round-2 segments and lists
+ *   WHERE THEY LIE (PeerView: same device, or a peer device over xGMI) with the counts from the peers' own words -> e2;
+ *   merge_kernel; with settling settle_publish -> e3 | wait every peer's e3; settle_commit -> e2 instead.
+ * The next tick's begin waits for every peer's e2 (they are done with my send buffers).  Nothing is copied but the replicas,
+ * nothing comes back to the host.  Not for handles with state pulls (join_pull, pull_ticks: exchange round 0 -- the phase
+ * calls) or with messages from outside pending. */
+static int cluster_step_dense(swimsim_t** hs, uint32_t n, uint32_t nticks) {
+  for (uint32_t k = 0; k < n; ++k) {
+    swimsim* h = hs[k];
+    if (h->d.join_pull || h->d.pull_T) return set_err(h, SWIMSIM_ERR_INVALID, "cluster_step: handles with join_pull / pull_ticks are stepped by the phase calls (their exchange round 0)");
+    if (!h->injections.empty()) return set_err(h, SWIMSIM_ERR_INVALID, "cluster_step: messages from outside are pending (swimsim_inject_rumor): step this tick by the phase calls");
+    if (h->begun) return set_err(h, SWIMSIM_ERR_STATE, "cluster_step: a tick is in progress on this handle");
+  }
+  const bool settling = hs[0]->d.G != 0;
+  std::vector<size_t> fend(n, 0), fpos(n, 0);
+  std::vector<std::vector<hipEvent_t>> ev(n, std::vector<hipEvent_t>(4, nullptr));
+  auto cleanup = [&]() { for (auto& e : ev) for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); };
+  auto broken = [&](swimsim* h, hipError_t e, const char* what) -> int {
+    for (uint32_t k = 0; k < n; ++k) { hs[k]->poisoned = true; (void)hipSetDevice(hs[k]->device); (void)hipStreamSynchronize(hs[k]->stream); }
+    cleanup();
+    return set_err(h, SWIMSIM_ERR_DEVICE, std::string("cluster_step: ") + what + ": " + hipGetErrorString(e) + " (the cluster's handles are poisoned)");
+  };
+#define CCHK(h, call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return broken((h), e_, #call); } while (0)
+  // handles on different devices: the kernels read the peers' buffers over xGMI -- peer access both ways
+  for (uint32_t k = 0; k < n; ++k)
+    for (uint32_t p = 0; p < n; ++p) {
+      if (hs[k]->device == hs[p]->device) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, hs[k]->device, hs[p]->device) != hipSuccess || !can)
+        return set_err(hs[k], SWIMSIM_ERR_DEVICE, "cluster_step: device " + std::to_string(hs[k]->device) + " cannot access device " + std::to_string(hs[p]->device) + " (peer access)");
+      (void)hipSetDevice(hs[k]->device);
+      const hipError_t e = hipDeviceEnablePeerAccess(hs[p]->device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return set_err(hs[k], SWIMSIM_ERR_DEVICE, std::string("cluster_step: hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+      (void)hipGetLastError();
+    }
+  std::vector<PeerView> pv(n);
+  for (uint32_t k = 0; k < n; ++k) {
+    swimsim* h = hs[k];
+    { const hipError_t e_ = hipSetDevice(h->device); if (e_ != hipSuccess) { cleanup(); return set_err(h, SWIMSIM_ERR_DEVICE, hipGetErrorString(e_)); } }
+    { int rc_ = upload_faults(h, nticks, &fend[k]); if (rc_) { cleanup(); return rc_; } }
+    for (int e = 0; e < 4; ++e) { const hipError_t e_ = hipEventCreateWithFlags(&ev[k][e], hipEventDisableTiming); if (e_ != hipSuccess) { cleanup(); return set_err(h, SWIMSIM_ERR_DEVICE, hipGetErrorString(e_)); } }
+    if (h->timing) while (h->ev_pool.size() < (size_t)nticks * 3) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { cleanup(); return set_err(h, SWIMSIM_ERR_DEVICE, "hipEventCreate"); } h->ev_pool.push_back(e); }
+    PeerView& v = pv[k];
+    v = PeerView{};
+    v.direct = 1u;
+    for (uint32_t p = 0; p < n; ++p) {
+      const DevState& q = hs[p]->d;
+      v.r[p] = q.r_send; v.rn[p] = q.g + G_XLINES;
+      v.q[p] = q.q_send + (size_t)k * q.p_cap; v.qn[p] = q.send_cnt + MAX_SHARDS + k;
+      v.mask[p] = q.mask_all; v.qb[p] = q.q_all;
+      v.st[p] = q.s_send ? q.s_send + (size_t)k * q.s_cap : nullptr; v.stn[p] = q.g + G_SETTLE_SEND;
+    }
+  }
+  for (uint32_t tck = 0; tck < nticks; ++tck) {
+    const uint32_t t = (uint32_t)hs[0]->tick, tk = tick_key(hs[0]->cfg.seed, t);
+    for (uint32_t k = 0; k < n; ++k) {                 // the start of the tick, my slice of the replicas
+      swimsim* h = hs[k];
+      CCHK(h, hipSetDevice(h->device));
+      const size_t f0 = fpos[k];
+      while (fpos[k] < fend[k] && h->faults[fpos[k]].tick <= t) ++fpos[k];
+      if (tck) for (uint32_t p = 0; p < n; ++p) if (p != k) CCHK(h, hipStreamWaitEvent(h->stream, ev[p][2], 0));   // the peers are done with my send buffers
+      hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, (uint32_t)(fpos[k] - f0), h->d_joined, 3u, PeerCounts{});
+      hipLaunchKernelGGL(publish_kernel, dim3(publish_grid(h)), dim3(BLOCK), 0, h->stream, h->d, t);
+      CCHK(h, hipEventRecord(ev[k][0], h->stream));
+    }
+    for (uint32_t k = 0; k < n; ++k) {                 // round 1 (read in place) + the probes
+      swimsim* h = hs[k];
+      CCHK(h, hipSetDevice(h->device));
+      for (uint32_t p = 0; p < n; ++p) if (p != k) CCHK(h, hipStreamWaitEvent(h->stream, ev[p][0], 0));
+      const uint32_t gather_blocks = std::max(1u, std::min<uint32_t>(512u, (h->d.NT - h->d.N + 4u * BLOCK - 1) / (4u * BLOCK)));
+      hipLaunchKernelGGL(xlat_kernel, dim3(n + XLAT_INDEX_BLOCKS + gather_blocks), dim3(BLOCK), 0, h->stream, h->d, t, PeerCounts{}, pv[k]);
+      if (h->timing) CCHK(h, hipEventRecord(h->ev_pool[(size_t)tck * 3], h->stream));
+      launch_probe(h, t, tk, 0u);
+      if (h->timing) CCHK(h, hipEventRecord(h->ev_pool[(size_t)tck * 3 + 1], h->stream));
+      CCHK(h, hipEventRecord(ev[k][1], h->stream));
+    }
+    for (uint32_t k = 0; k < n; ++k) {                 // round 2 (read in place) + the end of the tick
+      swimsim* h = hs[k];
+      CCHK(h, hipSetDevice(h->device));
+      for (uint32_t p = 0; p < n; ++p) if (p != k) CCHK(h, hipStreamWaitEvent(h->stream, ev[p][1], 0));
+      hipLaunchKernelGGL(ingest_kernel, dim3(ingest_grid(h)), dim3(BLOCK), 0, h->stream, h->d, t, PeerCounts{}, pv[k]);
+      if (!settling) CCHK(h, hipEventRecord(ev[k][2], h->stream));
+      const bool rk = records_kernel_every_tick(h);
+      if (rk) hipLaunchKernelGGL(records_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
+      hipLaunchKernelGGL(merge_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, SWIM_STATE_ARG(h), t, rk ? 0u : 1u, 0u);
+      if (h->timing) CCHK(h, hipEventRecord(h->ev_pool[(size_t)tck * 3 + 2], h->stream));
+      if (settling) {
+        hipLaunchKernelGGL(settle_publish_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t);
+        CCHK(h, hipEventRecord(ev[k][3], h->stream));
+      }
+    }
+    if (settling)
+      for (uint32_t k = 0; k < n; ++k) {               // round 3: every shard's word about its rows, read in place
+        swimsim* h = hs[k];
+        CCHK(h, hipSetDevice(h->device));
+        for (uint32_t p = 0; p < n; ++p) if (p != k) CCHK(h, hipStreamWaitEvent(h->stream, ev[p][3], 0));
+        hipLaunchKernelGGL(settle_commit_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, PeerCounts{}, pv[k]);
+        CCHK(h, hipEventRecord(ev[k][2], h->stream));
+        h->settled_alive_tick = ~0ull;
+      }
+    for (uint32_t k = 0; k < n; ++k) hs[k]->tick++;
+  }
+  int rc = SWIMSIM_OK;
+  for (uint32_t k = 0; k < n; ++k) {
+    swimsim* h = hs[k];
+    (void)hipSetDevice(h->device);
+    h->faults.erase(h->faults.begin(), h->faults.begin() + (long)fpos[k]);
+    hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(h->stream);
+    if (e1 != hipSuccess || e2 != hipSuccess) { rc = set_err(h, SWIMSIM_ERR_DEVICE, std::string("cluster_step: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2)); continue; }
+    if (h->timing) {
+      for (uint32_t q = 0; q < nticks; ++q) {
+        float a = 0, b = 0;
+        if (hipEventElapsedTime(&a, h->ev_pool[(size_t)q * 3], h->ev_pool[(size_t)q * 3 + 1]) == hipSuccess &&
+            hipEventElapsedTime(&b, h->ev_pool[(size_t)q * 3 + 1], h->ev_pool[(size_t)q * 3 + 2]) == hipSuccess) { h->probe_ms += a; h->merge_ms += b; }
+      }
+      h->timed_ticks += nticks;
+    }
+    const int rc_ = check_device_errors(h);
+    if (rc_ && !rc) rc = rc_;
+  }
+  cleanup();
+  return rc;
+#undef CCHK
+}
+
 int swimsim_cluster_step(swimsim_t** hs, uint32_t n, uint32_t nticks) {
   if (!hs || n < 2 || n > (uint32_t)MAX_SHARDS) return SWIMSIM_ERR_INVALID;
   for (uint32_t k = 0; k < n; ++k) {
     swimsim* h = hs[k];
     if (!h) return SWIMSIM_ERR_INVALID;
     if (h->poisoned) return set_err(h, SWIMSIM_ERR_STATE, "handle is poisoned by an earlier capacity error");
-    if (!h->d.C || h->d.n_shards != n || h->d.shard != k || h->shard_phase != 0 || h->tick != hs[0]->tick || h->d.NT != hs[0]->d.NT)
-      return set_err(h, SWIMSIM_ERR_INVALID, "cluster_step: hs[k] must be shard k of n bounded handles of one cluster, between ticks");
+    for (uint32_t j = 0; j < k; ++j) if (hs[j] == h) return set_err(h, SWIMSIM_ERR_INVALID, "cluster_step: the same handle twice");
+    if (h->d.n_shards != n || h->d.shard != k || h->shard_phase != 0 || h->tick != hs[0]->tick || !same_cluster_config(h->cfg, hs[0]->cfg))
+      return set_err(h, SWIMSIM_ERR_INVALID, "cluster_step: hs[k] must be shard k of n handles of ONE cluster configuration (seed, sizes, every option), between ticks");
   }
+  if (!hs[0]->d.C) return cluster_step_dense(hs, n, nticks);
   std::vector<size_t> fend(n, 0), fpos(n, 0);
   // per handle: [0] its slice of the replicas is published, [1] its records are routed, [2] it has copied what it needs from its
   // peers' send buffers (a peer may then reuse them: the next tick's publish zeroes the counters, its route overwrites the segments)
@@ -1488,11 +1634,12 @@ int swimsim_shard_step(swimsim_t* h, uint32_t nticks, swimsim_exchange_fn xchg, 
     }
     rc = swimsim_shard_phase1(h, out.data());
     if (rc) return rc;
-    if (h->d.rm || h->d.C)                          // round 1 also all-gathers the queue masks (kind 5) and queue bytes
+    {                                               // round 1 also all-gathers the queue masks / lines (kind 5) and queue bytes
       for (uint32_t p = 0; p < G; ++p) {            // (kind 6): N records to every peer, counted at [G + p] and [2G + p]
         out[G + p] = p == h->d.shard ? 0u : h->d.N;
         out[2 * G + p] = p == h->d.shard ? 0u : h->d.N;
       }
+    }
     std::fill(in.begin(), in.end(), 0u);
     if (xchg(ctx, 1, out.data(), in.data())) { h->poisoned = true; return set_err(h, SWIMSIM_ERR_STATE, "shard_step: the exchange callback failed in round 1 (the tick is half done: the handle is poisoned)"); }
     rc = swimsim_shard_phase2(h, in.data(), out.data());

@@ -5,10 +5,9 @@ fault schedule.  Probe outcomes need no communication (ground truth and the loss
 known everywhere); only piggyback payloads cross shards, in two rounds per tick
 (include/swimsim.h, "sharded clusters"):
 
-    phase1  begin + probe + split   -> round 1: the tick's id dictionary + pull requests {dst, src}
-                                       (to the owner of src)
-    phase2  xlat + serve            -> round 2: payloads to the owner of dst, as 16-byte masks over the
-                                       sender's dictionary (normal case) or 72-byte explicit id lists
+    phase1  begin + publish         -> round 1: ALL-GATHER of every shard's ring dictionary (+ the queues that travel
+                                       as lists), queue masks (8 B / member) and queue bytes (1 B / member)
+    phase2  xlat + probe            -> round 2: 8-byte records {dst, src} "dst merges src's queue" to the owner of dst
     phase3  ingest + merge
 
 Two fabrics move the records:
@@ -26,8 +25,9 @@ from .sim import Sim, SwimError
 from .types import SimConfig
 
 _M64 = (1 << 64) - 1
-REC_BYTES = (16, 16, 72, 8, 16, 8, 1)   # record kinds: round-1 records (+dictionary), mask payloads, explicit payloads, settle
-                                        # records, join pulls, replicated queue masks, replicated queue bytes (all-gathered)
+REC_BYTES = (16, 8, 72, 8, 16, 8, 1)    # record kinds: round-1 records (dictionary + lists: ONE segment for every peer), round-2
+                                        # records {dst, src}, (none any more), settle records, join pulls, replicated queue masks,
+                                        # replicated queue bytes (all-gathered)
 
 
 def _wrap(ptr: int, nbytes: int, device):
@@ -53,17 +53,26 @@ class _Shard:
         a, h, G = abi, self.sim._h, n_shards
         # record sizes by kind; bounded handles (view_cap) all-gather whole 64-byte queue lines where dense ones gather 8-byte masks
         self.rec_bytes = list(REC_BYTES)
-        if self.sim.resolved.view_cap:
+        bounded = bool(self.sim.resolved.view_cap)
+        if bounded:
             self.rec_bytes[5] = 64
+            self.rec_bytes[1] = 16
         REC = self.rec_bytes
+        # kinds whose send "segments" are ONE slice that goes to every peer
+        self.shared_kinds = (5, 6) if bounded else (0, 5, 6)
         vals = [C.c_uint32() for _ in range(5)]
         self.sim._check(a.shard_info(h, *[C.byref(v) for v in vals]))
         self.lo, self.n_local = vals[0].value, vals[1].value
         caps = [v.value for v in vals[2:]]
         sp, rp = (C.c_void_p * 3)(), (C.c_void_p * 3)()
         self.sim._check(a.shard_buffers(h, sp, rp))
-        self.send = [_wrap(sp[k], G * caps[k] * REC[k], device).view(G, caps[k] * REC[k]) for k in range(3)]
-        self.recv = [_wrap(rp[k], G * caps[k] * REC[k], device).view(G, caps[k] * REC[k]) for k in range(3)]
+        def seg(ptr, k, shared):
+            nb = caps[k] * REC[k] if ptr else 0
+            if shared:
+                return _wrap(ptr or 0, nb, device).view(1, nb).expand(G, nb)
+            return _wrap(ptr or 0, G * nb, device).view(G, nb)
+        self.send = [seg(sp[k], k, k in self.shared_kinds) for k in range(3)]
+        self.recv = [seg(rp[k], k, False) for k in range(3)]
         self.settling = self.sim.resolved.gc_ticks != 0
         self.join_pull = self.sim.resolved.join_pull != 0 or self.sim.resolved.pull_ticks != 0   # state pulls: exchange round 0 (kind 4)
         # kind 3: what every shard says about its rows (round 3, settling); kind 4: join-time pulls (round 0)
@@ -144,7 +153,7 @@ class LocalFabric:
                         continue
                     assert p != src.index, "a shard never sends to itself"
                     nb = n * src.rec_bytes[kind]
-                    shards[p].recv[kind][src.index, :nb].copy_(src.send[kind][p, :nb])
+                    shards[p].recv[kind][src.index, :nb].copy_(src.send[kind][0 if kind in src.shared_kinds else p, :nb])
                     recv[p][j][src.index] = n
         if shards and shards[0].send[0].is_cuda:
             import torch
@@ -220,9 +229,10 @@ class DistFabric:
         if not hasattr(self, "_stage"):
             torch = self.torch
             dev = "cpu" if host else self.device
-            mk = lambda: [None if b is None else torch.empty(tuple(b.shape), dtype=torch.uint8, device=dev,
-                                                             pin_memory=(host and self.on_gpu)) for b in sh.send]
-            self._stage = (mk(), mk())
+            mk = lambda bufs, one: [None if b is None else torch.empty((1, b.shape[1]) if (one and k in sh.shared_kinds) else tuple(b.shape),
+                                                                       dtype=torch.uint8, device=dev, pin_memory=(host and self.on_gpu))
+                                    for k, b in enumerate(bufs)]
+            self._stage = (mk(sh.send, True), mk(sh.recv, False))
         return self._stage
 
     def exchange(self, shards, kinds, counts):
@@ -252,7 +262,7 @@ class DistFabric:
                 n_out, n_in = counts[0][j][p], recv[j][p]
                 if n_out:
                     nb = n_out * sh.rec_bytes[kind]
-                    row = 0 if kind in (5, 6) else p   # the same slice goes to every peer: staged once
+                    row = 0 if kind in sh.shared_kinds else p   # the same slice goes to every peer: staged once
                     out = stage[0][kind][row, :nb]
                     if (kind, row) not in staged:
                         out.copy_(sh.send[kind][row, :nb])
@@ -295,6 +305,9 @@ class ShardedSim:
         self.n_local = self.shards[0].n_local
         self.resolved = self.shards[0].sim.resolved
         self._fd_synced_at = -1
+        self._injected = False
+        import os
+        self._in_library = os.environ.get("SWIMSIM_CLUSTER_STEP", "1") != "0"   # read when the cluster is made (tests force the phase calls)
         self.phase_seconds = [0.0] * 5          # host-side wall time per step part: phase1, round1, phase2, round2, phase3
         self.timed_ticks = 0
 
@@ -314,6 +327,7 @@ class ShardedSim:
         """A message from outside the simulation (swimsim_inject_rumor) goes to the shard that owns the observer; in a cluster of one
         process per shard every rank makes the call, the owner's takes it."""
         s = self._owner(observer)
+        self._injected = True
         if s is not None:
             s.sim.injectRumor(observer, subject, state, incarnation)
 
@@ -330,7 +344,7 @@ class ShardedSim:
             try:
                 t0 = time.perf_counter()
                 acc[{0: 0, 1: 0, 2: 2, 3: 4}[rnd]] += t0 - state["t"]  # the phase that just ended
-                kinds = {0: (4,), 1: (0, 5, 6) if sh.replicated else (0,), 2: (1, 2), 3: (3,)}[rnd]
+                kinds = {0: (4,), 1: (0, 5, 6) if sh.replicated else (0,), 2: (1,), 3: (3,)}[rnd]
                 # rounds 0 and 3: one kind, its counts at [p]; round 1 with replicated masks: kinds 5 and 6 at [G + p], [2G + p]
                 at = (lambda k: 0) if rnd in (0, 3) else (lambda k: (k - 4) * G if k >= 5 else k * G)
                 counts = [[[c_out[at(k) + p] for p in range(G)] for k in kinds]]
@@ -357,8 +371,10 @@ class ShardedSim:
         if len(sh) == 1 and self.n_shards > 1:
             return self._step_by_library(nticks)
         import os
-        if len(sh) == self.n_shards > 1 and self.resolved.view_cap and os.environ.get("SWIMSIM_CLUSTER_STEP", "1") != "0":
-            # every shard of a cluster of bounded handles lives in this process: the library steps the cluster itself, the
+        in_library = self.resolved.view_cap or not (sh[0].join_pull or self._injected)    # (state pulls / messages from outside: the phase calls)
+        self._injected = False
+        if len(sh) == self.n_shards > 1 and in_library and self._in_library:
+            # every shard of the cluster lives in this process: the library steps the cluster itself, the
             # exchange enqueued on the handles' streams (swimsim_cluster_step: no host in the loop)
             import time
             t0 = time.perf_counter()
@@ -390,10 +406,10 @@ class ShardedSim:
             t2 = time.perf_counter()
             c2 = [s.phase2(r_in[k][0]) for k, s in enumerate(sh)]
             t3 = time.perf_counter()
-            px_in = f.exchange(sh, (1, 2), [[c[1], c[2]] for c in c2])              # round 2
+            px_in = f.exchange(sh, (1,), [[c[1]] for c in c2])                      # round 2
             t4 = time.perf_counter()
             for k, s in enumerate(sh):
-                s.phase3(px_in[k][0], px_in[k][1])
+                s.phase3(px_in[k][0], [0] * self.n_shards)
             if sh[0].settling:                                                      # round 3: settle records
                 s_in = f.exchange(sh, (3,), [[s.settle_counts()] for s in sh])
                 for k, s in enumerate(sh):

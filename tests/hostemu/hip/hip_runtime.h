@@ -52,7 +52,7 @@ using std::max;
 using std::min;
 
 // ---- error / runtime API (single "device", synchronous) ----------------------------------------
-typedef enum hipError_t { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 } hipError_t;
+typedef enum hipError_t { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorPeerAccessAlreadyEnabled = 704 } hipError_t;
 typedef struct hostemu_stream* hipStream_t;
 typedef struct hostemu_event { std::chrono::steady_clock::time_point t; }* hipEvent_t;
 enum { hipStreamNonBlocking = 1 };
@@ -83,6 +83,10 @@ static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hostemu_event(); return hipSuccess; }
+enum { hipEventDisableTiming = 2 };
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new hostemu_event(); return hipSuccess; }
+static inline hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = 1; return hipSuccess; }
+static inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }

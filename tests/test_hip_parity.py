@@ -237,10 +237,10 @@ def test_sharded_join_pull_on_one_gpu(oracle_abi, hip_abi):
 
 
 @pytest.mark.parametrize("n,shards,loss,seed", [(4096, 4, 0, 1), (65536, 8, 20000, 3)])
-def test_replicated_masks_on_one_gpu(oracle_abi, hip_abi, monkeypatch, n, shards, loss, seed):
-    """SWIMSIM_SHARD_REPLICATED_MASKS=1 (off by default until timed): the direct probes between shards through
-    all-gathered queue masks -- no records for clean probers (remote_kernel) -- must give the same run."""
-    monkeypatch.setenv("SWIMSIM_SHARD_REPLICATED_MASKS", "1")
+def test_sharded_cluster_by_phase_calls_on_one_gpu(oracle_abi, hip_abi, monkeypatch, n, shards, loss, seed):
+    """SWIMSIM_CLUSTER_STEP=0: the same cluster stepped through swimsim_shard_phase1/2/3 with the embedder's copies (LocalFabric)
+    instead of swimsim_cluster_step (the exchange inside the library) -- must give the same run."""
+    monkeypatch.setenv("SWIMSIM_CLUSTER_STEP", "0")
     test_sharded_cluster_on_one_gpu(oracle_abi, hip_abi, n, shards, loss, seed)
 
 

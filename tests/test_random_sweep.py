@@ -33,11 +33,11 @@ def test_random_configurations(oracle_abi, block):
         sc.pushPull = bool(sc.pullTicks) and shards == 1 and (seed >> 7) % 2 == 1
         a = Sim.create(oracle_abi, sc)
         rm = shards > 1 and rng.random() < 0.5       # replicated queue masks instead of probe records (read at create)
-        os.environ["SWIMSIM_SHARD_REPLICATED_MASKS"] = "1" if rm else "0"
+        os.environ["SWIMSIM_CLUSTER_STEP"] = "0" if rm else "1"
         try:
             b = Sim.create(emu, sc) if shards == 1 else ShardedSim(emu, sc, LocalFabric(shards))
         finally:
-            del os.environ["SWIMSIM_SHARD_REPLICATED_MASKS"]
+            del os.environ["SWIMSIM_CLUSTER_STEP"]
         for _f in range(rng.randrange(0, max(1, n // 8) + 1)):
             m, t = rng.randrange(n), rng.randrange(1, 40)
             for s in (a, b):

@@ -44,11 +44,11 @@ def test_one_process_per_shard_gloo_with_periodic_state_pulls():
     run_world(4, (256, 3, 100000, 14, 60, 7), 29621)
 
 
-def test_one_process_per_shard_gloo_with_replicated_masks():
-    """SWIMSIM_SHARD_REPLICATED_MASKS=1: the all-gather of queue masks (round 4) through swimsim_shard_step's callback,
-    with loss, settling and the join-time pull on top."""
-    run_world(4, (256, 3, 50000, 9, 60, 0), 29616, SWIMSIM_SHARD_REPLICATED_MASKS="1")
-    run_world(2, (192, 3, 20000, 8, 130, 3), 29617, SWIMSIM_SHARD_REPLICATED_MASKS="1")
+def test_one_process_per_shard_gloo_more_configurations():
+    """The all-gather of dictionaries, queue masks and queue bytes (round 1) and the {dst, src} records (round 2) through
+    swimsim_shard_step's callback, with loss, settling and the join-time pull on top."""
+    run_world(4, (256, 3, 50000, 9, 60, 0), 29616)
+    run_world(2, (192, 3, 20000, 8, 130, 3), 29617)
 
 
 def test_one_process_per_shard_gloo_with_bounded_member_maps():

@@ -146,32 +146,32 @@ def test_sharded_join_pull_with_churn(oracle_abi, emu_abi, shards, gc):
 
 
 @pytest.fixture
-def replicated_masks(monkeypatch):
-    """SWIMSIM_SHARD_REPLICATED_MASKS=1 (read at create): the direct probes between shards through all-gathered queue
-    masks, no records for clean probers."""
-    monkeypatch.setenv("SWIMSIM_SHARD_REPLICATED_MASKS", "1")
+def phase_calls(monkeypatch):
+    """SWIMSIM_CLUSTER_STEP=0: ShardedSim steps a one-process cluster through swimsim_shard_phase1/2/3 with LocalFabric's copies
+    (the embedder's exchange) instead of swimsim_cluster_step (the exchange inside the library, peers' buffers read in place):
+    the same tick through both forms of the exchange."""
+    monkeypatch.setenv("SWIMSIM_CLUSTER_STEP", "0")
 
 
 @pytest.mark.parametrize("n,shards,p,loss,seed", [(256, 4, 3, 0, 2), (512, 8, 3, 200000, 4), (64, 2, 10, 300000, 5)])
-def test_replicated_masks_match_oracle(oracle_abi, emu_abi, replicated_masks, n, shards, p, loss, seed):
+def test_phase_calls_match_oracle(oracle_abi, emu_abi, phase_calls, n, shards, p, loss, seed):
     test_sharded_matches_oracle(oracle_abi, emu_abi, n, shards, p, loss, seed)
 
 
-def test_replicated_masks_saturated_queues(oracle_abi, emu_abi, replicated_masks):
+def test_phase_calls_saturated_queues(oracle_abi, emu_abi, phase_calls):
     test_sharded_saturated_queues(oracle_abi, emu_abi)
 
 
-def test_replicated_masks_with_tiny_mask_window(oracle_abi, replicated_masks):
+def test_phase_calls_with_tiny_mask_window(oracle_abi, phase_calls):
     test_sharded_with_tiny_mask_window(oracle_abi)
 
 
-def test_replicated_masks_with_settling_and_join_pull(oracle_abi, emu_abi, replicated_masks):
+def test_phase_calls_with_settling_and_join_pull(oracle_abi, emu_abi, phase_calls):
     test_sharded_settling_with_churn(oracle_abi, emu_abi, 2, 20000, 210)
     test_sharded_join_pull_with_churn(oracle_abi, emu_abi, 3, True)
 
 
-def test_replicated_masks_with_the_robust_scheme(oracle_abi, emu_abi, replicated_masks):
-    """Clean = no target of the period's rotation skipped; both ends compute the rotation instead of the first draws."""
+def test_phase_calls_with_the_robust_scheme(oracle_abi, emu_abi, phase_calls):
     test_sharded_robust_target_scheme(oracle_abi, emu_abi, 256, 4, 3, 0, 1)
     test_sharded_robust_target_scheme(oracle_abi, emu_abi, 300, 3, 2, 100000, 2)
 
