@@ -115,7 +115,9 @@ def oracle_replay(sc, crashes, t_window, t_end, gpu_digest, gpu_counters, budget
     return base, ok
 
 
-def main():
+def main(argv=None, abi=None):
+    """abi: tests hand in the host emulation of the kernels (tests/hostemu_binding) to drive this file's flows on a box without a
+    GPU; the bench itself always loads libswimsim.so (no fallback: without a HIP device swimsim_create fails)."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
@@ -140,28 +142,46 @@ def main():
     ap.add_argument("--replicated-masks", action="store_true",
                     help="multi-GPU: the direct probes between shards through all-gathered queue masks instead of records "
                          "(DESIGN.md section 7; off by default until timed on hardware)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    # SWIM_BENCH_SHARE_GPU=1 (test hook, not a reporting mode): all ranks share GPU 0 over gloo with
-    # host-staged records, to exercise this file's multi-rank flow on a one-GPU box
+    # SWIM_BENCH_SHARE_GPU=1 (test hook, not a reporting mode): all shards share GPU 0, to exercise this file's multi-GPU flows on a
+    # one-GPU box (one process per rank: gloo with host-staged records; one process: all handles on device 0)
     share_gpu = os.environ.get("SWIM_BENCH_SHARE_GPU") == "1"
+    # `python bench.py --gpus N` as the driver starts it -- ONE process: N handles on N devices, the tick loop and the exchange
+    # inside the library (swimsim_cluster_step: what a single Haskell host with eight GPUs calls).  Under torch.distributed.run
+    # (WORLD_SIZE set): one process per GPU, swimsim_shard_step with torch.distributed as the embedder's exchange.
+    single = args.gpus > 1 and "WORLD_SIZE" not in os.environ
+    if args.gpus > 1 and not single and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (or without it: one process steps all %d GPUs)" % (args.gpus, args.gpus))
+    devices = None
+    if single:
+        ndev = torch.cuda.device_count()
+        if not share_gpu and ndev < args.gpus and abi is None:
+            raise SystemExit("bench: --gpus %d but %d device(s) visible (SWIM_BENCH_SHARE_GPU=1 puts every shard on device 0: a test hook)" % (args.gpus, ndev))
+        devices = [0 if share_gpu else k for k in range(args.gpus)]
+        world = args.gpus                     # shards of the cluster; this process is all of its ranks
     if share_gpu:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    if world > 1:
+    has_cuda = torch.cuda.is_available()
+    if has_cuda:
+        torch.cuda.set_device(local_rank)
+    if single:
+        world_procs = 1
+    else:
+        world_procs = world
+    if world_procs > 1:
         if share_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("cpu:gloo,cuda:nccl", device_id=torch.device("cuda", local_rank))
 
     from swim_amd import Sim, _abi, _lib, workloads
+    LIB = abi if abi is not None else _lib.load()
     n = args.members                          # per GPU: weak scaling, ONE cluster of world * n members
     nt = n * world
     saturated = args.regime == "saturated" and not args.view_cap
@@ -189,11 +209,16 @@ def main():
     if args.replicated_masks:
         os.environ["SWIMSIM_SHARD_REPLICATED_MASKS"] = "1"      # read by swimsim_create
     if world == 1:
-        sim = Sim.create(_lib.load(), sc)
+        sim = Sim.create(LIB, sc)
+    elif single:
+        from swim_amd.shard import LocalFabric, ShardedSim
+        sim = ShardedSim(LIB, sc, LocalFabric(world), devices=devices if has_cuda else None)
+        exchange = "inside the library (swimsim_cluster_step): the peers' buffers read in place over %s, ordered by events on the handles' streams" % (
+            "device memory (all shards on ONE GPU: test hook)" if share_gpu else "xGMI peer access")
     else:
         from swim_amd.shard import DistFabric, ShardedSim
         fabric = DistFabric("cuda:%d" % local_rank, transport="host" if share_gpu else "auto")
-        sim = ShardedSim(_lib.load(), sc, fabric, device="cuda:%d" % local_rank)
+        sim = ShardedSim(LIB, sc, fabric, device="cuda:%d" % local_rank)
         exchange = "torch.distributed p2p, transport=%s%s%s" % (fabric.transport, (" [" + fabric.note + "]") if fabric.note else "",
                                                                  ", replicated queue masks" if args.replicated_masks else "")
     workloads.apply_crashes(sim, crashes)
@@ -202,10 +227,12 @@ def main():
             sim.scheduleFault(t + 8 + (m % 5), m, True)       # churn: back after 8-12 ticks
 
     def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
+        for d in ((sorted(set(devices)) if single else [local_rank]) if has_cuda else []):
+            torch.cuda.synchronize(d)
+        if world_procs > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            if has_cuda:
+                torch.cuda.synchronize()
 
     # ---- pre-roll (untimed): step until the cluster carries the saturated load, whatever --warmup is
     preroll = 0
@@ -236,13 +263,13 @@ def main():
     dt = time.perf_counter() - t0
     kt = sim.kernelTiming()
     c1 = sim.counters()
-    if world > 1:
+    if world_procs > 1:
         tt = torch.tensor([dt], device="cpu" if share_gpu else "cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     t_window, t_end = preroll + args.warmup, preroll + args.warmup + args.steps
     lat_all = first_detection_latency(sim, crashes, t_window, t_end - 2)   # collective on a sharded cluster
-    gpu_digest = sim.digest() if world == 1 else None
+    gpu_digest = sim.digest() if (world == 1 or single) else None
     if rank == 0:
         P = sim.resolved.probes_per_tick
         K = sim.resolved.indirect_k
@@ -310,7 +337,8 @@ def main():
                            ", settling every %d quiet ticks" % sim.resolved.gc_ticks if sim.resolved.gc_ticks else ""),
                        "members_per_gpu": n, "num_to_gossip": sim.resolved.num_to_gossip, "target_scheme": args.scheme,
                        "preroll_ticks": preroll, "timed_ticks": [t_window, t_end],
-                       "parallelism": "1 GPU" if world == 1 else "ONE cluster of %d members in %d shards (contiguous id ranges, one per GPU); piggyback payloads cross shards in two rounds per tick (%s)" % (nt, world, exchange)},
+                       "parallelism": "1 GPU" if world == 1 else "ONE cluster of %d members in %d shards (contiguous id ranges, one per GPU%s); piggyback payloads cross shards in two rounds per tick (%s)" % (
+                           nt, world, ", ONE process" if single else ", one process per GPU", exchange)},
             "ticks_per_s": args.steps / dt,
             "mean_first_detection_latency_ticks": lat, "crashes_measured": nlat,
             "per_member_tick": rt,
@@ -348,7 +376,16 @@ def main():
                 "source": "profiles/r04o_microbench_random_access.txt, profiles/r01_microbench_gather_rate.txt"}
         if world > 1:
             out["shard_tick_breakdown_us_rank0"] = sim.phaseBreakdown()      # where a sharded tick goes (host view)
-        if not args.no_cpu_baseline and world == 1:
+            # what crosses xGMI per GPU and tick (the last tick's counts, swimsim_shard_traffic): round 1 = the all-gather of replica
+            # slices, dictionaries and lists (received from every peer), round 2 = the {dst, src} records; against 7 links x 153 GB/s
+            tr = sim.traffic()[0]
+            per_gpu = tr["round1_bytes_to_each_peer"] * (world - 1) + tr["round2_bytes_to_all_peers"]
+            xgmi = 7 * 153.0
+            out["exchange"] = {"bytes_per_gpu_per_tick": per_gpu, "detail_shard0": tr, "members_per_gpu": n,
+                               "xgmi_peak_GBs": xgmi, "achieved_GBs_if_on_xgmi": per_gpu / (dt / args.steps) / 1e9,
+                               "frac_of_xgmi": per_gpu / (dt / args.steps) / 1e9 / xgmi,
+                               "note": "all shards on ONE GPU (test hook): nothing crossed xGMI" if share_gpu else None}
+        if not args.no_cpu_baseline and (world == 1 or single):
             base, ok = oracle_replay(sc, crashes, t_window, t_end, gpu_digest, c1)
             out["cpu_baseline"] = base
             out["verified_vs_oracle"] = ok       # digest + counters at the end of the timed region; None = replay skipped
@@ -357,7 +394,7 @@ def main():
                 raise SystemExit("bench: GPU state diverged from the oracle at tick %d" % t_end)
         print(json.dumps(out))
     sim.close()
-    if world > 1:
+    if world_procs > 1:
         dist.destroy_process_group()
 
 

@@ -97,7 +97,7 @@ foreign import ccall unsafe "swimsim_shard_buffers" c_shard_buffers :: Ptr Swims
 foreign import ccall unsafe "swimsim_shard_settle_buffers" c_shard_settle_buffers :: Ptr SwimsimT -> Ptr (Ptr ()) -> Ptr (Ptr ()) -> Ptr Word32 -> IO CInt
 -- join_pull on a sharded cluster: the kind-4 buffers of exchange round 0 (16-byte records {joiner, subject, entry, -})
 foreign import ccall unsafe "swimsim_shard_join_buffers" c_shard_join_buffers :: Ptr SwimsimT -> Ptr (Ptr ()) -> Ptr (Ptr ()) -> Ptr Word32 -> IO CInt
--- replicated queue masks (SWIMSIM_SHARD_REPLICATED_MASKS=1): the two tables all-gathered with exchange round 1
+-- the replicas of a shard (queue masks / lines, queue bytes): the two tables all-gathered with exchange round 1
 foreign import ccall unsafe "swimsim_shard_gather_buffers" c_shard_gather_buffers :: Ptr SwimsimT -> Ptr (Ptr ()) -> Ptr (Ptr ()) -> Ptr Word32 -> IO CInt
 foreign import ccall safe   "swimsim_shard_phase1"  c_shard_phase1  :: Ptr SwimsimT -> Ptr Word32 -> IO CInt
 foreign import ccall safe   "swimsim_shard_phase2"  c_shard_phase2  :: Ptr SwimsimT -> Ptr Word32 -> Ptr Word32 -> IO CInt
@@ -106,7 +106,7 @@ foreign import ccall safe   "swimsim_shard_phase3"  c_shard_phase3  :: Ptr Swims
 type ExchangeFn = Ptr () -> CInt -> Ptr Word32 -> Ptr Word32 -> IO CInt
 foreign import ccall "wrapper" mkExchange :: ExchangeFn -> IO (FunPtr ExchangeFn)
 foreign import ccall safe   "swimsim_shard_step"    c_shard_step    :: Ptr SwimsimT -> Word32 -> FunPtr ExchangeFn -> Ptr () -> IO CInt
--- a whole cluster of BOUNDED handles (simViewCap > 0) owned by this process, the exchange inside the library (include/swimsim.h)
+-- a whole cluster of handles (dense or bounded) owned by this process, the exchange inside the library (include/swimsim.h)
 foreign import ccall safe   "swimsim_cluster_step"  c_cluster_step  :: Ptr (Ptr SwimsimT) -> Word32 -> Word32 -> IO CInt
 
 defaultSimConfig :: Config -> SimConfig
@@ -332,9 +332,10 @@ decodeEnvelope bytes = BSU.unsafeUseAsCStringLen bytes $ \(src, len) ->
 -- 3 * nShards counts that arrived.  With settling on (gcTicks) every tick ends with a round 3 over the buffers of
 -- swimsim_shard_settle_buffers, and with joinPull a tick in which members come up starts with a round 0 over the
 -- buffers of swimsim_shard_join_buffers: the counts of those rounds sit at indices [0 .. nShards).  Every shard of
--- the cluster must make the same call.  With SWIMSIM_SHARD_REPLICATED_MASKS=1 in the environment round 1 also
--- all-gathers every shard's slice of the two tables of swimsim_shard_gather_buffers (counts of the 8-byte kind at
--- [nShards .. 2 nShards), of the 1-byte kind at [2 nShards .. 3 nShards)).
+-- the cluster must make the same call.  Round 1 is an all-gather: kind 0 (ONE segment for every peer: the tick's ring
+-- dictionary and the queues that travel as lists; counts at [0 .. nShards)) and every shard's slice of the two tables of
+-- swimsim_shard_gather_buffers (counts of the 8-byte kind at [nShards .. 2 nShards), of the 1-byte kind at
+-- [2 nShards .. 3 nShards)); round 2 delivers the 8-byte records {dst, src} of kind 1 (counts at [nShards .. 2 nShards)).
 -- The handle must have been configured as a shard (simShardIndex / simNShards).  A Haskell exception in `exchange` does
 -- not cross the C frames: the callback reports failure (1), the library returns SWIMSIM_ERR_STATE and the exception is
 -- re-thrown here; the FunPtr is freed on every path.
@@ -351,9 +352,11 @@ stepShard s nticks nShards exchange = withSim s $ \h -> do
   rc <- bracket (mkExchange body) freeHaskellFunPtr $ \cb -> c_shard_step h nticks cb nullPtr
   readIORef failure >>= maybe (check h rc) throwIO
 
--- | All shards of a cluster of bounded handles (simViewCap > 0) in ONE process -- one GPU, or the GPUs of a node with peer access --
--- stepped together: the two exchange rounds of a tick run as copies on the handles' own streams, nothing comes back to the host
--- between the phases (`swimsim_cluster_step`; DESIGN.md section 7b).  `sims` = shard 0, 1, ... of the cluster, in that order.
+-- | All shards of a cluster in ONE process -- one GPU, or the GPUs of a node with peer access -- stepped together: the two
+-- exchange rounds of a tick run on the handles' own streams (dense handles: the kernels read the peers' buffers in place;
+-- bounded handles, simViewCap > 0: peer copies), nothing comes back to the host between the phases (`swimsim_cluster_step`;
+-- DESIGN.md sections 7, 7b).  `sims` = shard 0, 1, ... of the cluster, in that order.  This is the host shape of the north
+-- star: one Haskell process, eight GPUs, no exchange of its own to bring.
 stepCluster :: [Sim] -> Word32 -> IO ()
 stepCluster sims nticks = go sims []
   where

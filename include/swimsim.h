@@ -413,20 +413,24 @@ int swimsim_inject_rumor(swimsim_t* h, uint32_t observer, uint32_t subject, uint
 /* ---- sharded clusters (one handle per GPU / process) -------------------------------
  * The population is split into n_shards contiguous id ranges.  Every shard gets the SAME
  * configuration (n_members = whole population) and the SAME fault schedule; ground truth and
- * probe outcomes need no communication, only piggyback payloads cross shards.  One tick is
- *   phase1  -> round 1: the caller delivers send[0][p][0 .. counts[p]) to shard p's recv[0][me][..]
- *   phase2  -> round 2: likewise for send[1] (mask payloads) and send[2] (explicit payloads)
+ * probe outcomes need no communication, only piggyback payloads cross shards.  View rows and rumour ids
+ * are per-shard numberings; what crosses shards is named by (subject, incarnation<<2|state).  Every shard
+ * holds a REPLICA of what a delivery "dst merges src's queue" reads about src: its start-of-tick queue mask
+ * (over its owner's ring of the tick) and a queue byte.  One tick (round 5) is
+ *   phase1  -> round 1, an ALL-GATHER: the caller delivers to every peer p this shard's
+ *                kind 0  send[0][0 .. counts[p]) -- ONE segment, the same for every peer --: 16-byte records, the tick's ring
+ *                        dictionary (64 x {subject, incarnation<<2|state}, one per mask position = 32 records), then the
+ *                        queues that travel as lists this tick (5 records each: {member, n, tick, -} + 8 x {subject, key}:
+ *                        a queue with an entry outside the mask window, every queue in a tick after a burst of rumour ids)
+ *                kinds 5 / 6  its slice of the queue masks (8 bytes per member) and queue bytes (1 byte)
+ *                        (swimsim_shard_gather_buffers), into peer p's recv[..][me]
+ *   phase2  -> round 2, an all-to-all-v: send[1][p][0 .. counts[n_shards + p]) -- 8-byte records {dst, src} "member dst (of
+ *                shard p) merges the start-of-tick queue of member src" -- to shard p's recv[1][me][..]
  *   phase3
- * on every shard in lock step (swim_amd/shard.py does the exchange with torch.distributed:
- * RCCL over xGMI on GPUs).  Buffers are [n_shards][cap] records owned by the library, three kinds:
- *   0  16 bytes  this tick's id dictionary (64 x {subject, incarnation<<2|state}, one per mask
- *                position = 32 records), then round-1 records {dst | tag<<27, src | flags<<27, mask}:
- *                pull requests (tag 0, to the owner of src) and fused direct probes of remote targets
- *                (tag = probe index + 1, to the owner of dst: the Ping's payload as a mask and the
- *                request for the Ack's payload in one record)
- *   1  16 bytes  {dst | tag<<27, -, 64-bit mask over the SENDER's dictionary}: a queue as it travels
- *                normally (tag: the answer to the receiver's own probe `tag-1`, stored without an atomic)
- *   2  72 bytes  {dst, n, n x {subject, incarnation<<2|state}}: the exact fallback
+ * on every shard in lock step (swim_amd/shard.py does the exchange with torch.distributed: RCCL over xGMI on
+ * GPUs).  Nothing is requested and nothing is answered: the probe outcomes, the Acks' payloads (read from the replica
+ * through the owner's dictionary) and every filter are local.  Buffers are owned by the library; kind 2 (72-byte explicit
+ * payloads before round 5) no longer exists: shard_info reports x_cap = 0, shard_buffers NULL.
  * counts[] arrays hold n_shards entries per kind (kind-major, 3 * n_shards).  swimsim_step is refused
  * on sharded handles; digest / counters / events return this shard's part (the parts add up /
  * concatenate); view and member reads are answered by the owner only; first-detection ticks must be
@@ -442,8 +446,9 @@ int swimsim_inject_rumor(swimsim_t* h, uint32_t observer, uint32_t subject, uint
  * swimsim_shard_step drives it like a dense cluster with replicated masks: xchg(ctx, 1, ..) gathers (kind-5 counts at
  * [n_shards + p], kind-6 at [2 n_shards + p], n_local each), xchg(ctx, 2, ..) delivers the kind-1 records. */
 #define SWIMSIM_RREC_BYTES 16u
-#define SWIMSIM_PREC_BYTES 16u
-#define SWIMSIM_XREC_BYTES 72u
+#define SWIMSIM_PREC_BYTES 8u            /* dense handles; bounded handles: */
+#define SWIMSIM_PREC_BOUNDED_BYTES 16u
+#define SWIMSIM_XREC_BYTES 72u           /* (unused since round 5) */
 int swimsim_shard_info(const swimsim_t* h, uint32_t* lo, uint32_t* n_local, uint32_t* r_cap,
                        uint32_t* p_cap, uint32_t* x_cap);
 int swimsim_shard_buffers(swimsim_t* h, void** send /*[3]*/, void** recv /*[3]*/);
@@ -452,18 +457,23 @@ int swimsim_shard_phase2(swimsim_t* h, const uint32_t* r_counts_in /*[n_shards]*
                          uint32_t* counts /*[3*n_shards] out: kinds 1 and 2 now final*/);
 int swimsim_shard_phase3(swimsim_t* h, const uint32_t* p_counts_in, const uint32_t* x_counts_in);
 /* The same tick driven by the library: `nticks` times phase1 -> xchg(round 1) -> phase2 -> xchg(round 2) ->
- * phase3.  `xchg` is the embedder's all-to-all-v: for every peer p != me and every kind k of the round
- * (round 1: kind 0; round 2: kinds 1 and 2) it delivers send[k][p][0 .. counts_out[k*n_shards + p]) records to
- * peer p's recv[k][me][..] and writes into counts_in[k*n_shards + p] how many records arrived from p (buffers:
- * swimsim_shard_buffers; record sizes: SWIMSIM_*REC_BYTES).  It returns 0, or a non-zero value that aborts the
+ * phase3.  `xchg` is the embedder's exchange: for every peer p != me and every kind k of the round
+ * (round 1: kind 0 at [p] + the gathered kinds 5 / 6 at [n_shards + p], [2 n_shards + p]; round 2: kind 1) it delivers
+ * counts_out[..] records to peer p's recv[k][me][..] and writes into counts_in[..] how many records arrived from p (buffers:
+ * swimsim_shard_buffers / swimsim_shard_gather_buffers; record sizes: SWIMSIM_*REC_BYTES; kind 0 and the gathered kinds send
+ * ONE segment to every peer).  It returns 0, or a non-zero value that aborts the
  * step with SWIMSIM_ERR_STATE.  Every shard of the cluster must make the same call; this is what a host
  * without swim_amd/shard.py binds (haskell/Swim/Sim.hs: stepShard) -- MPI_Alltoallv, RCCL send/recv or, as
  * swim_amd/shard.py does, torch.distributed. */
-/* A cluster of BOUNDED handles (view_cap) that live in one process -- one per GPU, or several on one GPU: `nticks` periods with the
- * tick loop AND the exchange inside the library.  The all-gather and the all-to-all-v of DESIGN.md 7b are device-to-device (peer)
- * copies enqueued on the handles' streams and ordered by events; the receiving kernels read the record counts from device
- * memory: no host synchronisation between the first tick and the last.  hs[k] = shard k of n handles of one configuration with
- * one fault schedule.  (Multi-process clusters use swimsim_shard_step with the embedder's exchange.) */
+/* A cluster whose handles live in ONE process -- one per GPU, or several on one GPU: `nticks` periods with the tick loop AND the
+ * exchange inside the library, no host synchronisation between the first tick and the last.  hs[k] = shard k of n handles of ONE
+ * configuration (checked field by field) with one fault schedule.  Dense handles (round 5): the kernels read the peers' send
+ * buffers WHERE THEY LIE (same device, or a peer device over xGMI: hipDeviceEnablePeerAccess, refused with SWIMSIM_ERR_DEVICE
+ * where the devices cannot) with the counts from the peers' own words, ordered by events on the handles' streams; only the
+ * replica slices are copied.  Settling (round 3) included; handles with join_pull / pull_ticks or with messages from outside
+ * pending are refused (SWIMSIM_ERR_INVALID: their exchange round 0 -- step them by the phase calls).  Bounded handles
+ * (view_cap): the all-gather and the all-to-all-v of DESIGN.md 7b as device-to-device (peer) copies.
+ * (Multi-process clusters use swimsim_shard_step with the embedder's exchange.) */
 int swimsim_cluster_step(swimsim_t** hs, uint32_t n, uint32_t nticks);
 typedef int (*swimsim_exchange_fn)(void* ctx, int round, const uint32_t* counts_out /*[3*n_shards]*/,
                                    uint32_t* counts_in /*[3*n_shards]*/);
@@ -489,17 +499,19 @@ int swimsim_shard_settle_commit(swimsim_t* h, const uint32_t* counts_in /*[n_sha
 int swimsim_shard_phase0(swimsim_t* h, uint32_t* counts /*[n_shards] out*/, int* round_needed);
 int swimsim_shard_join_buffers(swimsim_t* h, void** send, void** recv, uint32_t* cap /* records per peer segment */);
 int swimsim_shard_join_ingest(swimsim_t* h, const uint32_t* counts_in /*[n_shards]*/);
-/* Replicated queue masks (environment SWIMSIM_SHARD_REPLICATED_MASKS=1 at create; off by default): after phase1 every
- * shard's slice of two tables -- 8 bytes (kind 5) and 1 byte (kind 6) per member, n_local records each -- is
- * all-gathered: send[k] is this shard's slice (the SAME bytes go to every peer), recv[k] the whole table, peer p's
- * slice at recv[k] + p * n_local * record size.  The direct probes between shards then need no records (DESIGN.md
- * section 7).  It travels WITH round 1: in that mode swimsim_shard_step's xchg(ctx, 1, ..) finds the kind-5 counts at
- * [n_shards + p] and the kind-6 counts at [2 n_shards + p] (n_local for every peer) next to the kind-0 counts at [p].
- * n_local = 0: the mode is off, there is nothing to gather. */
+/* The replicas of a dense shard (and of a bounded one: queue lines instead of masks): after phase1 every shard's slice of two
+ * tables -- 8 bytes (kind 5) and 1 byte (kind 6) per member, n_local records each -- is all-gathered: send[k] is this shard's
+ * slice (the SAME bytes go to every peer), recv[k] the whole table, peer p's slice at recv[k] + p * n_local * record size.  It
+ * travels WITH round 1: swimsim_shard_step's xchg(ctx, 1, ..) finds the kind-5 counts at [n_shards + p] and the kind-6 counts at
+ * [2 n_shards + p] (n_local for every peer) next to the kind-0 counts at [p]. */
 #define SWIMSIM_GREC5_BYTES 8u          /* dense handles; bounded handles gather 64-byte queue lines: */
 #define SWIMSIM_GREC5_BOUNDED_BYTES 64u
 #define SWIMSIM_GREC6_BYTES 1u
 int swimsim_shard_gather_buffers(swimsim_t* h, void** send /*[2]*/, void** recv /*[2]*/, uint32_t* n_local);
+/* What this shard put on the wire in the LAST tick it stepped (for the bench's xGMI figure): out[0] = bytes of round 1 it publishes
+ * to EACH peer (replica slices + dictionary + lists), out[1] = bytes of round-2 records it sent to all peers together, out[2] =
+ * round-2 records it kept (deliveries its own ingest completes), out[3] = queues that travelled as lists. */
+int swimsim_shard_traffic(swimsim_t* h, uint64_t out[4]);
 int swimsim_shard_get_first_suspect(swimsim_t* h, uint32_t* out, size_t n);
 int swimsim_shard_set_first_suspect(swimsim_t* h, const uint32_t* combined, size_t n);
 

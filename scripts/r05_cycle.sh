@@ -14,4 +14,9 @@ b)  # the new dense exchange: sharded GPU tests, one popul
   KERNELS=1 timeout 900 python scripts/shard_time.py 1 2 4 8 2>&1 | grep -v amdgpu.ids | tee $O/r05b_shard_overhead_one_gpu.txt
   timeout 1200 python scripts/config4_one_gpu.py 2>&1 | grep -v amdgpu.ids | tee $O/r05b_config4_one_gpu.txt
   ;;
+c)  # dense shards after the begin_kernel fix: overhead by handle count, where a sharded tick goes (kernel trace), bench.py --gpus 2 in one process
+  KERNELS=1 timeout 900 python scripts/shard_time.py 1 2 4 8 2>&1 | grep -v amdgpu.ids | tee $O/r05c_shard_overhead_one_gpu.txt
+  (cd /tmp && export TMPDIR=/tmp && for G in 2 8; do FORMS=cluster WARM=100 TICKS=30 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c$G -o t -- python $R/scripts/shard_time.py $G > /dev/null 2>&1; echo "# $G handles of one 1 048 576-member population, swimsim_cluster_step (130 ticks; Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs):"; cut -d, -f1-7 $(find /tmp/prof_c$G -name "*kernel_stats.csv" | head -1) | head -14; done) 2>&1 | tee $O/r05c_rocprof_sharded_kernels.txt
+  SWIM_BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 2 --steps 20 --warmup 5 --members 524288 2>&1 | grep -v amdgpu.ids | tee $O/r05c_bench_gpus2_one_process_shared_gpu.json
+  ;;
 esac

@@ -2,7 +2,7 @@
 exchange: `cluster` = swimsim_cluster_step (the exchange inside the library: the peers' buffers read in place,
 ordered by events on the handles' streams, no host in the loop), `phases` = swimsim_shard_phase1/2/3 + LocalFabric's copies (what a
 one-process-per-GPU embedder drives).  One GPU runs the handles' kernels one after the other (or overlapped where they fit): the
-figure is what sharding COSTS in kernel work, not how it scales.  usage: shard_time.py [G ...]   env: MEMBERS WARM TICKS KERNELS=1"""
+figure is what sharding COSTS in kernel work, not how it scales.  usage: shard_time.py [G ...]   env: MEMBERS WARM TICKS KERNELS=1 FORMS=cluster,phases"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +11,7 @@ from swim_amd.shard import LocalFabric, ShardedSim
 abi = _lib.load()
 N = int(os.environ.get("MEMBERS", 1 << 20)); WARM = int(os.environ.get("WARM", 150)); TICKS = int(os.environ.get("TICKS", 50))
 base = None
-for G, form in [(g, f) for g in ([int(x) for x in sys.argv[1:]] or [1, 2, 4, 8]) for f in (("cluster", "phases") if g > 1 else ("one handle",))]:
+for G, form in [(g, f) for g in ([int(x) for x in sys.argv[1:]] or [1, 2, 4, 8]) for f in (tuple(os.environ.get("FORMS", "cluster,phases").split(",")) if g > 1 else ("one handle",))]:
     os.environ["SWIMSIM_CLUSTER_STEP"] = "0" if form == "phases" else "1"
     sc, crashes, _ = workloads.saturated(N, WARM + TICKS)
     s = Sim.create(abi, sc) if G == 1 else ShardedSim(abi, sc, LocalFabric(G), device="cuda:0")

@@ -114,6 +114,7 @@ _PRODUCT_ONLY = {
     "shard_gather_buffers": (C.c_int, [_H, _VPP, _VPP, _U32P]),
     "shard_join_buffers": (C.c_int, [_H, _VPP, _VPP, _U32P]),
     "shard_join_ingest": (C.c_int, [_H, _U32P]),
+    "shard_traffic": (C.c_int, [_H, C.POINTER(C.c_uint64)]),
     "shard_get_first_suspect": (C.c_int, [_H, _U32P, C.c_size_t]),
     "shard_set_first_suspect": (C.c_int, [_H, _U32P, C.c_size_t]),
     "table_stats": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_size_t]),

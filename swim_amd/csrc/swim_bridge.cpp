@@ -54,10 +54,12 @@ bool same_addr(const sockaddr_in& a, const sockaddr_in& b) { return a.sin_addr.s
 
 void name_of(uint32_t id, char* out) { std::snprintf(out, SWIMWIRE_NAME_MAX + 1, "m%u", id); }
 
-// `peer_chosen`: the destination address came out of a datagram (an IndirectPing's target) or is a remote peer's: a send
-// that fails because of the ADDRESS (0.0.0.0:0, a broadcast address, an unreachable net) is the input's fault -- counted
-// and dropped, never a failure of the poll (one garbled datagram must not take the bridge down: the reference's receiver
-// dies on bad input, D16; this one does not)
+// The destination address came out of a datagram (an IndirectPing's target) or is a remote peer's: a send that fails because
+// of the ADDRESS (0.0.0.0:0, a broadcast address, an unreachable net) or of a transient local condition (a full socket buffer,
+// an interrupted call) is counted and DROPPED -- SEND_DROPPED, so that the caller does not book a datagram that never left --,
+// never a failure of the poll (one garbled datagram must not take the bridge down: the reference's receiver dies on bad
+// input, D16; this one does not).  Only a broken local socket / host is an error.
+constexpr int SEND_DROPPED = 1;
 int send_env(swimbridge* b, const std::vector<swimwire_msg_t>& msgs, const sockaddr_in& to) {
   size_t n = 0;
   b->tx.resize(SWIMWIRE_MAX_DATAGRAM);
@@ -67,8 +69,8 @@ int send_env(swimbridge* b, const std::vector<swimwire_msg_t>& msgs, const socka
     const int e = errno;
     if (e == EBADF || e == ENOTSOCK || e == EFAULT || e == ENOMEM || e == ENOBUFS)      // the local socket / host
       return berr(b, SWIMSIM_ERR_DEVICE, std::string("sendto: ") + std::strerror(e));
-    b->st.sends_failed++;                                                               // EINVAL, EACCES, ENETUNREACH, EHOSTUNREACH, ...
-    return SWIMSIM_OK;
+    b->st.sends_failed++;                                   // EINVAL, EACCES, ENETUNREACH, EHOSTUNREACH, EAGAIN, EINTR, EMSGSIZE, ...
+    return SEND_DROPPED;
   }
   b->st.datagrams_out++;
   return SWIMSIM_OK;
@@ -95,7 +97,8 @@ int answer_ping(swimbridge* b, uint32_t id, uint32_t seq, const sockaddr_in& to)
     if (r.state == SWIMSIM_ALIVE) m.addr = r.subject;               // Alive.addr = the member id
     b->out.push_back(m);
   }
-  return send_env(b, b->out, to);
+  const int rcs = send_env(b, b->out, to);
+  return rcs == SEND_DROPPED ? SWIMSIM_OK : rcs;
 }
 
 int handle(swimbridge* b, const sockaddr_in& from, size_t len) {
@@ -124,7 +127,7 @@ int handle(swimbridge* b, const sockaddr_in& from, size_t len) {
           swimsim_member_t mem{};
           const int rc = swimsim_read_member(b->sim, id, &mem);
           if (rc) return berr(b, rc, std::string("read_member: ") + swimsim_last_error(b->sim));
-          if (mem.up) { b->out.assign(1, ack_of(m.seq_no)); const int rc2 = send_env(b, b->out, from); if (rc2) return rc2; b->st.relayed_acks++; }
+          if (mem.up) { b->out.assign(1, ack_of(m.seq_no)); const int rc2 = send_env(b, b->out, from); if (rc2 < 0) return rc2; if (rc2 == SWIMSIM_OK) b->st.relayed_acks++; }
         } else {
           // target = the HostAddress the reference takes out of a SockAddrInet (src/Core.hs:264-266): already in network
           // byte order as a word (include/swimwire.h) -- reinterpreted, not converted; the port is a PortNumber's value
@@ -132,7 +135,8 @@ int handle(swimbridge* b, const sockaddr_in& from, size_t len) {
           swimwire_msg_t p{}; p.type = SWIMWIRE_PING; p.seq_no = m.seq_no; std::memcpy(p.node, m.node, sizeof p.node);
           b->out.assign(1, p);
           const int rc = send_env(b, b->out, via);
-          if (rc) return rc;
+          if (rc < 0) return rc;
+          if (rc == SEND_DROPPED) break;                                           // nothing went out: nothing to wait for
           if (b->pending.size() >= 4096) b->pending.erase(b->pending.begin());     // the oldest request has timed out long ago
           b->pending.push_back(swimbridge::Pending{m.seq_no, via, from});
         }
@@ -145,8 +149,9 @@ int handle(swimbridge* b, const sockaddr_in& from, size_t len) {
             const sockaddr_in to = b->pending[x].requester;
             b->pending.erase(b->pending.begin() + (long)x);
             const int rc = send_env(b, b->out, to);
-            if (rc) return rc;
-            b->st.relayed_acks++; relayed = true;
+            if (rc < 0) return rc;
+            if (rc == SWIMSIM_OK) b->st.relayed_acks++;
+            relayed = true;
             break;
           }
         if (!relayed) b->st.acks_in++;

@@ -2156,12 +2156,14 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
     __syncthreads();
     if (threadIdx.x == 0) { s.g[G_SETTLE_N] = nset; s.g[G_SETTLE_TICK] = t; s.g[G_SETTLE_PENDING] = 1; }
   }
-  if (s.n_shards > 1 && threadIdx.x == 0) {
+  if (s.n_shards > 1) {
     const uint32_t H = s.g[G_NRUM];
-    for (int k = 0; k < 3 * MAX_SHARDS; ++k) s.send_cnt[k] = 0;
-    s.g[G_FLDYN] = 0; s.g[G_XLINES] = 0;
-    // this tick's dictionary for the peers: ring position -> {subject, key} of the id that owns it
-    for (uint32_t p = 0; p < DICT_ENTRIES; ++p) {
+    if (threadIdx.x < 3u * MAX_SHARDS) s.send_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { s.g[G_FLDYN] = 0; s.g[G_XLINES] = 0; }
+    // this tick's dictionary for the peers: ring position -> {subject, key} of the id that owns it (one thread per position:
+    // a single thread walking the 64 positions made three dependent loads each -- ~100 us of every sharded tick)
+    if (threadIdx.x < DICT_ENTRIES) {
+      const uint32_t p = threadIdx.x;
       const uint32_t rid = rid_at(p, H);
       uint2 e = make_uint2(NONE32, 0u);
       if (rid < H) {                                   // else: no such id yet

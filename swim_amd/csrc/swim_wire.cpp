@@ -272,9 +272,11 @@ int swimwire_decode_any(const uint8_t* buf, size_t len, swimwire_msg_t* out, siz
   if (!n_out || (!buf && len)) return SWIMSIM_ERR_INVALID;
   if (len && ((buf[0] & 0xf0) == 0x80 || buf[0] == 0xde || buf[0] == 0xdf)) {
     if (was_bare) *was_bare = 1;
-    *n_out = 1;
-    if (cap < 1 || !out) return SWIMSIM_ERR_BUFFER;
-    return get_body(buf, len, &out[0]);
+    *n_out = 0;
+    if (cap < 1 || !out) { *n_out = 1; return SWIMSIM_ERR_BUFFER; }          // (room for one message is what it needs)
+    const int rc = get_body(buf, len, &out[0]);
+    if (rc == SWIMSIM_OK) *n_out = 1;
+    return rc;
   }
   return swimwire_decode(buf, len, out, cap, n_out);
 }

@@ -162,10 +162,11 @@ int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, std::string*
   if (c->target_scheme > SWIMSIM_TARGETS_ROBUST) { *err = "unknown target_scheme"; return SWIMSIM_ERR_INVALID; }
   if (c->join_pull > 1) { *err = "join_pull must be 0 or 1"; return SWIMSIM_ERR_INVALID; }
   if (c->pull_ticks == 1) { *err = "pull_ticks must be 0 (off) or >= 2"; return SWIMSIM_ERR_INVALID; }
-  if (c->push_pull && c->n_shards > 1) { *err = "push_pull (the push half of the periodic state exchange) is not available on sharded handles"; return SWIMSIM_ERR_INVALID; }
-  if (c->n_shards > 1 && c->n_members > (1u << 27)) { *err = "sharded clusters: n_members must be <= 2^27"; return SWIMSIM_ERR_INVALID; }
+  // (ranges first, combinations after: a value out of range gets the message that says so)
   if (c->push_pull > 1 || (c->push_pull && !c->pull_ticks)) { *err = "push_pull must be 0 or 1 and needs pull_ticks"; return SWIMSIM_ERR_INVALID; }
   if (c->strict_reference_rules > 1) { *err = "strict_reference_rules must be 0 or 1"; return SWIMSIM_ERR_INVALID; }
+  if (c->push_pull && c->n_shards > 1) { *err = "push_pull (the push half of the periodic state exchange) is not available on sharded handles"; return SWIMSIM_ERR_INVALID; }
+  if (c->n_shards > 1 && c->n_members > (1u << 27)) { *err = "sharded clusters: n_members must be <= 2^27"; return SWIMSIM_ERR_INVALID; }
   if (c->strict_reference_rules && (c->view_cap || c->gc_ticks || c->join_pull || c->pull_ticks || c->n_shards > 1)) {
     *err = "strict_reference_rules cannot be combined with view_cap, gc_ticks, join_pull, pull_ticks or sharding"; return SWIMSIM_ERR_INVALID; }
   if (c->view_cap) {
@@ -606,7 +607,10 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
     // round 2: records per owner -- my members' deliveries spread over the shards; a degraded cluster under heavy loss sends
     // everything to the few members it still holds Alive (they may all sit on one shard): up to 65 536 members the hard bound
     const double per_peer = (double)N * per_member / d.n_shards;
-    d.p_cap = (uint32_t)std::min<double>(4.0e8, std::max(per_peer * 2.0 + 8.0 * std::sqrt(per_peer) + 4096.0,
+    // ... and the segment a shard keeps for ITSELF takes every Ack of a remote target in a tick in which its masks are off (a
+    // burst of rumour ids: a few ticks per hundred in the saturated regime): P per member, plus the chains' hops
+    d.p_cap = (uint32_t)std::min<double>(4.0e8, std::max(std::max(per_peer * 2.0 + 8.0 * std::sqrt(per_peer) + 4096.0,
+                                                                     (double)N * std::max(1u, d.P) * (1.0 + 4.0 * std::max(1u, d.K) * pfail) * 1.25 + 4096.0),
                                                             N <= 65536u ? (double)N * std::max(1u, d.P) * (2.0 + 4.0 * std::max(1u, d.K)) : 0.0));
     d.x_cap = 0;
     // round 1: the queues that travel as lists -- in a tick without masks every member's
@@ -748,6 +752,8 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
   static const bool want_graph = [] { const char* e = std::getenv("SWIMSIM_GRAPH"); return e && e[0] == '1'; }();
   const bool graph = want_graph && !h->timing && h->injections.empty() && nticks > 0;
   if (graph) HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+  // (an early return between here and hipStreamEndCapture must not leave the stream capturing: every later call would fail)
+  struct CaptureGuard { swimsim* h; bool on; ~CaptureGuard() { if (on) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(h->stream, &g); if (g) (void)hipGraphDestroy(g); } } } capture{h, graph};
   for (uint32_t k = 0; k < nticks; ++k) {
     const uint32_t t = (uint32_t)h->tick;
     hipEvent_t* ev = h->timing ? &h->ev_pool[(size_t)k * 3] : nullptr;
@@ -779,7 +785,7 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
     // A PLAIN tick -- no scheduled change, no message from outside, no state pull, no settling, no explicit-record kernel -- needs
     // nothing of begin_kernel but the window heads, the tick's ring and three resets: probe_kernel's workgroup 0 does that on the
     // side (`fold`), the launch and its kernel boundary are saved (SWIMSIM_FOLD_BEGIN=0 at create: always launch it; A/B, tests)
-    const uint32_t fold = (h->fold_begin && part == 3u && fpos == f0 && !(nup + npp) && !h->d.G && !records_kernel_every_tick(h)) ? 1u : 0u;
+    const uint32_t fold = (h->fold_begin && part == 3u && fpos == f0 && !(nup + npp) && !h->d.G && !h->d.strict && !records_kernel_every_tick(h)) ? 1u : 0u;   // (strict rules: begin_kernel declares the ids untrusted in every tick)
     if (!fold)
       hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, (uint32_t)(fpos - f0),
                          h->d_joined, part, PeerCounts{});
@@ -791,6 +797,7 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
   if (h->d.G && nticks) hipLaunchKernelGGL(settle_flush_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d);
   if (graph) {
     hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+    capture.on = false;
     HIPCHK(h, hipStreamEndCapture(h->stream, &g));
     HIPCHK(h, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
     const auto w0 = std::chrono::steady_clock::now();
@@ -1657,6 +1664,25 @@ int swimsim_shard_step(swimsim_t* h, uint32_t nticks, swimsim_exchange_fn xchg, 
       rc = swimsim_shard_settle_commit(h, in.data());
       if (rc) return rc;
     }
+  }
+  return SWIMSIM_OK;
+}
+
+int swimsim_shard_traffic(swimsim_t* h, uint64_t out[4]) {
+  if (!h || !out || h->d.n_shards < 2) return SWIMSIM_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  uint32_t g[G_WORDS];
+  HIPCHK(h, hipMemcpy(g, h->d.g, sizeof g, hipMemcpyDeviceToHost));
+  const uint32_t G = h->d.n_shards;
+  uint64_t recs = 0;
+  for (uint32_t p = 0; p < G; ++p) if (p != h->d.shard) recs += std::min(g[G_SEND + MAX_SHARDS + p], h->d.p_cap);
+  if (h->d.C) {
+    out[0] = (uint64_t)h->d.N * (PB_SLOTS * sizeof(uint2) + 1u);
+    out[1] = recs * sizeof(uint4); out[2] = 0; out[3] = 0;
+  } else {
+    out[0] = (uint64_t)h->d.N * 9u + DICT_RECS * sizeof(uint4) + (uint64_t)g[G_XLINES] * XLINE_RECS * sizeof(uint4);
+    out[1] = recs * sizeof(uint2); out[2] = std::min(g[G_SEND + MAX_SHARDS + h->d.shard], h->d.p_cap); out[3] = g[G_XLINES];
   }
   return SWIMSIM_OK;
 }

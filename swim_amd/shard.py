@@ -296,11 +296,19 @@ class DistFabric:
 class ShardedSim:
     """The whole population behind one object, whatever the number of shards / processes."""
 
-    def __init__(self, abi, sim_config: SimConfig, fabric, device="cpu"):
+    def __init__(self, abi, sim_config: SimConfig, fabric, device="cpu", devices=None):
+        """devices: one HIP device ordinal per LOCAL shard (a one-process cluster over the GPUs of a node: shard k on GPU
+        devices[k], stepped by swimsim_cluster_step); default: every shard on sim_config.device, buffers wrapped for `device`."""
+        import copy
         self.fabric = fabric
         self.n_shards = fabric.n_shards
         self.simConfig = sim_config
-        self.shards = [_Shard(abi, sim_config, k, self.n_shards, device) for k in fabric.local]
+        self.shards = []
+        for j, k in enumerate(fabric.local):
+            sc_k, dev_k = sim_config, device
+            if devices is not None:
+                sc_k = copy.copy(sim_config); sc_k.device = devices[j]; dev_k = "cuda:%d" % devices[j]
+            self.shards.append(_Shard(abi, sc_k, k, self.n_shards, dev_k))
         self.nMembers = sim_config.nMembers
         self.n_local = self.shards[0].n_local
         self.resolved = self.shards[0].sim.resolved
@@ -495,3 +503,13 @@ class ShardedSim:
 
     def kernelTiming(self):
         return self.shards[0].sim.kernelTiming()
+
+    def traffic(self):
+        """What each local shard put on the wire in the last tick (swimsim_shard_traffic): a list of dicts."""
+        out = []
+        for s in self.shards:
+            v = (C.c_uint64 * 4)()
+            s.sim._check(s.sim._abi.shard_traffic(s.sim._h, v))
+            out.append({"round1_bytes_to_each_peer": int(v[0]), "round2_bytes_to_all_peers": int(v[1]), "round2_records_kept": int(v[2]),
+                        "queues_as_lists": int(v[3])})
+        return out
