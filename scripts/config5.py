@@ -11,7 +11,9 @@ count -- next to ms/tick.  One JSON line per case.
 usage (GPU box): config5.py [members ...]      default: 16384 32768  (a dense view stops there: 65 536 members at 30 % loss
 need more view rows than a handle has).  CAP=<C>: bounded member maps (view_cap = C; include/swimsim.h) -- what runs config 5 at
 its per-GPU size: `CAP=64 config5.py 2097152`.   ORACLE=1: the same run on the CPU oracle (all host threads), numbers
-compared;  LOSS=<ppm>, TICKS=<n>, T0=<tick>, ROWS=<max subjects>, CHURN=<per-mille list> override the defaults."""
+compared;  LOSS=<ppm>, TICKS=<n>, T0=<tick>, ROWS=<max subjects>, CHURN=<per-mille list>, S=<suspicion ticks> override the defaults.
+(S: with bounded maps an entry lives ~C / (changes per member-tick) ticks; a suspicion timeout beyond that never fires -- DESIGN.md
+section 6 -- so the capacity sweep is run with timeouts on both sides of the entries' lifetime.)"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from swim_amd import Config, Sim, SimConfig, _abi, _lib, workloads
@@ -25,7 +27,7 @@ NTRACK = 8
 def run(abi, n, per_mille, threads=0):
     cap = int(os.environ.get("CAP", 0))
     sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=1, lossPpm=LOSS, maxSubjects=int(os.environ.get("ROWS", min(n, 60000))), eventMask=0x10 if cap else 0,
-                   gcTicks=_abi.GC_AUTO if (per_mille and not cap) else 0, viewCap=cap)
+                   gcTicks=_abi.GC_AUTO if (per_mille and not cap) else 0, viewCap=cap, suspicionTicks=int(os.environ.get("S", 0)))
     s = Sim.create(abi, sc)
     if threads:                                      # the oracle only (scales to ~32 threads)
         from tests import oracle_binding

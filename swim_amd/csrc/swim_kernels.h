@@ -1732,64 +1732,121 @@ __device__ inline void push_foreign(const DevState& s, uint32_t t, uint32_t dst_
 // travel as lists, become foreign lines.
 __global__ __launch_bounds__(BLOCK) void ingest_kernel(DevState s, uint32_t t, PeerCounts q_counts, PeerView pv) {
   __shared__ uint2 xls[MAX_SHARDS * DICT_ENTRIES];
-  for (uint32_t k = threadIdx.x; k < s.n_shards * DICT_ENTRIES; k += BLOCK) xls[k] = s.xl[k];
+  __shared__ uint32_t pref[MAX_SHARDS + 1];           // the peers' segments as ONE index space (a pass per peer made the kernel
+  for (uint32_t k = threadIdx.x; k < s.n_shards * DICT_ENTRIES; k += BLOCK) xls[k] = s.xl[k];   // wait out its round trips G times)
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (uint32_t peer = 0; peer < s.n_shards; ++peer) {
+      pref[peer] = acc;
+      acc += min(peer == s.shard ? s.send_cnt[MAX_SHARDS + peer] : (pv.direct ? *pv.qn[peer] : q_counts.v[peer]), s.p_cap);
+    }
+    pref[s.n_shards] = acc;
+  }
   __syncthreads();
   const uint32_t Hprev = s.g[G_PREV], H = s.g[G_HEAD];
   const bool use_mask = H - Hprev <= MASK_SLACK;
   const unsigned long long stale = stale_positions(Hprev, H);
-  for (uint32_t peer = 0; peer < s.n_shards; ++peer) {
-    const uint32_t n = min(peer == s.shard ? s.send_cnt[MAX_SHARDS + peer] : (pv.direct ? *pv.qn[peer] : q_counts.v[peer]), s.p_cap);
+  const uint32_t total = pref[s.n_shards];
+  auto record_at = [&](uint32_t k) -> uint2 {
+    uint32_t peer = 0;
+    while (peer + 1u < s.n_shards && k >= pref[peer + 1u]) ++peer;
     const uint2* list = peer == s.shard ? s.q_send + (size_t)peer * s.p_cap : (pv.direct ? pv.q[peer] : s.q_recv + (size_t)peer * s.p_cap);
-    for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < n; k += gridDim.x * BLOCK) {
-      const uint2 o = list[k];
-      const uint32_t dst = o.x, src = o.y;
-      if (!is_local(s, dst) || src >= s.NT) continue;
-      const uint32_t dl = dst - s.lo;
-      if (is_local(s, src)) {                        // a peer's prober walked a chain through two of my members
-        const uint32_t ms = s.minfo[src];
-        if (!mi_pbn(ms)) continue;
-        deliver_local(s, t, use_mask, stale, dl, src - s.lo, ms, use_mask ? s.pk[src - s.lo].x : 0ull);
-        if (!use_mask || (ms & MI_OOW)) s.g[G_ANYREC] = t + 1u;
-        continue;
+    return list[k - pref[peer]];
+  };
+  // the rare forms of a delivery, one record at a time: a local source (a peer's prober walked a chain through two of my
+  // members), a queue that travels as a list, a mask with entries my masks cannot carry
+  auto slow = [&](uint32_t dl, uint32_t src, uint32_t qs) {
+    if (is_local(s, src)) {
+      const uint32_t ms = s.minfo[src];
+      if (!mi_pbn(ms)) return;
+      deliver_local(s, t, use_mask, stale, dl, src - s.lo, ms, use_mask ? s.pk[src - s.lo].x : 0ull);
+      if (!use_mask || (ms & MI_OOW)) s.g[G_ANYREC] = t + 1u;
+      return;
+    }
+    unsigned long long bits = 0;
+    uint32_t ent[2 * PB_SLOTS], nf = 0;
+    if (!(qs & Q_OOW)) {
+      unsigned long long m = s.mask_all[src];
+      const uint2* d = xls + owner_of(s, src) * DICT_ENTRIES;
+      while (m) {
+        const uint32_t q = (uint32_t)__ffsll((unsigned long long)m) - 1u;
+        m &= m - 1ull;
+        const uint2 e = d[q];
+        if (e.x == NONE32) continue;               // cannot happen: the owner set the bit from an entry of its ring
+        if ((e.y >> 24) != 0xFFu) bits |= 1ull << (e.y >> 24);
+        else if (nf < (uint32_t)PB_SLOTS) { ent[2 * nf] = e.x; ent[2 * nf + 1] = pe_hi(pe_key(e.y), 1u); nf++; }
       }
-      const uint32_t qs = s.q_all[src];
-      if (!(qs & Q_PBN)) continue;
-      unsigned long long bits = 0;
-      uint32_t ent[2 * PB_SLOTS], nf = 0;
-      if (!(qs & Q_OOW)) {
-        unsigned long long m = s.mask_all[src];
+    } else {
+      // the queue as a list of (subject, key): where it lies was noted by xlat_kernel; the list carries its member and tick
+      const uint32_t at = s.xidx[src], own = owner_of(s, src);
+      const uint4* seg = pv.direct ? pv.r[own] : s.r_recv + (size_t)own * (DICT_RECS + s.r_cap);
+      const uint4* rec = seg + DICT_RECS + (size_t)at * XLINE_RECS;
+      const uint4 hd = at < s.r_cap / XLINE_RECS ? rec[0] : make_uint4(NONE32, 0u, 0u, 0u);
+      if (hd.x != src || hd.z != t) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG); return; }
+      const uint32_t ne = min(hd.y, (uint32_t)PB_SLOTS);
+      const uint2* pe = reinterpret_cast<const uint2*>(rec + 1);
+      for (uint32_t e = 0; e < ne; ++e) {
+        const uint2 sk = pe[e];
+        const uint32_t slot = get_slot(s, sk.x);
+        uint32_t num = 0;
+        const uint32_t rid0 = find_rid(s, slot, sk.y, &num), rid = young_rid(rid0, num, H);
+        if (use_mask && rid_in_ring(rid, H)) bits |= rid_bit(rid);     // an id of an earlier tick
+        else { ent[2 * nf] = pe_lo(slot, rid); ent[2 * nf + 1] = pe_hi(sk.y, 1u); nf++; }
+      }
+    }
+    if (bits) {
+      const unsigned long long mm = bits & ~(s.pk[dl].y & ~stale);
+      if (mm) atomicOr(&s.inmask[dl], mm);
+    }
+    if (nf) push_foreign(s, t, dl, ent, nf);
+  };
+  // the common form -- a remote source whose queue is a mask my ring can carry in full -- two records per thread and round:
+  // records, then queue bytes, then masks and known-rings, each round of loads issued together
+  constexpr int U = 2;
+  const uint32_t stride = gridDim.x * BLOCK;
+  for (uint32_t k0 = blockIdx.x * BLOCK + threadIdx.x; k0 < total; k0 += stride * U) {
+    uint2 o[U]; uint32_t qs[U]; bool live[U], fast[U];
+    unsigned long long m[U], kn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t k = k0 + (uint32_t)u * stride;
+      live[u] = k < total;
+      o[u] = live[u] ? record_at(k) : make_uint2(NONE32, NONE32);
+      live[u] = live[u] && is_local(s, o[u].x) && o[u].y < s.NT;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      qs[u] = (live[u] && !is_local(s, o[u].y)) ? (uint32_t)s.q_all[o[u].y] : 0u;
+      fast[u] = live[u] && !is_local(s, o[u].y) && (qs[u] & Q_PBN) && !(qs[u] & Q_OOW) && use_mask;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      m[u] = fast[u] ? s.mask_all[o[u].y] : 0ull;
+      kn[u] = fast[u] ? s.pk[o[u].x - s.lo].y : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!live[u]) continue;
+      const uint32_t dl = o[u].x - s.lo, src = o[u].y;
+      if (fast[u]) {
         const uint2* d = xls + owner_of(s, src) * DICT_ENTRIES;
-        while (m) {
-          const uint32_t q = (uint32_t)__ffsll((unsigned long long)m) - 1u;
-          m &= m - 1ull;
+        unsigned long long bits = 0, mm = m[u];
+        bool whole = true;
+        while (mm) {
+          const uint32_t q = (uint32_t)__ffsll((unsigned long long)mm) - 1u;
+          mm &= mm - 1ull;
           const uint2 e = d[q];
-          if (e.x == NONE32) continue;               // cannot happen: the owner set the bit from an entry of its ring
-          if ((e.y >> 24) != 0xFFu) bits |= 1ull << (e.y >> 24);
-          else if (nf < (uint32_t)PB_SLOTS) { ent[2 * nf] = e.x; ent[2 * nf + 1] = pe_hi(pe_key(e.y), 1u); nf++; }
+          if (e.x == NONE32) continue;
+          if ((e.y >> 24) == 0xFFu) { whole = false; break; }
+          bits |= 1ull << (e.y >> 24);
         }
-      } else {
-        // the queue as a list of (subject, key): where it lies was noted by xlat_kernel; the list carries its member and tick
-        const uint32_t at = s.xidx[src], own = owner_of(s, src);
-        const uint4* seg = pv.direct ? pv.r[own] : s.r_recv + (size_t)own * (DICT_RECS + s.r_cap);
-        const uint4* rec = seg + DICT_RECS + (size_t)at * XLINE_RECS;
-        const uint4 hd = at < s.r_cap / XLINE_RECS ? rec[0] : make_uint4(NONE32, 0u, 0u, 0u);
-        if (hd.x != src || hd.z != t) { atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG); continue; }
-        const uint32_t ne = min(hd.y, (uint32_t)PB_SLOTS);
-        const uint2* pe = reinterpret_cast<const uint2*>(rec + 1);
-        for (uint32_t e = 0; e < ne; ++e) {
-          const uint2 sk = pe[e];
-          const uint32_t slot = get_slot(s, sk.x);
-          uint32_t num = 0;
-          const uint32_t rid0 = find_rid(s, slot, sk.y, &num), rid = young_rid(rid0, num, H);
-          if (use_mask && rid_in_ring(rid, H)) bits |= rid_bit(rid);     // an id of an earlier tick
-          else { ent[2 * nf] = pe_lo(slot, rid); ent[2 * nf + 1] = pe_hi(sk.y, 1u); nf++; }
+        if (whole) {
+          const unsigned long long news = bits & ~(kn[u] & ~stale);
+          if (news) atomicOr(&s.inmask[dl], news);
+          continue;
         }
       }
-      if (bits) {
-        const unsigned long long mm = bits & ~(s.pk[dl].y & ~stale);
-        if (mm) atomicOr(&s.inmask[dl], mm);
-      }
-      if (nf) push_foreign(s, t, dl, ent, nf);
+      if (is_local(s, src) || (qs[u] & Q_PBN)) slow(dl, src, qs[u]);
     }
   }
 }
