@@ -25,4 +25,11 @@ d)  # dense shards, ingest flattened: strong (1 M members as G handles) and weak
   (cd /tmp && export TMPDIR=/tmp && for G in 2 8; do FORMS=cluster WARM=100 TICKS=30 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_d$G -o t -- python $R/scripts/shard_time.py $G > /dev/null 2>&1; echo "# $G handles of one 1 048 576-member population, swimsim_cluster_step (130 ticks), rocprofv3 --kernel-trace --stats:"; python $R/scripts/kernel_stats.py /tmp/prof_d$G 10; done) 2>&1 | tee $O/r05d_rocprof_sharded_kernels.txt
   (for cs in "256 8" "256 16" "128 6"; do set -- $cs; echo "# view_cap $1, suspicion timeout $2 ticks, 262 144 members, oracle-checked:"; CAP=$1 S=$2 TICKS=80 T0=30 ORACLE=1 CHURN=0,10 timeout 1200 python scripts/config5.py 262144; done) 2>&1 | grep -v amdgpu.ids | tee $O/r05d_config5_bounded_short_timeouts.txt
   ;;
+e)  # sharded probe with batched replica gathers; grid barrier vs kernel boundary; the whole GPU suite
+  (cd scripts/microbench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o grid_barrier grid_barrier.hip 2>/dev/null && timeout 120 ./grid_barrier 20 50) 2>&1 | tee $O/r05e_microbench_grid_barrier.txt
+  (echo "# strong: 1 048 576 members as G handles"; FORMS=cluster KERNELS=1 timeout 900 python scripts/shard_time.py 1 2 4 8;
+   for G in 2 4; do echo "# weak: $G x 1 048 576 members vs one handle of $((G * 1048576))"; MEMBERS=$((G * 1048576)) FORMS=cluster WARM=100 TICKS=30 timeout 900 python scripts/shard_time.py 1 $G; done) 2>&1 | grep -v amdgpu.ids | tee $O/r05e_shard_overhead_one_gpu.txt
+  (cd /tmp && export TMPDIR=/tmp && for G in 2; do FORMS=cluster WARM=100 TICKS=30 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_e$G -o t -- python $R/scripts/shard_time.py $G > /dev/null 2>&1; echo "# $G handles of one 1 048 576-member population, swimsim_cluster_step (130 ticks), rocprofv3 --kernel-trace --stats:"; python $R/scripts/kernel_stats.py /tmp/prof_e$G 8; done) 2>&1 | tee $O/r05e_rocprof_sharded_kernels.txt
+  timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 | tee $O/r05e_pytest_gpu.log
+  ;;
 esac

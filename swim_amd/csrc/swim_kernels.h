@@ -298,10 +298,10 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
   // the queue of REMOTE member src as a mask over MY ring: its replicated mask through its owner's dictionary.  false: the
   // queue travels as a list this tick, or holds an entry my masks cannot carry (an id younger than my head) -- then the
   // delivery goes to ingest_kernel, which has the machinery (foreign lines, explicit records)
-  auto pull_remote = [&](uint32_t src, uint32_t qsrc, unsigned long long* bits) -> bool {
+  auto pull_remote = [&](uint32_t src, uint32_t qsrc, unsigned long long m, unsigned long long* bits) -> bool {   // m = mask_all[src]
     if (!SH) return false;
     if ((qsrc & Q_OOW) || !use_mask) return false;
-    unsigned long long m = s.mask_all[src], acc = 0;
+    unsigned long long acc = 0;
     const uint8_t* d = xpos + owner_of(s, src) * DICT_ENTRIES;
     while (m) {
       const uint32_t q = (uint32_t)__ffsll((unsigned long long)m) - 1u;
@@ -367,12 +367,16 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
     // pass 2: one 16-byte gather per reached LOCAL target, issued together: its queue mask (the Ack's
     // payload, pulled by the prober itself) and its known-ring (what my Ping's payload can still tell it)
     ulonglong2 tk2[CH];
+    uint32_t qrem[CH];                              // sharded: the replicated queue byte of a remote target whose Ack arrives
 #pragma unroll
     for (int q = 0; q < CH; ++q) {
       const int p = c0 + q;
-      tk2[q] = make_ulonglong2(0ull, 0ull);
+      tk2[q] = make_ulonglong2(0ull, 0ull); qrem[q] = 0u;
       if (use_mask && ping_ok[q] && (!SH || is_local(s, picks[p])) && (mymask || (ack_ok[q] && mi_pbn(pinfo[p]))) && !ABL(ABL_PK_GATHER))
         tk2[q] = s.pk[picks[p] - s.lo];
+      // ... and of a remote target: byte and mask from the replicas, in the same round of loads (one after the other per probe
+      // they were two dependent round trips x P: 30 us of a 90 us launch at 524 288 members, profiles/r05d_*)
+      if (SH && ack_ok[q] && !is_local(s, picks[p])) { qrem[q] = s.q_all[picks[p]]; tk2[q].x = s.mask_all[picks[p]]; }
     }
     SECT(33);                                       // outcomes + the targets' pk gathers issued
     // pass 3: the Pings' piggyback payloads: at most one atomicOr per target
@@ -424,10 +428,10 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
       if (!ack_ok[q]) continue;
       if (SH && !is_local(s, picks[p])) {
         // a remote target's queue comes from the replicas: translated here, or handed to my own ingest
-        const uint32_t qc = s.q_all[picks[p]];
+        const uint32_t qc = qrem[q];
         if (qc & Q_PBN) {
           payloads++; rumors += qc & Q_PBN;
-          if (!pull_remote(picks[p], qc, &ackacc)) emit_order(i, picks[p]);
+          if (!pull_remote(picks[p], qc, tk2[q].x, &ackacc)) emit_order(i, picks[p]);
         }
         continue;
       }
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
       if (!cnt) return;                                             // empty payload
       payloads++; rumors += cnt;
       if (!src_here) {
-        if (dst == pi && pull_remote(src, qsrc, got)) return;       // pulled by the prober itself
+        if (dst == pi && pull_remote(src, qsrc, (qsrc & Q_OOW) ? 0ull : s.mask_all[src], got)) return;       // pulled by the prober itself
         emit_order(dst, src);                                       // dst's owner (maybe this shard) delivers it
         return;
       }
