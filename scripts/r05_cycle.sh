@@ -32,4 +32,24 @@ e)  # sharded probe with batched replica gathers; grid barrier vs kernel boundar
   (cd /tmp && export TMPDIR=/tmp && for G in 2; do FORMS=cluster WARM=100 TICKS=30 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_e$G -o t -- python $R/scripts/shard_time.py $G > /dev/null 2>&1; echo "# $G handles of one 1 048 576-member population, swimsim_cluster_step (130 ticks), rocprofv3 --kernel-trace --stats:"; python $R/scripts/kernel_stats.py /tmp/prof_e$G 8; done) 2>&1 | tee $O/r05e_rocprof_sharded_kernels.txt
   timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 | tee $O/r05e_pytest_gpu.log
   ;;
+f)  # sp_merge_kernel with the next member's inputs prefetched (A/B against the library of cycle e); sharded probe with register-held Ping records
+  (for L in $C/libswimsim_x_before_prefetch.so $C/libswimsim.so; do echo "# $L"; LIB=$L timeout 600 python scripts/bounded_time.py 2097152 64 1048576 256 2097152 128; done) 2>&1 | grep -v amdgpu.ids | tee $O/r05f_bounded_time_prefetch_ab.txt
+  (echo "# strong: 1 048 576 members as G handles"; FORMS=cluster KERNELS=1 timeout 900 python scripts/shard_time.py 1 2 4) 2>&1 | grep -v amdgpu.ids | tee $O/r05f_shard_overhead_one_gpu.txt
+  (cd /tmp && export TMPDIR=/tmp && for G in 2; do FORMS=cluster WARM=100 TICKS=30 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_f$G -o t -- python $R/scripts/shard_time.py $G > /dev/null 2>&1; echo "# $G handles of one 1 048 576-member population, swimsim_cluster_step (130 ticks), rocprofv3 --kernel-trace --stats:"; python $R/scripts/kernel_stats.py /tmp/prof_f$G 8; done) 2>&1 | tee $O/r05f_rocprof_sharded_kernels.txt
+  ;;
+g)  # sp_merge_kernel with its wave-uniform values in scalar registers (A/B against the library of cycle e)
+  (for L in $C/libswimsim_x_r05e.so $C/libswimsim.so; do echo "# $L"; LIB=$L timeout 600 python scripts/bounded_time.py 2097152 64 1048576 256 2097152 128; done) 2>&1 | grep -v amdgpu.ids | tee $O/r05g_bounded_time_scalarized_ab.txt
+  ;;
+h)  # where a shard's tick goes at the per-GPU size: 8 x 1 048 576 members and 4 x 1 048 576 on one GPU, kernel statistics
+  (cd /tmp && export TMPDIR=/tmp && for G in 4 8; do MEMBERS=$((G * 1048576)) FORMS=cluster WARM=60 TICKS=20 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_h$G -o t -- python $R/scripts/shard_time.py $G > /tmp/h$G.out 2>&1; grep shards_on /tmp/h$G.out; echo "# $G handles x 1 048 576 members, swimsim_cluster_step (80 ticks), rocprofv3 --kernel-trace --stats:"; python $R/scripts/kernel_stats.py /tmp/prof_h$G 8; done) 2>&1 | tee $O/r05h_rocprof_sharded_kernels_weak.txt
+  ;;
+fin)  # the cycle of the FINAL kernels: tests, the bench lines, kernel trace over the timed window, PMC traffic, the multi-GPU forms on one GPU
+  bash scripts/gpu_cycle.sh r05fin tests bench extra prof pmc
+  SWIMSIM_FOLD_BEGIN=0 timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/r05fin_bench_driver_flags_with_begin_kernel.json 2>/dev/null
+  SWIMSIM_FOLD_BEGIN=0 timeout 400 python bench.py --steps 300 --warmup 150 --no-cpu-baseline > $O/r05fin_bench_saturated_with_begin_kernel.json 2>/dev/null
+  for G in 2 4; do SWIM_BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus $G --steps 20 --warmup 5 2>/dev/null | grep -v amdgpu.ids > $O/r05fin_bench_gpus${G}_one_process_shared_gpu.json; done
+  (echo "# strong: 1 048 576 members as G handles"; FORMS=cluster,phases KERNELS=1 timeout 900 python scripts/shard_time.py 1 2 4 8;
+   for G in 2 4 8; do echo "# weak: $G x 1 048 576 members vs one handle of $((G * 1048576))"; MEMBERS=$((G * 1048576)) FORMS=cluster WARM=100 TICKS=30 timeout 900 python scripts/shard_time.py 1 $G; done) 2>&1 | grep -v amdgpu.ids | tee $O/r05fin_shard_overhead_one_gpu.txt
+  timeout 1200 python scripts/config4_one_gpu.py 2>&1 | grep -v amdgpu.ids | tee $O/r05fin_config4_one_gpu.txt
+  ;;
 esac

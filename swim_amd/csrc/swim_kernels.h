@@ -208,6 +208,14 @@ __device__ inline void deliver_local(const DevState& s, uint32_t t, bool use_mas
   if (!use_mask || (msrc & MI_OOW)) push(s, t, dst_li, mi_src(src_li, msrc));
 }
 
+struct FaultRec { uint32_t member, up; };
+// A tick whose scheduled changes are a few CRASHES (the benchmarked regime: ~1 per tick) runs without begin_kernel too (`fold`,
+// round 5): the tick's crash list rides into probe_kernel as an overlay on ground truth -- whatever a prober reads about a member
+// on the list, it reads "down, empty queue" (what begin_kernel would have stored before the launch) --, workgroup 0 stores the
+// changes on the side for merge_kernel and everything after it.  Joins are not folded (an announcement takes a rumour id: the
+// window head of the tick depends on it).
+constexpr uint32_t FOLD_MAX_CRASHES = 8;
+struct CrashList { uint32_t n; uint32_t member[FOLD_MAX_CRASHES]; };
 #ifndef SWIM_PROBE_WAVES
 #define SWIM_PROBE_WAVES 5
 #endif
@@ -226,7 +234,7 @@ constexpr int PX_KG = 4;        // proxy indices per round of the wave's indirec
 // ground truth (minfo / mb), queue byte (q_all), queue mask (mask_all, through the owner's ring dictionary xl).  A delivery to
 // a member of another shard is an 8-byte record {dst, src} for the owner of dst.  The unsharded instantiation has none of it.
 template <int PMAX, bool SH>
-__global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? SWIM_PROBE_WAVES8 : PMAX <= 12 ? SWIM_PROBE_WAVES12 : SWIM_PROBE_WAVES16) void probe_kernel(SWIM_STATE_PARAM, uint32_t t, uint32_t tk, Offsets off, uint32_t fold) {
+__global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? SWIM_PROBE_WAVES8 : PMAX <= 12 ? SWIM_PROBE_WAVES12 : SWIM_PROBE_WAVES16) void probe_kernel(SWIM_STATE_PARAM, uint32_t t, uint32_t tk, Offsets off, uint32_t fold, CrashList crashes) {
   SWIM_STATE_BIND
   __shared__ BlockCounters sh;
   __shared__ uint32_t ordn;                        // deliveries handed to a shard's ingest (sharded runs)
@@ -234,6 +242,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
   // cannot carry that rumour this tick, 0xFE: the position is empty
   __shared__ uint8_t xpos[SH ? MAX_SHARDS * DICT_ENTRIES : 1];
   __shared__ uint32_t rt_cnt[MAX_SHARDS], rt_base[MAX_SHARDS];
+  __shared__ uint32_t rt_wave[SH ? MAX_SHARDS : 1][BLOCK / 64];   // a wave's Ping records per owner, then where its run starts
   if (SH) for (uint32_t k = threadIdx.x; k < s.n_shards * DICT_ENTRIES; k += BLOCK) { const uint2 e = s.xl[k]; xpos[k] = e.x == NONE32 ? (uint8_t)0xFEu : (uint8_t)(e.y >> 24); }   // (ctr_init's barrier publishes it)
   // pass 5, per wave: the (prober, proxy) pairs of a round, the probers' context, the chains' outcomes
   __shared__ uint4 px_item[BLOCK / 64][64 * PX_KG];      // {proxy, its minfo, prober lane | proxy index << 8, -}
@@ -245,7 +254,14 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
   ctr_init(&sh);
   const uint32_t li = blockIdx.x * BLOCK + threadIdx.x;
   const uint32_t i = s.lo + li;                    // global id
-  const uint32_t mi = li < s.N ? s.minfo[i] : 0u;
+  // the tick's crashes as an overlay on what is read about a member (a folded tick; crashes.n = 0 otherwise): down, queue gone
+  auto overlay = [&](uint32_t member, uint32_t m) -> uint32_t {
+    bool hit = false;
+#pragma unroll
+    for (uint32_t k = 0; k < FOLD_MAX_CRASHES; ++k) hit |= k < crashes.n && crashes.member[k] == member;
+    return hit ? (m & ~(MI_UP | MI_PB)) : m;
+  };
+  const uint32_t mi = li < s.N ? overlay(i, s.minfo[i]) : 0u;
   const bool act = mi_up(mi);
   // masks are exact only if few rumour ids appeared since they were built (swim_device.h)
   // `fold` (swimsim_step, a PLAIN tick: no scheduled change, no message from outside, no pull, no settling, one handle): there is
@@ -259,6 +275,20 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
     if (threadIdx.x == 0) {
       s.g[G_PREV_NEW] = Hprev; s.g[G_HEAD_NEW] = H;
       s.g[G_RIDS_OFF] = (H - Hprev > RID_MASK + 1u - RID_NEAR - KW_BITS) ? 1u : 0u;
+    }
+    // the tick's crashes, as begin_kernel stores them (a member that is down already: nothing; first_suspect needs no reset --
+    // it is reset when a member comes up and only ever set while it is down)
+    // -- with atomics: the probers of a member that crashes in this very tick give it a view row in this launch (ensure_slot:
+    // a CAS on the same word, an atomicOr on the byte's word)
+    if (threadIdx.x < crashes.n) {
+      const uint32_t mbr = crashes.member[threadIdx.x];
+      const uint32_t m0 = atomicAnd(&s.minfo[mbr], ~(MI_UP | MI_PB));
+      atomicAnd(reinterpret_cast<uint32_t*>(s.mb) + (mbr >> 2), ~((MB_UP | (0xFu << MB_PBN_SHIFT) | MB_OOW) << (8u * (mbr & 3u))));
+      if (mi_up(m0)) {
+        s.crash_tick[mbr] = t;
+        s.pk[mbr - s.lo].x = 0ull;
+        s.inbox_cnt[mbr - s.lo] = 0u;
+      }
     }
     for (uint32_t k = threadIdx.x; k <= TODO_REGIONS; k += blockDim.x) s.todo_n[k * 16u] = 0;
     if (t)
@@ -285,6 +315,8 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
   unsigned long long mymask = 0;
   uint32_t picks[PMAX], pinfo[PMAX];
   uint32_t failmask = 0;                           // probe indices that ended without an Ack (unlessAck; D2, D3)
+  uint32_t pingmask = 0;                           // sharded: probe indices whose Ping carries my queue to a REMOTE target: records {target, me}
+  unsigned long long pingown = 0;                  //   ... and the owners of those targets, 4 bits per probe index
   uint32_t nfail = 0, nack = 0;
 #pragma unroll
   for (int p = 0; p < PMAX; ++p) { picks[p] = 0; pinfo[p] = 0; }
@@ -325,6 +357,10 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
     if (!robust) {
       // ms <- kRandomMembers store (numToGossip cfg) []        (src/Core.hs:239)
       np = select_members<PMAX>(s, mk, i, s.P, P_SELECT, 0, nullptr, 0, picks, pinfo, use_mask);
+      if (crashes.n) {
+#pragma unroll
+        for (int p = 0; p < PMAX; ++p) pinfo[p] = overlay(picks[p], pinfo[p]);
+      }
       n_pings = np;
 #pragma unroll
       for (int p = 0; p < PMAX; ++p) valid[p] = (uint32_t)p < np;
@@ -338,7 +374,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
         valid[p] = false; picks[p] = 0; pinfo[p] = 0;
         if ((uint32_t)p < np && off.o[p]) {
           uint32_t c = i + off.o[p]; if (c >= s.NT) c -= s.NT;
-          picks[p] = c; pinfo[p] = probe_mi(s, c, use_mask);
+          picks[p] = c; pinfo[p] = overlay(c, probe_mi(s, c, use_mask));
           valid[p] = view_alive(s, li, pinfo[p]);
           n_pings += valid[p] ? 1u : 0u;
         }
@@ -396,7 +432,8 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
             if (m && !ABL(ABL_PUSH_ATOMIC)) atomicOr(&s.inmask[dl], m);
             if (expl) { pos[q] = atomicAdd(&s.inbox_cnt[dl], 1u); wrote_rec = true; }
           } else if (SH) {
-            emit_order(picks[p], i);                 // the target's owner delivers it (from its replica of my queue)
+            pingmask |= 1u << p;                     // the target's owner delivers it (from its replica of my queue): a record, written at the end
+            pingown |= (unsigned long long)owner_of(s, picks[p]) << (4 * p);
           }
         }
       }
@@ -415,7 +452,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
         const int p = c0 + qq;
         if ((uint32_t)p >= s.P || !off.o[p]) continue;
         uint32_t q = i + s.NT - off.o[p]; if (q >= s.NT) q -= s.NT;
-        const uint32_t mq = probe_mi(s, q, use_mask);
+        const uint32_t mq = overlay(q, probe_mi(s, q, use_mask));
         if (!mi_up(mq) || !mi_pbn(mq) || !view_alive(s, q - s.lo, mi) || lost(s, tk, P_L_PING, q, i, p)) continue;
         if (use_mask) ackacc |= s.pk[q - s.lo].x;
         if (!use_mask || (mq & MI_OOW)) { push(s, t, li, mi_src(q - s.lo, mq)); wrote_rec = true; }
@@ -499,6 +536,10 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
           dfail++;
           const uint32_t excl = j;
           nq = select_members<PMAX>(s, mk, i, s.K, P_PROXY, (uint32_t)p, &excl, 1, qs, qinfo, use_mask);
+          if (crashes.n) {
+#pragma unroll
+            for (int k = 0; k < PMAX; ++k) qinfo[k] = overlay(qs[k], qinfo[k]);
+          }
           preqs += nq;
           px_ctx[wv][lane] = make_uint4(mi, j, mj, 0u);
           px_mask[wv][lane] = mymask;
@@ -586,11 +627,48 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
   ctr_flush(s, &sh, blockIdx.x);
   SECT(38);
   if (SH) {
-    // the block routes its own records into the per-owner segments of q_send: count (LDS), one reservation per owner and
-    // block, write -- the list is this block's own (written above, visible behind the barrier)
+    // The block routes its own records into the per-owner segments of q_send.  The common ones -- the Pings' payloads for remote
+    // targets, {target, me} -- never left the registers (picks, pingmask): per owner a prefix sum over the wave, the waves'
+    // totals through LDS, ONE reservation per owner and block, and every lane writes its records in place, neighbours next to
+    // each other.  (Each of them appended to a list with an LDS atomic and read back cost the 524 288-member kernel a quarter
+    // of its time: the compiler turns a per-lane atomic on one LDS word into a loop over the lanes.)
+    const uint32_t lane_ = threadIdx.x & 63u, wv_ = threadIdx.x >> 6;
+    auto mine_for = [&](uint32_t g) -> uint32_t {
+      uint32_t c = 0;
+#pragma unroll
+      for (int p = 0; p < PMAX; ++p) c += (((pingmask >> p) & 1u) && (uint32_t)((pingown >> (4 * p)) & 15u) == g) ? 1u : 0u;
+      return c;
+    };
+    for (uint32_t g = 0; g < s.n_shards; ++g) {
+      const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_prefix_incl(mine_for(g)), 63);
+      if (lane_ == 0u) rt_wave[g][wv_] = tot;
+    }
+    __syncthreads();
+    if (threadIdx.x < s.n_shards) {
+      uint32_t acc = 0;
+      for (int w = 0; w < BLOCK / 64; ++w) { const uint32_t c = rt_wave[threadIdx.x][w]; rt_wave[threadIdx.x][w] = acc; acc += c; }
+      rt_base[threadIdx.x] = acc ? atomicAdd(&s.send_cnt[MAX_SHARDS + threadIdx.x], acc) : 0u;
+    }
+    __syncthreads();
+    for (uint32_t g = 0; g < s.n_shards; ++g) {
+      const uint32_t c = mine_for(g);
+      const uint32_t incl = wave_prefix_incl(c);               // (wave-uniform call: every lane takes part)
+      if (!c) continue;
+      uint32_t pos = rt_base[g] + rt_wave[g][wv_] + incl - c;
+#pragma unroll
+      for (int p = 0; p < PMAX; ++p)
+        if (((pingmask >> p) & 1u) && (uint32_t)((pingown >> (4 * p)) & 15u) == g) {
+          if (pos < s.p_cap) s.q_send[(size_t)g * s.p_cap + pos] = make_uint2(picks[p], i);
+          else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG);
+          pos++;
+        }
+    }
+    // the rare ones (ord: a remote source whose payload needs more than a translation, the hops of an indirect probe): the
+    // list is this block's own (written above, visible behind the barriers): count (LDS), reserve, write
     if (threadIdx.x < (uint32_t)MAX_SHARDS) rt_cnt[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t n = ordn < s.ord_cap ? ordn : s.ord_cap;
+    if (n == 0u) return;                                        // (block-uniform)
     const uint2* list = s.ord + (size_t)blockIdx.x * s.ord_cap;
     for (uint32_t k = threadIdx.x; k < n; k += BLOCK) atomicAdd(&rt_cnt[owner_of(s, list[k].x)], 1u);
     __syncthreads();
@@ -1858,7 +1936,6 @@ __global__ __launch_bounds__(BLOCK) void ingest_kernel(DevState s, uint32_t t, P
 // ================================================================================================
 // auxiliary kernels
 // ================================================================================================
-struct FaultRec { uint32_t member, up; };
 
 // Settling, the bookkeeping part (one block; include/swimsim.h).  After merge_kernel of
 // tick u: (a) the rows it cleared go to the free stack; (b) every row of its eligible list whose subject

@@ -288,12 +288,12 @@ int flush_injections(swimsim* h, uint32_t t, bool* any) {
 
 // one period of failureDetector for the handle's members; registers follow the probe / proxy arrays: four sizes (12: the
 // reference's default numToGossip = 10, src/Util.hs:48); a shard of a cluster runs the instantiation that knows about remote members
-void launch_probe(swimsim* h, uint32_t t, uint32_t tk, uint32_t fold) {
+void launch_probe(swimsim* h, uint32_t t, uint32_t tk, uint32_t fold, const CrashList& cl = CrashList{}) {
   const uint32_t pk = std::max(h->d.P, h->d.K);
   const Offsets off = robust_offsets(h, t);
   const dim3 g(h->d.nblocks), b(BLOCK);
-#define SWIM_LAUNCH_PROBE(PM) do { if (h->d.n_shards > 1) hipLaunchKernelGGL((probe_kernel<PM, true>), g, b, 0, h->stream, SWIM_STATE_ARG(h), t, tk, off, fold); \
-                                   else hipLaunchKernelGGL((probe_kernel<PM, false>), g, b, 0, h->stream, SWIM_STATE_ARG(h), t, tk, off, fold); } while (0)
+#define SWIM_LAUNCH_PROBE(PM) do { if (h->d.n_shards > 1) hipLaunchKernelGGL((probe_kernel<PM, true>), g, b, 0, h->stream, SWIM_STATE_ARG(h), t, tk, off, fold, cl); \
+                                   else hipLaunchKernelGGL((probe_kernel<PM, false>), g, b, 0, h->stream, SWIM_STATE_ARG(h), t, tk, off, fold, cl); } while (0)
   if (pk <= 4) SWIM_LAUNCH_PROBE(4);
   else if (pk <= 8) SWIM_LAUNCH_PROBE(8);
   else if (pk <= 12) SWIM_LAUNCH_PROBE(12);
@@ -305,9 +305,9 @@ void launch_probe(swimsim* h, uint32_t t, uint32_t tk, uint32_t fold) {
 uint32_t publish_grid(const swimsim* h) { return std::max(1u, std::min<uint32_t>(h->d.nblocks, 2048u)); }
 uint32_t ingest_grid(const swimsim* h) { return std::max(1u, std::min<uint32_t>(h->d.nblocks, 2048u)); }
 
-void launch_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev, uint32_t fold) {
+void launch_tick(swimsim* h, uint32_t t, uint32_t tk, hipEvent_t* ev, uint32_t fold, const CrashList& cl) {
   if (ev) (void)hipEventRecord(ev[0], h->stream);
-  launch_probe(h, t, tk, fold);
+  launch_probe(h, t, tk, fold, cl);
   if (ev) (void)hipEventRecord(ev[1], h->stream);
   const bool rk = records_kernel_every_tick(h);
   if (rk) hipLaunchKernelGGL(records_kernel, dim3(h->d.nblocks), dim3(BLOCK), 0, h->stream, h->d, t);
@@ -785,11 +785,22 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
     // A PLAIN tick -- no scheduled change, no message from outside, no state pull, no settling, no explicit-record kernel -- needs
     // nothing of begin_kernel but the window heads, the tick's ring and three resets: probe_kernel's workgroup 0 does that on the
     // side (`fold`), the launch and its kernel boundary are saved (SWIMSIM_FOLD_BEGIN=0 at create: always launch it; A/B, tests)
-    const uint32_t fold = (h->fold_begin && part == 3u && fpos == f0 && !(nup + npp) && !h->d.G && !h->d.strict && !records_kernel_every_tick(h)) ? 1u : 0u;   // (strict rules: begin_kernel declares the ids untrusted in every tick)
+    // ... and so does a tick whose scheduled changes are a few crashes of different members (round 5: the benchmarked regime has one
+    // per tick): the list rides into probe_kernel as an overlay on ground truth (swim_kernels.h CrashList)
+    CrashList cl{};
+    bool crashes_only = fpos - f0 <= FOLD_MAX_CRASHES;
+    for (size_t f = f0; f < fpos && crashes_only; ++f) {
+      crashes_only = h->faults[f].up == 0;
+      for (size_t g2 = f0; g2 < f; ++g2) crashes_only = crashes_only && h->faults[g2].member != h->faults[f].member;
+      if (crashes_only) cl.member[cl.n++] = h->faults[f].member;
+    }
+    if (!crashes_only) cl = CrashList{};
+    const uint32_t fold = (h->fold_begin && part == 3u && crashes_only && !(nup + npp) && !h->d.G && !h->d.strict && !records_kernel_every_tick(h)) ? 1u : 0u;   // (strict rules: begin_kernel declares the ids untrusted in every tick)
+    if (!fold) cl = CrashList{};
     if (!fold)
       hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, (uint32_t)(fpos - f0),
                          h->d_joined, part, PeerCounts{});
-    launch_tick(h, t, tk, ev, fold);
+    launch_tick(h, t, tk, ev, fold, cl);
     h->tick++;
   }
   h->faults.erase(h->faults.begin(), h->faults.begin() + (long)fpos);
