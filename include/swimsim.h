@@ -407,7 +407,9 @@ int swimsim_get_config(const swimsim_t* h, swimsim_config_t* out);
  * rule, same events, re-gossiped if accepted) -- if `observer` is up when that tick starts and stays up through the
  * tick's scheduled changes; nobody listens otherwise.  The subject gets a view row like any subject somebody states a
  * rumour about.  On a sharded cluster the message goes to the handle that owns `observer` (SWIMSIM_ERR_INVALID on the others).  Not
- * available with bounded member maps. */
+ * available with bounded member maps.  A known limit: an observer that has MORE than inbox_cap messages pending, goes
+ * down and comes back up within the one tick that delivers them keeps the part of them that sat in the inbox overflow list (the
+ * oracle drops all of them); no test or workload gets there (inbox_cap messages to one observer between two ticks). */
 int swimsim_inject_rumor(swimsim_t* h, uint32_t observer, uint32_t subject, uint8_t state, uint32_t incarnation);
 
 /* ---- sharded clusters (one handle per GPU / process) -------------------------------
