@@ -139,9 +139,6 @@ def main(argv=None, abi=None):
                          "--members 2097152 --loss-ppm 300000 --view-cap 64 [--churn 10]; no crash schedule of its own, no pre-roll")
     ap.add_argument("--churn", type=int, default=0, help="with --view-cap: per mille of the members crash and rejoin per 100 ticks")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle replay (baseline + verification)")
-    ap.add_argument("--replicated-masks", action="store_true",
-                    help="multi-GPU: the direct probes between shards through all-gathered queue masks instead of records "
-                         "(DESIGN.md section 7; off by default until timed on hardware)")
     args = ap.parse_args(argv)
 
     import torch
@@ -206,8 +203,6 @@ def main(argv=None, abi=None):
     if args.max_subjects:
         sc.maxSubjects = args.max_subjects
     exchange = "none (one shard)"
-    if args.replicated_masks:
-        os.environ["SWIMSIM_SHARD_REPLICATED_MASKS"] = "1"      # read by swimsim_create
     if world == 1:
         sim = Sim.create(LIB, sc)
     elif single:
@@ -219,8 +214,7 @@ def main(argv=None, abi=None):
         from swim_amd.shard import DistFabric, ShardedSim
         fabric = DistFabric("cuda:%d" % local_rank, transport="host" if share_gpu else "auto")
         sim = ShardedSim(LIB, sc, fabric, device="cuda:%d" % local_rank)
-        exchange = "torch.distributed p2p, transport=%s%s%s" % (fabric.transport, (" [" + fabric.note + "]") if fabric.note else "",
-                                                                 ", replicated queue masks" if args.replicated_masks else "")
+        exchange = "swimsim_shard_step with torch.distributed as the exchange, transport=%s%s" % (fabric.transport, (" [" + fabric.note + "]") if fabric.note else "")
     workloads.apply_crashes(sim, crashes)
     if args.view_cap:
         for (t, m) in crashes:

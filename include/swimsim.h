@@ -445,7 +445,7 @@ int swimsim_inject_rumor(swimsim_t* h, uint32_t observer, uint32_t subject, uint
  *           "dst merges src's queue" for members dst of the peer (the receiver appends src to dst's inbox and reads src's line
  *           from its replica).  Nothing of kind 2.
  *   phase3  end of tick.
- * swimsim_shard_step drives it like a dense cluster with replicated masks: xchg(ctx, 1, ..) gathers (kind-5 counts at
+ * swimsim_shard_step drives it like a dense cluster: xchg(ctx, 1, ..) gathers (kind-5 counts at
  * [n_shards + p], kind-6 at [2 n_shards + p], n_local each), xchg(ctx, 2, ..) delivers the kind-1 records. */
 #define SWIMSIM_RREC_BYTES 16u
 #define SWIMSIM_PREC_BYTES 8u            /* dense handles; bounded handles: */
@@ -472,8 +472,8 @@ int swimsim_shard_phase3(swimsim_t* h, const uint32_t* p_counts_in, const uint32
  * configuration (checked field by field) with one fault schedule.  Dense handles (round 5): the kernels read the peers' send
  * buffers WHERE THEY LIE (same device, or a peer device over xGMI: hipDeviceEnablePeerAccess, refused with SWIMSIM_ERR_DEVICE
  * where the devices cannot) with the counts from the peers' own words, ordered by events on the handles' streams; only the
- * replica slices are copied.  Settling (round 3) included; handles with join_pull / pull_ticks or with messages from outside
- * pending are refused (SWIMSIM_ERR_INVALID: their exchange round 0 -- step them by the phase calls).  Bounded handles
+ * replica slices are copied.  Settling (round 3) and messages from outside (swimsim_inject_rumor) included; handles with join_pull /
+ * pull_ticks are refused (SWIMSIM_ERR_INVALID: their exchange round 0 -- step them by the phase calls).  Bounded handles
  * (view_cap): the all-gather and the all-to-all-v of DESIGN.md 7b as device-to-device (peer) copies.
  * (Multi-process clusters use swimsim_shard_step with the embedder's exchange.) */
 int swimsim_cluster_step(swimsim_t** hs, uint32_t n, uint32_t nticks);

@@ -28,7 +28,7 @@ if has variants; then
   timeout 600 python scripts/ab_time.py swim_amd/csrc/libswimsim.so swim_amd/csrc/libswimsim_sptr.so 2>&1 | tee $O/${TAG}_variants_state_by_pointer.txt
 fi
 if has shard; then
-  # one population as 1 / 2 / 4 / 8 handles on this GPU, record path against replicated queue masks
+  # one population as 1 / 2 / 4 / 8 handles on this GPU, both forms of the exchange
   timeout 600 python scripts/shard_time.py 1 2 4 8 2>&1 | tee $O/${TAG}_shard_overhead_one_gpu.txt
 fi
 if has bounded; then

@@ -9,7 +9,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = sys.argv[1:] or ["merge_kernel", "probe_kernelILi4", "remote_kernel", "split_kernel", "serve_kernel", "ingest_kernel"]
+KERNELS = sys.argv[1:] or ["merge_kernel", "probe_kernelILi4", "publish_kernel", "xlat_kernel", "ingest_kernel"]
 CLASSES = [("int mul (quarter rate)", ("v_mul_lo", "v_mul_hi", "v_mad_u64", "v_mad_i64")),
            ("lane moves (scalar spills, broadcasts)", ("v_readlane", "v_writelane", "v_readfirstlane")),
            ("s_waitcnt", ("s_waitcnt",)), ("global loads", ("global_load", "flat_load", "buffer_load")),

@@ -52,4 +52,10 @@ fin)  # the cycle of the FINAL kernels: tests, the bench lines, kernel trace ove
    for G in 2 4 8; do echo "# weak: $G x 1 048 576 members vs one handle of $((G * 1048576))"; MEMBERS=$((G * 1048576)) FORMS=cluster WARM=100 TICKS=30 timeout 900 python scripts/shard_time.py 1 $G; done) 2>&1 | grep -v amdgpu.ids | tee $O/r05fin_shard_overhead_one_gpu.txt
   timeout 1200 python scripts/config4_one_gpu.py 2>&1 | grep -v amdgpu.ids | tee $O/r05fin_config4_one_gpu.txt
   ;;
+i)  # merge_kernel's stores as non-temporal stores (A/B on one cluster: kernels and wall)
+  (ROUNDS=7 timeout 600 python scripts/ab_time.py $C/libswimsim_x_base.so $C/libswimsim_x_nt.so) 2>&1 | grep -v amdgpu.ids | tee $O/r05i_ab_nt_stores.txt
+  ;;
+fin2)  # tests, bench lines, kernel trace and PMC once more after the round's last source change
+  bash scripts/gpu_cycle.sh r05fin2 tests bench prof pmc
+  ;;
 esac

@@ -320,12 +320,35 @@ __device__ inline uint2 v_full(const DevState& s, size_t ix) {
   return s.V[ix];
 #endif
 }
+// -DSWIM_NT_STORES=1 (measurement knob, round 5): merge_kernel's stores -- view cells, queue lines, pk, deadline cells -- as
+// non-temporal stores (streamed past the L2: less dirty data for the kernel boundary behind it to write back)
+#ifndef SWIM_NT_STORES
+#define SWIM_NT_STORES 0
+#endif
+typedef uint32_t swim_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t swim_u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline void st_u32x2(uint2* p, uint2 v) {
+#if SWIM_NT_STORES && defined(__HIP_DEVICE_COMPILE__)
+  swim_u32x2 w; w.x = v.x; w.y = v.y;
+  __builtin_nontemporal_store(w, reinterpret_cast<swim_u32x2*>(p));
+#else
+  *p = v;
+#endif
+}
+__device__ inline void st_u32x4(uint4* p, uint4 v) {
+#if SWIM_NT_STORES && defined(__HIP_DEVICE_COMPILE__)
+  swim_u32x4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+  __builtin_nontemporal_store(w, reinterpret_cast<swim_u32x4*>(p));
+#else
+  *p = v;
+#endif
+}
 __device__ inline void v_put(const DevState& s, size_t ix, uint32_t key, uint32_t since1) {
 #if SWIM_VSPLIT
   s.Vk[ix] = (key << 8) | (since1 & 0xFFu);
   s.Vs[ix] = since1;
 #else
-  s.V[ix] = make_uint2(key, since1);
+  st_u32x2(&s.V[ix], make_uint2(key, since1));
 #endif
 }
 // has the entry changed in tick t already?  (c = v_hot of the same cell, loaded before)

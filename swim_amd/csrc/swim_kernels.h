@@ -11,8 +11,8 @@
 //                  closed form of the message exchange; delivers the piggyback payloads as masks.
 //   merge_kernel : owner-computes end of tick: delivered rumours, timers, state rule, piggyback queue
 //                  (src/Core.hs:89-117, 127-138, 142-218).
-// Sharded clusters add split_kernel / xlat_kernel + serve_kernel / ingest_kernel around the two
-// exchange rounds.
+// Sharded clusters add publish_kernel / xlat_kernel / ingest_kernel around the two exchange rounds
+// (DESIGN.md section 7).
 #pragma once
 #include "swim_device.h"
 
@@ -1615,9 +1615,9 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
     }
     SECT(5);                                        // queue rebuilt
     if (!ABL(ABL_STATE_STORES)) {
-    s.pk[li] = make_ulonglong2(nout ? qmask : 0ull, kn);
+    { const unsigned long long qm_ = nout ? qmask : 0ull; st_u32x4(reinterpret_cast<uint4*>(&s.pk[li]), make_uint4((uint32_t)qm_, (uint32_t)(qm_ >> 32), (uint32_t)kn, (uint32_t)(kn >> 32))); }
     if (pushed) s.inmask[li] = 0;
-    if (timer_due || tnew.n || woke) trow_now[li] = tc_pack(tnew);   // consumed and refilled in one store
+    if (timer_due || tnew.n || woke) st_u32x4(&trow_now[li], tc_pack(tnew));   // consumed and refilled in one store
     }
     if (self_inc != hot0.x || woke) s.hot[li] = make_uint2(self_inc, hot0.y & ~1u);
     if (cnt) s.inbox_cnt[li] = 0;
@@ -1655,7 +1655,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
         const uint32_t gm = blockIdx.x * BLOCK + m;
 #endif
         uint4* line = reinterpret_cast<uint4*>(s.pb + ((size_t)(fl >> 1) * s.N + gm) * PB_SLOTS);
-        line[q] = make_uint4(asm_[4 * q][m], asm_[4 * q + 1][m], asm_[4 * q + 2][m], asm_[4 * q + 3][m]);
+        st_u32x4(&line[q], make_uint4(asm_[4 * q][m], asm_[4 * q + 1][m], asm_[4 * q + 2][m], asm_[4 * q + 3][m]));
       }
     }
   }

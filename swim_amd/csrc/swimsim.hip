@@ -1419,12 +1419,11 @@ static bool same_cluster_config(const swimsim_config_t& a, const swimsim_config_
  *   merge_kernel; with settling settle_publish -> e3 | wait every peer's e3; settle_commit -> e2 instead.
  * The next tick's begin waits for every peer's e2 (they are done with my send buffers).  Nothing is copied but the replicas,
  * nothing comes back to the host.  Not for handles with state pulls (join_pull, pull_ticks: exchange round 0 -- the phase
- * calls) or with messages from outside pending. */
+ * calls). */
 static int cluster_step_dense(swimsim_t** hs, uint32_t n, uint32_t nticks) {
   for (uint32_t k = 0; k < n; ++k) {
     swimsim* h = hs[k];
     if (h->d.join_pull || h->d.pull_T) return set_err(h, SWIMSIM_ERR_INVALID, "cluster_step: handles with join_pull / pull_ticks are stepped by the phase calls (their exchange round 0)");
-    if (!h->injections.empty()) return set_err(h, SWIMSIM_ERR_INVALID, "cluster_step: messages from outside are pending (swimsim_inject_rumor): step this tick by the phase calls");
     if (h->begun) return set_err(h, SWIMSIM_ERR_STATE, "cluster_step: a tick is in progress on this handle");
   }
   const bool settling = hs[0]->d.G != 0;
@@ -1475,7 +1474,9 @@ static int cluster_step_dense(swimsim_t** hs, uint32_t n, uint32_t nticks) {
       const size_t f0 = fpos[k];
       while (fpos[k] < fend[k] && h->faults[fpos[k]].tick <= t) ++fpos[k];
       if (tck) for (uint32_t p = 0; p < n; ++p) if (p != k) CCHK(h, hipStreamWaitEvent(h->stream, ev[p][2], 0));   // the peers are done with my send buffers
-      hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, (uint32_t)(fpos[k] - f0), h->d_joined, 3u, PeerCounts{});
+      bool inj = false;                                // messages from outside (swimsim_inject_rumor) go into the first tick's inboxes
+      if (!h->injections.empty()) { const int rc_ = flush_injections(h, t, &inj); if (rc_) { for (uint32_t q = 0; q < n; ++q) hs[q]->poisoned = hs[q]->poisoned || tck != 0; cleanup(); return rc_; } }
+      hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, (uint32_t)(fpos[k] - f0), h->d_joined, inj ? 7u : 3u, PeerCounts{});
       hipLaunchKernelGGL(publish_kernel, dim3(publish_grid(h)), dim3(BLOCK), 0, h->stream, h->d, t);
       CCHK(h, hipEventRecord(ev[k][0], h->stream));
     }

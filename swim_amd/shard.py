@@ -353,7 +353,7 @@ class ShardedSim:
                 t0 = time.perf_counter()
                 acc[{0: 0, 1: 0, 2: 2, 3: 4}[rnd]] += t0 - state["t"]  # the phase that just ended
                 kinds = {0: (4,), 1: (0, 5, 6) if sh.replicated else (0,), 2: (1,), 3: (3,)}[rnd]
-                # rounds 0 and 3: one kind, its counts at [p]; round 1 with replicated masks: kinds 5 and 6 at [G + p], [2G + p]
+                # rounds 0 and 3: one kind, its counts at [p]; round 1: kind 0 at [p], the gathered kinds 5 and 6 at [G + p], [2G + p]
                 at = (lambda k: 0) if rnd in (0, 3) else (lambda k: (k - 4) * G if k >= 5 else k * G)
                 counts = [[[c_out[at(k) + p] for p in range(G)] for k in kinds]]
                 got = f.exchange([sh], kinds, counts)[0]
@@ -379,7 +379,7 @@ class ShardedSim:
         if len(sh) == 1 and self.n_shards > 1:
             return self._step_by_library(nticks)
         import os
-        in_library = self.resolved.view_cap or not (sh[0].join_pull or self._injected)    # (state pulls / messages from outside: the phase calls)
+        in_library = not sh[0].join_pull and not (self.resolved.view_cap and self._injected)    # (state pulls: the phase calls -- their exchange round 0)
         self._injected = False
         if len(sh) == self.n_shards > 1 and in_library and self._in_library:
             # every shard of the cluster lives in this process: the library steps the cluster itself, the

@@ -199,3 +199,24 @@ def test_shard_phases_are_refused_out_of_order(emu_abi):
     plain = Sim.create(emu_abi, SimConfig(cfg=Config(numToGossip=3), nMembers=64, seed=1))
     assert emu_abi.shard_phase1(plain._h, c3) == _abi.ERR_STATE             # not a sharded handle
     plain.close()
+
+
+def test_cluster_step_checks_its_handles(emu_abi):
+    """swimsim_cluster_step takes n DISTINCT shards of ONE resolved configuration, between ticks: a handle twice, a different
+    seed or option, a handle with state pulls are refused with a message -- never stepped into silent divergence; and
+    swimsim_shard_traffic reports what a shard put on the wire."""
+    import ctypes as C
+    from swim_amd import _abi
+    mk = lambda k, **kw: Sim.create(emu_abi, SimConfig(cfg=Config(numToGossip=3), nMembers=256, seed=kw.pop("seed", 5), suspicionTicks=6, **kw), shard_index=k, n_shards=2)
+    a, b = mk(0), mk(1)
+    arr = lambda *hs: (C.c_void_p * len(hs))(*[h._h for h in hs])
+    assert emu_abi.cluster_step(arr(a, b), 2, 3) == _abi.OK and a.tick == b.tick == 3
+    out = (C.c_uint64 * 4)()
+    assert emu_abi.shard_traffic(a._h, out) == _abi.OK and out[0] >= 128 * 9 + 512 and out[1] % 8 == 0
+    assert emu_abi.cluster_step(arr(a, a), 2, 1) == _abi.ERR_INVALID                       # the same handle twice
+    c = mk(1, seed=6)
+    assert emu_abi.cluster_step(arr(a, c), 2, 1) == _abi.ERR_INVALID and b"ONE cluster" in emu_abi.last_error(c._h)   # another seed (and another tick)
+    d0, d1 = mk(0, joinPull=1), mk(1, joinPull=1)
+    assert emu_abi.cluster_step(arr(d0, d1), 2, 1) == _abi.ERR_INVALID and b"phase calls" in emu_abi.last_error(d0._h)
+    for s in (a, b, c, d0, d1):
+        s.close()
