@@ -208,6 +208,25 @@ def main(argv=None, abi=None):
     elif single:
         from swim_amd.shard import LocalFabric, ShardedSim
         sim = ShardedSim(LIB, sc, LocalFabric(world), devices=devices if has_cuda else None)
+        if not share_gpu and abi is None:
+            # the in-library exchange reads the peers' buffers over xGMI: it needs peer access between the devices.  Where the node
+            # cannot (or the first tick fails on the device), the same job is started again as one process per GPU under
+            # torch.distributed.run -- the other launch shape of this file -- instead of failing the line.
+            from swim_amd.sim import SwimError
+            try:
+                sim.step(1)
+                for d in sorted(set(devices)):
+                    torch.cuda.synchronize(d)
+            except SwimError as e:
+                import socket
+                sys.stderr.write("bench: one-process cluster step failed (%s): restarting as one process per GPU\n" % e)
+                with socket.socket() as so:
+                    so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+                av = sys.argv[1:] if argv is None else list(argv)
+                os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + av)
+            sim.close()
+            sim = ShardedSim(LIB, sc, LocalFabric(world), devices=devices)
         exchange = "inside the library (swimsim_cluster_step): the peers' buffers read in place over %s, ordered by events on the handles' streams" % (
             "device memory (all shards on ONE GPU: test hook)" if share_gpu else "xGMI peer access")
     else:

@@ -472,8 +472,8 @@ int swimsim_shard_phase3(swimsim_t* h, const uint32_t* p_counts_in, const uint32
  * configuration (checked field by field) with one fault schedule.  Dense handles (round 5): the kernels read the peers' send
  * buffers WHERE THEY LIE (same device, or a peer device over xGMI: hipDeviceEnablePeerAccess, refused with SWIMSIM_ERR_DEVICE
  * where the devices cannot) with the counts from the peers' own words, ordered by events on the handles' streams; only the
- * replica slices are copied.  Settling (round 3) and messages from outside (swimsim_inject_rumor) included; handles with join_pull /
- * pull_ticks are refused (SWIMSIM_ERR_INVALID: their exchange round 0 -- step them by the phase calls).  Bounded handles
+ * replica slices are copied.  Every option of a sharded handle included: settling (round 3), state pulls (round 0: join_pull, pull_ticks),
+ * messages from outside (swimsim_inject_rumor).  Bounded handles
  * (view_cap): the all-gather and the all-to-all-v of DESIGN.md 7b as device-to-device (peer) copies.
  * (Multi-process clusters use swimsim_shard_step with the embedder's exchange.) */
 int swimsim_cluster_step(swimsim_t** hs, uint32_t n, uint32_t nticks);

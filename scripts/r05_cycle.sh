@@ -58,4 +58,9 @@ i)  # merge_kernel's stores as non-temporal stores (A/B on one cluster: kernels 
 fin2)  # tests, bench lines, kernel trace and PMC once more after the round's last source change
   bash scripts/gpu_cycle.sh r05fin2 tests bench prof pmc
   ;;
+fin3)  # tests, bench lines, kernel trace and PMC on the round's LAST sources; the one-process multi-GPU line once more
+  bash scripts/gpu_cycle.sh r05fin3 tests bench prof pmc
+  SWIM_BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 2 --steps 20 --warmup 5 2>/dev/null | grep -v amdgpu.ids > $O/r05fin3_bench_gpus2_one_process_shared_gpu.json
+  (FORMS=cluster KERNELS=1 timeout 600 python scripts/shard_time.py 1 2) 2>&1 | grep -v amdgpu.ids | tee $O/r05fin3_shard_overhead_one_gpu.txt
+  ;;
 esac

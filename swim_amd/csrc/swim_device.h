@@ -262,6 +262,8 @@ struct PeerView {
   const uint2* st[MAX_SHARDS];                // settling: peer p's list for me, its length (g + G_SETTLE_SEND)
   const uint32_t* stn[MAX_SHARDS];
 };
+// the same for exchange round 0 (state pulls): peer p's records for me and their number (g + G_JSEND + me)
+struct JoinView { uint32_t direct; const uint4* jl[MAX_SHARDS]; const uint32_t* jn[MAX_SHARDS]; };
 struct Offsets { uint32_t o[16]; };              // robust scheme: this period's rotation per probe index (0 = none)
 
 constexpr uint32_t SRC_FOREIGN = 1u << 30;      // explicit-record source word: index into fl, not a member

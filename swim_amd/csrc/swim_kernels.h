@@ -2140,7 +2140,7 @@ __device__ inline void pull_entry(const DevState& s, uint32_t t, uint32_t mbr, u
 //      window head H (no ids are allocated between here and merge_kernel), the tick's ring and dictionary, the rows
 //      eligible for settling at the end of t.
 __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, uint32_t tk, const FaultRec* faults, uint32_t nfaults,
-                                                      uint32_t* joined, uint32_t part, PeerCounts jc) {
+                                                      uint32_t* joined, uint32_t part, PeerCounts jc, JoinView jv) {
   __shared__ unsigned long long evd_sh;
   __shared__ unsigned dropped_sh, nset, changes_sh;
   if (part & 1u) settle_finish(s);
@@ -2217,9 +2217,10 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
     // during the tick merges its host's member map: (i) hosts on other shards sent theirs as records {joiner,
     // subject, entry} (rows are opened for subjects this shard has not heard of); (ii) hosts on this shard are read.
     for (uint32_t p = 0; p < s.n_shards; ++p) {
-      const uint32_t n = s.n_shards > 1 && p != s.shard ? min(jc.v[p], s.j_cap) : 0u;
+      const uint32_t n = s.n_shards > 1 && p != s.shard ? min(jv.direct ? *jv.jn[p] : jc.v[p], s.j_cap) : 0u;
+      const uint4* jlist = jv.direct ? jv.jl[p] : s.j_recv + (size_t)p * s.j_cap;     // (swimsim_cluster_step: the peer's records where they lie)
       for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
-        const uint4 r = s.j_recv[(size_t)p * s.j_cap + k];
+        const uint4 r = jlist[k];
         if (!is_local(s, r.x) || r.y >= s.NT) continue;
         unsigned long long evd = 0; unsigned pulled = 0;
         pull_entry(s, t, r.x, get_slot(s, r.y), r.y, r.z, &evd, &pulled);

@@ -775,7 +775,7 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
     if (nup + npp) {
       // a tick with state pulls: between the two parts of the start of the tick, one block per puller
       hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, (uint32_t)(fpos - f0),
-                         h->d_joined, 1u, PeerCounts{});
+                         h->d_joined, 1u, PeerCounts{}, JoinView{});
       hipLaunchKernelGGL(join_pull_kernel, dim3(std::min(nup + npp, 16384u)), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0,
                          (uint32_t)(fpos - f0), h->d_joined, nup);
       // push-pull: once every pull has read its host, the hosts merge their pullers' maps
@@ -799,7 +799,7 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
     if (!fold) cl = CrashList{};
     if (!fold)
       hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, (uint32_t)(fpos - f0),
-                         h->d_joined, part, PeerCounts{});
+                         h->d_joined, part, PeerCounts{}, JoinView{});
     launch_tick(h, t, tk, ev, fold, cl);
     h->tick++;
   }
@@ -1203,7 +1203,7 @@ int swimsim_shard_phase0(swimsim_t* h, uint32_t* counts, int* round_needed) {
   const uint32_t t = (uint32_t)h->tick;
   const uint32_t tk = tick_key(h->cfg.seed, t);
   { bool inj = false; rc = flush_injections(h, t, &inj); if (rc) return rc; h->tick_inj = inj; }   // before the tick's scheduled changes (swimsim_step does the same)
-  hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults, (uint32_t)fend, h->d_joined, 1u, PeerCounts{});
+  hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults, (uint32_t)fend, h->d_joined, 1u, PeerCounts{}, JoinView{});
   {
     const uint32_t T = h->d.pull_T, first = T ? t % T : 0u;
     const uint32_t items = (uint32_t)fend + ((T && first < h->d.NT) ? (h->d.NT - first + T - 1u) / T : 0u);   // joiners (at most) + the tick's periodic pullers, everywhere
@@ -1272,7 +1272,7 @@ int swimsim_shard_phase1(swimsim_t* h, uint32_t* counts) {
                                       (uint32_t)fend, h->d_joined, nup);
   }
   hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults, (uint32_t)fend,
-                     h->d_joined, (h->begun ? (2u | 8u) : 3u) | (h->tick_inj ? 4u : 0u), peer_counts(h, h->j_in));
+                     h->d_joined, (h->begun ? (2u | 8u) : 3u) | (h->tick_inj ? 4u : 0u), peer_counts(h, h->j_in), JoinView{});
   h->begun = false; h->tick_inj = false;
   std::fill(h->j_in, h->j_in + MAX_SHARDS, 0u);
   h->faults.erase(h->faults.begin(), h->faults.begin() + (long)fend);
@@ -1418,17 +1418,17 @@ static bool same_cluster_config(const swimsim_config_t& a, const swimsim_config_
  *   WHERE THEY LIE (PeerView: same device, or a peer device over xGMI) with the counts from the peers' own words -> e2;
  *   merge_kernel; with settling settle_publish -> e3 | wait every peer's e3; settle_commit -> e2 instead.
  * The next tick's begin waits for every peer's e2 (they are done with my send buffers).  Nothing is copied but the replicas,
- * nothing comes back to the host.  Not for handles with state pulls (join_pull, pull_ticks: exchange round 0 -- the phase
- * calls). */
+ * nothing comes back to the host.  State pulls (join_pull, pull_ticks) split the start of the tick around round 0 as the phase calls do:
+ * begin part A + pull_send -> eJ | wait every peer's eJ; the pulls from local hosts, begin part B (the peers' records read in place),
+ * publish -> e0. */
 static int cluster_step_dense(swimsim_t** hs, uint32_t n, uint32_t nticks) {
   for (uint32_t k = 0; k < n; ++k) {
     swimsim* h = hs[k];
-    if (h->d.join_pull || h->d.pull_T) return set_err(h, SWIMSIM_ERR_INVALID, "cluster_step: handles with join_pull / pull_ticks are stepped by the phase calls (their exchange round 0)");
     if (h->begun) return set_err(h, SWIMSIM_ERR_STATE, "cluster_step: a tick is in progress on this handle");
   }
   const bool settling = hs[0]->d.G != 0;
   std::vector<size_t> fend(n, 0), fpos(n, 0);
-  std::vector<std::vector<hipEvent_t>> ev(n, std::vector<hipEvent_t>(4, nullptr));
+  std::vector<std::vector<hipEvent_t>> ev(n, std::vector<hipEvent_t>(5, nullptr));   // e0 .. e3 (above), [4] = eJ: round 0 published
   auto cleanup = [&]() { for (auto& e : ev) for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); };
   auto broken = [&](swimsim* h, hipError_t e, const char* what) -> int {
     for (uint32_t k = 0; k < n; ++k) { hs[k]->poisoned = true; (void)hipSetDevice(hs[k]->device); (void)hipStreamSynchronize(hs[k]->stream); }
@@ -1449,11 +1449,12 @@ static int cluster_step_dense(swimsim_t** hs, uint32_t n, uint32_t nticks) {
       (void)hipGetLastError();
     }
   std::vector<PeerView> pv(n);
+  std::vector<JoinView> jv(n);
   for (uint32_t k = 0; k < n; ++k) {
     swimsim* h = hs[k];
     { const hipError_t e_ = hipSetDevice(h->device); if (e_ != hipSuccess) { cleanup(); return set_err(h, SWIMSIM_ERR_DEVICE, hipGetErrorString(e_)); } }
     { int rc_ = upload_faults(h, nticks, &fend[k]); if (rc_) { cleanup(); return rc_; } }
-    for (int e = 0; e < 4; ++e) { const hipError_t e_ = hipEventCreateWithFlags(&ev[k][e], hipEventDisableTiming); if (e_ != hipSuccess) { cleanup(); return set_err(h, SWIMSIM_ERR_DEVICE, hipGetErrorString(e_)); } }
+    for (int e = 0; e < 5; ++e) { const hipError_t e_ = hipEventCreateWithFlags(&ev[k][e], hipEventDisableTiming); if (e_ != hipSuccess) { cleanup(); return set_err(h, SWIMSIM_ERR_DEVICE, hipGetErrorString(e_)); } }
     if (h->timing) while (h->ev_pool.size() < (size_t)nticks * 3) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { cleanup(); return set_err(h, SWIMSIM_ERR_DEVICE, "hipEventCreate"); } h->ev_pool.push_back(e); }
     PeerView& v = pv[k];
     v = PeerView{};
@@ -1464,22 +1465,63 @@ static int cluster_step_dense(swimsim_t** hs, uint32_t n, uint32_t nticks) {
       v.q[p] = q.q_send + (size_t)k * q.p_cap; v.qn[p] = q.send_cnt + MAX_SHARDS + k;
       v.mask[p] = q.mask_all; v.qb[p] = q.q_all;
       v.st[p] = q.s_send ? q.s_send + (size_t)k * q.s_cap : nullptr; v.stn[p] = q.g + G_SETTLE_SEND;
+      jv[k].direct = 1u;
+      jv[k].jl[p] = q.j_send ? q.j_send + (size_t)k * q.j_cap : nullptr; jv[k].jn[p] = q.g + G_JSEND + k;
     }
   }
   for (uint32_t tck = 0; tck < nticks; ++tck) {
     const uint32_t t = (uint32_t)hs[0]->tick, tk = tick_key(hs[0]->cfg.seed, t);
-    for (uint32_t k = 0; k < n; ++k) {                 // the start of the tick, my slice of the replicas
+    // state pulls (join_pull: a tick in which members come up; pull_ticks: every tick) split the start of the tick around
+    // exchange round 0, as swimsim_shard_phase0 / phase1 do: faults, then the owners of the pull hosts write what the hosts hold for
+    // the pullers' owners, then -- behind everybody's round 0 -- the pulls from local hosts, the peers' records (read in place) and
+    // the rest of the start of the tick.  The schedule is replicated: every handle takes the same branch.
+    std::vector<size_t> f0s(n);
+    std::vector<bool> injs(n, false);
+    bool round0 = hs[0]->d.pull_T != 0 && (uint32_t)(t % hs[0]->d.pull_T) < hs[0]->d.NT;
+    for (uint32_t k = 0; k < n; ++k) {
+      swimsim* h = hs[k];
+      f0s[k] = fpos[k];
+      while (fpos[k] < fend[k] && h->faults[fpos[k]].tick <= t) ++fpos[k];
+      if (h->d.join_pull) for (size_t f = f0s[k]; f < fpos[k]; ++f) round0 = round0 || h->faults[f].up != 0;
+    }
+    for (uint32_t k = 0; k < n; ++k) {                 // the start of the tick (or its first part), my slice of the replicas
       swimsim* h = hs[k];
       CCHK(h, hipSetDevice(h->device));
-      const size_t f0 = fpos[k];
-      while (fpos[k] < fend[k] && h->faults[fpos[k]].tick <= t) ++fpos[k];
+      const size_t f0 = f0s[k];
+      const uint32_t nf = (uint32_t)(fpos[k] - f0);
       if (tck) for (uint32_t p = 0; p < n; ++p) if (p != k) CCHK(h, hipStreamWaitEvent(h->stream, ev[p][2], 0));   // the peers are done with my send buffers
       bool inj = false;                                // messages from outside (swimsim_inject_rumor) go into the first tick's inboxes
       if (!h->injections.empty()) { const int rc_ = flush_injections(h, t, &inj); if (rc_) { for (uint32_t q = 0; q < n; ++q) hs[q]->poisoned = hs[q]->poisoned || tck != 0; cleanup(); return rc_; } }
-      hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, (uint32_t)(fpos[k] - f0), h->d_joined, inj ? 7u : 3u, PeerCounts{});
+      injs[k] = inj;
+      if (round0) {
+        hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, nf, h->d_joined, 1u, PeerCounts{}, JoinView{});
+        const uint32_t T = h->d.pull_T, first = T ? t % T : 0u;
+        const uint32_t items = nf + ((T && first < h->d.NT) ? (h->d.NT - first + T - 1u) / T : 0u);
+        hipLaunchKernelGGL(pull_send_kernel, dim3(std::max(1u, std::min<uint32_t>(1024u, (items + BLOCK - 1) / BLOCK))), dim3(BLOCK), 0, h->stream,
+                           h->d, t, tk, h->d_faults + f0, nf, h->d_joined);
+        CCHK(h, hipEventRecord(ev[k][4], h->stream));
+        continue;
+      }
+      hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, nf, h->d_joined, inj ? 7u : 3u, PeerCounts{}, JoinView{});
       hipLaunchKernelGGL(publish_kernel, dim3(publish_grid(h)), dim3(BLOCK), 0, h->stream, h->d, t);
       CCHK(h, hipEventRecord(ev[k][0], h->stream));
     }
+    if (round0)
+      for (uint32_t k = 0; k < n; ++k) {               // round 0 (read in place) + the rest of the start of the tick
+        swimsim* h = hs[k];
+        CCHK(h, hipSetDevice(h->device));
+        const size_t f0 = f0s[k];
+        const uint32_t nf = (uint32_t)(fpos[k] - f0);
+        for (uint32_t p = 0; p < n; ++p) if (p != k) CCHK(h, hipStreamWaitEvent(h->stream, ev[p][4], 0));
+        uint32_t nup = 0;
+        if (h->d.join_pull) for (size_t f = f0; f < fpos[k]; ++f) nup += h->faults[f].up != 0;
+        const uint32_t T = h->d.pull_T, first = T ? (t % T + T - h->d.lo % T) % T : 0u;       // my first periodic puller, as a local index
+        const uint32_t npp = (T && first < h->d.N) ? (h->d.N - first + T - 1u) / T : 0u;
+        if (nup + npp) hipLaunchKernelGGL(join_pull_kernel, dim3(std::min(nup + npp, 4096u)), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, nf, h->d_joined, nup);
+        hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, nf, h->d_joined, (2u | 8u) | (injs[k] ? 4u : 0u), PeerCounts{}, jv[k]);
+        hipLaunchKernelGGL(publish_kernel, dim3(publish_grid(h)), dim3(BLOCK), 0, h->stream, h->d, t);
+        CCHK(h, hipEventRecord(ev[k][0], h->stream));
+      }
     for (uint32_t k = 0; k < n; ++k) {                 // round 1 (read in place) + the probes
       swimsim* h = hs[k];
       CCHK(h, hipSetDevice(h->device));

@@ -379,7 +379,7 @@ class ShardedSim:
         if len(sh) == 1 and self.n_shards > 1:
             return self._step_by_library(nticks)
         import os
-        in_library = not sh[0].join_pull and not (self.resolved.view_cap and self._injected)    # (state pulls: the phase calls -- their exchange round 0)
+        in_library = True
         self._injected = False
         if len(sh) == self.n_shards > 1 and in_library and self._in_library:
             # every shard of the cluster lives in this process: the library steps the cluster itself, the
