@@ -63,4 +63,12 @@ fin3)  # tests, bench lines, kernel trace and PMC on the round's LAST sources; t
   SWIM_BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 2 --steps 20 --warmup 5 2>/dev/null | grep -v amdgpu.ids > $O/r05fin3_bench_gpus2_one_process_shared_gpu.json
   (FORMS=cluster KERNELS=1 timeout 600 python scripts/shard_time.py 1 2) 2>&1 | grep -v amdgpu.ids | tee $O/r05fin3_shard_overhead_one_gpu.txt
   ;;
+j)  # the sharded probe by sections against an unsharded handle of the same size
+  timeout 600 python scripts/section_clocks_sharded.py 2 2>&1 | grep -v amdgpu.ids | tee $O/r05j_section_clocks_sharded_probe.txt
+  ;;
+k)  # the sharded probe's routing tail behind LDS-only barriers
+  (echo "# strong: 1 048 576 members as G handles"; FORMS=cluster KERNELS=1 timeout 900 python scripts/shard_time.py 1 2 4 8;
+   for G in 2 4; do echo "# weak: $G x 1 048 576 members vs one handle of $((G * 1048576))"; MEMBERS=$((G * 1048576)) FORMS=cluster WARM=100 TICKS=30 timeout 900 python scripts/shard_time.py 1 $G; done) 2>&1 | grep -v amdgpu.ids | tee $O/r05k_shard_overhead_one_gpu.txt
+  (cd /tmp && export TMPDIR=/tmp && for G in 2; do FORMS=cluster WARM=100 TICKS=30 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_k$G -o t -- python $R/scripts/shard_time.py $G > /dev/null 2>&1; echo "# $G handles of one 1 048 576-member population, swimsim_cluster_step (130 ticks), rocprofv3 --kernel-trace --stats:"; python $R/scripts/kernel_stats.py /tmp/prof_k$G 8; done) 2>&1 | tee $O/r05k_rocprof_sharded_kernels.txt
+  ;;
 esac
