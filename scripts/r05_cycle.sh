@@ -71,4 +71,12 @@ k)  # the sharded probe's routing tail behind LDS-only barriers
    for G in 2 4; do echo "# weak: $G x 1 048 576 members vs one handle of $((G * 1048576))"; MEMBERS=$((G * 1048576)) FORMS=cluster WARM=100 TICKS=30 timeout 900 python scripts/shard_time.py 1 $G; done) 2>&1 | grep -v amdgpu.ids | tee $O/r05k_shard_overhead_one_gpu.txt
   (cd /tmp && export TMPDIR=/tmp && for G in 2; do FORMS=cluster WARM=100 TICKS=30 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_k$G -o t -- python $R/scripts/shard_time.py $G > /dev/null 2>&1; echo "# $G handles of one 1 048 576-member population, swimsim_cluster_step (130 ticks), rocprofv3 --kernel-trace --stats:"; python $R/scripts/kernel_stats.py /tmp/prof_k$G 8; done) 2>&1 | tee $O/r05k_rocprof_sharded_kernels.txt
   ;;
+l)  # the known-ring learns the rumours a member states itself (A/B on one cluster)
+  (ROUNDS=7 timeout 600 python scripts/ab_time.py $C/libswimsim_x_noown.so $C/libswimsim_x_own.so; echo '# 1 % loss:'; LOSS=10000 ROUNDS=5 CHUNK=20 timeout 600 python scripts/ab_time.py $C/libswimsim_x_noown.so $C/libswimsim_x_own.so) 2>&1 | grep -v amdgpu.ids | tee $O/r05l_ab_own_known.txt
+  ;;
+fin4)  # the round's last kernels (the known-ring learns what a member states itself): tests, bench lines, trace, PMC, the sharded forms
+  bash scripts/gpu_cycle.sh r05fin4 tests bench prof pmc
+  SWIM_BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 2 --steps 20 --warmup 5 2>/dev/null | grep -v amdgpu.ids > $O/r05fin4_bench_gpus2_one_process_shared_gpu.json
+  (FORMS=cluster KERNELS=1 timeout 600 python scripts/shard_time.py 1 2 4) 2>&1 | grep -v amdgpu.ids | tee $O/r05fin4_shard_overhead_one_gpu.txt
+  ;;
 esac
