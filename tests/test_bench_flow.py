@@ -44,21 +44,3 @@ def test_bench_line_single_process(monkeypatch, gpus):
         assert ex["bytes_per_gpu_per_tick"] >= 512 * 9 * (gpus - 1) and ex["xgmi_peak_GBs"] == 7 * 153.0
         assert "ONE process" in out["config"]["parallelism"]
 
-
-@pytest.mark.gpu
-def test_bench_gpus2_as_the_driver_starts_it_on_the_gpu():
-    """`python bench.py --gpus 2 --steps K --warmup W` exactly as the driver starts it (no torch.distributed.run): ONE process, two
-    handles stepped by swimsim_cluster_step -- here both on device 0 (SWIM_BENCH_SHARE_GPU=1: a one-GPU box) --, one JSON line,
-    the cluster verified against the oracle inside the run."""
-    import subprocess
-    env = dict(os.environ, SWIM_BENCH_SHARE_GPU="1")
-    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
-        env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "3", "--members", "65536"],
-                         env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["warmup"] == 3 and d["verified_vs_oracle"] is True
-    assert d["exchange"]["bytes_per_gpu_per_tick"] > 0 and d["roofline"]["frac"] > 0 and d["cpu_baseline"]["cores"] >= 1
