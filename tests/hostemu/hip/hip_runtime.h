@@ -63,7 +63,11 @@ static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; 
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t bytes) {
+#ifdef HOSTEMU_EXACT_ALLOC            // (AddressSanitizer runs: no slack behind an allocation, so that an access one element past it is caught)
+  if (posix_memalign(p, 256, bytes ? bytes : 1)) *p = nullptr;
+#else
   *p = aligned_alloc(256, (bytes + 255) & ~(size_t)255);
+#endif
   return *p ? hipSuccess : hipErrorOutOfMemory;
 }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
