@@ -5,6 +5,12 @@ TAG=$1; shift; WHAT="${*:-tests bench extra variants shard prof pmc}"
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out; mkdir -p $O
 cd $R
 has() { [[ " $WHAT " == *" $1 "* ]]; }
+# canary (round 5: one cycle ran on a box on which every process died of a GPU memory access fault and dumped core for minutes each,
+# the whole budget of the round went with it): the smoke run first, nothing else on a box that fails it
+if ! timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_canary.log 2>&1; then
+  tail -5 $O/${TAG}_canary.log; echo "gpu_cycle: the smoke run failed on this box -- nothing else is started"; exit 3
+fi
+ulimit -c 0            # (no core dumps of processes with 100+ GB of mappings)
 b() { name=$1; shift; timeout 400 python bench.py "$@" > $O/${TAG}_bench_$name.json 2> $O/${TAG}_bench_$name.err; tail -c 1800 $O/${TAG}_bench_$name.json; tail -2 $O/${TAG}_bench_$name.err; }
 if has tests; then
   timeout 1500 python -m pytest tests -m gpu -x -q --durations=6 2>&1 | tail -16 | tee $O/${TAG}_pytest.log
