@@ -311,7 +311,7 @@ def test_periodic_state_pull_parity(oracle_abi, emu_abi, T, gc, loss, push):
     settling; compared every few ticks -- counters, digest, views, queues, timers (via the digest) and events.  push = 1: a push-pull --
     the host merges the puller's map too (push_kernel: several pullers of one host raise its cells with atomics)."""
     from swim_amd import _abi
-    n = 700 if loss < 300000 else 300                # (30 % loss: every member a subject, the emulation is slow)
+    n = 700 if loss < 150000 else 300                # (15-30 % loss: every member a subject, the emulation is slow)
     sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=31 + T, lossPpm=loss, eventMask=0x1F, suspicionTicks=6,
                    maxSubjects=n, gcTicks=_abi.GC_AUTO if gc else 0, joinPull=1, pullTicks=T, pushPull=bool(push))
     crashes = [(3 + 2 * k, (37 * k + 11) % n) for k in range(40)]
