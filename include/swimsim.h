@@ -409,7 +409,10 @@ int swimsim_get_config(const swimsim_t* h, swimsim_config_t* out);
  * rumour about.  On a sharded cluster the message goes to the handle that owns `observer` (SWIMSIM_ERR_INVALID on the others).  Not
  * available with bounded member maps.  A known limit: an observer that has MORE than inbox_cap messages pending, goes
  * down and comes back up within the one tick that delivers them keeps the part of them that sat in the inbox overflow list (the
- * oracle drops all of them); no test or workload gets there (inbox_cap messages to one observer between two ticks). */
+ * oracle drops all of them); no test or workload gets there (inbox_cap messages to one observer between two ticks).  Another, on
+ * sharded clusters with pull_ticks: the view row such a message opens exists on the observer's shard only, so a member of ANOTHER shard
+ * that pulls the named subject's own map in that very tick does not take the subject's own incarnation over as the specification's
+ * cluster-wide row would have it (found by a soak, not by a workload). */
 int swimsim_inject_rumor(swimsim_t* h, uint32_t observer, uint32_t subject, uint8_t state, uint32_t incarnation);
 
 /* ---- sharded clusters (one handle per GPU / process) -------------------------------
