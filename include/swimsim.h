@@ -34,10 +34,13 @@
 extern "C" {
 #endif
 
-/* 6: config fields strict_reference_rules, push_pull (round 4); 5: view_cap, counter EVICTED, swimsim_cluster_step, the wire codec's
+/* 7: the embedder-facing exchange of dense shards (round 5: SWIMSIM_PREC_BYTES 16 -> 8, kind 0 = one segment for every peer, kind 2
+ * gone, the kind-5/6 gathers mandatory in round 1 of swimsim_shard_step) + swimsim_note_outside_rumor (round 6) -- a host built against
+ * the header of version 6 would copy the wrong strides, so it is refused at swimsim_create instead; 6: config fields
+ * strict_reference_rules, push_pull (round 4); 5: view_cap, counter EVICTED, swimsim_cluster_step, the wire codec's
  * bare form (round 4); 4: pull_ticks, swimsim_inject_rumor, the bridge (round 3).  A handle is refused unless struct_size and
  * abi_version match the library's. */
-#define SWIMSIM_ABI_VERSION 6u
+#define SWIMSIM_ABI_VERSION 7u
 
 /* ---- status codes ------------------------------------------------------ */
 typedef enum swimsim_status {
@@ -409,11 +412,11 @@ int swimsim_get_config(const swimsim_t* h, swimsim_config_t* out);
  * rumour about.  On a sharded cluster the message goes to the handle that owns `observer` (SWIMSIM_ERR_INVALID on the others).  Not
  * available with bounded member maps.  A known limit: an observer that has MORE than inbox_cap messages pending, goes
  * down and comes back up within the one tick that delivers them keeps the part of them that sat in the inbox overflow list (the
- * oracle drops all of them); no test or workload gets there (inbox_cap messages to one observer between two ticks).  Another, on
- * sharded clusters with pull_ticks: the view row such a message opens exists on the observer's shard only, so a member of ANOTHER shard
- * that pulls the named subject's own map in that very tick does not take the subject's own incarnation over as the specification's
- * cluster-wide row would have it (found by a soak, not by a workload). */
+ * oracle drops all of them); no test or workload gets there (inbox_cap messages to one observer between two ticks). */
 int swimsim_inject_rumor(swimsim_t* h, uint32_t observer, uint32_t subject, uint8_t state, uint32_t incarnation);
+/* Sharded clusters: the handles that do NOT own `observer` are told of the message too -- it opens the subject's view row, and a view
+ * row is a property of the whole cluster (a state pull on any shard walks it in the tick the message is delivered). */
+int swimsim_note_outside_rumor(swimsim_t* h, uint32_t observer, uint32_t subject);
 
 /* ---- sharded clusters (one handle per GPU / process) -------------------------------
  * The population is split into n_shards contiguous id ranges.  Every shard gets the SAME
@@ -453,7 +456,6 @@ int swimsim_inject_rumor(swimsim_t* h, uint32_t observer, uint32_t subject, uint
 #define SWIMSIM_RREC_BYTES 16u
 #define SWIMSIM_PREC_BYTES 8u            /* dense handles; bounded handles: */
 #define SWIMSIM_PREC_BOUNDED_BYTES 16u
-#define SWIMSIM_XREC_BYTES 72u           /* (unused since round 5) */
 int swimsim_shard_info(const swimsim_t* h, uint32_t* lo, uint32_t* n_local, uint32_t* r_cap,
                        uint32_t* p_cap, uint32_t* x_cap);
 int swimsim_shard_buffers(swimsim_t* h, void** send /*[3]*/, void** recv /*[3]*/);

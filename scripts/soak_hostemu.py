@@ -11,15 +11,28 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from swim_amd import Config, Sim, SimConfig, workloads, _abi
 from swim_amd.shard import LocalFabric, ShardedSim
 from tests import hostemu_binding, oracle_binding
-orc = oracle_binding.load()
-variants = {"": hostemu_binding.load(), "rid10": hostemu_binding.load_variant("rid10", ["SWIM_RID_BITS=10"]),
-            "rid8": hostemu_binding.load_variant("rid8", ["SWIM_RID_BITS=8"]), "win4": hostemu_binding.load_variant("win4", ["SWIM_MASK_WIN=4", "SWIM_MASK_SLACK=2"])}
-seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-t_end = time.time() + float(sys.argv[2]) if len(sys.argv) > 2 else time.time() + 1200
-k = 0
-while time.time() < t_end:
-    rng = random.Random(seed0 * 100003 + k); k += 1
-    vname = rng.choice(list(variants))
+_VARIANT_DEFS = {"": None, "rid10": ["SWIM_RID_BITS=10"], "rid8": ["SWIM_RID_BITS=8"], "win4": ["SWIM_MASK_WIN=4", "SWIM_MASK_SLACK=2"]}
+_loaded = {}
+
+
+def _variant(name):
+    """The emulation build `name` (built on first use: a test that replays one case needs one build, not four)."""
+    if name not in _loaded:
+        _loaded[name] = hostemu_binding.load() if _VARIANT_DEFS[name] is None else hostemu_binding.load_variant(name, _VARIANT_DEFS[name])
+    return _loaded[name]
+
+
+def _oracle():
+    if "orc" not in _loaded:
+        _loaded["orc"] = oracle_binding.load()
+    return _loaded["orc"]
+
+
+def run_case(seed0, k, log=print):
+    """Case k of the soak with seed seed0 (the whole case is a function of the two): returns (ok, what).  Every 20 ticks: counters,
+    digest, events; first-detection ticks at the end.  tests/test_shard_hostemu.py replays the cases that once diverged."""
+    rng = random.Random(seed0 * 100003 + k)
+    vname = rng.choice(list(_VARIANT_DEFS))
     n = rng.choice([130, 300, 700, 1500, 3000])
     shards = rng.choice([1, 1, 2, 3, 4, 8])                      # sharded clusters take every option of the plain handle
     n -= n % shards
@@ -39,14 +52,14 @@ while time.time() < t_end:
                    joinPull=1 if jp else 0, inboxCap=rng.choice([0, 0, 2]), targetScheme=scheme,
                    pullTicks=pt, pushPull=pp, strictReferenceRules=strict)
     os.environ["SWIMSIM_FOLD_BEGIN"] = fold
-    a = Sim.create(orc, sc)
+    a = Sim.create(_oracle(), sc)
     rm = shards > 1 and rng.random() < 0.5                       # replicated queue masks (read from the environment at create)
     os.environ["SWIMSIM_CLUSTER_STEP"] = "0" if rm else "1"
     rk = rng.choice(["", "0", "1"])                              # explicit records: the handle's own choice / phase in merge_kernel / records_kernel
     if rk: os.environ["SWIMSIM_RECORDS_KERNEL"] = rk
     else: os.environ.pop("SWIMSIM_RECORDS_KERNEL", None)
     inject = rng.random() < 0.4                                  # rumours from outside the simulation (swimsim_inject_rumor; on shards: to the observer's owner)
-    b = Sim.create(variants[vname], sc) if shards == 1 else ShardedSim(variants[vname], sc, LocalFabric(shards))
+    b = Sim.create(_variant(vname), sc) if shards == 1 else ShardedSim(_variant(vname), sc, LocalFabric(shards))
     nf = rng.randrange(0, n // 4)
     for _ in range(nf):
         m, t = rng.randrange(n), rng.randrange(1, ticks)
@@ -71,8 +84,19 @@ while time.time() < t_end:
             if da == 0 and db == 0: assert ea == eb, "events"
         assert a.firstDetection() == b.firstDetection(), "fd"
     except AssertionError as e:
-        ok = False; print("DIVERGED", e, what, "tick", a.tick, flush=True)
+        ok = False; log("DIVERGED", e, what, "tick", a.tick, flush=True)
     except Exception as e:
-        ok = False; print("ERROR", repr(e)[:200], what, flush=True)
-    print("ok" if ok else "FAIL", what, b.tableStats() if ok and shards == 1 else "", flush=True)
+        ok = False; log("ERROR", repr(e)[:200], what, flush=True)
+    finally:
+        for v in ("SWIMSIM_FOLD_BEGIN", "SWIMSIM_CLUSTER_STEP", "SWIMSIM_RECORDS_KERNEL"): os.environ.pop(v, None)
+    log("ok" if ok else "FAIL", what, b.tableStats() if ok and shards == 1 else "", flush=True)
     a.close(); b.close()
+    return ok, what
+
+
+if __name__ == "__main__":
+    seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    t_end = time.time() + float(sys.argv[2]) if len(sys.argv) > 2 else time.time() + 1200
+    k = 0
+    while time.time() < t_end:
+        run_case(seed0, k); k += 1

@@ -8,7 +8,7 @@ that loading happens in tests/ only, never in this package.
 """
 import ctypes as C
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 OK = 0
 ERR_INVALID, ERR_DEVICE, ERR_NOMEM, ERR_CAPACITY, ERR_STATE, ERR_BUFFER = -1, -2, -3, -4, -5, -6
@@ -115,6 +115,7 @@ _PRODUCT_ONLY = {
     "shard_join_buffers": (C.c_int, [_H, _VPP, _VPP, _U32P]),
     "shard_join_ingest": (C.c_int, [_H, _U32P]),
     "shard_traffic": (C.c_int, [_H, C.POINTER(C.c_uint64)]),
+    "note_outside_rumor": (C.c_int, [_H, C.c_uint32, C.c_uint32]),
     "shard_get_first_suspect": (C.c_int, [_H, _U32P, C.c_size_t]),
     "shard_set_first_suspect": (C.c_int, [_H, _U32P, C.c_size_t]),
     "table_stats": (C.c_int, [_H, C.POINTER(C.c_uint64), C.c_size_t]),

@@ -1260,6 +1260,17 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
 #pragma unroll
       for (int h = 0; h < PB_SLOTS / 2; ++h)
         oslot[h] = (pe_tx(ol[h].y) ? pe_slot(ol[h].x) : 0xFFFFu) | ((pe_tx(ol[h].w) ? pe_slot(ol[h].z) : 0xFFFFu) << 16);
+#ifndef SWIM_NO_OWN_KNOWN
+      // My view dominates every rumour of my own queue (I accepted or stated each of them, entries only grow): their ring
+      // positions are KNOWN.  The ring learns what gossip delivers (`fresh` below) -- but a rumour this member STATED itself (its
+      // suspicion deadline firing: one per member and crash) was news to the ring when the same rumour came round by gossip: one
+      // futile view-cell load per member-tick of the saturated regime, a quarter of the kernel's scattered loads (round 5).
+#pragma unroll
+      for (int h = 0; h < PB_SLOTS / 2; ++h) {
+        if (pe_tx(ol[h].y) && rid_in_ring(pe_rid(ol[h].x), H)) kn |= rid_bit(pe_rid(ol[h].x));
+        if (pe_tx(ol[h].w) && rid_in_ring(pe_rid(ol[h].z), H)) kn |= rid_bit(pe_rid(ol[h].z));
+      }
+#endif
     }
   }
   auto kill_slot = [&](uint32_t slot) {
@@ -1336,6 +1347,9 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
     if (cause == 1u) timers_fired += 1u + ((uint32_t)mi_up(s.minfo[subject]) << 16);
     if ((key & 3u) == ST_SUSPECT) tput(slot + 1);                     // deadline t + S (D4)
     const uint32_t rid = (hasrid || ABL(ABL_FIND_RID)) ? rid_in : find_rid(s, slot, key);
+#ifndef SWIM_NO_OWN_KNOWN
+    if (!hasrid && rid_in_ring(rid, H)) kn |= rid_bit(rid);          // a rumour I state under an id of the window: known from now on
+#endif
     if (!ABL(ABL_GROUP)) {
     kill_slot(slot);
     group_put(slot, rid, key, subject);          // `Just msg` -> Broadcast -> enqueue (D5)
@@ -2495,6 +2509,9 @@ __global__ void inject_kernel(DevState s, uint32_t t, const InjectRec* recs, uin
   const InjectRec r = recs[k];
   if (!mi_up(s.minfo[r.observer])) return;          // nobody listening
   const uint32_t slot = get_slot(s, r.subject);
+  // (a shard that does not own the observer: the subject's view row only -- a row is a property of the whole cluster, DESIGN.md 2.4 /
+  // 2.6: a state pull on THIS shard walks it in this very tick)
+  if (r.pad) return;
   uint32_t num = 0;
   (void)num;
   const uint32_t rid = find_rid(s, slot, r.key, &num);      // handed out before the tick's window head is taken: an id like any of the tick before

@@ -675,10 +675,19 @@ int swimsim_inject_rumor(swimsim_t* h, uint32_t observer, uint32_t subject, uint
   if (!h) return SWIMSIM_ERR_INVALID;
   if (observer >= h->d.NT || subject >= h->d.NT || state > 2 || incarnation > INC_MAX)
     return set_err(h, SWIMSIM_ERR_INVALID, "inject_rumor: bad member / state / incarnation");
-  if (observer - h->d.lo >= h->d.N) return set_err(h, SWIMSIM_ERR_INVALID, "inject_rumor: the observer is a member of another shard (its owner takes the message)");
+  if (observer - h->d.lo >= h->d.N) return set_err(h, SWIMSIM_ERR_INVALID, "inject_rumor: the observer is a member of another shard (its owner takes the message; the others: swimsim_note_outside_rumor)");
   if (h->d.C) return set_err(h, SWIMSIM_ERR_INVALID, "inject_rumor: not available with bounded member maps (view_cap)");
   if (h->injections.size() >= INJECT_CAP) return set_err(h, SWIMSIM_ERR_BUFFER, "inject_rumor: more than 4096 rumours before the next tick");
   h->injections.push_back(InjectRec{observer, subject, (incarnation << 2) | state, 0u});
+  return SWIMSIM_OK;
+}
+
+int swimsim_note_outside_rumor(swimsim_t* h, uint32_t observer, uint32_t subject) {
+  if (!h) return SWIMSIM_ERR_INVALID;
+  if (observer >= h->d.NT || subject >= h->d.NT) return set_err(h, SWIMSIM_ERR_INVALID, "note_outside_rumor: bad member");
+  if (h->d.C || h->d.n_shards < 2 || observer - h->d.lo < h->d.N) return set_err(h, SWIMSIM_ERR_INVALID, "note_outside_rumor: for the shards that do NOT own the observer of a message from outside");
+  if (h->injections.size() >= INJECT_CAP) return set_err(h, SWIMSIM_ERR_BUFFER, "note_outside_rumor: more than 4096 before the next tick");
+  h->injections.push_back(InjectRec{observer, subject, 0u, 1u});
   return SWIMSIM_OK;
 }
 
@@ -1406,10 +1415,15 @@ int swimsim_shard_settle_commit(swimsim_t* h, const uint32_t* counts_in) {
  * an exchange callback to swimsim_shard_step.  hs[k] must be shard k of n bounded (view_cap) handles of one configuration with the
  * same fault schedule. */
 // what must be equal across the handles of a cluster: the resolved configuration apart from the shard index and the device
+// (field by field: the struct has padding -- behind num_to_gossip and n_members -- that resolve_config copies from the caller's
+// struct as it finds it; a memcmp refused valid clusters whose configs were filled in on the stack)
 static bool same_cluster_config(const swimsim_config_t& a, const swimsim_config_t& b) {
-  swimsim_config_t x = a, y = b;
-  x.shard_index = y.shard_index = 0; x.device = y.device = 0;
-  return std::memcmp(&x, &y, sizeof x) == 0;
+#define SAME(f) (a.f == b.f)
+  return SAME(struct_size) && SAME(abi_version) && SAME(num_to_gossip) && SAME(gossip_interval_us) && SAME(n_members) && SAME(seed) &&
+         SAME(probes_per_tick) && SAME(indirect_k) && SAME(loss_ppm) && SAME(suspicion_ticks) && SAME(retransmit_mult) &&
+         SAME(max_subjects) && SAME(gc_ticks) && SAME(event_cap) && SAME(event_mask) && SAME(inbox_cap) && SAME(n_shards) &&
+         SAME(target_scheme) && SAME(join_pull) && SAME(pull_ticks) && SAME(view_cap) && SAME(strict_reference_rules) && SAME(push_pull);
+#undef SAME
 }
 
 /* The same for DENSE handles.  Per tick and handle, on the handle's own stream:
@@ -1491,7 +1505,7 @@ static int cluster_step_dense(swimsim_t** hs, uint32_t n, uint32_t nticks) {
       const uint32_t nf = (uint32_t)(fpos[k] - f0);
       if (tck) for (uint32_t p = 0; p < n; ++p) if (p != k) CCHK(h, hipStreamWaitEvent(h->stream, ev[p][2], 0));   // the peers are done with my send buffers
       bool inj = false;                                // messages from outside (swimsim_inject_rumor) go into the first tick's inboxes
-      if (!h->injections.empty()) { const int rc_ = flush_injections(h, t, &inj); if (rc_) { for (uint32_t q = 0; q < n; ++q) hs[q]->poisoned = hs[q]->poisoned || tck != 0; cleanup(); return rc_; } }
+      if (!h->injections.empty()) { const int rc_ = flush_injections(h, t, &inj); if (rc_) { for (uint32_t q = 0; q < n; ++q) hs[q]->poisoned = hs[q]->poisoned || tck != 0 || k != 0; cleanup(); return rc_; } }   // (k != 0: handles 0..k-1 are past begin_kernel of this tick)
       injs[k] = inj;
       if (round0) {
         hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, nf, h->d_joined, 1u, PeerCounts{}, JoinView{});

@@ -365,6 +365,9 @@ class ShardedSim:
         self._injected = True
         if s is not None:
             s.sim.injectRumor(observer, subject, state, incarnation)
+        for o in self.shards:                         # the other shards open the subject's view row (a row belongs to the whole cluster)
+            if o is not s:
+                o.sim._check(o.sim._abi.note_outside_rumor(o.sim._h, observer, subject))
 
     # -- the hot path ------------------------------------------------------------------------------------
     def _step_by_library(self, nticks: int):

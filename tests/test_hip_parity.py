@@ -685,6 +685,37 @@ def test_periodic_state_pull_on_sharded_clusters_on_one_gpu(oracle_abi, hip_abi,
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("n,shards,T,loss", [(3000, 2, 3, 100000), (4096, 4, 5, 50000), (65536, 4, 64, 10000)])
+def test_messages_from_outside_with_state_pulls_and_settling_on_sharded_clusters_on_one_gpu(oracle_abi, hip_abi, n, shards, T, loss):
+    """swimsim_inject_rumor x pull_ticks x settling x 2-4 shards on MI355X (the soak case 703/24 is replayed on the
+    emulation, tests/test_shard_hostemu.py): a message from outside opens its subject's view row on EVERY shard
+    (swimsim_note_outside_rumor), so a puller of another shard that pulls the subject's own map in that tick sees it.  = the unsharded oracle."""
+    from swim_amd import _abi
+    from swim_amd.shard import LocalFabric, ShardedSim
+    events = n <= 4096
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=91 + T, lossPpm=loss, eventMask=0x1F if events else 0, suspicionTicks=5,
+                   maxSubjects=min(n, 4096), gcTicks=_abi.GC_AUTO, joinPull=1, pullTicks=T)
+    a, b = Sim.create(oracle_abi, sc), ShardedSim(hip_abi, sc, LocalFabric(shards), device="cuda:0")
+    _oracle_threads(a)
+    for s in (a, b):
+        for k in range(12):
+            s.crash((53 * k + 7) % n, 4 + 3 * k)
+            if k % 2 == 0:
+                s.scheduleFault(4 + 3 * k + 11 + k, (53 * k + 7) % n, True)
+    for blk in range(30):
+        for s in (a, b):
+            for j in range(10):
+                x = blk * 10 + j
+                s.injectRumor((977 * x + 5) % n, (1201 * x + 40) % n, x % 3, (x // 3) % 3)
+        a.step(2); b.step(2)
+        assert a.counters() == b.counters() and a.digest() == b.digest(), "tick %d" % a.tick
+        if events:
+            assert a.drainEventsRaw() == b.drainEventsRaw()
+    assert a.firstDetection() == b.firstDetection()
+    assert b.counters()["settled"] > 0
+    a.close(); b.close()
+
+
 # ---- bounded member maps (view_cap; swim_sparse.h): BASELINE config 5 at the sizes a dense view cannot reach --------------------
 def _config5_case(n, cap, churn_per_mille, ticks, seed=1):
     """30 % message loss x `churn_per_mille`/1000 of the members crash-and-rejoin per 100 ticks."""

@@ -218,3 +218,50 @@ def test_cluster_step_checks_its_handles(emu_abi):
     assert emu_abi.cluster_step(arr(a, c), 2, 1) == _abi.ERR_INVALID and b"ONE cluster" in emu_abi.last_error(c._h)   # another seed (and another tick)
     for s in (a, b, c):
         s.close()
+
+
+def _soak():
+    import importlib.util, os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "soak_hostemu.py")
+    spec = importlib.util.spec_from_file_location("soak_hostemu", path)
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    return mod
+
+
+def test_soak_case_703_24_a_message_from_outside_opens_its_row_on_every_shard():
+    """The case a round-5 soak found (scripts/soak_hostemu.py 703, case 24): 130 members on 2 shards, 20 % loss, settling, join pulls,
+    pull_ticks = 40, messages from outside.  A message from outside gives its subject a view row -- on EVERY shard:
+    a member of another shard than the observer's that pulls the subject's own map in that very tick must take the subject's own
+    incarnation over (src/Core.hs:110-117 feeds the rule; the row is what a state pull walks).  Before swimsim_note_outside_rumor the
+    row existed on the observer's shard only and counters / settled counts parted from the oracle at tick 300."""
+    ok, what = _soak().run_case(703, 24, log=lambda *a, **k: None)
+    assert ok, what
+
+
+@pytest.mark.parametrize("shards,T,n", [(2, 3, 600), (4, 5, 1000), (3, 40, 300)])
+def test_messages_from_outside_with_state_pulls_and_settling_on_shards(oracle_abi, emu_abi, shards, T, n):
+    """swimsim_inject_rumor x pull_ticks x settling x shards, deliberately dense in the combination that diverged: many messages from
+    outside per tick about members nobody else talks about (their row exists only because of the message), pullers on every shard in
+    every tick (small T), hosts that ARE the named subjects."""
+    from swim_amd import _abi
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=91 + T, lossPpm=100000, eventMask=0x1F, suspicionTicks=5,
+                   maxSubjects=n, gcTicks=_abi.GC_AUTO, joinPull=1, pullTicks=T)
+    a = Sim.create(oracle_abi, sc)
+    b = ShardedSim(emu_abi, sc, LocalFabric(shards))
+    for s in (a, b):
+        for k in range(12):
+            s.crash((53 * k + 7) % n, 4 + 3 * k)
+            if k % 2 == 0:
+                s.scheduleFault(4 + 3 * k + 11 + k, (53 * k + 7) % n, True)
+    for blk in range(30):
+        for s in (a, b):
+            for j in range(10):
+                x = blk * 10 + j
+                s.injectRumor((977 * x + 5) % n, (1201 * x + 40) % n, x % 3, (x // 3) % 3)
+        a.step(2); b.step(2)
+        assert a.counters() == b.counters(), "counters differ at tick %d" % a.tick
+        assert a.digest() == b.digest(), "digest differs at tick %d" % a.tick
+        assert a.drainEventsRaw() == b.drainEventsRaw(), "events differ at tick %d" % a.tick
+    assert a.firstDetection() == b.firstDetection()
+    assert b.counters()["settled"] > 0
+    a.close(); b.close()
