@@ -2,16 +2,20 @@
 digests), are warmed up together and then stepped in turn, CHUNK ticks at a time, for ROUNDS rounds -- so that clock
 drift, the phase of the workload and the placement of a fresh allocation hit every variant alike.  Reports the median
 (and min) over the rounds of each tick kernel's HIP-event time per tick.
-usage: ab_time.py lib.so [lib.so ...]    env: WARM, CHUNK, ROUNDS, MEMBERS, LOSS (ppm), GC=1, SCHEME=robust, P"""
+usage: ab_time.py lib.so [lib.so ...]    env: WARM, CHUNK, ROUNDS, MEMBERS, LOSS (ppm), GC=1, SCHEME=robust, P, CPT (crashes per tick: 9.5 = BASELINE.md
+row 3(s) as written, with GC=1 MAXSUBJ=8192), MAXSUBJ"""
 import json, os, statistics, sys, time, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from swim_amd import Sim, workloads, _abi
 WARM = int(os.environ.get('WARM', 150)); CHUNK = int(os.environ.get('CHUNK', 40)); ROUNDS = int(os.environ.get('ROUNDS', 7))
 N = int(os.environ.get('MEMBERS', 1 << 20)); LOSS = int(os.environ.get('LOSS', 0)); P = int(os.environ.get('P', 3))
+CPT = float(os.environ.get('CPT', 1.0)); MAXSUBJ = int(os.environ.get('MAXSUBJ', 0))
 sims = []
 for path in sys.argv[1:]:
     abi = _abi.bind(C.CDLL(os.path.abspath(path)), "swimsim_")
-    sc, crashes, _ = workloads.saturated(N, WARM + CHUNK * ROUNDS, loss_ppm=LOSS, num_to_gossip=P)
+    sc, crashes, _ = workloads.saturated(N, WARM + CHUNK * ROUNDS, loss_ppm=LOSS, num_to_gossip=P, crashes_per_tick=CPT, t0=0)
+    if MAXSUBJ:
+        sc.maxSubjects = MAXSUBJ
     if os.environ.get('GC'):
         sc.gcTicks = _abi.GC_AUTO
     sc.targetScheme = 1 if os.environ.get('SCHEME') == 'robust' else 0

@@ -8,4 +8,22 @@ case "$1" in
 a)  # the two patches of round 5 (a message from outside opens its row on every shard; the known-ring learns what a member states): suite, bench lines, trace, PMC
   bash scripts/gpu_cycle.sh r06a tests bench prof pmc
   ;;
+b)  # merge_kernel: decide (wave-uniform union walk, coalesced rows) + book (per-lane, from LDS) against the per-lane walk of rounds 2-5,
+    # interleaved on one cluster, in both regimes (the headline's 1 crash per tick; BASELINE.md row 3(s) as written: 9.5 per tick);
+    # the guide's grid barriers
+  canary b
+  (echo "# headline regime (1 crash per tick): per-lane walk | union walk, batches of 4 | of 2 | of 8"; ROUNDS=7 timeout 900 python scripts/ab_time.py $C/libswimsim_x_nounion.so $C/libswimsim.so $C/libswimsim_x_u2.so $C/libswimsim_x_u8.so;
+   echo "# BASELINE.md row 3(s) as written (9.5 crashes per tick, settling, 8192 rows):"; CPT=9.5 GC=1 MAXSUBJ=8192 WARM=200 CHUNK=20 ROUNDS=5 timeout 900 python scripts/ab_time.py $C/libswimsim_x_nounion.so $C/libswimsim.so $C/libswimsim_x_u2.so $C/libswimsim_x_u8.so;
+   echo "# 1 % loss:"; LOSS=10000 GC=1 ROUNDS=5 CHUNK=20 timeout 900 python scripts/ab_time.py $C/libswimsim_x_nounion.so $C/libswimsim.so) 2>&1 | grep -v amdgpu.ids | tee $O/r06b_ab_merge_union.txt
+  (cd scripts/microbench && timeout 300 ./grid_barrier_xcd 20 50) 2>&1 | tee $O/r06b_microbench_grid_barrier.txt
+  ;;
+c)  # the ring directory (a stated rumour takes id and subject from the tick's ring: no find_rid / subject_of / minfo chain) A/B; the union walk in
+    # BASELINE.md row 3(s) as written; the default bench run with its second window
+  canary c
+  (echo "# headline regime: without | with the ring directory | union walk + directory"; ROUNDS=7 timeout 900 python scripts/ab_time.py $C/libswimsim_x_nodir.so $C/libswimsim.so $C/libswimsim_x_union.so;
+   echo "# 1 % loss, settling:"; LOSS=10000 GC=1 ROUNDS=5 CHUNK=20 timeout 900 python scripts/ab_time.py $C/libswimsim_x_nodir.so $C/libswimsim.so;
+   echo "# BASELINE.md row 3(s) as written (9.5 crashes per tick, settling, 8192 rows): per-lane walk | union walk"; CPT=9.5 GC=1 MAXSUBJ=8192 WARM=200 CHUNK=20 ROUNDS=5 timeout 900 python scripts/ab_time.py $C/libswimsim.so $C/libswimsim_x_union.so;
+   echo "# ... without | with the ring directory"; CPT=9.5 GC=1 MAXSUBJ=8192 WARM=200 CHUNK=20 ROUNDS=5 timeout 900 python scripts/ab_time.py $C/libswimsim_x_nodir.so $C/libswimsim.so) 2>&1 | grep -v amdgpu.ids | tee $O/r06c_ab_ring_directory.txt
+  timeout 900 python bench.py --steps 20 --warmup 5 > $O/r06c_bench_default.json 2> $O/r06c_bench_default.err; tail -c 3000 $O/r06c_bench_default.json; tail -3 $O/r06c_bench_default.err
+  ;;
 esac

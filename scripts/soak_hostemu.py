@@ -44,7 +44,7 @@ def run_case(seed0, k, log=print):
     S = rng.choice([4, 7, 12])
     pt = rng.choice([0, 0, 2, 3, 9, 40])                          # periodic state pull (on shards: exchange round 0 in every tick)
     pp = bool(pt) and shards == 1 and rng.random() < 0.5         # ... as a push-pull (one handle only)
-    strict = shards == 1 and not gc and not jp and not pt and rng.random() < 0.5   # the literal suspectOrDeadNode' (no other option with it)
+    strict = not gc and not jp and not pt and rng.random() < 0.5   # the literal suspectOrDeadNode' (no other option with it; on shards too since round 6)
     fold = rng.choice(["0", "1"])                                # plain ticks with / without begin_kernel
     ticks = rng.choice([200, 400, 800])
     sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=rng.randrange(1, 1 << 30), lossPpm=loss, eventMask=0x1F,

@@ -71,6 +71,16 @@ __device__ inline unsigned long long wave_sum64(unsigned long long x) {
   return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, 63) |
          ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), 63) << 32);
 }
+// OR over the 64 lanes of a wave, in every lane (all lanes executing): the DPP steps of wave_sum with | (lanes without a source
+// read 0, the identity of both)
+__device__ inline unsigned long long wave_or64(unsigned long long x) {
+#define SWIM_DPP64(ctrl, rows) x |= (unsigned long long)SWIM_DPP((uint32_t)x, ctrl, rows) | ((unsigned long long)SWIM_DPP((uint32_t)(x >> 32), ctrl, rows) << 32)
+  SWIM_DPP64(0x111, 0xf); SWIM_DPP64(0x112, 0xf); SWIM_DPP64(0x114, 0xf); SWIM_DPP64(0x118, 0xf);
+  SWIM_DPP64(0x142, 0xa); SWIM_DPP64(0x143, 0xc);
+#undef SWIM_DPP64
+  return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, 63) |
+         ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), 63) << 32);
+}
 // inclusive prefix sum over the lanes of a wave (the DPP steps of wave_sum leave it in every lane)
 __device__ inline unsigned wave_prefix_incl(unsigned x) {
   x += SWIM_DPP(x, 0x111, 0xf); x += SWIM_DPP(x, 0x112, 0xf); x += SWIM_DPP(x, 0x114, 0xf); x += SWIM_DPP(x, 0x118, 0xf);
@@ -1107,6 +1117,26 @@ __global__ __launch_bounds__(BLOCK, 5) void records_kernel(DevState s, uint32_t 
 #ifndef SWIM_TODO_BATCH         // todo entries (explicit records' survivors) whose view cells merge_kernel loads together
 #define SWIM_TODO_BATCH 2
 #endif
+#ifndef SWIM_MERGE_UNION        // 1: the delivered rumours are DECIDED in a wave-uniform walk over the union of the lanes' new ring positions --
+#define SWIM_MERGE_UNION 0      //    per position a predicated load / compare / store of ONE view row for the wave's 64 consecutive members -- and
+#endif                          //    booked (queue, deadlines, digest, events) by a per-lane walk over what was accepted; 0 (product): each lane walks
+                                //    its own positions.  Round 6, interleaved A/B on one cluster (profiles/r06b_ab_merge_union.txt): the union walk is
+                                //    SLOWER -- 157.4 against 144.7 us saturated, 728 against 707 us at 1 % loss: it saves sector requests (1.4 cells of a
+                                //    wave share a sector) but doubles the rounds of dependent loads a wave waits for (popc(union) / batch against the
+                                //    busiest lane's count / 2), and the kernel is bound by those round trips at the chip's random-access rate.
+#ifndef SWIM_RING_DIR           // 1: a rumour this member STATES itself (a suspicion deadline firing, a failed probe) is looked up in the tick's ring
+#define SWIM_RING_DIR 1         //    first -- an LDS hash of the 64 positions -- and takes its id and subject from there: the Dead a deadline declares
+#endif                          //    is in circulation already for all but the first members to declare it; find_rid + subject_of + minfo were four
+                                //    dependent memory round trips per firing deadline (round 6)
+constexpr uint32_t RDIR_SLOTS = 128;
+__device__ inline uint32_t rdir_hash(uint32_t slot, uint32_t key) { return (slot * 0x9E3779B1u + key * 0x85EBCA77u) >> 25; }   // 7 bits
+#ifndef SWIM_UNION_BATCH        //    positions (rounds 2-5; A/B)
+#define SWIM_UNION_BATCH 4      // union positions whose view cells are loaded together
+#endif
+#ifndef SWIM_ACC_CAP
+#define SWIM_ACC_CAP 8
+#endif
+constexpr int ACC_CAP = SWIM_ACC_CAP;            // accepted rumours a lane parks in LDS between two bookkeeping passes
 constexpr int ASM_STRIDE = BLOCK + 2;   // words per LDS column: keeps the transposed line store conflict-free
 
 // Settling, the per-member part (swim_device.h; begin_kernel builds the lists, settle_finish commits):
@@ -1138,6 +1168,12 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
   __shared__ uint32_t wfl[BLOCK];
   __shared__ uint32_t wmax[BLOCK / 64];
   __shared__ uint4 ring_sh[KN_BITS];                    // this tick's ring (begin_kernel): position -> {slot, key, base, subject}
+#if SWIM_RING_DIR
+  __shared__ uint32_t rdir[RDIR_SLOTS];                 // (slot, key) -> ring position + 1: the tick's ring as a hash table (below)
+#endif
+#if SWIM_MERGE_UNION
+  __shared__ uint32_t acc_sh[ACC_CAP][ASM_STRIDE];      // accepted rumours awaiting their bookkeeping: position | changed-already << 6 | (key - old key) << 7
+#endif
   const uint32_t tid = threadIdx.x;
 #if SWIM_MERGE_SORT
   // Members to threads BY WORK: a wave executes the state rule as often as its busiest lane (the rumour loop runs max-over-lanes
@@ -1203,8 +1239,23 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
   SECT(14);                                         // records phase
   if (up) cnt = s.inbox_cnt[li];                    // entries of my todo list
   if (s.G) settle_pass(s, li, up, wmax);
-  if (tid < KN_BITS) ring_sh[tid] = s.ring[tid];
+  uint4 ring_mine = make_uint4(NONE32, 0u, 0u, 0u);
+  if (tid < KN_BITS) { ring_mine = s.ring[tid]; ring_sh[tid] = ring_mine; }
+#if SWIM_RING_DIR
+  if (tid < RDIR_SLOTS) rdir[tid] = 0u;
+#endif
   ctr_init(&sh);                                   // its barrier also publishes the ring
+#if SWIM_RING_DIR
+  // the ring as a hash table keyed by (slot, key): open addressing, 64 entries in 128 slots, claimed by LDS compare-and-swap.  Two ids
+  // may name one rumour (its cache way was taken over in between, find_rid): either one serves -- ids are never observable.
+  // (an id handed out before its row was given to the row's present subject names a rumour of the PREVIOUS subject -- settling
+  // recycles rows, and a row may have changed hands in this very tick, after the ring was built: not in the table)
+  if (tid < KN_BITS && ring_mine.x < s.R_phys && (int32_t)(rid_at(tid, H) - s.slot_born[ring_mine.x]) >= 0) {
+    uint32_t h = rdir_hash(ring_mine.x, ring_mine.y);
+    while (atomicCAS(&rdir[h], 0u, tid + 1u) != 0u) h = (h + 1u) & (RDIR_SLOTS - 1u);
+  }
+  lds_barrier();
+#endif
   const uint32_t pcount = mi_pbn(mi), cur = mi_buf(mi);
   const bool woke = (hot0.y & 1u) != 0;            // came back up: deadlines it slept through are still in trow
   const bool timer_due = (due.x | due.y | due.z | due.w) != 0u;
@@ -1319,6 +1370,33 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
   // row's base, its subject
   enum { HAVE_CELL = 1, HAVE_BASE = 2, HAVE_SUBJ = 4, EX_LOAD = 0, EX_ALL = HAVE_CELL | HAVE_BASE | HAVE_SUBJ };
   int psite = 47; (void)psite;     // PSITE/PSTAT: path statistics of the host emulation, nothing in the product
+  // an ACCEPTED proposal's bookkeeping (the view cell is stored already): everything `saveMember m'` / `Just msg` entail beyond the
+  // entry itself (src/Core.hs:169-179) -- digest, counters, the deadline of a new suspicion, the queue, the event.  dkey = new key
+  // - old key; again_: the entry changed in this tick before.
+  auto account = [&](uint32_t slot, uint32_t key, uint32_t cause, bool hasrid, uint32_t rid_in, uint32_t dkey, bool again_, uint32_t subject, bool stated) {
+    if (s.G) s.slot_last[slot] = t;              // same value from every writer
+    if (!ha) ha = mix64(mix64((uint64_t)TAG_EV) + (((uint64_t)t << 32) | i));
+    // the running event digest moves by E(t, i, subject) * (key - old key): linear in the key, so the changes of one
+    // entry in one tick telescope whatever their order -- one hash per change (three before: 6 % of the kernel)
+    if (!ABL(ABL_EVD)) evd += (mix64(ha + subject) | 1ull) * (unsigned long long)dkey;
+    changes += again_ ? 0u : 1u;
+    // Suspect -> Dead by timeout; ... of a member that is up all the same (a false positive: ground truth, replicated)
+    if (cause == 1u) timers_fired += 1u + ((uint32_t)(s.mb[subject] & MB_UP) << 16);
+    if ((key & 3u) == ST_SUSPECT) tput(slot + 1);                     // deadline t + S (D4)
+    const uint32_t rid = (hasrid || ABL(ABL_FIND_RID)) ? rid_in : find_rid(s, slot, key);
+#ifndef SWIM_NO_OWN_KNOWN
+    if (stated && rid_in_ring(rid, H)) kn |= rid_bit(rid);           // a rumour I state under an id of the window: known from now on
+#endif
+    if (!ABL(ABL_GROUP)) {
+    kill_slot(slot);
+    group_put(slot, rid, key, subject);          // `Just msg` -> Broadcast -> enqueue (D5)
+    }
+    if (s.event_mask & (1u << cause)) {
+      const uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
+      if (pos < s.event_cap) s.events[pos] = make_uint4(t, i, subject, (key << 8) | cause);
+      else evdropped++;
+    }
+  };
   auto examine_with = [&](uint32_t slot, uint32_t key, uint32_t cause, bool hasrid, uint32_t rid_in, int have, VCell e,
                           uint32_t sbase, uint32_t subject) {
     if (slot + 1 == my_slot1) {
@@ -1336,29 +1414,21 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
     PSTAT(6); PSTAT(psite); SECT_COUNT(21);
     const bool again_ = v_changed_in(s, vidx(s, li, slot), e, t);     // (before the store below)
     if (!ABL(ABL_V_STORE)) v_put(s, vidx(s, li, slot), key, t + 1);                    // memberLastChange = now (:176)
-    if (s.G) s.slot_last[slot] = t;              // same value from every writer
-    if (!(have & HAVE_SUBJ)) subject = s.subject_of[slot];
-    if (!ha) ha = mix64(mix64((uint64_t)TAG_EV) + (((uint64_t)t << 32) | i));
-    // the running event digest moves by E(t, i, subject) * (key - old key): linear in the key, so the changes of one
-    // entry in one tick telescope whatever their order -- one hash per change (three before: 6 % of the kernel)
-    if (!ABL(ABL_EVD)) evd += (mix64(ha + subject) | 1ull) * (unsigned long long)(key - curk);
-    changes += again_ ? 0u : 1u;
-    // Suspect -> Dead by timeout; ... of a member that is up all the same (a false positive: ground truth, replicated)
-    if (cause == 1u) timers_fired += 1u + ((uint32_t)mi_up(s.minfo[subject]) << 16);
-    if ((key & 3u) == ST_SUSPECT) tput(slot + 1);                     // deadline t + S (D4)
-    const uint32_t rid = (hasrid || ABL(ABL_FIND_RID)) ? rid_in : find_rid(s, slot, key);
-#ifndef SWIM_NO_OWN_KNOWN
-    if (!hasrid && rid_in_ring(rid, H)) kn |= rid_bit(rid);          // a rumour I state under an id of the window: known from now on
+    bool stated = !hasrid;                       // a rumour I state myself: the ring learns it (below)
+#if SWIM_RING_DIR
+    if (!hasrid) {
+      // in circulation already?  Then the tick's ring names its id and its subject: no find_rid, no subject_of (two + one
+      // dependent loads; the fourth, ground truth about the subject for FALSE_DEADS, is a byte of the L2-resident mb table)
+      for (uint32_t h = rdir_hash(slot, key);; h = (h + 1u) & (RDIR_SLOTS - 1u)) {
+        const uint32_t v = rdir[h];
+        if (!v) break;
+        const uint4 r = ring_sh[v - 1u];
+        if (r.x == slot && r.y == key) { hasrid = true; rid_in = rid_at(v - 1u, H) & RID_MASK; subject = r.w; have |= HAVE_SUBJ; break; }
+      }
+    }
 #endif
-    if (!ABL(ABL_GROUP)) {
-    kill_slot(slot);
-    group_put(slot, rid, key, subject);          // `Just msg` -> Broadcast -> enqueue (D5)
-    }
-    if (s.event_mask & (1u << cause)) {
-      const uint32_t pos = atomicAdd(&s.g[G_EVCUR], 1u);
-      if (pos < s.event_cap) s.events[pos] = make_uint4(t, i, subject, (key << 8) | cause);
-      else evdropped++;
-    }
+    if (!(have & HAVE_SUBJ)) subject = s.subject_of[slot];
+    account(slot, key, cause, hasrid, rid_in, key - curk, again_, subject, stated);
   };
   auto examine = [&](uint32_t slot, uint32_t key, uint32_t cause, bool hasrid, uint32_t rid_in) {
     examine_with(slot, key, cause, hasrid, rid_in, EX_LOAD, VCell{0u, 0u}, 0u, 0u);
@@ -1459,14 +1529,89 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
       if (key > curk) examine(sl, key, 0u, false, 0u);
     }
   }
-  // phase 3: rumours received this tick (any order: the merge is commutative).  Each lane walks its own new
+  // phase 3: rumours received this tick (any order: the merge is commutative).
+  SECT(2);                                          // deadlines, failed probes
+#if SWIM_MERGE_UNION
+  // DECIDE, then BOOK (round 6).  The lanes of a wave are 64 consecutive members and a view row keeps consecutive members next to
+  // each other (V[tile][row][256]), so the wave walks the UNION of its lanes' new ring positions in one wave-uniform order: per
+  // position ONE predicated load of that row for the lanes that hold the bit -- a run of <= 512 contiguous bytes instead of 64
+  // lanes looking at 64 different rows --, the state rule's comparison (src/Core.hs:151-152), the predicated store (saveMember
+  // m', :169-179) and one word parked in the lane's LDS column {position, changed-before, key step}.  Nothing else rides in that
+  // loop (round 2's union walk dragged the whole bookkeeping through every iteration and lost: 237 us against 188): digest,
+  // deadline, queue entry and event of what was ACCEPTED are booked by a per-lane walk over the parked words -- as many steps as
+  // the busiest lane accepted, all from LDS (the ring's copy says what a position stands for), no memory round trip.
+  {
+    constexpr int UB = SWIM_UNION_BATCH;
+    unsigned long long fresh = act ? (pushed | pulled) & ~kn : 0ull;
+    kn |= fresh;
+    if (ABL(ABL_RUMOURS)) fresh = 0;
+    unsigned long long U = wave_or64(fresh);          // wave-uniform: the positions anybody of the wave has news at
+    uint32_t nacc = 0;
+    auto book = [&]() {
+      for (uint32_t k = 0; k < nacc; ++k) {
+        PSTAT(11);
+        const uint32_t w = acc_sh[k][tid], p = w & 63u;
+        const uint4 r = ring_sh[p];                  // {slot, key, base, subject} of the id at position p
+        account(r.x, r.y, 2u, true, rid_at(p, H) & RID_MASK, w >> 7, ((w >> 6) & 1u) != 0u, r.w, false);
+      }
+      nacc = 0;
+    };
+    while (U) {
+      PSTAT(10);
+      uint32_t p[UB]; uint4 r[UB]; VCell e[UB]; bool has[UB];
+      uint32_t n = 0;
+#pragma unroll
+      for (int k = 0; k < UB; ++k) {
+        p[k] = 0; r[k] = make_uint4(0u, 0u, 0u, 0u); e[k] = VCell{0u, 0u}; has[k] = false;
+        if (U) {
+          p[k] = (uint32_t)__ffsll((unsigned long long)U) - 1u;
+          U &= U - 1ull;
+          r[k] = ring_sh[p[k]];
+          has[k] = ((fresh >> p[k]) & 1ull) != 0ull;
+          n = (uint32_t)k + 1u;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < UB; ++k) {
+        if (!has[k]) continue;
+        if (r[k].x + 1 == my_slot1) {
+          // about self -> refute (src/Core.hs:155-166): remember the largest non-Alive incarnation
+          if ((r[k].y & 3u) != ST_ALIVE) refute = (refute == NONE32 || (r[k].y >> 2) > refute) ? (r[k].y >> 2) : refute;
+          has[k] = false;
+        } else if (!ABL(ABL_V_LOAD)) e[k] = v_hot(s, vidx(s, li, r[k].x));
+      }
+#pragma unroll
+      for (int k = 0; k < UB; ++k) {
+        if ((uint32_t)k >= n) continue;
+        // two rumours about one subject in a batch (Suspect and Dead arriving together; wave-uniform: the rows are): the later
+        // one looks at the cell again (this thread's own store is visible to it)
+        bool again = false;
+#pragma unroll
+        for (int j = 0; j < UB; ++j) again |= (j < k) && (r[j].x == r[k].x);
+        if (!has[k]) continue;
+        PSITE(22 + (k & 1));
+        const size_t ix = vidx(s, li, r[k].x);
+        if (again && !ABL(ABL_V_LOAD)) e[k] = v_hot(s, ix);
+        const uint32_t key = r[k].y, curk = e[k].key ? e[k].key : r[k].z;      // untouched cell: the settled base
+        if (key <= curk) continue;                    // old incarnation / weaker state: ignore (:151)
+        if (s.strict && (((key & 3u) == ST_SUSPECT && (curk & 3u) != ST_ALIVE) || ((key & 3u) == ST_DEAD && (curk & 3u) == ST_DEAD))) continue;
+        PSTAT(5); PSTAT(6); PSTAT(psite); SECT_COUNT(21);
+        const bool again_ = v_changed_in(s, ix, e[k], t);               // (before the store below)
+        if (!ABL(ABL_V_STORE)) v_put(s, ix, key, t + 1);                // memberLastChange = now (:176)
+        acc_sh[nacc][tid] = p[k] | ((uint32_t)again_ << 6) | ((key - curk) << 7);    // (keys are < 2^24: the step fits)
+        nacc++;
+      }
+      if (!U || __ballot(nacc + (uint32_t)UB > (uint32_t)ACC_CAP)) book();   // wave-uniform: a lane's column could overflow in the next batch
+    }
+  }
+#else
+  // Each lane walks its own new
   // positions.  (Measured on MI355X, profiles/r02c_variants.txt: a wave-uniform walk over the UNION of the
   // lanes' positions coalesces the view rows but triples the iterations -- 237 us against 188 us; one
   // candidate loop shared by all sources with the bookkeeping parked in LDS -- 258 us.)
   // The loads are batched: a member's next GB positions are decoded together -- what each position stands for
   // comes from the block's copy of the tick's ring in LDS, so the only round trip is the batch's view cells
   // (the kernel waits on such chains most of its time, profiles/r02a_pmc_summary.txt).
-  SECT(2);                                          // deadlines, failed probes
   if (act) {
     constexpr int GB = SWIM_GOSSIP_BATCH;
     unsigned long long fresh = (pushed | pulled) & ~kn;
@@ -1503,6 +1648,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
       }
     }
   }
+#endif
   SECT(3);                                          // delivered rumours
   if (act) {
     if (cnt) {
@@ -1691,7 +1837,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
 // key) behind the dictionary, the same list for every peer.  One thread per member, one list reservation per wave.
 __global__ __launch_bounds__(BLOCK) void publish_kernel(DevState s, uint32_t t) {
   const uint32_t Hprev = s.g[G_PREV], H = s.g[G_HEAD];
-  const bool use_mask = H - Hprev <= MASK_SLACK;
+  const bool use_mask = H - Hprev <= MASK_SLACK && !s.strict;   // (strict reference rules: no delivery is ever filtered -- every queue travels as a list)
   for (uint32_t l0 = blockIdx.x * BLOCK; l0 < s.N; l0 += gridDim.x * BLOCK) {      // (wave-uniform trip count)
     const uint32_t li = l0 + threadIdx.x, i = s.lo + li;
     uint32_t mi = 0;
@@ -1747,7 +1893,7 @@ __device__ inline const uint4* r_list_of(const DevState& s, const PeerView& pv, 
 constexpr uint32_t XLAT_INDEX_BLOCKS = 32;
 __global__ __launch_bounds__(BLOCK) void xlat_kernel(DevState s, uint32_t t, PeerCounts r_counts, PeerView pv) {
   const uint32_t H = s.g[G_HEAD];
-  const bool use_mask = H - s.g[G_PREV] <= MASK_SLACK;
+  const bool use_mask = H - s.g[G_PREV] <= MASK_SLACK && !s.strict;
   if (blockIdx.x >= s.n_shards + XLAT_INDEX_BLOCKS) {
     // the replicas: everybody else's slice from its owner (8 + 1 bytes per member, coalesced)
     const uint32_t nb = gridDim.x - s.n_shards - XLAT_INDEX_BLOCKS, b = blockIdx.x - s.n_shards - XLAT_INDEX_BLOCKS;
@@ -1840,7 +1986,7 @@ __global__ __launch_bounds__(BLOCK) void ingest_kernel(DevState s, uint32_t t, P
   }
   __syncthreads();
   const uint32_t Hprev = s.g[G_PREV], H = s.g[G_HEAD];
-  const bool use_mask = H - Hprev <= MASK_SLACK;
+  const bool use_mask = H - Hprev <= MASK_SLACK && !s.strict;
   const unsigned long long stale = stale_positions(Hprev, H);
   const uint32_t total = pref[s.n_shards];
   auto record_at = [&](uint32_t k) -> uint2 {

@@ -44,3 +44,19 @@ def test_bench_line_single_process(monkeypatch, gpus):
         assert ex["bytes_per_gpu_per_tick"] >= 512 * 9 * (gpus - 1) and ex["xgmi_peak_GBs"] == 7 * 153.0
         assert "ONE process" in out["config"]["parallelism"]
 
+
+
+def test_default_run_carries_baseline_row_3s_as_written(monkeypatch):
+    """The default one-GPU run measures TWO clusters: the headline (1 crash per tick) and BASELINE.md row 3(s) as
+    written (9.5 per tick, settling, 100 warm-up ticks) -- each with its own roofline and oracle check."""
+    import bench
+    monkeypatch.setattr(bench, "N_MEMBERS", 2048)
+    out = run_bench(["--steps", "6", "--warmup", "3", "--members", "2048"], monkeypatch)
+    assert out["verified_vs_oracle"] is True and "settling" not in out["config"]["workload"]
+    w = out["config3s_as_written"]
+    assert w["verified_vs_oracle"] is True and w["cpu_baseline"]["kind"] == "port"
+    assert w["steps"] == 6 and w["warmup"] == 100 and "9.5 crashes per tick" in w["config"]["workload"] and "settling" in w["config"]["workload"]
+    assert w["roofline"]["bound"] == "hbm" and set(w["roofline"]["kernels"]) == {"probe_kernel", "merge_kernel"}
+    assert set(w["per_member_tick"]) == {"d", "r", "c", "f"} and w["value"] > 0 and w["ms_per_step"] > 0
+    out2 = run_bench(["--steps", "6", "--warmup", "3", "--members", "2048", "--no-as-written"], monkeypatch)
+    assert "config3s_as_written" not in out2

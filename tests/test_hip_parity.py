@@ -335,6 +335,29 @@ def test_strict_reference_rules_on_the_gpu(oracle_abi, hip_abi, n, p, loss, seed
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("n,shards,p,loss,seed", [(3000, 3, 3, 150000, 4), (4096, 4, 10, 200000, 5), (65536, 8, 3, 50000, 3)])
+def test_strict_reference_rules_on_sharded_clusters_on_one_gpu(oracle_abi, hip_abi, n, shards, p, loss, seed):
+    """The literal suspectOrDeadNode' (src/Core.hs:151-152,182-184) on 3-8 shards on MI355X (round 6): across shards every queue travels as
+    a list, nothing is filtered, the owner applies a member's rumours in the canonical order.  = the UNSHARDED oracle's literal mode."""
+    from swim_amd.shard import LocalFabric, ShardedSim
+    events = n <= 4096
+    sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, eventMask=0x1F if events else 0, suspicionTicks=8,
+                   maxSubjects=min(n, 4096), strictReferenceRules=True)
+    a, b = Sim.create(oracle_abi, sc), ShardedSim(hip_abi, sc, LocalFabric(shards), device="cuda:0")
+    _oracle_threads(a)
+    for s in (a, b):
+        s.crash(7, 5); s.crash(n // 2, 9)
+        s.scheduleFault(40, 7, True)
+    for _ in range(12):
+        a.step(5); b.step(5)
+        assert a.counters() == b.counters() and a.digest() == b.digest(), "tick %d" % a.tick
+        if events:
+            assert a.drainEventsRaw() == b.drainEventsRaw()
+    assert a.firstDetection() == b.firstDetection()
+    assert oracle_abi.lib.swimoracle_d13_hits(a._h) > 0
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("fold,n", [("0", 4096), ("1", 4096), ("1", 65536)])
 def test_plain_ticks_with_and_without_begin_kernel_on_the_gpu(oracle_abi, hip_abi, monkeypatch, fold, n):
     """Ticks without scheduled changes run without begin_kernel (probe_kernel's workgroup 0 does its part on the side, merge_kernel's

@@ -67,6 +67,24 @@ def test_explicit_record_paths(oracle_abi):
     run_lockstep(a, b, 70, 5, observers=(0, 1, n - 1), members=(0, 1, n - 1))
 
 
+@pytest.mark.parametrize("n,loss,gc,strict", [(700, 0, 1, 0), (1500, 30000, 0, 0), (300, 100000, 0, 1)])
+def test_merge_union_walk_build_is_bit_exact(oracle_abi, n, loss, gc, strict):
+    """-DSWIM_MERGE_UNION=1 (A/B knob, round 6): merge_kernel decides the delivered rumours in a wave-uniform walk over the union of
+    its lanes' ring positions (one view row at a time for 64 consecutive members) and books what was accepted from LDS.  Slower than the
+    per-lane walk on MI355X (profiles/r06b_ab_merge_union.txt), kept for A/B -- and kept exact: many crashes (full queues, Suspect and
+    Dead of one subject in one batch), rejoins (refutations: rumours about the member itself), loss, settling, the literal rule."""
+    from swim_amd import _abi
+    from tests import hostemu_binding
+    emu = hostemu_binding.load_variant("union", ["SWIM_MERGE_UNION=1", "SWIM_UNION_BATCH=4", "SWIM_ACC_CAP=6"])
+    crashes = workloads.hashed_crashes(n, 9, 1, 5, 3, 60)
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=12, lossPpm=loss, eventMask=0x1F, suspicionTicks=6, maxSubjects=n,
+                   gcTicks=_abi.GC_AUTO if gc else 0, strictReferenceRules=bool(strict))
+    faults = [(t + 9 + (m % 11), m, True) for (t, m) in crashes[::2]]
+    a, b = make_pair(oracle_abi, emu, sc, crashes, faults)
+    run_lockstep(a, b, 90, 5, observers=(0, 1, n - 1), members=(0, 1, n - 1))
+    assert b.counters()["changes"] > 10 * n and (b.counters()["refutes"] > 0 or not loss)
+
+
 def test_dissemination_is_logarithmic_small(emu_abi):
     """The O(log N) dissemination check of tests/test_hip_parity.py at a size the emulation handles."""
     import math

@@ -56,3 +56,10 @@ def test_one_process_per_shard_gloo_with_bounded_member_maps():
     and member bytes and the 8-byte delivery records through swimsim_shard_step's callback, 30 % loss, a crash and a rejoin."""
     run_world(2, (192, 3, 300000, 11, 40, 16 << 8), 29618)
     run_world(4, (256, 3, 300000, 12, 30, 64 << 8), 29619)
+
+
+def test_one_process_per_shard_gloo_with_the_literal_rule():
+    """strict_reference_rules on a sharded cluster, one process per shard: every queue travels as a list in round 1, every delivery is
+    an explicit record; = the unsharded oracle's literal mode (15 % / 25 % loss: the rules part)."""
+    run_world(2, (192, 3, 150000, 21, 60, 8), 29622)
+    run_world(4, (256, 3, 250000, 22, 50, 8), 29623)

@@ -81,7 +81,26 @@ def test_strict_rules_refuse_the_options_they_cannot_carry(oracle_abi, emu_abi, 
             Sim.create(abi, strict_config(64, 3, 0, 1, **kw))
 
 
-def test_strict_rules_are_refused_on_shards(emu_abi):
+@pytest.mark.parametrize("n,shards,p,loss,seed,cluster", [(64, 2, 2, 300000, 9, "1"), (300, 3, 3, 150000, 4, "1"), (256, 4, 10, 200000, 5, "0"),
+                                                          (1000, 8, 5, 50000, 3, "1"), (500, 2, 3, 250000, 11, "0"), (128, 4, 3, 0, 2, "1")])
+def test_the_literal_rule_on_sharded_clusters(oracle_abi, emu_abi, monkeypatch, n, shards, p, loss, seed, cluster):
+    """strict_reference_rules on 2-8 shards (round 6): every delivery is an explicit record -- across shards every
+    queue travels as a list of (subject, key), nothing is filtered through a mask or a known-ring -- and the owner applies a member's
+    rumours in the canonical order by (row, key).  Both forms of the exchange (SWIMSIM_CLUSTER_STEP: in the library / phase calls).
+    = the UNSHARDED oracle under the literal rule, on runs where the two rules do part."""
     from swim_amd.shard import LocalFabric, ShardedSim
-    with pytest.raises(SwimError):
-        ShardedSim(emu_abi, strict_config(64, 3, 0, 1), LocalFabric(2))
+    monkeypatch.setenv("SWIMSIM_CLUSTER_STEP", cluster)
+    sc = strict_config(n, p, loss, seed)
+    a, b = Sim.create(oracle_abi, sc), ShardedSim(emu_abi, sc, LocalFabric(shards))
+    for s in (a, b):
+        s.crash(7, 5); s.crash(n // 2, 9)
+        s.scheduleFault(60, 7, True)
+    for _ in range(20):
+        a.step(5); b.step(5)
+        assert a.counters() == b.counters(), "counters differ at tick %d" % a.tick
+        assert a.digest() == b.digest(), "digest differs at tick %d" % a.tick
+        assert a.drainEventsRaw() == b.drainEventsRaw(), "events differ at tick %d" % a.tick
+    assert a.firstDetection() == b.firstDetection()
+    if loss >= 150000:
+        assert oracle_abi.lib.swimoracle_d13_hits(a._h) > 0
+    a.close(); b.close()
