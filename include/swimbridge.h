@@ -53,8 +53,14 @@ typedef struct swimbridge_stats {
 
 /* Bind a UDP socket on bind_ip:port (port 0 = any free port; the reference binds 127.0.0.1:4000, src/Core.hs:278)
  * for the members of `sim`.  SWIMSIM_ERR_INVALID (also: a sharded handle -- one endpoint answers for the whole
- * population) / SWIMSIM_ERR_DEVICE (socket errors; swimbridge_last_error). */
+ * population: swimbridge_open_cluster) / SWIMSIM_ERR_DEVICE (socket errors; swimbridge_last_error). */
 int swimbridge_open(swimsim_t* sim, const char* bind_ip, uint16_t port, swimbridge_t** out);
+/* The same endpoint for a SHARDED cluster whose shards are all handles of this process (round 6): shards[k] = shard k of n_shards of
+ * one population.  A Ping is answered from the owner of the named member; a Suspect / Alive / Dead message goes to the owner of the
+ * member it addresses (swimsim_inject_rumor) and is made known to every other shard (swimsim_note_outside_rumor: its subject's view
+ * row belongs to the whole cluster).  The embedder alternates swimbridge_poll with the cluster's tick (swimsim_cluster_step or the
+ * phase calls) on one thread. */
+int swimbridge_open_cluster(swimsim_t* const* shards, uint32_t n_shards, const char* bind_ip, uint16_t port, swimbridge_t** out);
 int swimbridge_port(const swimbridge_t* b, uint16_t* port);
 /* The reference's send side encodes a bare `Message`, its receive side decodes an `Envelope` (D11; src/Core.hs:133-134
  * against :84): with on = 1 the bridge also accepts bare-Message datagrams -- what a LITERAL reference node sends --

@@ -26,4 +26,20 @@ c)  # the ring directory (a stated rumour takes id and subject from the tick's r
    echo "# ... without | with the ring directory"; CPT=9.5 GC=1 MAXSUBJ=8192 WARM=200 CHUNK=20 ROUNDS=5 timeout 900 python scripts/ab_time.py $C/libswimsim_x_nodir.so $C/libswimsim.so) 2>&1 | grep -v amdgpu.ids | tee $O/r06c_ab_ring_directory.txt
   timeout 900 python bench.py --steps 20 --warmup 5 > $O/r06c_bench_default.json 2> $O/r06c_bench_default.err; tail -c 3000 $O/r06c_bench_default.json; tail -3 $O/r06c_bench_default.err
   ;;
+d)  # merge_kernel with ONE round of input loads (the known-ring among them) and the first rumour batch's cells asked for with the deadline
+    # cells, the own line kept in registers -- against the kernels of the commit before (x_base); the whole GPU suite
+  canary d
+  (echo "# headline regime: before | after"; ROUNDS=7 timeout 900 python scripts/ab_time.py $C/libswimsim_x_base.so $C/libswimsim.so;
+   echo "# 1 % loss, settling:"; LOSS=10000 GC=1 ROUNDS=5 CHUNK=20 timeout 900 python scripts/ab_time.py $C/libswimsim_x_base.so $C/libswimsim.so;
+   echo "# BASELINE.md row 3(s) as written:"; CPT=9.5 GC=1 MAXSUBJ=8192 WARM=200 CHUNK=20 ROUNDS=5 timeout 900 python scripts/ab_time.py $C/libswimsim_x_base.so $C/libswimsim.so) 2>&1 | grep -v amdgpu.ids | tee $O/r06d_ab_merge_rounds.txt
+  timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 | tee $O/r06d_pytest.log
+  ;;
+e)  # probe_kernel with the first draws' bytes and the own queue mask in the round of loads of the member's own word (x_base: the kernels of
+    # two commits before: neither this nor merge_kernel's single round of inputs); the GPU suite
+  canary e
+  (echo "# headline regime: before | after"; ROUNDS=7 timeout 900 python scripts/ab_time.py $C/libswimsim_x_base.so $C/libswimsim.so;
+   echo "# quiescent-like (numToGossip 10):"; P=10 ROUNDS=5 CHUNK=20 timeout 900 python scripts/ab_time.py $C/libswimsim_x_base.so $C/libswimsim.so;
+   echo "# 1 % loss, settling:"; LOSS=10000 GC=1 ROUNDS=5 CHUNK=20 timeout 900 python scripts/ab_time.py $C/libswimsim_x_base.so $C/libswimsim.so) 2>&1 | grep -v amdgpu.ids | tee $O/r06e_ab_probe_first_draws.txt
+  timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 | tee $O/r06e_pytest.log
+  ;;
 esac

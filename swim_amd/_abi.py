@@ -153,6 +153,7 @@ class BridgeStats(C.Structure):
 # include/swimbridge.h: the live-node bridge (prefix swimbridge_, product library only)
 _BRIDGE = {
     "open": (C.c_int, [_H, C.c_char_p, C.c_uint16, C.POINTER(C.c_void_p)]),
+    "open_cluster": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint32, C.c_char_p, C.c_uint16, C.POINTER(C.c_void_p)]),
     "port": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint16)]),
     "poll": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
     "stats": (C.c_int, [C.c_void_p, C.POINTER(BridgeStats)]),

@@ -15,9 +15,17 @@ from . import _abi
 
 class Bridge:
     def __init__(self, sim, bind_ip: str = "127.0.0.1", port: int = 0):
-        self._abi = sim._abi
+        """sim: a Sim, or a ShardedSim whose shards all live in this process (swimbridge_open_cluster: one endpoint for the cluster)."""
         self._b = C.c_void_p()
-        rc = self._abi.bridge_open(sim._h, bind_ip.encode(), port, C.byref(self._b))
+        if hasattr(sim, "shards"):
+            if len(sim.shards) != sim.n_shards:
+                raise OSError("the bridge of a cluster needs every shard in this process")
+            self._abi = sim.shards[0].sim._abi
+            arr = (C.c_void_p * sim.n_shards)(*[s.sim._h for s in sim.shards])
+            rc = self._abi.bridge_open_cluster(arr, sim.n_shards, bind_ip.encode(), port, C.byref(self._b))
+        else:
+            self._abi = sim._abi
+            rc = self._abi.bridge_open(sim._h, bind_ip.encode(), port, C.byref(self._b))
         if rc:
             raise OSError("swimbridge_open(%s:%d) failed with status %d" % (bind_ip, port, rc))
         self._sim = sim

@@ -20,6 +20,9 @@
 
 struct swimbridge {
   swimsim_t* sim = nullptr;
+  // a sharded cluster behind ONE endpoint (swimbridge_open_cluster): shard k owns members [k * per, (k + 1) * per)
+  std::vector<swimsim_t*> shards;
+  uint32_t per = 0;
   int fd = -1;
   uint32_t n_members = 0;
   swimbridge_stats_t st{};
@@ -35,6 +38,20 @@ struct swimbridge {
 namespace {
 
 int berr(swimbridge* b, int code, const std::string& m) { if (b) b->err = m; return code; }
+
+// the handle that owns member `id` (the only handle of an unsharded population)
+swimsim_t* owner_of(swimbridge* b, uint32_t id) { return b->shards.empty() ? b->sim : b->shards[id / b->per]; }
+// a Suspect / Alive / Dead message from outside for `obs` about `id`: to the observer's owner; on a cluster every OTHER shard is
+// told too -- the message opens the subject's view row, and a row is a property of the whole cluster (include/swimsim.h)
+int inject(swimbridge* b, uint32_t obs, uint32_t id, uint8_t st, uint32_t inc, swimsim_t** failed) {
+  swimsim_t* own = owner_of(b, obs);
+  *failed = own;
+  const int rc = swimsim_inject_rumor(own, obs, id, st, inc);
+  if (rc) return rc;
+  for (swimsim_t* h : b->shards)
+    if (h != own) { const int rc2 = swimsim_note_outside_rumor(h, obs, id); if (rc2 && rc2 != SWIMSIM_ERR_BUFFER) { *failed = h; return rc2; } }
+  return SWIMSIM_OK;
+}
 
 // "m<id>" -> id (the names the simulator gives its members, include/swimsim.h); false for anything else
 bool member_id(const char* name, uint32_t n_members, uint32_t* id) {
@@ -81,8 +98,8 @@ swimwire_msg_t ack_of(uint32_t seq) { swimwire_msg_t m{}; m.type = SWIMWIRE_ACK;
 // `Direct (Ack seq []) sender` for simulated member `id` (src/Core.hs:97-99), its piggyback queue riding along (D5)
 int answer_ping(swimbridge* b, uint32_t id, uint32_t seq, const sockaddr_in& to) {
   swimsim_member_t mem{};
-  const int rc = swimsim_read_member(b->sim, id, &mem);
-  if (rc) return berr(b, rc, std::string("read_member: ") + swimsim_last_error(b->sim));
+  const int rc = swimsim_read_member(owner_of(b, id), id, &mem);
+  if (rc) return berr(b, rc, std::string("read_member: ") + swimsim_last_error(owner_of(b, id)));
   if (!mem.up) { b->st.pings_unanswered++; return SWIMSIM_OK; }      // a node that is down answers nothing
   b->out.clear();
   b->out.push_back(ack_of(seq));
@@ -125,8 +142,8 @@ int handle(swimbridge* b, const sockaddr_in& from, size_t len) {
         b->st.indirect_pings++;
         if (member_id(m.node, b->n_members, &id)) {
           swimsim_member_t mem{};
-          const int rc = swimsim_read_member(b->sim, id, &mem);
-          if (rc) return berr(b, rc, std::string("read_member: ") + swimsim_last_error(b->sim));
+          const int rc = swimsim_read_member(owner_of(b, id), id, &mem);
+          if (rc) return berr(b, rc, std::string("read_member: ") + swimsim_last_error(owner_of(b, id)));
           if (mem.up) { b->out.assign(1, ack_of(m.seq_no)); const int rc2 = send_env(b, b->out, from); if (rc2 < 0) return rc2; if (rc2 == SWIMSIM_OK) b->st.relayed_acks++; }
         } else {
           // target = the HostAddress the reference takes out of a SockAddrInet (src/Core.hs:264-266): already in network
@@ -162,9 +179,10 @@ int handle(swimbridge* b, const sockaddr_in& from, size_t len) {
           const uint32_t obs = have_addressee ? addressee : (id + 1u) % b->n_members;
           const uint8_t st = m.type == SWIMWIRE_SUSPECT ? SWIMSIM_SUSPECT : m.type == SWIMWIRE_DEAD ? SWIMSIM_DEAD : SWIMSIM_ALIVE;
           // more rumours than the simulation takes before its next tick (SWIMSIM_ERR_BUFFER): a flood, dropped and counted
-          const int rc = swimsim_inject_rumor(b->sim, obs, id, st, (uint32_t)m.incarnation);
+          swimsim_t* failed = nullptr;
+          const int rc = inject(b, obs, id, st, (uint32_t)m.incarnation, &failed);
           if (rc == SWIMSIM_ERR_BUFFER) { b->st.rumors_dropped++; break; }
-          if (rc) return berr(b, rc, std::string("inject_rumor: ") + swimsim_last_error(b->sim));
+          if (rc) return berr(b, rc, std::string("inject_rumor: ") + swimsim_last_error(failed));
           b->st.rumors_injected++;
         } else b->st.rumors_foreign++;
         break;
@@ -178,17 +196,7 @@ int handle(swimbridge* b, const sockaddr_in& from, size_t len) {
 
 extern "C" {
 
-int swimbridge_open(swimsim_t* sim, const char* bind_ip, uint16_t port, swimbridge_t** out) {
-  if (!sim || !out) return SWIMSIM_ERR_INVALID;
-  *out = nullptr;
-  swimsim_config_t cfg;
-  if (swimsim_get_config(sim, &cfg) != SWIMSIM_OK) return SWIMSIM_ERR_INVALID;
-  // one endpoint answers for the WHOLE population: a shard owns a slice of it (read_member of another shard's member
-  // and inject_rumor are refused there), so the bridge wants an unsharded handle
-  if (cfg.n_shards > 1) return SWIMSIM_ERR_INVALID;
-  swimbridge* b = new (std::nothrow) swimbridge();
-  if (!b) return SWIMSIM_ERR_NOMEM;
-  b->sim = sim; b->n_members = cfg.n_members;
+static int open_socket(swimbridge* b, const char* bind_ip, uint16_t port, swimbridge_t** out) {
   b->rx.resize(SWIMWIRE_MAX_DATAGRAM + 1);
   b->fd = socket(AF_INET, SOCK_DGRAM, 0);
   sockaddr_in a{}; a.sin_family = AF_INET; a.sin_port = htons(port);
@@ -202,6 +210,38 @@ int swimbridge_open(swimsim_t* sim, const char* bind_ip, uint16_t port, swimbrid
   }
   *out = b;
   return SWIMSIM_OK;
+}
+
+int swimbridge_open(swimsim_t* sim, const char* bind_ip, uint16_t port, swimbridge_t** out) {
+  if (!sim || !out) return SWIMSIM_ERR_INVALID;
+  *out = nullptr;
+  swimsim_config_t cfg;
+  if (swimsim_get_config(sim, &cfg) != SWIMSIM_OK) return SWIMSIM_ERR_INVALID;
+  // one endpoint answers for the WHOLE population: a shard owns a slice of it (read_member of another shard's member
+  // and inject_rumor are refused there): the shards of a cluster go to swimbridge_open_cluster
+  if (cfg.n_shards > 1) return SWIMSIM_ERR_INVALID;
+  swimbridge* b = new (std::nothrow) swimbridge();
+  if (!b) return SWIMSIM_ERR_NOMEM;
+  b->sim = sim; b->n_members = cfg.n_members;
+  return open_socket(b, bind_ip, port, out);
+}
+
+int swimbridge_open_cluster(swimsim_t* const* shards, uint32_t n_shards, const char* bind_ip, uint16_t port, swimbridge_t** out) {
+  if (!shards || !out || n_shards < 2 || n_shards > 16) return SWIMSIM_ERR_INVALID;
+  *out = nullptr;
+  swimbridge* b = new (std::nothrow) swimbridge();
+  if (!b) return SWIMSIM_ERR_NOMEM;
+  for (uint32_t k = 0; k < n_shards; ++k) {
+    swimsim_config_t cfg;
+    // shards[k] must be shard k of n_shards of ONE population with unbounded member maps (messages from outside are not
+    // available with view_cap)
+    if (!shards[k] || swimsim_get_config(shards[k], &cfg) != SWIMSIM_OK || cfg.n_shards != n_shards || cfg.shard_index != k ||
+        cfg.view_cap || (k && cfg.n_members != b->n_members)) { delete b; return SWIMSIM_ERR_INVALID; }
+    b->n_members = cfg.n_members;
+    b->shards.push_back(shards[k]);
+  }
+  b->sim = shards[0]; b->per = b->n_members / n_shards;
+  return open_socket(b, bind_ip, port, out);
 }
 
 int swimbridge_port(const swimbridge_t* b, uint16_t* port) {

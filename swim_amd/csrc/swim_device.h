@@ -546,14 +546,20 @@ __device__ inline void mb_set_row(const DevState& s, uint32_t g) {
 // minfo of a probe target / proxy as far as the prober needs it: from the byte table, the full word only for
 // members with a view row or an unmaskable queue and on ticks that travel as explicit records (the line
 // buffer bit is needed then)
+// ... from the member's byte b = mb[c], gathered by the caller (probe_kernel asks for the first draws' bytes with its own word)
+__device__ inline uint32_t probe_mi_byte(const DevState& s, uint32_t c, uint32_t b, bool use_mask) {
+  if ((b & (MB_ROW | MB_OOW)) || !use_mask) return s.minfo[c];
+  return ((b & MB_UP) ? MI_UP : 0u) | (((b >> MB_PBN_SHIFT) & 0xFu) << MI_PBN_SHIFT) |
+         ((b & MB_BASE_NA) ? ((uint32_t)ST_DEAD << MI_BASE_SHIFT) : 0u);
+}
+__device__ inline uint32_t probe_mb(const DevState& s, uint32_t c) {
+  return ABL(ABL_MB_GATHER) ? (MB_UP | (8u << MB_PBN_SHIFT)) : (uint32_t)s.mb[c];
+}
 __device__ inline uint32_t probe_mi(const DevState& s, uint32_t c, bool use_mask) {
 #ifdef SWIM_NO_MB            // measurement knob: always gather the full word
   return s.minfo[c];
 #endif
-  const uint32_t b = ABL(ABL_MB_GATHER) ? (MB_UP | (8u << MB_PBN_SHIFT)) : s.mb[c];
-  if ((b & (MB_ROW | MB_OOW)) || !use_mask) return s.minfo[c];
-  return ((b & MB_UP) ? MI_UP : 0u) | (((b >> MB_PBN_SHIFT) & 0xFu) << MI_PBN_SHIFT) |
-         ((b & MB_BASE_NA) ? ((uint32_t)ST_DEAD << MI_BASE_SHIFT) : 0u);
+  return probe_mi_byte(s, c, probe_mb(s, c), use_mask);
 }
 __device__ inline uint32_t mi_pbn(uint32_t mi) { return (mi >> MI_PBN_SHIFT) & 0xFu; }
 __device__ inline uint32_t mi_buf(uint32_t mi) { return (mi >> 20) & 1u; }
@@ -605,6 +611,21 @@ __device__ inline uint4 tc_pack(const TimerCell& c) {
   return make_uint4((uint32_t)c.lo, (uint32_t)(c.lo >> 32), (uint32_t)c.hi, (uint32_t)(c.hi >> 32));
 }
 
+// (forward: the overload without first draws gathered ahead is below select_members)
+// the first draw of each of the n picks of kRandomMembers(.., P_SELECT) and its byte of the mb table: pure functions of (tick, member),
+// so probe_kernel asks for them in the SAME round of loads as the member's own word (round 6: they were a round trip of their own)
+template <int MAXN>
+__device__ inline void select_first_draws(const DevState& s, uint32_t mk, uint32_t n, uint32_t (&c)[MAXN], uint32_t (&b)[MAXN]) {
+#pragma unroll
+  for (int p = 0; p < MAXN; ++p) {
+    c[p] = 0; b[p] = 0;
+    if ((uint32_t)p < n) {
+      c[p] = __umulhi(hash_mk(mk, ((uint32_t)P_SELECT << 24) | ((uint32_t)p << 8), 0), s.NT);
+      b[p] = probe_mb(s, c[p]);
+    }
+  }
+}
+
 // kRandomMembers (src/Core.hs:69-74) + shuffle (src/Util.hs:37-42) as n draws without
 // replacement: rejection sampling on the counter RNG, then a cyclic scan so that "fewer than
 // n candidates => all of them" holds exactly (test/Spec.hs:117-128).  Self never eligible (D15).
@@ -612,7 +633,9 @@ template <int MAXN>
 __device__ inline uint32_t select_members(const DevState& s, uint32_t mk, uint32_t i, uint32_t n,
                                           uint32_t purpose, uint32_t hi_idx, const uint32_t* excl,
                                           uint32_t nexcl, uint32_t (&out)[MAXN],
-                                          uint32_t (&info)[MAXN], bool use_mask = false, bool* all_first = nullptr) {
+                                          uint32_t (&info)[MAXN], bool use_mask, bool* all_first,
+                                          bool pre, const uint32_t (&pre_c)[MAXN], const uint32_t (&pre_b)[MAXN]) {
+  // pre: pre_c / pre_b hold the first draw of every index and its byte of `mb`, gathered by the caller ahead of time (select_first_draws)
   uint32_t np = 0;
   bool first_only = true;          // every pick so far was the first draw of its index
   const uint32_t N = s.NT;
@@ -625,8 +648,12 @@ __device__ inline uint32_t select_members(const DevState& s, uint32_t mk, uint32
       c0[p] = 0; m0[p] = 0;
       if ((uint32_t)p < n) {
         const uint32_t base = (purpose << 24) | (purpose == P_SELECT ? ((uint32_t)p << 8) : ((hi_idx << 16) | ((uint32_t)p << 8)));
-        c0[p] = __umulhi(hash_mk(mk, base, 0), N);
+        c0[p] = pre ? pre_c[p] : __umulhi(hash_mk(mk, base, 0), N);
+#ifdef SWIM_NO_MB
         m0[p] = probe_mi(s, c0[p], use_mask);
+#else
+        m0[p] = pre ? probe_mi_byte(s, c0[p], pre_b[p], use_mask) : probe_mi(s, c0[p], use_mask);
+#endif
       }
     }
   }
@@ -668,6 +695,16 @@ __device__ inline uint32_t select_members(const DevState& s, uint32_t mk, uint32
   }
   if (all_first) *all_first = first_only && np == n;
   return np;
+}
+template <int MAXN>
+__device__ inline uint32_t select_members(const DevState& s, uint32_t mk, uint32_t i, uint32_t n,
+                                          uint32_t purpose, uint32_t hi_idx, const uint32_t* excl,
+                                          uint32_t nexcl, uint32_t (&out)[MAXN],
+                                          uint32_t (&info)[MAXN], bool use_mask = false, bool* all_first = nullptr) {
+  uint32_t none[MAXN];
+#pragma unroll
+  for (int p = 0; p < MAXN; ++p) none[p] = 0;
+  return select_members<MAXN>(s, mk, i, n, purpose, hi_idx, excl, nexcl, out, info, use_mask, all_first, false, none, none);
 }
 
 }  // namespace swim

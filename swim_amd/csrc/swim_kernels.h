@@ -271,6 +271,18 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
     for (uint32_t k = 0; k < FOLD_MAX_CRASHES; ++k) hit |= k < crashes.n && crashes.member[k] == member;
     return hit ? (m & ~(MI_UP | MI_PB)) : m;
   };
+  // ONE round of loads at the start (round 6): the member's own word, its queue mask, and the bytes of the first draw of each of its
+  // probe targets -- the draws are pure functions of (tick, member), so they need not wait for the member's own word
+  const uint32_t mk = mix32(tk ^ i);
+  uint32_t pre_c[PMAX], pre_b[PMAX];
+  unsigned long long mymask0 = 0;
+  // (the narrow instantiation only: with numToGossip = 10 the twelve draws' registers cost more than the round trip saves --
+  // 346 -> 377 us per launch, profiles/r06e_ab_probe_first_draws.txt)
+  const bool pre_sel = PMAX <= 4 && li < s.N && s.scheme != 1u;
+#pragma unroll
+  for (int p = 0; p < PMAX; ++p) { pre_c[p] = 0; pre_b[p] = 0; }
+  if (pre_sel) select_first_draws<PMAX>(s, mk, s.P, pre_c, pre_b);
+  if (li < s.N) mymask0 = s.pk[li].x;
   const uint32_t mi = li < s.N ? overlay(i, s.minfo[i]) : 0u;
   const bool act = mi_up(mi);
   // masks are exact only if few rumour ids appeared since they were built (swim_device.h)
@@ -320,7 +332,6 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
   bool wrote_rec = false;                          // this member left an explicit record somewhere: the records phase of merge_kernel has work
   SECT_BEGIN(32);
   // what passes 1-4 leave for the wave's pass 5 (indirect probes) and for the outputs
-  const uint32_t mk = mix32(tk ^ i);
   const uint32_t mycnt = mi_pbn(mi);
   unsigned long long mymask = 0;
   uint32_t picks[PMAX], pinfo[PMAX];
@@ -357,7 +368,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
     return true;
   };
   if (act) {
-    mymask = (mycnt && use_mask) ? s.pk[li].x : 0ull;
+    mymask = (mycnt && use_mask) ? mymask0 : 0ull;
     bool valid[PMAX];                               // probe index p is in use this period
     const bool robust = s.scheme == 1u;
     // the robust scheme's Ping payloads are PULLED by the target (its pingers are computable) -- on one handle; on
@@ -366,7 +377,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
     uint32_t np;                                    // probe indices in play
     if (!robust) {
       // ms <- kRandomMembers store (numToGossip cfg) []        (src/Core.hs:239)
-      np = select_members<PMAX>(s, mk, i, s.P, P_SELECT, 0, nullptr, 0, picks, pinfo, use_mask);
+      np = select_members<PMAX>(s, mk, i, s.P, P_SELECT, 0, nullptr, 0, picks, pinfo, use_mask, nullptr, pre_sel, pre_c, pre_b);
       if (crashes.n) {
 #pragma unroll
         for (int p = 0; p < PMAX; ++p) pinfo[p] = overlay(picks[p], pinfo[p]);
@@ -1225,19 +1236,27 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
   // a 64-bit per-lane index held from the load to the final store was spilled to scratch, and its reload waited
   // for every store the wave had in flight
   uint4* const trow_now = s.trow + (size_t)(t % s.S) * s.N;
-  if (up) {
+  // ONE round of loads with the member's own word (round 6): every coalesced per-member stream the tick reads -- issued for every
+  // member of the handle, up or not (nearly all are; behind `up` they were a second round trip in front of the kernel's first
+  // barrier), the known-ring and the inbox count among them (they waited for the round after)
+  ulonglong2 pk0 = make_ulonglong2(0ull, 0ull);
+  uint32_t cnt0 = 0;
+  const bool rids_off = s.g[G_RIDS_OFF] != 0u;     // (a scalar load: with the others at the start, not in front of the queue rebuild)
+  if (li < s.N) {
     const uint32_t po = s.probe_out[li];
-    nsent = po & 31u; nfail = (po >> 5) & 31u;
-    pushed = s.inmask[li];
-    pulled = s.ackmask[li];
-    hot0 = s.hot[li];
-    due = trow_now[li];
+    const unsigned long long pu = s.inmask[li], pl = s.ackmask[li];
+    const uint2 h0 = s.hot[li];
+    const uint4 d0 = trow_now[li];
+    pk0 = s.pk[li];
+    cnt0 = s.inbox_cnt[li];
+    if (up) { nsent = po & 31u; nfail = (po >> 5) & 31u; pushed = pu; pulled = pl; hot0 = h0; due = d0; }
   }
   // the records phase, behind the loads above (the wait for its flag -- a scalar load at the cold start of the kernel --
   // used to stand in front of them: 7 500 clocks per wave in a tick without records, profiles/r03r_*)
-  if (rec_inline && s.g[G_ANYREC] == t + 1u) records_phase(s, t, li, mi, pushed | pulled, H, Hprev SECT_ARG);   // wave-uniform: somebody wrote an explicit record this tick
+  const bool recs_inline = rec_inline && s.g[G_ANYREC] == t + 1u;   // wave-uniform: somebody wrote an explicit record this tick
+  if (recs_inline) records_phase(s, t, li, mi, pushed | pulled, H, Hprev SECT_ARG);
   SECT(14);                                         // records phase
-  if (up) cnt = s.inbox_cnt[li];                    // entries of my todo list
+  if (up) cnt = recs_inline ? s.inbox_cnt[li] : cnt0;   // entries of my todo list (the phase above leaves its length there)
   if (s.G) settle_pass(s, li, up, wmax);
   uint4 ring_mine = make_uint4(NONE32, 0u, 0u, 0u);
   if (tid < KN_BITS) { ring_mine = s.ring[tid]; ring_sh[tid] = ring_mine; }
@@ -1257,11 +1276,12 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
   lds_barrier();
 #endif
   const uint32_t pcount = mi_pbn(mi), cur = mi_buf(mi);
+  const uint32_t my_slot1 = mi & MI_SLOT;          // slot+1 of rumours about me
   const bool woke = (hot0.y & 1u) != 0;            // came back up: deadlines it slept through are still in trow
   const bool timer_due = (due.x | due.y | due.z | due.w) != 0u;
   const bool act = up && ((pushed | pulled) != 0ull || (cnt | nfail | pcount | (uint32_t)timer_due | (uint32_t)woke));
   // idle this tick: only keep the ring valid (swim_device.h); nothing to write when no id was allocated
-  if (up && !act && stale) { const ulonglong2 v = s.pk[li]; if (v.y & stale) s.pk[li] = make_ulonglong2(v.x, v.y & ~stale); }
+  if (up && !act && stale) { if (pk0.y & stale) s.pk[li] = make_ulonglong2(pk0.x, pk0.y & ~stale); }
 
   uint32_t wflag = 0;                              // bit 0: my line was rebuilt in asm_, bit 1: into which buffer
   uint32_t self_inc = hot0.x;
@@ -1275,7 +1295,6 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
 #pragma unroll
   for (int h = 0; h < PB_SLOTS / 2; ++h) oslot[h] = 0xFFFFFFFFu;   // no entry: matches no slot (< 0xFFFF)
   const uint4* own_line = reinterpret_cast<const uint4*>(s.pb + ((size_t)cur * s.N + (li < s.N ? li : 0u)) * PB_SLOTS);
-  const uint32_t my_slot1 = mi & MI_SLOT;          // slot+1 of rumours about me
   uint32_t refute = NONE32;
   unsigned changes = 0, timers_fired = 0, evdropped = 0, refutes = 0, pb_writes = 0;   // timers_fired: low half; high half = ... about a member that is up
   unsigned long long evd = 0, ha = 0;
@@ -1290,10 +1309,19 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
 #pragma unroll
   for (int k = 0; k < DB; ++k) { dsl[k] = 0; dcell[k] = VCell{0u, 0u}; }
   const bool plain_due = timer_due && !woke && (uint32_t)(due.w >> 16) != TR_FULL;
+  // ... and (round 6) the view cells of the first GB delivered rumours the known-ring does not cover: with the ring in round one the
+  // positions are known here, a round trip before the rumour loop asks for them.  A cell this thread stores to in between (a
+  // deadline or a failed probe about the same subject) is looked at again (pf_ok).
+  constexpr int GBP = SWIM_GOSSIP_BATCH;
+  uint32_t pf_pos[GBP], pf_slot[GBP], pf_ok = 0; VCell pf_e[GBP];
+#pragma unroll
+  for (int k = 0; k < GBP; ++k) { pf_pos[k] = NONE32; pf_slot[k] = NONE32; pf_e[k] = VCell{0u, 0u}; }
+  uint4 ol[PB_SLOTS / 2];                          // the own queue line: stays in registers for the queue rebuild
+#pragma unroll
+  for (int h = 0; h < PB_SLOTS / 2; ++h) ol[h] = make_uint4(0u, 0u, 0u, 0u);
   if (act) {
     PSTAT(0);
-    const unsigned long long known0 = s.pk[li].y;
-    uint4 ol[PB_SLOTS / 2];
+    const unsigned long long known0 = pk0.y;
     if (pcount) {
       PSTAT(1);
 #pragma unroll
@@ -1307,6 +1335,22 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
       }
     }
     kn = known0 & ~stale;
+#if !SWIM_MERGE_UNION
+    {
+      unsigned long long pre = (pushed | pulled) & ~kn;   // (the own queue's positions are not taken off yet: a few cells asked for in vain)
+      if (ABL(ABL_RUMOURS)) pre = 0;
+#pragma unroll
+      for (int k = 0; k < GBP; ++k) {
+        if (!pre) break;
+        const uint32_t p = (uint32_t)__ffsll((unsigned long long)pre) - 1u;
+        pre &= pre - 1ull;
+        const uint32_t sl = ring_sh[p].x;
+        if (sl + 1 == my_slot1 || sl >= s.R_phys) continue;
+        pf_pos[k] = p; pf_slot[k] = sl; pf_ok |= 1u << k;
+        if (!ABL(ABL_V_LOAD)) pf_e[k] = v_hot(s, vidx(s, li, sl));
+      }
+    }
+#endif
     if (pcount) {
 #pragma unroll
       for (int h = 0; h < PB_SLOTS / 2; ++h)
@@ -1414,6 +1458,8 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
     PSTAT(6); PSTAT(psite); SECT_COUNT(21);
     const bool again_ = v_changed_in(s, vidx(s, li, slot), e, t);     // (before the store below)
     if (!ABL(ABL_V_STORE)) v_put(s, vidx(s, li, slot), key, t + 1);                    // memberLastChange = now (:176)
+#pragma unroll
+    for (int k = 0; k < GBP; ++k) if (pf_slot[k] == slot) pf_ok &= ~(1u << k);     // a cell asked for ahead of time is stale now
     bool stated = !hasrid;                       // a rumour I state myself: the ring learns it (below)
 #if SWIM_RING_DIR
     if (!hasrid) {
@@ -1617,24 +1663,32 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
     unsigned long long fresh = (pushed | pulled) & ~kn;
     kn |= fresh;
     if (ABL(ABL_RUMOURS)) fresh = 0;
-    while (fresh) {
+    for (bool first = true; fresh; first = false) {
       PSTAT(10);
-      uint32_t rid[GB]; uint4 r[GB]; VCell e[GB];
+      uint32_t rid[GB]; uint4 r[GB]; VCell e[GB]; uint32_t pos[GB];
       uint32_t n = 0;
 #pragma unroll
       for (int k = 0; k < GB; ++k) {
-        rid[k] = 0; r[k] = make_uint4(0u, 0u, 0u, 0u); e[k] = VCell{0u, 0u};
+        rid[k] = 0; r[k] = make_uint4(0u, 0u, 0u, 0u); e[k] = VCell{0u, 0u}; pos[k] = NONE32 - 1u;
         if (fresh) {
           const uint32_t p = (uint32_t)__ffsll((unsigned long long)fresh) - 1u;
           fresh &= fresh - 1ull;
+          pos[k] = p;
           rid[k] = rid_at(p, H) & RID_MASK;
           r[k] = ring_sh[p];                       // {slot, key, base, subject} of the id at position p
           n = (uint32_t)k + 1u;
         }
       }
 #pragma unroll
-      for (int k = 0; k < GB; ++k)
-        if ((uint32_t)k < n && r[k].x + 1 != my_slot1 && !ABL(ABL_V_LOAD)) e[k] = v_hot(s, vidx(s, li, r[k].x));
+      for (int k = 0; k < GB; ++k) {
+        if ((uint32_t)k >= n || r[k].x + 1 == my_slot1 || ABL(ABL_V_LOAD)) continue;
+        // the first batch's cells were asked for a round trip ago (above), unless this thread has stored to one since
+        bool got = false;
+#pragma unroll
+        for (int j = 0; j < GBP; ++j)
+          if (first && pf_pos[j] == pos[k] && ((pf_ok >> j) & 1u)) { e[k] = pf_e[j]; got = true; }
+        if (!got) e[k] = v_hot(s, vidx(s, li, r[k].x));
+      }
 #pragma unroll
       for (int k = 0; k < GB; ++k) {
         if ((uint32_t)k >= n) continue;
@@ -1736,7 +1790,6 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
     uint32_t nout = gn;
     unsigned long long qmask = 0;
     uint32_t oow = 0;
-    const bool rids_off = s.g[G_RIDS_OFF] != 0u;
     auto publish = [&](uint32_t lo) -> uint32_t {  // mask bit or "cannot express", id parked if too old
       if (rids_off) { oow = MI_OOW; return pe_lo(pe_slot(lo), RID_PARKED); }
       const uint32_t rid = pe_rid(lo);
@@ -1751,7 +1804,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
     if (pcount) {
 #pragma unroll
       for (int h = 0; h < PB_SLOTS / 2; ++h) {
-        const uint4 v = ABL(ABL_OWN_LINE) ? make_uint4(0u, 0u, 0u, 0u) : own_line[h];
+        const uint4 v = ol[h];                     // (held since the second round of loads; it was read again here)
 #pragma unroll
         for (int w = 0; w < 2; ++w) {
           const uint32_t lo = w ? v.z : v.x, hi = w ? v.w : v.y, tx = pe_tx(hi);

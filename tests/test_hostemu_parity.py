@@ -449,3 +449,19 @@ def test_plain_ticks_with_and_without_begin_kernel(oracle_abi, emu_abi, monkeypa
         assert a.drainEventsRaw() == b.drainEventsRaw()
     assert a.firstDetection() == b.firstDetection()
     a.close(); b.close()
+
+
+def test_events_as_numpy_records_are_the_same_stream(oracle_abi, emu_abi):
+    """Sim.drainEventsArray (the bulk form the million-member event test uses) = drainEventsRaw, record by record, on both sides."""
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=600, seed=3, lossPpm=50000, eventMask=0x1F, suspicionTicks=5, maxSubjects=600)
+    a, b = make_pair(oracle_abi, emu_abi, sc, [(2, 5), (3, 77)], [(20, 5, True)])
+    a2, b2 = make_pair(oracle_abi, emu_abi, sc, [(2, 5), (3, 77)], [(20, 5, True)])
+    for _ in range(6):
+        for s_ in (a, b, a2, b2):
+            s_.step(5)
+        raw, arr, arr_b = a.drainEventsRaw(), a2.drainEventsArray(), b2.drainEventsArray()
+        assert raw == b.drainEventsRaw()
+        assert [(int(e["tick"]), int(e["observer"]), int(e["subject"]), int(e["incarnation"]), int(e["state"]), int(e["cause"])) for e in arr] == raw
+        assert (arr == arr_b).all() and len(arr) == len(arr_b)
+    for s_ in (a, b, a2, b2):
+        s_.close()
