@@ -25,11 +25,12 @@ module Swim.Sim
   , drainEvents, simulate, memberView, firstDetection, digest
   , encodeEnvelope, decodeEnvelope
   , stepShard, stepCluster
+  , injectRumor, injectRumorCluster
   ) where
 
 import           Control.Concurrent.MVar (MVar, newMVar, withMVar)
 import           Control.Exception (SomeException, bracket, throwIO, try)
-import           Control.Monad (forM, unless, when)
+import           Control.Monad (forM, forM_, unless, when)
 import           Data.IORef (newIORef, readIORef, writeIORef)
 import           Control.Monad.IO.Class (liftIO)
 import           Data.Conduit (Source, yield)
@@ -108,6 +109,9 @@ foreign import ccall "wrapper" mkExchange :: ExchangeFn -> IO (FunPtr ExchangeFn
 foreign import ccall safe   "swimsim_shard_step"    c_shard_step    :: Ptr SwimsimT -> Word32 -> FunPtr ExchangeFn -> Ptr () -> IO CInt
 -- a whole cluster of handles (dense or bounded) owned by this process, the exchange inside the library (include/swimsim.h)
 foreign import ccall safe   "swimsim_cluster_step"  c_cluster_step  :: Ptr (Ptr SwimsimT) -> Word32 -> Word32 -> IO CInt
+-- messages from outside the simulation (what `process` does with a Suspect / Alive / Dead off the socket, src/Core.hs:110-117)
+foreign import ccall unsafe "swimsim_inject_rumor"       c_inject :: Ptr SwimsimT -> Word32 -> Word32 -> Word8 -> Word32 -> IO CInt
+foreign import ccall unsafe "swimsim_note_outside_rumor" c_note   :: Ptr SwimsimT -> Word32 -> Word32 -> IO CInt
 
 defaultSimConfig :: Config -> SimConfig
 defaultSimConfig c = SimConfig c 128 1 0 0 0 0 0 0 0 0 0 0 False False 0 1
@@ -370,3 +374,17 @@ stepCluster sims nticks = go sims []
       msg <- c_last_error h >>= peekCString
       if null msg && not (null rest) then firstError rest rc else ioError (userError (if null msg then "swimsim_cluster_step: status " ++ show rc else msg))
     firstError [] rc = ioError (userError ("swimsim_cluster_step: status " ++ show rc))
+
+-- | A Suspect / Alive / Dead message about member @subject@ that reaches simulated member @observer@ from OUTSIDE the simulation
+-- (`process`, src/Core.hs:110-117): delivered in the next tick stepped, ruled on like any rumour.  State as the reference's
+-- constructor index (0 Alive, 1 Suspect, 2 Dead).
+injectRumor :: Sim -> Word32 -> Word32 -> Word8 -> Word32 -> IO ()
+injectRumor s observer subject st inc = withSim s $ \h -> c_inject h observer subject st inc >>= check h
+
+-- | The same on a cluster (the shards in order, equal-sized contiguous id ranges): the owner of @observer@ takes the message, every
+-- other shard is told of it (the subject's view row belongs to the whole cluster; include/swimsim.h).
+injectRumorCluster :: [Sim] -> Word32 -> Word32 -> Word32 -> Word8 -> Word32 -> IO ()
+injectRumorCluster sims nMembers observer subject st inc =
+  forM_ (zip [0 ..] sims) $ \(k, s) -> withSim s $ \h ->
+    if k == owner then c_inject h observer subject st inc >>= check h else c_note h observer subject >>= check h
+  where owner = observer `div` (nMembers `div` fromIntegral (length sims)) :: Word32

@@ -202,7 +202,8 @@ typedef struct swimsim_config {
  * what the map before the pull would have (max is idempotent).
  * On sharded handles the periodic pull works as the join-time pull does: a puller whose host lives on another shard receives the host's
  * map as kind-4 records in exchange round 0, so a shard with pull_ticks starts EVERY tick with swimsim_shard_phase0 (swimsim_shard_step
- * does).  push_pull is not available on sharded handles (SWIMSIM_ERR_INVALID). */
+ * does).  push_pull on sharded handles (round 6): a puller whose host lives on another shard hands the host's owner its map as records of
+ * the same round 0 ({host | 1 << 31, subject, entry}); pairs of one shard push as on one handle. */
 
 #define SWIMSIM_GC_AUTO 0xFFFFFFFFu
 

@@ -11,7 +11,11 @@ WARM = int(os.environ.get('WARM', 150)); CHUNK = int(os.environ.get('CHUNK', 40)
 N = int(os.environ.get('MEMBERS', 1 << 20)); LOSS = int(os.environ.get('LOSS', 0)); P = int(os.environ.get('P', 3))
 CPT = float(os.environ.get('CPT', 1.0)); MAXSUBJ = int(os.environ.get('MAXSUBJ', 0))
 sims = []
-for path in sys.argv[1:]:
+envs = {}                                           # "lib.so@VAR=VAL[,VAR=VAL]": environment knobs the library reads per call, set around this variant's steps
+for spec in sys.argv[1:]:
+    path, _, ev = spec.partition("@")
+    envs[spec] = dict(kv.split("=", 1) for kv in ev.split(",")) if ev else {}
+    os.environ.update(envs[spec])
     abi = _abi.bind(C.CDLL(os.path.abspath(path)), "swimsim_")
     sc, crashes, _ = workloads.saturated(N, WARM + CHUNK * ROUNDS, loss_ppm=LOSS, num_to_gossip=P, crashes_per_tick=CPT, t0=0)
     if MAXSUBJ:
@@ -21,12 +25,16 @@ for path in sys.argv[1:]:
     sc.targetScheme = 1 if os.environ.get('SCHEME') == 'robust' else 0
     s = Sim.create(abi, sc); workloads.apply_crashes(s, crashes)
     s.step(WARM)
-    sims.append((os.path.basename(path), s, {"probe": [], "merge": [], "wall": []}))
+    for k_ in envs[spec]: os.environ.pop(k_, None)
+    sims.append((os.path.basename(spec), s, {"probe": [], "merge": [], "wall": []}))
 for r in range(ROUNDS):
     order = sims if r % 2 == 0 else sims[::-1]
     for name, s, acc in order:
+        os.environ.update(envs.get(name, {}) or next((v for k_, v in envs.items() if os.path.basename(k_) == name), {}))
         s.kernelTimingEnable(True)
         t0 = time.time(); s.step(CHUNK); dt = time.time() - t0
+        for v_ in envs.values():
+            for k_ in v_: os.environ.pop(k_, None)
         kt = s.kernelTiming()
         acc["probe"].append(kt["probe_ms"] * 1e3 / kt["ticks"]); acc["merge"].append(kt["merge_ms"] * 1e3 / kt["ticks"])
         acc["wall"].append(dt / CHUNK * 1e6)

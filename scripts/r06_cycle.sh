@@ -42,4 +42,25 @@ e)  # probe_kernel with the first draws' bytes and the own queue mask in the rou
    echo "# 1 % loss, settling:"; LOSS=10000 GC=1 ROUNDS=5 CHUNK=20 timeout 900 python scripts/ab_time.py $C/libswimsim_x_base.so $C/libswimsim.so) 2>&1 | grep -v amdgpu.ids | tee $O/r06e_ab_probe_first_draws.txt
   timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 | tee $O/r06e_pytest.log
   ;;
+f)  # where the waves of the two tick kernels spend their time now (section clocks); binned pushes against global atomics; the new tests
+  canary f
+  timeout 600 python scripts/section_clocks.py 2>/dev/null | grep -v amdgpu.ids > $O/r06f_section_clocks_saturated.json; python -c "
+import json; d=json.load(open('$O/r06f_section_clocks_saturated.json'))
+for k in ('merge_kernel','probe_kernel'):
+    print(k, d[k]['clocks_per_wave'], {n: v['clocks_per_wave'] for n, v in d[k]['sections'].items() if v['clocks_per_wave'] > 100})
+print(d['events_per_tick'], d['probe_us'], d['merge_us'])"
+  (cd scripts/microbench && timeout 300 ./push_binning 20 50) 2>&1 | tee $O/r06f_microbench_push_binning.txt
+  timeout 1200 python -m pytest tests -m gpu -x -q -k "event_stream or bridge or golden" 2>&1 | tail -5 | tee $O/r06f_pytest_subset.log
+  ;;
+g)  # the slow regimes: explicit records as a phase of merge_kernel against records_kernel in BASELINE.md row 3(s) as written; where the waves go there and at 1 % loss
+  canary g
+  (echo "# BASELINE.md row 3(s) as written: records as a phase of merge_kernel (the lossless handle's choice) | records_kernel"; CPT=9.5 GC=1 MAXSUBJ=8192 WARM=200 CHUNK=20 ROUNDS=5 timeout 900 python scripts/ab_time.py $C/libswimsim.so@SWIMSIM_RECORDS_KERNEL=0 $C/libswimsim.so@SWIMSIM_RECORDS_KERNEL=1) 2>&1 | grep -v amdgpu.ids | tee $O/r06g_ab_records_kernel_as_written.txt
+  CPT=9.5 GC=1 MAXSUBJ=8192 WARM=200 TICKS=40 timeout 600 python scripts/section_clocks.py 2>/dev/null | grep -v amdgpu.ids > $O/r06g_section_clocks_as_written.json
+  LOSS=10000 GC=1 WARM=150 TICKS=40 timeout 600 python scripts/section_clocks.py 2>/dev/null | grep -v amdgpu.ids > $O/r06g_section_clocks_loss1pct.json
+  for f in as_written loss1pct; do python -c "
+import json; d=json.load(open('$O/r06g_section_clocks_$f.json'))
+for k in ('merge_kernel','probe_kernel','records_kernel'):
+    print('$f', k, d[k]['clocks_per_wave'], {n: v['clocks_per_wave'] for n, v in d[k]['sections'].items() if v['clocks_per_wave'] > 300})
+print(d['events_per_tick'], d['probe_us'], d['merge_us'])"; done
+  ;;
 esac

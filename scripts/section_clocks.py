@@ -1,7 +1,7 @@
 """Where the waves of probe_kernel / merge_kernel spend their time (MI355X): the -DSWIM_SECTION_CLOCKS build adds,
 per wave, the shader clocks between marks in the kernels to a table (swim_kernels.h SECT).  Time waiting for a
 load is charged to the section that first USES the value.  usage: section_clocks.py [libswimsim_sect.so]
-env: WARM, TICKS, MEMBERS, SCHEME=robust, GC=1, LOSS (ppm)"""
+env: WARM, TICKS, MEMBERS, SCHEME=robust, GC=1, LOSS (ppm), CPT (crashes per tick), MAXSUBJ"""
 import ctypes as C
 import json
 import os
@@ -25,7 +25,9 @@ def main():
     lib = C.CDLL(os.path.abspath(path))
     abi = _abi.bind(lib, "swimsim_")
     lib.swimsim_debug_sections.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
-    sc, crashes, _ = workloads.saturated(n, warm + ticks, loss_ppm=int(os.environ.get("LOSS", 0)))
+    sc, crashes, _ = workloads.saturated(n, warm + ticks, loss_ppm=int(os.environ.get("LOSS", 0)), crashes_per_tick=float(os.environ.get("CPT", 1.0)))
+    if os.environ.get("MAXSUBJ"):
+        sc.maxSubjects = int(os.environ["MAXSUBJ"])
     sc.targetScheme = 1 if os.environ.get("SCHEME") == "robust" else 0
     if os.environ.get("GC"):
         sc.gcTicks = _abi.GC_AUTO

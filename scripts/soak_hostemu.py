@@ -32,6 +32,7 @@ def run_case(seed0, k, log=print):
     """Case k of the soak with seed seed0 (the whole case is a function of the two): returns (ok, what).  Every 20 ticks: counters,
     digest, events; first-detection ticks at the end.  tests/test_shard_hostemu.py replays the cases that once diverged."""
     rng = random.Random(seed0 * 100003 + k)
+    rng2 = random.Random(seed0 * 100003 + k + 7777777)    # options added in later rounds draw from here
     vname = rng.choice(list(_VARIANT_DEFS))
     n = rng.choice([130, 300, 700, 1500, 3000])
     shards = rng.choice([1, 1, 2, 3, 4, 8])                      # sharded clusters take every option of the plain handle
@@ -43,8 +44,8 @@ def run_case(seed0, k, log=print):
     jp = rng.random() < 0.5
     S = rng.choice([4, 7, 12])
     pt = rng.choice([0, 0, 2, 3, 9, 40])                          # periodic state pull (on shards: exchange round 0 in every tick)
-    pp = bool(pt) and shards == 1 and rng.random() < 0.5         # ... as a push-pull (one handle only)
-    strict = not gc and not jp and not pt and rng.random() < 0.5   # the literal suspectOrDeadNode' (no other option with it; on shards too since round 6)
+    pp = bool(pt) and (rng.random() < 0.5 if shards == 1 else rng2.random() < 0.5)   # ... as a push-pull (on shards too since round 6: drawn from a generator of its own, so that the cases of earlier rounds replay as they were)
+    strict = not gc and not jp and not pt and (rng.random() < 0.5 if shards == 1 else rng2.random() < 0.5)   # the literal suspectOrDeadNode' (no other option with it; on shards too since round 6)
     fold = rng.choice(["0", "1"])                                # plain ticks with / without begin_kernel
     ticks = rng.choice([200, 400, 800])
     sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=rng.randrange(1, 1 << 30), lossPpm=loss, eventMask=0x1F,

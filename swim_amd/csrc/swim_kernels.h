@@ -2332,6 +2332,22 @@ __device__ inline uint32_t join_host(const DevState& s, uint32_t t, uint32_t tk,
 }
 
 // one pulled entry: joiner ml's cell of `slot` becomes kh if that is news to it
+constexpr uint32_t PUSH_REC = 1u << 31;             // round-0 record {member | PUSH_REC, subject, entry}: a PUSH into a host's map (ids are < 2^27 on shards)
+// the push half of a push-pull for one entry of a puller's map (km about `subject`): the host's entry is raised to it.  Several pullers
+// -- blocks of push_kernel, records from other shards -- may raise one entry: atomicMax on the key, whoever raises it accounts for its
+// step (the event digest is linear in the key), the first to stamp lastChange counts the change
+__device__ inline void push_entry(const DevState& s, uint32_t t, uint32_t host, uint32_t slot, uint32_t subject, uint32_t km,
+                                  unsigned long long* evd, unsigned* pushed, unsigned* suspects) {
+  if (!km || km <= s.slot_base[slot]) return;       // (an untouched cell of the host reads 0: never raise it to below the base)
+  const size_t ix = vidx(s, host - s.lo, slot);
+  const uint32_t old = v_raise_key(s, ix, km, t);
+  const uint32_t curk = old ? old : s.slot_base[slot];
+  if (km <= curk) return;
+  *evd += (mix64(mix64(mix64((uint64_t)TAG_EV) + (((uint64_t)t << 32) | host)) + subject) | 1ull) * (unsigned long long)(km - curk);
+  if (v_stamp(s, ix, t) != t + 1u) (*pushed)++;
+  if (s.G) s.slot_last[slot] = t;
+  *suspects += (km & 3u) == ST_SUSPECT ? 1u : 0u;
+}
 __device__ inline void pull_entry(const DevState& s, uint32_t t, uint32_t mbr, uint32_t slot, uint32_t subject, uint32_t kh,
                                   unsigned long long* evd, unsigned* pulled) {
   const size_t ix = vidx(s, mbr - s.lo, slot);
@@ -2434,6 +2450,17 @@ __global__ __launch_bounds__(BLOCK) void begin_kernel(DevState s, uint32_t t, ui
       const uint4* jlist = jv.direct ? jv.jl[p] : s.j_recv + (size_t)p * s.j_cap;     // (swimsim_cluster_step: the peer's records where they lie)
       for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
         const uint4 r = jlist[k];
+        if (r.x & PUSH_REC) {
+          // the push half of a push-pull whose puller lives on another shard: my member (the host) merges the entry
+          const uint32_t host = r.x & ~PUSH_REC;
+          if (!is_local(s, host) || r.y >= s.NT) continue;
+          unsigned long long evd = 0; unsigned pushed = 0, suspects = 0;
+          push_entry(s, t, host, get_slot(s, r.y), r.y, r.z, &evd, &pushed, &suspects);
+          if (suspects) atomicOr(&s.hot[host - s.lo].y, 1u);   // a host that took a Suspect over: merge_kernel rebuilds its deadline cells
+          if (evd) atomicAdd(&evd_sh, evd);
+          if (pushed) atomicAdd(&changes_sh, pushed);
+          continue;
+        }
         if (!is_local(s, r.x) || r.y >= s.NT) continue;
         unsigned long long evd = 0; unsigned pulled = 0;
         pull_entry(s, t, r.x, get_slot(s, r.y), r.y, r.z, &evd, &pulled);
@@ -2609,7 +2636,7 @@ __global__ __launch_bounds__(BLOCK) void push_kernel(DevState s, uint32_t t, uin
   __shared__ unsigned long long evd_sh;
   __shared__ unsigned pushed_sh, suspects_sh;
   __shared__ uint32_t host_sh;
-  const uint32_t T = s.pull_T, first = t % T;
+  const uint32_t T = s.pull_T, first = (t % T + T - s.lo % T) % T;   // my first periodic puller (local index; a shard starts at lo)
   const uint32_t npp = first < s.N ? (s.N - first + T - 1u) / T : 0u;
   const uint32_t nrows = min(s.g[G_NSLOTS], s.R_phys);
   constexpr int U = 4;
@@ -2617,7 +2644,10 @@ __global__ __launch_bounds__(BLOCK) void push_kernel(DevState s, uint32_t t, uin
     const uint32_t mbr = s.lo + first + k * T;
     if (threadIdx.x == 0) {
       evd_sh = 0; pushed_sh = 0; suspects_sh = 0;
-      host_sh = (mi_up(s.minfo[mbr]) && !changes_this_tick(faults, nfaults, mbr)) ? pull_host(s, t, tk, mbr, faults, nfaults, P_PULL) : NONE32;
+      uint32_t hst = (mi_up(s.minfo[mbr]) && !changes_this_tick(faults, nfaults, mbr)) ? pull_host(s, t, tk, mbr, faults, nfaults, P_PULL) : NONE32;
+      // (a host on another shard takes my map as records: pull_send_kernel wrote them, its begin_kernel merges them)
+      if (hst != NONE32 && !is_local(s, hst)) hst = NONE32;
+      host_sh = hst;
     }
     __syncthreads();
     const uint32_t host = host_sh;
@@ -2679,7 +2709,26 @@ __global__ __launch_bounds__(BLOCK) void pull_send_kernel(DevState s, uint32_t t
   for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nj + npp; k += gridDim.x * blockDim.x) {
     const bool joiner = k < nj;
     const uint32_t mbr = joiner ? joined[k] : first + (k - nj) * T;
-    if (is_local(s, mbr)) continue;
+    if (is_local(s, mbr)) {
+      // push_pull (round 6): a periodic puller of MINE whose host lives elsewhere hands the host's owner its map -- one record
+      // {host | PUSH_REC, subject, my entry} per entry that differs from the base, itself as Alive at its own incarnation.  The map
+      // BEFORE the pull: the host ends at max(its map, mine) either way (the pull adds nothing to my map the host does not hold)
+      if (joiner || !s.push_pull || !mi_up(s.minfo[mbr]) || changes_this_tick(faults, nfaults, mbr)) continue;
+      const uint32_t host = pull_host(s, t, tk, mbr, faults, nfaults, P_PULL);
+      if (host == NONE32 || is_local(s, host)) continue;
+      const uint32_t peer = owner_of(s, host), nrows = min(s.g[G_NSLOTS], s.R_phys), ml = mbr - s.lo;
+      for (uint32_t r = 0; r < nrows; ++r) {
+        if (!s.slot_used[r]) continue;
+        const uint32_t subject = s.subject_of[r];
+        if (subject == host) continue;
+        const uint32_t km = subject == mbr ? ((s.hot[ml].x << 2) | ST_ALIVE) : v_key(s, vidx(s, ml, r));
+        if (!km) continue;
+        const uint32_t pos = atomicAdd(&s.g[G_JSEND + peer], 1u);
+        if (pos < s.j_cap) s.j_send[(size_t)peer * s.j_cap + pos] = make_uint4(host | PUSH_REC, subject, km, 0u);
+        else atomicOr(&s.g[G_ERR], (uint32_t)ERRF_XCHG);
+      }
+      continue;
+    }
     if (!joiner && (!mi_up(s.minfo[mbr]) || changes_this_tick(faults, nfaults, mbr))) continue;   // (a puller is up and has no change in this tick)
     const uint32_t host = joiner ? join_host(s, t, tk, mbr, faults, nfaults) : pull_host(s, t, tk, mbr, faults, nfaults, P_PULL);
     if (host == NONE32 || !is_local(s, host)) continue;

@@ -165,7 +165,6 @@ int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, std::string*
   // (ranges first, combinations after: a value out of range gets the message that says so)
   if (c->push_pull > 1 || (c->push_pull && !c->pull_ticks)) { *err = "push_pull must be 0 or 1 and needs pull_ticks"; return SWIMSIM_ERR_INVALID; }
   if (c->strict_reference_rules > 1) { *err = "strict_reference_rules must be 0 or 1"; return SWIMSIM_ERR_INVALID; }
-  if (c->push_pull && c->n_shards > 1) { *err = "push_pull (the push half of the periodic state exchange) is not available on sharded handles"; return SWIMSIM_ERR_INVALID; }
   if (c->n_shards > 1 && c->n_members > (1u << 27)) { *err = "sharded clusters: n_members must be <= 2^27"; return SWIMSIM_ERR_INVALID; }
   if (c->strict_reference_rules && (c->view_cap || c->gc_ticks || c->join_pull || c->pull_ticks)) {
     *err = "strict_reference_rules cannot be combined with view_cap, gc_ticks, join_pull or pull_ticks"; return SWIMSIM_ERR_INVALID; }
@@ -644,7 +643,7 @@ int swimsim_create(const swimsim_config_t* cfg, swimsim_t** out) {
       // loss that is every row in use (3 000 members at 15 % loss, T = 3: 250 pulls x 1 500 entries to one peer per tick, the GPU
       // test that found the first sizing too small): room for min(rows, 2 048) entries per pull and twice the share, at most 8 M
       // records per peer (a loud capacity error beyond: SWIMSIM_ERR_CAPACITY)
-      if (d.pull_T) d.j_cap = (uint32_t)std::min<double>(8388608.0, std::max<double>(d.j_cap, 2.0 * std::min<double>(d.R_phys, 2048.0) * ((double)NT / d.pull_T / d.n_shards + 64.0)));
+      if (d.pull_T) d.j_cap = (uint32_t)std::min<double>(8388608.0, std::max<double>(d.j_cap, (d.push_pull ? 4.0 : 2.0) * std::min<double>(d.R_phys, 2048.0) * ((double)NT / d.pull_T / d.n_shards + 64.0)));   // (push_pull: the pullers' maps travel too)
       CK(dev_alloc(h, &d.j_send, (size_t)d.n_shards * d.j_cap, 0));
       CK(dev_alloc(h, &d.j_recv, (size_t)d.n_shards * d.j_cap, 0));
     }
@@ -1279,6 +1278,9 @@ int swimsim_shard_phase1(swimsim_t* h, uint32_t* counts) {
     const uint32_t npp = (T && first < h->d.N) ? (h->d.N - first + T - 1u) / T : 0u;
     if (nup + npp) hipLaunchKernelGGL(join_pull_kernel, dim3(std::min(nup + npp, 4096u)), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults,
                                       (uint32_t)fend, h->d_joined, nup);
+    // push-pull: once every local pull has read its host, my hosts merge the maps of their pullers on THIS shard (those of pullers
+    // elsewhere arrived as records: begin_kernel below)
+    if (h->d.push_pull && npp) hipLaunchKernelGGL(push_kernel, dim3(std::min(npp, 4096u)), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults, (uint32_t)fend);
   }
   hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults, (uint32_t)fend,
                      h->d_joined, (h->begun ? (2u | 8u) : 3u) | (h->tick_inj ? 4u : 0u), peer_counts(h, h->j_in), JoinView{});
@@ -1532,6 +1534,7 @@ static int cluster_step_dense(swimsim_t** hs, uint32_t n, uint32_t nticks) {
         const uint32_t T = h->d.pull_T, first = T ? (t % T + T - h->d.lo % T) % T : 0u;       // my first periodic puller, as a local index
         const uint32_t npp = (T && first < h->d.N) ? (h->d.N - first + T - 1u) / T : 0u;
         if (nup + npp) hipLaunchKernelGGL(join_pull_kernel, dim3(std::min(nup + npp, 4096u)), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, nf, h->d_joined, nup);
+        if (h->d.push_pull && npp) hipLaunchKernelGGL(push_kernel, dim3(std::min(npp, 4096u)), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, nf);
         hipLaunchKernelGGL(begin_kernel, dim3(1), dim3(BLOCK), 0, h->stream, h->d, t, tk, h->d_faults + f0, nf, h->d_joined, (2u | 8u) | (injs[k] ? 4u : 0u), PeerCounts{}, jv[k]);
         hipLaunchKernelGGL(publish_kernel, dim3(publish_grid(h)), dim3(BLOCK), 0, h->stream, h->d, t);
         CCHK(h, hipEventRecord(ev[k][0], h->stream));

@@ -2,7 +2,7 @@
 Every rank drives its shard through the host emulation of the product kernels; rank 0 also runs the
 oracle and compares every observable.  usage: dist_worker.py <n_members> <p> <loss_ppm> <seed> <ticks> [mode]
 (mode bit 0: settling on, suspicion 5 ticks, retransmit x1, and the member that went down comes back twice; bit 1: join pull;
-bit 2: periodic state pull every 5 periods; bit 3: strict_reference_rules; bits 8..: view_cap)"""
+bit 2: periodic state pull every 5 periods; bit 3: strict_reference_rules; bit 4: push_pull (with bit 2); bits 8..: view_cap)"""
 import os
 import sys
 
@@ -15,7 +15,8 @@ def main():
     mode = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     gc, pull, ppull = bool(mode & 1), bool(mode & 2), bool(mode & 4)       # 1: settling, 2: join-time pull (round 0), 4: periodic pull (round 0 in every tick)
     strict = bool(mode & 8)                         # 8: the literal suspectOrDeadNode' (every queue travels as a list)
-    cap = mode >> 8                                 # bits 8..: bounded member maps with this view_cap (no other option)
+    push = bool(mode & 16)                          # 16: the periodic pull is a push-pull
+    cap = (mode >> 8)                               # bits 8..: bounded member maps with this view_cap (no other option)
     import torch.distributed as dist
     dist.init_process_group("gloo")
     rank = dist.get_rank()
@@ -34,6 +35,8 @@ def main():
         sc.viewCap, sc.maxSubjects = cap, 0
     if strict:
         sc.strictReferenceRules = True
+    if push:
+        sc.pushPull = True
     if os.environ.get("SWIM_DIST_DEVICE", "cpu") == "cuda":
         # all ranks share GPU 0 (RCCL refuses two ranks on one device): the real HIP library, device
         # buffers wrapped zero-copy, records staged through host memory over gloo

@@ -639,6 +639,12 @@ def test_live_node_bridge_on_the_gpu(hip_abi):
     bridge_scenario(hip_abi)
 
 
+def test_live_node_bridge_for_a_sharded_cluster_on_the_gpu(hip_abi):
+    """swimbridge_open_cluster: the same scenario with the population as 4 shards on the MI355X behind one endpoint."""
+    from tests.test_bridge import bridge_scenario
+    bridge_scenario(hip_abi, shards=4, device="cuda:0")
+
+
 def test_injected_rumours_match_the_oracle_on_the_gpu(oracle_abi, hip_abi):
     """swimsim_inject_rumor (messages from outside the simulation) at 20 000 members with loss: HIP vs oracle."""
     sc = SimConfig(cfg=Config(numToGossip=3), nMembers=20000, seed=8, lossPpm=10000, eventMask=0, suspicionTicks=8)
@@ -681,8 +687,9 @@ def test_periodic_state_pull_on_the_gpu(oracle_abi, hip_abi, T, gc, loss, n, pus
     assert b.counters()["changes"] > 0
 
 
+@pytest.mark.parametrize("push", [0, 1])
 @pytest.mark.parametrize("n,loss,T,gc,join,shards", [(4096, 50000, 5, 1, 1, 4), (65536, 10000, 64, 0, 1, 8), (1500, 150000, 3, 0, 0, 2), (3000, 150000, 3, 0, 0, 2)])
-def test_periodic_state_pull_on_sharded_clusters_on_one_gpu(oracle_abi, hip_abi, n, loss, T, gc, join, shards):
+def test_periodic_state_pull_on_sharded_clusters_on_one_gpu(oracle_abi, hip_abi, n, loss, T, gc, join, shards, push):
     """pull_ticks on a cluster of dense shards (several handles on this GPU, the exchange as device-to-device copies): pullers whose
     hosts live on other shards are served in exchange round 0 (pull_send_kernel / begin_kernel's record merge).  MI355X = the
     unsharded oracle."""
@@ -690,7 +697,7 @@ def test_periodic_state_pull_on_sharded_clusters_on_one_gpu(oracle_abi, hip_abi,
     from swim_amd.shard import LocalFabric, ShardedSim
     events = n <= 4096 and not (n >= 3000 and loss >= 100000)      # (3 000 members at 15 % loss fill the event ring within 6 ticks: what is dropped then is implementation-defined)
     sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=41 + T, lossPpm=loss, eventMask=0x1F if events else 0, suspicionTicks=6,
-                   maxSubjects=min(n, 4096), pullTicks=T, gcTicks=_abi.GC_AUTO if gc else 0, joinPull=join)
+                   maxSubjects=min(n, 4096), pullTicks=T, gcTicks=_abi.GC_AUTO if gc else 0, joinPull=join, pushPull=bool(push))   # push: push_pull on shards (round 6)
     a, b = Sim.create(oracle_abi, sc), ShardedSim(hip_abi, sc, LocalFabric(shards), device="cuda:0")
     _oracle_threads(a)
     crashes = [(3 + 2 * k, (37 * k + 11) % n) for k in range(40)]

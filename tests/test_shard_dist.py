@@ -63,3 +63,9 @@ def test_one_process_per_shard_gloo_with_the_literal_rule():
     an explicit record; = the unsharded oracle's literal mode (15 % / 25 % loss: the rules part)."""
     run_world(2, (192, 3, 150000, 21, 60, 8), 29622)
     run_world(4, (256, 3, 250000, 22, 50, 8), 29623)
+
+
+def test_one_process_per_shard_gloo_with_push_pull():
+    """push_pull on a sharded cluster, one process per shard: the pullers' maps travel to their hosts' owners in round 0."""
+    run_world(2, (192, 3, 20000, 15, 60, 4 | 16), 29624)
+    run_world(4, (256, 3, 100000, 16, 60, 7 | 16), 29625)
