@@ -138,6 +138,10 @@ def main(argv=None, abi=None):
                     help="bounded member maps (view_cap = C; include/swimsim.h): BASELINE config 5's regime at its per-GPU size, e.g. "
                          "--members 2097152 --loss-ppm 300000 --view-cap 64 [--churn 10]; no crash schedule of its own, no pre-roll")
     ap.add_argument("--churn", type=int, default=0, help="with --view-cap: per mille of the members crash and rejoin per 100 ticks")
+    ap.add_argument("--launch", default="auto", choices=["auto", "single", "dist"],
+                    help="--gpus N > 1: 'single' = ONE process, N handles (swimsim_cluster_step: what the driver's plain `python bench.py --gpus N` "
+                         "gets); 'dist' = one process per GPU under torch.distributed.run (re-executed that way if started without it); "
+                         "'auto' = dist when WORLD_SIZE is set, single otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle replay (baseline + verification)")
     ap.add_argument("--no-as-written", action="store_true",
                     help="skip the second window of the default run: BASELINE.md row 3(s) as written (9.5 crashes per tick, settling, 8 192 rows)")
@@ -154,6 +158,16 @@ def main(argv=None, abi=None):
     # `python bench.py --gpus N` as the driver starts it -- ONE process: N handles on N devices, the tick loop and the exchange
     # inside the library (swimsim_cluster_step: what a single Haskell host with eight GPUs calls).  Under torch.distributed.run
     # (WORLD_SIZE set): one process per GPU, swimsim_shard_step with torch.distributed as the embedder's exchange.
+    if args.gpus > 1 and args.launch == "dist" and "WORLD_SIZE" not in os.environ and abi is None:
+        # the other launch shape, without editing code or wrapping the command: the same arguments under torch.distributed.run
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+        av = sys.argv[1:] if argv is None else list(argv)
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + av)
+    if args.gpus > 1 and args.launch == "single" and "WORLD_SIZE" in os.environ:
+        raise SystemExit("bench: --launch single under torch.distributed.run (start it as `python bench.py --gpus N`)")
     single = args.gpus > 1 and "WORLD_SIZE" not in os.environ
     if args.gpus > 1 and not single and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (or without it: one process steps all %d GPUs)" % (args.gpus, args.gpus))

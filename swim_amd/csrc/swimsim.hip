@@ -57,6 +57,7 @@ struct swimsim {
   double graph_ms = 0;                      // SWIMSIM_GRAPH=1: launch-to-completion time of the last step's graph
   bool poisoned = false;
   std::string err;
+  bool recs_busy = false;                      // the last tick looked at allocated more rumour ids than the masks tolerate: records_kernel_every_tick
   std::vector<InjectRec> injections;           // swimsim_inject_rumor: delivered in the next tick stepped
   InjectRec* d_inject = nullptr;
   std::vector<swimsim_view_entry_t> settled_alive;   // settled subjects that stay listed (Alive at i > 0), as of settled_alive_tick
@@ -180,6 +181,7 @@ int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, std::string*
 int check_device_errors(swimsim* h) {
   uint32_t g[G_WORDS];
   HIPCHK(h, hipMemcpy(g, h->d.g, sizeof g, hipMemcpyDeviceToHost));
+  h->recs_busy = !h->d.C && h->d.n_shards == 1 && g[G_HEAD] - g[G_PREV] > MASK_SLACK;
   if (g[G_ERR]) {
     std::string m = "capacity exceeded:";
     if (g[G_ERR] & ERRF_SUBJECTS) m += h->d.C ? " subjects-a-member-hears-of-in-one-tick (bounded member maps: the per-tick working set)" : " max_subjects";
@@ -267,7 +269,10 @@ Offsets robust_offsets(const swimsim* h, uint32_t t) {
 bool records_kernel_every_tick(const swimsim* h) {
   const char* force = std::getenv("SWIMSIM_RECORDS_KERNEL");             // test / measurement knob: 0 = never, 1 = always
   if (force && (force[0] == '0' || force[0] == '1')) return force[0] == '1';
-  return h->cfg.loss_ppm != 0 || h->d.strict;   // strict reference rules: every delivery is an explicit record
+  // ... or the cluster states more new rumours per tick than the masks tolerate (BASELINE.md row 3(s) as written: 9.5 crashes per tick =
+  // ~20 ids per tick against MASK_SLACK = 16): every tick travels as explicit records for every member, as under loss.  Looked at
+  // once per swimsim_step call (check_device_errors reads the words anyway); merge 1 139 -> 1 064 us there (profiles/r06g_*)
+  return h->cfg.loss_ppm != 0 || h->d.strict || h->recs_busy;   // strict reference rules: every delivery is an explicit record
 }
 
 // messages from outside the simulation (swimsim_inject_rumor) go into this tick's inboxes BEFORE the start of the tick: the rows they
