@@ -396,7 +396,7 @@ def main(argv=None, abi=None):
                              "kernels": per_kernel},
             }
             if not args.view_cap:
-                # what the 8 TB/s yardstick hides (DESIGN.md section 6, "Round 4: merge_kernel against the chip's RANDOM-access rate"): both
+                # what the 8 TB/s yardstick hides (DESIGN.md section 5, "Round 4: merge_kernel against the chip's RANDOM-access rate"): both
                 # tick kernels are made of scattered 8-byte accesses, which the chip serves at fixed RATES (microbenchmarks under profiles/)
                 chg = rt["r"] * n
                 png = (c1["pings"] - c0["pings"]) / float(steps) / world

@@ -426,7 +426,7 @@ int swimsim_note_outside_rumor(swimsim_t* h, uint32_t observer, uint32_t subject
  * probe outcomes need no communication, only piggyback payloads cross shards.  View rows and rumour ids
  * are per-shard numberings; what crosses shards is named by (subject, incarnation<<2|state).  Every shard
  * holds a REPLICA of what a delivery "dst merges src's queue" reads about src: its start-of-tick queue mask
- * (over its owner's ring of the tick) and a queue byte.  One tick (round 5; DESIGN.md section 7) is
+ * (over its owner's ring of the tick) and a queue byte.  One tick (round 5; DESIGN.md section 6) is
  *   phase1  -> round 1, an ALL-GATHER: the caller delivers to every peer p this shard's
  *                kind 0  send[0][0 .. counts[p]) -- ONE segment, the same for every peer --: 16-byte records, the tick's ring
  *                        dictionary (64 x {subject, incarnation<<2|state}, one per mask position = 32 records), then the
@@ -445,7 +445,7 @@ int swimsim_note_outside_rumor(swimsim_t* h, uint32_t observer, uint32_t subject
  * on sharded handles; digest / counters / events return this shard's part (the parts add up /
  * concatenate); view and member reads are answered by the owner only; first-detection ticks must be
  * combined (element-wise minimum) and set back before digest or first_detect are read. */
-/* Bounded handles (view_cap > 0) shard the same way and are stepped by the same calls, with a simpler exchange (DESIGN.md 7b):
+/* Bounded handles (view_cap > 0) shard the same way and are stepped by the same calls, with a simpler exchange (DESIGN.md 6):
  *   phase1  the tick's scheduled changes; this shard's slice of two replicated tables is ready to be ALL-GATHERED in round 1
  *           (swimsim_shard_gather_buffers): everybody's start-of-tick queue line (64-byte records, kind 5) and member byte
  *           (1 byte: up, queue length; kind 6).  No records of kind 0 (shard_info reports r_cap = x_cap = 0).
@@ -481,7 +481,7 @@ int swimsim_shard_phase3(swimsim_t* h, const uint32_t* p_counts_in, const uint32
  * where the devices cannot) with the counts from the peers' own words, ordered by events on the handles' streams; only the
  * replica slices are copied.  Every option of a sharded handle included: settling (round 3), state pulls (round 0: join_pull, pull_ticks),
  * messages from outside (swimsim_inject_rumor).  Bounded handles
- * (view_cap): the all-gather and the all-to-all-v of DESIGN.md 7b as device-to-device (peer) copies.
+ * (view_cap): the all-gather and the all-to-all-v of DESIGN.md 6 as device-to-device (peer) copies.
  * (Multi-process clusters use swimsim_shard_step with the embedder's exchange.) */
 int swimsim_cluster_step(swimsim_t** hs, uint32_t n, uint32_t nticks);
 typedef int (*swimsim_exchange_fn)(void* ctx, int round, const uint32_t* counts_out /*[3*n_shards]*/,

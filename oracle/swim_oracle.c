@@ -466,7 +466,7 @@ static void probe_node(octx_t* c, uint32_t i, uint32_t p, uint32_t j) {
 
 /* The "robust scheme" the reference asks for (FIXME at src/Core.hs:232): the round-robin target
  * selection of the SWIM paper (section 4.3) as a population-wide rotation (include/swimsim.h,
- * DESIGN.md section 9).  Rounds of R = ceil((N-1)/P) periods; round r uses a pseudo-random permutation
+ * DESIGN.md section 8).  Rounds of R = ceil((N-1)/P) periods; round r uses a pseudo-random permutation
  * pi_r of 0..N-2 and probe p of period u of the round has offset 1 + pi_r(u*P + p) (no probe once
  * u*P + p >= N-1).  pi_r = a keyed bijection on ceil(log2(N-1))-bit words (xor, odd multiplications,
  * xor-shifts, one addition: each step is invertible) restricted to [0, N-1) by cycle walking.  An

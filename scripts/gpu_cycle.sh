@@ -30,11 +30,11 @@ if has extra; then
   b loss30pct_32k --steps 100 --warmup 20 --members 32768 --loss-ppm 300000   # (65 536 members at 30 % loss: every member a subject, beyond the 65 534 view rows a handle can have)
 fi
 if has variants; then
-  # the tick kernels with the state by value (product) against by pointer (libswimsim_sptr.so, DESIGN.md 11.1d): the same cluster, stepped in turn
+  # the tick kernels with the state by value (product) against by pointer (libswimsim_sptr.so, DESIGN.md 9): the same cluster, stepped in turn
   timeout 600 python scripts/ab_time.py swim_amd/csrc/libswimsim.so swim_amd/csrc/libswimsim_sptr.so 2>&1 | tee $O/${TAG}_variants_state_by_pointer.txt
 fi
 if has shard; then
-  # one population as 1 / 2 / 4 / 8 handles on this GPU, both forms of the exchange (DESIGN.md section 7)
+  # one population as 1 / 2 / 4 / 8 handles on this GPU, both forms of the exchange (DESIGN.md section 6)
   timeout 600 python scripts/shard_time.py 1 2 4 8 2>&1 | tee $O/${TAG}_shard_overhead_one_gpu.txt
 fi
 if has bounded; then
@@ -47,7 +47,7 @@ if has bounded; then
   (CAP=64 TICKS=160 T0=60 timeout 600 python scripts/config5.py 2097152; CAP=256 TICKS=200 T0=60 timeout 900 python scripts/config5.py 2097152; echo '# oracle-checked at 262 144 members:'; CAP=64 TICKS=80 T0=30 ORACLE=1 timeout 900 python scripts/config5.py 262144) 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_config5_bounded.txt
   timeout 300 python scripts/bounded_sections.py 2097152 64 2>&1 | grep -v amdgpu.ids > $O/${TAG}_bounded_sections_2m_cap64.json
 fi
-if has cluster; then   # BASELINE config 5 at FULL size as 8 handles on this GPU (DESIGN.md 7b): the exchange on the handles' streams, then through the host
+if has cluster; then   # BASELINE config 5 at FULL size as 8 handles on this GPU (DESIGN.md 6): the exchange on the handles' streams, then through the host
   (echo "# swimsim_cluster_step (exchange on the handles' streams):"; MEMBERS=4194304 SHARDS=4 timeout 600 python scripts/config5_cluster_one_gpu.py; timeout 900 python scripts/config5_cluster_one_gpu.py;
    echo "# phase calls + LocalFabric (host in the loop: SWIMSIM_CLUSTER_STEP=0):"; SWIMSIM_CLUSTER_STEP=0 timeout 900 python scripts/config5_cluster_one_gpu.py) 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_config5_cluster_one_gpu.txt
 fi

@@ -25,12 +25,15 @@ while time.time()-t0 < BUDGET:
     sc=SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=seed, lossPpm=loss, eventMask=0x1F if n<=4096 else 0, suspicionTicks=rng.choice([3,6,12]),
                  maxSubjects=min(n,4096), targetScheme=scheme, inboxCap=rng.choice([0,0,1,2]) if n <= 4096 else 0,
                  gcTicks=_abi.GC_AUTO if rng.random()<0.5 else 0, joinPull=1 if rng.random()<0.5 else 0,
-                 pullTicks=rng.choice([0,0,2,5,17,60]) if shards==1 else 0)
+                 pullTicks=rng.choice([0,0,2,5,17,60]) if shards==1 else rng.choice([0,0,0,3,17]))
+    sc.pushPull = bool(sc.pullTicks) and rng.random() < 0.5                      # (on shards too since round 6)
+    if not sc.gcTicks and not sc.joinPull and not sc.pullTicks and rng.random() < 0.3:
+        sc.strictReferenceRules = True                                          # the literal rule, on shards too since round 6
     rk=rng.choice(["","0","1"])
     if rk: os.environ["SWIMSIM_RECORDS_KERNEL"]=rk
     else: os.environ.pop("SWIMSIM_RECORDS_KERNEL", None)
-    inject = shards==1 and rng.random()<0.4
-    print("cfg", n,p,loss,scheme,shards,seed, "gc", sc.gcTicks!=0, "jp", sc.joinPull, "pull", sc.pullTicks, "rk"+rk, "inject", inject, flush=True)
+    inject = rng.random()<0.4                                                   # (sharded clusters: ShardedSim.injectRumor routes and notes)
+    print("cfg", n,p,loss,scheme,shards,seed, "gc", sc.gcTicks!=0, "jp", sc.joinPull, "pull", sc.pullTicks, "rk"+rk, "inject", inject, "push", sc.pushPull, "strict", sc.strictReferenceRules, flush=True)
     a=Sim.create(orc, sc)
     oracle_binding.set_threads(a, min(32, os.cpu_count() or 1))
     b=Sim.create(emu, sc) if shards==1 else ShardedSim(emu, sc, LocalFabric(shards), device="cuda:0")

@@ -1,4 +1,4 @@
-"""What a HIP graph does to the tick's kernel boundaries (DESIGN.md 11.1; VERDICT r3 item 4's "cheap first step").
+"""What a HIP graph does to the tick's kernel boundaries (DESIGN.md 9; VERDICT r3 item 4's "cheap first step").
 The same cluster stepped K ticks per call as stream launches and -- SWIMSIM_GRAPH=1 -- as ONE captured graph (3 K kernel nodes)
 whose launch-to-completion time the library reports; both interleaved, saturated and quiescent regimes.  Child processes:
 the knob is read once per process.  usage: graph_time.py   env: MEMBERS, K (ticks per call), REPS"""

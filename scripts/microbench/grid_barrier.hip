@@ -1,4 +1,4 @@
-// What would ONE launch per tick buy?  (DESIGN.md section 11.1; VERDICT r4 item 6.)  The tick's two big kernels are separated by a
+// What would ONE launch per tick buy?  (DESIGN.md section 9; VERDICT r4 item 6.)  The tick's two big kernels are separated by a
 // kernel boundary (~6 us on this chip: every XCD's L2 is written back and invalidated).  A persistent probe + merge kernel replaces
 // that boundary by a GRID BARRIER, which has to do the same release / acquire itself.  This microbenchmark has the tick's shape
 // without its logic: phase 1 = one thread per "member" pushes a 64-bit atomicOr to P random members' words and stores a word of

@@ -1,4 +1,4 @@
-// How many random 8-byte accesses per second does an MI355X serve?  (DESIGN.md section 6: what bounds merge_kernel.)
+// How many random 8-byte accesses per second does an MI355X serve?  (DESIGN.md section 5: what bounds merge_kernel.)
 // Each lane draws addresses from a counter hash over a table of `cells` 8-byte cells (default 1 G cells = 8 GB: merge_kernel's view
 // rows at a million members), B independent loads in flight per lane and round (B = 1, 2, 4), optionally stores the cell back
 // changed (the state rule: load -> compare -> store).  Reported: accesses / s, the 64-byte sectors they touch per second.

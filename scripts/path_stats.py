@@ -1,4 +1,4 @@
-"""Divergence profile of merge_kernel (DESIGN.md section 6): the product's kernels in the host emulation with
+"""Divergence profile of merge_kernel (DESIGN.md section 5): the product's kernels in the host emulation with
 -DSWIM_PATH_STATS count, for every marked site, how often it runs per lane and per wave (a wave executes a site
 max-over-its-lanes times).  usage: python scripts/path_stats.py [members] [ticks measured]   env: LOSS (ppm), GC=1"""
 import ctypes as C

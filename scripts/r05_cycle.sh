@@ -9,7 +9,7 @@ a)  # view-cell layout A/B (SWIM_VSPLIT), random-sector rate by table size, BASE
   timeout 900 python bench.py --crashes-per-tick 9.5 --gc --max-subjects 8192 --steps 300 --warmup 100 2>&1 | grep -v amdgpu.ids | tee $O/r05a_bench_config3s_as_written.json
   timeout 300 python -m pytest tests/test_hip_parity.py -m gpu -x -q -k "golden or config1 or small_populations" 2>&1 | tail -3 | tee $O/r05a_pytest_subset.log
   ;;
-b)  # the new dense exchange (DESIGN.md section 7): sharded GPU tests, one population as 1 / 2 / 4 / 8 handles, config 4 at full size
+b)  # the new dense exchange (DESIGN.md section 6): sharded GPU tests, one population as 1 / 2 / 4 / 8 handles, config 4 at full size
   timeout 900 python -m pytest tests/test_hip_parity.py -m gpu -x -q -k "sharded or shard or golden" 2>&1 | tail -5 | tee $O/r05b_pytest_sharded.log
   KERNELS=1 timeout 900 python scripts/shard_time.py 1 2 4 8 2>&1 | grep -v amdgpu.ids | tee $O/r05b_shard_overhead_one_gpu.txt
   timeout 1200 python scripts/config4_one_gpu.py 2>&1 | grep -v amdgpu.ids | tee $O/r05b_config4_one_gpu.txt

@@ -63,4 +63,20 @@ for k in ('merge_kernel','probe_kernel','records_kernel'):
     print('$f', k, d[k]['clocks_per_wave'], {n: v['clocks_per_wave'] for n, v in d[k]['sections'].items() if v['clocks_per_wave'] > 300})
 print(d['events_per_tick'], d['probe_us'], d['merge_us'])"; done
   ;;
+fin)  # the cycle of the round's kernels: the GPU suite, the bench lines (the driver's flags first: both windows), kernel trace over the timed
+      # window, PMC traffic, the loss / robust / P=10 / settling lines, shards on one GPU, config 4 at full size, config 5 per GPU
+  bash scripts/gpu_cycle.sh r06fin tests bench extra prof pmc
+  for G in 2 4; do SWIM_BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus $G --steps 20 --warmup 5 2>/dev/null | grep -v amdgpu.ids > $O/r06fin_bench_gpus${G}_one_process_shared_gpu.json; done
+  (echo "# strong: 1 048 576 members as G handles"; FORMS=cluster,phases KERNELS=1 timeout 900 python scripts/shard_time.py 1 2 4 8;
+   for G in 2 4; do echo "# weak: $G x 1 048 576 members vs one handle of $((G * 1048576))"; MEMBERS=$((G * 1048576)) FORMS=cluster WARM=100 TICKS=30 timeout 900 python scripts/shard_time.py 1 $G; done) 2>&1 | grep -v amdgpu.ids | tee $O/r06fin_shard_overhead_one_gpu.txt
+  timeout 1200 python scripts/config4_one_gpu.py 2>&1 | grep -v amdgpu.ids | tee $O/r06fin_config4_one_gpu.txt
+  timeout 600 python bench.py --steps 20 --warmup 5 --members 2097152 --loss-ppm 300000 --view-cap 64 > $O/r06fin_bench_config5_2m_cap64.json 2> $O/r06fin_bench_config5_2m_cap64.err; tail -c 600 $O/r06fin_bench_config5_2m_cap64.json
+  ;;
+fin2)  # the kernel trace over the timed window of BOTH windows of the driver's line (the first fin cycle traced the second window only), the
+       # driver's line once more with traffic.json in place, a random parity sweep on the round's kernels
+  canary fin2
+  (cd /tmp && export TMPDIR=/tmp && bash $R/scripts/prof_timed_window.sh r06fin --steps 20 --warmup 5 && AS_WRITTEN=1 bash $R/scripts/prof_timed_window.sh r06fin_as_written --steps 20 --warmup 5)
+  timeout 900 python bench.py --steps 20 --warmup 5 > $O/r06fin_bench_driver_flags.json 2> $O/r06fin_bench_driver_flags.err; tail -c 400 $O/r06fin_bench_driver_flags.json
+  timeout 1500 python scripts/gpu_parity_sweep.py 2>&1 | grep -v amdgpu.ids | tail -15 | tee $O/r06fin_gpu_parity_sweep.txt
+  ;;
 esac

@@ -1,5 +1,5 @@
 """Cost of the sharded path on ONE GPU: the same saturated workload as 1 handle vs G handles of one population, both forms of the
-exchange (DESIGN.md section 7): `cluster` = swimsim_cluster_step (the exchange inside the library: the peers' buffers read in place,
+exchange (DESIGN.md section 6): `cluster` = swimsim_cluster_step (the exchange inside the library: the peers' buffers read in place,
 ordered by events on the handles' streams, no host in the loop), `phases` = swimsim_shard_phase1/2/3 + LocalFabric's copies (what a
 one-process-per-GPU embedder drives).  One GPU runs the handles' kernels one after the other (or overlapped where they fit): the
 figure is what sharding COSTS in kernel work, not how it scales.  usage: shard_time.py [G ...]   env: MEMBERS WARM TICKS KERNELS=1 FORMS=cluster,phases"""

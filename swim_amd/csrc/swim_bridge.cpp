@@ -111,7 +111,7 @@ int answer_ping(swimbridge* b, uint32_t id, uint32_t seq, const sockaddr_in& to)
     m.incarnation = r.incarnation;
     name_of(r.subject, m.node);
     if (r.state == SWIMSIM_DEAD) name_of(id, m.dead_from);          // the simulator has no addresses: deadFrom = the sender
-    if (r.state == SWIMSIM_ALIVE) m.addr = r.subject;               // Alive.addr = the member id (DESIGN.md section 10)
+    if (r.state == SWIMSIM_ALIVE) m.addr = r.subject;               // Alive.addr = the member id (DESIGN.md section 8)
     b->out.push_back(m);
   }
   const int rcs = send_env(b, b->out, to);

@@ -150,7 +150,7 @@ struct DevState {
   uint2* V;                // [R_phys][N] {key = inc<<2|state, lastChange+1}; key 0 = default = slot_base[slot]
   // SWIM_VSPLIT (round 5): the same cells as two 4-byte planes -- Vk[row][member] = key << 8 | (lastChange + 1) & 0xFF, the
   // only word the hot path LOADS (16 members per 64-byte sector instead of 8: merge_kernel runs at the chip's random-SECTOR
-  // rate, DESIGN.md section 6), Vs[row][member] = lastChange + 1 in full: stored with every change, loaded by the cold paths
+  // rate, DESIGN.md section 5), Vs[row][member] = lastChange + 1 in full: stored with every change, loaded by the cold paths
   // (digest, views, the walk of a member that woke up) and where the low byte cannot decide (below)
   uint32_t* Vk; uint32_t* Vs;
   // ---- settling (gc_ticks; include/swimsim.h): removeDeadNodes (src/Core.hs:65-67)
@@ -173,7 +173,7 @@ struct DevState {
   uint2* ovf;              // [2][ovf_cap] inbox overflow (dst, src)
   uint4* events;           // {tick, observer, subject, key<<8|cause}
   uint64_t* blk;           // [nblocks+1][C_COUNT] per-block counter rows (no atomics)
-  // ---- cross-shard exchange (n_shards > 1; DESIGN.md section 7, round 5) ------------------------------
+  // ---- cross-shard exchange (n_shards > 1; DESIGN.md section 6, round 5) ------------------------------
   // Slots (view rows) and rumour ids are per-shard numberings; what crosses shards is named by (subject, key).  Every shard
   // holds a REPLICA of what a delivery "dst merges src's queue" reads about src -- its start-of-tick queue mask (over its
   // OWNER's ring of the tick) and a queue byte -- all-gathered at the start of the tick together with every shard's ring
@@ -215,7 +215,7 @@ struct DevState {
   uint2* sp_q;             // [2][N][8] queue lines {subject, key | tx << 24}; buffer (t & 1) is read in tick t, the other written
   uint32_t* sp_out;        // [N] probe -> merge: Pings sent | failed probes << 5 | own Ack sources << 10
   uint32_t sp_ack_cap;     // own Ack sources per member: P (1 + K), in ackfrom[N][sp_ack_cap]
-  // shards of a bounded cluster (swim_sparse.h, DESIGN.md 7b): a replica of everybody's start-of-tick queue line (all-gathered with
+  // shards of a bounded cluster (swim_sparse.h, DESIGN.md 6): a replica of everybody's start-of-tick queue line (all-gathered with
   // `mb` at the start of the tick), the tick's deliveries to members of other shards
   uint2* sp_qall;          // [NT][8]
   uint2* sp_ord;           // [64][sp_ord_cap] {dst, src} (global ids), unsorted; sp_ord_n[64 * 16] entries per list

@@ -12,7 +12,7 @@
 //   merge_kernel : owner-computes end of tick: delivered rumours, timers, state rule, piggyback queue
 //                  (src/Core.hs:89-117, 127-138, 142-218).
 // Sharded clusters add publish_kernel / xlat_kernel / ingest_kernel around the two exchange rounds
-// (DESIGN.md section 7).
+// (DESIGN.md section 6).
 #pragma once
 #include "swim_device.h"
 
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
   uint32_t nfail = 0, nack = 0;
 #pragma unroll
   for (int p = 0; p < PMAX; ++p) { picks[p] = 0; pinfo[p] = 0; }
-  // "dst merges src's start-of-tick queue", left to the ingest of dst's owner (DESIGN.md section 7): dst on another shard,
+  // "dst merges src's start-of-tick queue", left to the ingest of dst's owner (DESIGN.md section 6): dst on another shard,
   // or a remote src whose queue takes more than a mask translation (then the owner may be this very shard)
   auto emit_order = [&](uint32_t dst, uint32_t src) {
     const uint32_t pos = atomicAdd(&ordn, 1u);
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(BLOCK, PMAX <= 4 ? SWIM_PROBE_WAVES : PMAX <= 8 ? S
     } else {
       // the "robust scheme" (FIXME at src/Core.hs:232): probe p goes to (i + o(t,p)) mod N -- a rotation
       // shared by everybody, so that a member's pingers are known to it; targets that are not Alive in
-      // my view are skipped (include/swimsim.h, DESIGN.md section 9)
+      // my view are skipped (include/swimsim.h, DESIGN.md section 8)
       np = s.P;
 #pragma unroll
       for (int p = 0; p < PMAX; ++p) {
@@ -1878,7 +1878,7 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
 }
 
 // ================================================================================================
-// cross-shard exchange kernels (n_shards > 1; DESIGN.md section 7, round 5)
+// cross-shard exchange kernels (n_shards > 1; DESIGN.md section 6, round 5)
 // ================================================================================================
 // One tick of a shard:  begin_kernel (faults, window head, ring, ring dictionary) -> publish_kernel (my slice of the
 // replicas) -> ROUND 1: all-gather of dictionary + lists (r), queue masks, queue bytes -> xlat_kernel -> probe_kernel<.., true>

@@ -988,7 +988,7 @@ __global__ __launch_bounds__(64 * WAVES) void sp_merge_kernel(DevState s, uint32
 }
 
 // ================================================================================================
-// sharded clusters of bounded handles (DESIGN.md section 7b): one exchange of 8-byte delivery records per tick + an all-gather
+// sharded clusters of bounded handles (DESIGN.md section 6): one exchange of 8-byte delivery records per tick + an all-gather
 // ================================================================================================
 // Members shard by contiguous id range as on dense handles.  What a delivery "dst merges src's queue" needs from another shard is
 // (a) the receiver learning of it: an 8-byte record {dst, src} to dst's owner, which appends src to dst's inbox; (b) src's

@@ -181,7 +181,11 @@ int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, std::string*
 int check_device_errors(swimsim* h) {
   uint32_t g[G_WORDS];
   HIPCHK(h, hipMemcpy(g, h->d.g, sizeof g, hipMemcpyDeviceToHost));
-  h->recs_busy = !h->d.C && h->d.n_shards == 1 && g[G_HEAD] - g[G_PREV] > MASK_SLACK;
+  // (with hysteresis: on above the masks' slack, off again below half of it -- the id rate of a regime fluctuates by a few per tick)
+  { const uint32_t ids = g[G_HEAD] - g[G_PREV];
+    if (h->d.C || h->d.n_shards != 1) h->recs_busy = false;
+    else if (ids > MASK_SLACK) h->recs_busy = true;
+    else if (ids <= MASK_SLACK / 2u) h->recs_busy = false; }
   if (g[G_ERR]) {
     std::string m = "capacity exceeded:";
     if (g[G_ERR] & ERRF_SUBJECTS) m += h->d.C ? " subjects-a-member-hears-of-in-one-tick (bounded member maps: the per-tick working set)" : " max_subjects";
@@ -233,7 +237,7 @@ int pull_events(swimsim* h) {
   return SWIMSIM_OK;
 }
 
-// The robust scheme's rotations for period t (include/swimsim.h; DESIGN.md section 9): rounds of
+// The robust scheme's rotations for period t (include/swimsim.h; DESIGN.md section 8): rounds of
 // R = ceil((N-1)/P) periods; round r uses a pseudo-random permutation pi_r of 0..N-2 (a keyed bijection on
 // ceil(log2(N-1))-bit words -- xor, odd multiplications, xor-shifts, one addition -- restricted to
 // [0, N-1) by cycle walking); probe p of period u of the round has offset 1 + pi_r(u P + p).
@@ -760,7 +764,7 @@ int swimsim_step(swimsim_t* h, uint32_t nticks) {
     }
   }
   size_t fpos = 0;
-  // measurement knob (DESIGN.md 11.1): SWIMSIM_GRAPH=1 captures the call's launches into ONE HIP graph and launches that --
+  // measurement knob (DESIGN.md 9): SWIMSIM_GRAPH=1 captures the call's launches into ONE HIP graph and launches that --
   // what a graph does to the boundaries between the tick's kernels (scripts/graph_time.py)
   static const bool want_graph = [] { const char* e = std::getenv("SWIMSIM_GRAPH"); return e && e[0] == '1'; }();
   const bool graph = want_graph && !h->timing && h->injections.empty() && nticks > 0;
@@ -1433,7 +1437,7 @@ static bool same_cluster_config(const swimsim_config_t& a, const swimsim_config_
 #undef SAME
 }
 
-/* The same for DENSE handles (DESIGN.md section 7, round 5).  Per tick and handle, on the handle's own stream:
+/* The same for DENSE handles (DESIGN.md section 6, round 5).  Per tick and handle, on the handle's own stream:
  *   begin_kernel + publish_kernel -> e0 | wait every peer's e0; xlat_kernel (dictionaries, list index, the peers' slices of the
  *   replicas pulled over) + probe_kernel -> e1 | wait every peer's e1; ingest_kernel reads the peers' round-2 segments and lists
  *   WHERE THEY LIE (PeerView: same device, or a peer device over xGMI) with the counts from the peers' own words -> e2;

@@ -3,7 +3,7 @@
 Members shard by contiguous id range; every shard holds the same configuration and the same
 fault schedule.  Probe outcomes need no communication (ground truth and the loss hashes are
 known everywhere); only piggyback payloads cross shards, in two rounds per tick
-(include/swimsim.h, "sharded clusters"; DESIGN.md section 7):
+(include/swimsim.h, "sharded clusters"; DESIGN.md section 6):
 
     phase1  begin + publish         -> round 1: ALL-GATHER of every shard's ring dictionary (+ the queues that travel
                                        as lists), queue masks (8 B / member) and queue bytes (1 B / member)

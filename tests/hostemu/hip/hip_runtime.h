@@ -215,7 +215,7 @@ void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, Args... args) {
   }
 }
 // ---- path statistics (-DSWIM_PATH_STATS): how often each marked site of a kernel runs, per lane and per wave
-// (a wave executes a site max-over-its-lanes times): the divergence profile of DESIGN.md section 6
+// (a wave executes a site max-over-its-lanes times): the divergence profile of DESIGN.md section 5
 constexpr int PSTAT_SITES = 48;
 struct PStat { std::vector<uint32_t> tab; uint32_t nthreads = 0; bool on = false; };
 inline PStat& pstat_state() { static PStat p; return p; }

@@ -89,7 +89,7 @@ def test_what_cannot_be_combined_with_bounded_maps_is_refused(oracle_abi, emu_ab
         with pytest.raises(SwimError):
             s.setView(1, 2, 1, 0)
         s.close()
-    Sim.create(emu_abi, base, shard_index=0, n_shards=2).close()     # sharded clusters of bounded handles exist (DESIGN.md 7b)
+    Sim.create(emu_abi, base, shard_index=0, n_shards=2).close()     # sharded clusters of bounded handles exist (DESIGN.md 6)
 
 
 CASES = [

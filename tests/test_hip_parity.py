@@ -236,6 +236,36 @@ def test_sharded_join_pull_on_one_gpu(oracle_abi, hip_abi):
     b.close()
 
 
+@pytest.mark.parametrize("n,loss,gc,T", [(65536, 20000, 0, 0), (262144, 0, 1, 0), (65536, 50000, 1, 16)])
+def test_cluster_step_across_two_devices(oracle_abi, hip_abi, n, loss, gc, T):
+    """swimsim_cluster_step with its handles on DIFFERENT devices: the kernels read the peers' buffers over xGMI (peer access),
+    cross-device events order the handles' streams -- the path no one-GPU box can run.  Skipped unless two devices are visible; = the
+    unsharded oracle."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (peer access between the handles' devices)")
+    from swim_amd import _abi
+    from swim_amd.shard import LocalFabric, ShardedSim
+    ndev = min(torch.cuda.device_count(), 8)
+    while n % ndev:
+        ndev -= 1
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=61, lossPpm=loss, eventMask=0, suspicionTicks=7, maxSubjects=4096,
+                   gcTicks=_abi.GC_AUTO if gc else 0, joinPull=1 if T else 0, pullTicks=T)
+    a, b = Sim.create(oracle_abi, sc), ShardedSim(hip_abi, sc, LocalFabric(ndev), devices=list(range(ndev)))
+    _oracle_threads(a)
+    crashes = [(3 + 2 * k, (37 * k + 11) % n) for k in range(30)]
+    for s in (a, b):
+        for t, m in crashes:
+            s.crash(m, t)
+        for t, m in crashes[::2]:
+            s.scheduleFault(t + 9 + (m % 13), m, True)
+    for _ in range(12):
+        a.step(5); b.step(5)
+        assert a.counters() == b.counters() and a.digest() == b.digest(), "tick %d" % a.tick
+    assert a.firstDetection() == b.firstDetection()
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("n,shards,loss,seed", [(4096, 4, 0, 1), (65536, 8, 20000, 3)])
 def test_sharded_cluster_by_phase_calls_on_one_gpu(oracle_abi, hip_abi, monkeypatch, n, shards, loss, seed):
     """SWIMSIM_CLUSTER_STEP=0: the same cluster stepped through swimsim_shard_phase1/2/3 with the embedder's copies (LocalFabric)
@@ -480,7 +510,7 @@ def test_forced_fallback_paths_on_the_gpu(oracle_abi):
 
 def test_state_by_pointer_build_on_the_gpu(oracle_abi):
     """The gfx950 build whose tick kernels take the state through a pointer to a device copy (-DSWIM_STATE_BY_POINTER:
-    no scalar spills, measurement knob of DESIGN.md 11.1d): the same sources must give the same run."""
+    no scalar spills, measurement knob of DESIGN.md 9): the same sources must give the same run."""
     from swim_amd import _lib
     hip = _lib.load_variant("sptr")
     n = 50000
@@ -879,7 +909,7 @@ def test_full_event_stream_at_a_million_members(oracle_abi, hip_abi, n, ncrash, 
 
 @pytest.mark.parametrize("n,shards,cap,churn", [(4096, 4, 16, 10), (65536, 8, 64, 10), (262144, 4, 64, 1)])
 def test_sharded_cluster_of_bounded_handles_on_one_gpu(oracle_abi, hip_abi, n, shards, cap, churn):
-    """BASELINE config 5 is a CLUSTER: 16 M members over 8 GPUs at 30 % loss.  Bounded handles sharded by id range (DESIGN.md 7b:
+    """BASELINE config 5 is a CLUSTER: 16 M members over 8 GPUs at 30 % loss.  Bounded handles sharded by id range (DESIGN.md 6:
     one all-gather of queue lines + member bytes and one all-to-all-v of 8-byte delivery records per tick), here as several
     handles on this GPU, against the unsharded oracle: digest, every counter, JOIN / REFUTE events, views and queues on
     either side of the shard borders, first-detection ticks."""

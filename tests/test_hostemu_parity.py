@@ -276,7 +276,7 @@ def test_more_new_ids_in_one_tick_than_the_id_space(oracle_abi, variant, bits, s
 
 def test_state_by_pointer_build_gives_the_same_run(oracle_abi):
     """-DSWIM_STATE_BY_POINTER (measurement knob: the tick kernels take the state through a pointer to a device copy,
-    which removes their scalar spills; DESIGN.md 11.1d): the same sources, the same run."""
+    which removes their scalar spills; DESIGN.md 9): the same sources, the same run."""
     from tests import hostemu_binding
     emu = hostemu_binding.load_variant("sptr", ["SWIM_STATE_BY_POINTER"])
     n = 600
@@ -426,7 +426,7 @@ def test_a_shard_with_pull_ticks_must_start_the_tick_with_phase0(emu_abi):
 @pytest.mark.parametrize("fold", ["0", "1"])
 def test_plain_ticks_with_and_without_begin_kernel(oracle_abi, emu_abi, monkeypatch, fold):
     """A tick without scheduled changes, messages from outside, pulls or settling runs WITHOUT begin_kernel (probe_kernel's workgroup 0
-    leaves the window heads, the ring and the resets for merge_kernel; DESIGN.md 11.1) unless SWIMSIM_FOLD_BEGIN=0 at create.  Both forms,
+    leaves the window heads, the ring and the resets for merge_kernel; DESIGN.md 9) unless SWIMSIM_FOLD_BEGIN=0 at create.  Both forms,
     with ticks of both kinds interleaved (crashes and rejoins in some ticks, set_view and injected rumours between others), against
     the oracle every tick."""
     monkeypatch.setenv("SWIMSIM_FOLD_BEGIN", fold)

@@ -80,7 +80,7 @@ def _random_bounded_case(rng, sizes, max_faults):
 def test_random_bounded_configurations(oracle_abi, block):
     """The same for bounded member maps (view_cap, swim_sparse.h): capacities 4 ... 256 (one, two and four map entries per lane;
     the 256- / 512- / 1 024-slot tables), numToGossip up to 10, loss up to 50 %, crashes and rejoins, inboxes smaller than the
-    fan-in, 1-8 shards (DESIGN.md 7b) -- every observable every 5 ticks."""
+    fan-in, 1-8 shards (DESIGN.md 6) -- every observable every 5 ticks."""
     from tests import hostemu_binding
     emu = hostemu_binding.load()
     rng = random.Random(7000 + block)

@@ -52,7 +52,7 @@ def test_one_process_per_shard_gloo_more_configurations():
 
 
 def test_one_process_per_shard_gloo_with_bounded_member_maps():
-    """A cluster of bounded handles (view_cap = 16 / 64; DESIGN.md section 7b), one process per shard: the all-gather of queue lines
+    """A cluster of bounded handles (view_cap = 16 / 64; DESIGN.md section 6), one process per shard: the all-gather of queue lines
     and member bytes and the 8-byte delivery records through swimsim_shard_step's callback, 30 % loss, a crash and a rejoin."""
     run_world(2, (192, 3, 300000, 11, 40, 16 << 8), 29618)
     run_world(4, (256, 3, 300000, 12, 30, 64 << 8), 29619)

@@ -149,7 +149,7 @@ def test_sharded_join_pull_with_churn(oracle_abi, emu_abi, shards, gc):
 def phase_calls(monkeypatch):
     """SWIMSIM_CLUSTER_STEP=0: ShardedSim steps a one-process cluster through swimsim_shard_phase1/2/3 with LocalFabric's copies
     (the embedder's exchange) instead of swimsim_cluster_step (the exchange inside the library, peers' buffers read in place):
-    the same tick through both forms of the exchange (DESIGN.md section 7)."""
+    the same tick through both forms of the exchange (DESIGN.md section 6)."""
     monkeypatch.setenv("SWIMSIM_CLUSTER_STEP", "0")
 
 
