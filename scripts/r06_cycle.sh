@@ -79,4 +79,12 @@ fin2)  # the kernel trace over the timed window of BOTH windows of the driver's 
   timeout 900 python bench.py --steps 20 --warmup 5 > $O/r06fin_bench_driver_flags.json 2> $O/r06fin_bench_driver_flags.err; tail -c 400 $O/r06fin_bench_driver_flags.json
   timeout 1500 python scripts/gpu_parity_sweep.py 2>&1 | grep -v amdgpu.ids | tail -15 | tee $O/r06fin_gpu_parity_sweep.txt
   ;;
+fin3)  # the round's LAST sources (records-mode hysteresis; comments renumbered: the sha of the kernel sources changed): suite, the driver's
+       # line, both traces, PMC passes -> traffic.json is re-keyed from this run
+  bash scripts/gpu_cycle.sh r06fin3 tests pmc
+  (cd /tmp && export TMPDIR=/tmp && bash $R/scripts/prof_timed_window.sh r06fin3 --steps 20 --warmup 5 && AS_WRITTEN=1 bash $R/scripts/prof_timed_window.sh r06fin3_as_written --steps 20 --warmup 5)
+  python scripts/make_traffic_json.py $O/r06fin3_pmc/summary.txt r06fin3 > /dev/null && cp profiles/traffic.json $O/r06fin3_traffic.json
+  timeout 900 python bench.py --steps 20 --warmup 5 > $O/r06fin3_bench_driver_flags.json 2> $O/r06fin3_bench_driver_flags.err; tail -c 300 $O/r06fin3_bench_driver_flags.json
+  timeout 900 python bench.py > $O/r06fin3_bench_default_flags.json 2> $O/r06fin3_bench_default_flags.err; tail -c 300 $O/r06fin3_bench_default_flags.json
+  ;;
 esac
