@@ -87,4 +87,12 @@ fin3)  # the round's LAST sources (records-mode hysteresis; comments renumbered:
   timeout 900 python bench.py --steps 20 --warmup 5 > $O/r06fin3_bench_driver_flags.json 2> $O/r06fin3_bench_driver_flags.err; tail -c 300 $O/r06fin3_bench_driver_flags.json
   timeout 900 python bench.py > $O/r06fin3_bench_default_flags.json 2> $O/r06fin3_bench_default_flags.err; tail -c 300 $O/r06fin3_bench_default_flags.json
   ;;
+h)  # batch sizes of merge_kernel's three loops of dependent view-cell loads (deadline cells 4 / 7, todo entries 2 / 4, rumour positions 2 / 4) and
+    # 3 waves per SIMD with all of them large: the headline, 1 % loss, row 3(s) as written (two handles at a time: 64 GB of view rows each)
+  canary h
+  L="$C/libswimsim_x_db4.so $C/libswimsim_x_db7.so $C/libswimsim_x_tb4.so $C/libswimsim_x_gb4.so $C/libswimsim_x_db7tb4.so $C/libswimsim_x_w3all.so"
+  (echo "# headline regime: product (deadline batch 4, todo 2, rumours 2) | deadline 7 | todo 4 | rumours 4 | deadline 7 + todo 4 | 3 waves, 7 / 4 / 4"; ROUNDS=7 timeout 900 python scripts/ab_time.py $L;
+   echo "# 1 % loss, settling:"; LOSS=10000 GC=1 ROUNDS=5 CHUNK=20 timeout 900 python scripts/ab_time.py $L;
+   for v in db7 tb4 db7tb4 w3all; do echo "# BASELINE.md row 3(s) as written: product | $v"; CPT=9.5 GC=1 MAXSUBJ=8192 WARM=200 CHUNK=20 ROUNDS=5 timeout 900 python scripts/ab_time.py $C/libswimsim_x_db4.so $C/libswimsim_x_$v.so; done) 2>&1 | grep -v amdgpu.ids | tee $O/r06h_ab_merge_batches.txt
+  ;;
 esac
