@@ -145,8 +145,10 @@ typedef struct swimsim_config {
  * Because an ignored rumour may be accepted later -- after a refutation has made the entry Alive again -- no delivery may be filtered
  * as "known already": every delivered queue entry is examined every time (the handle runs the exact record path in every tick), so a
  * tick costs several times the default's.  Sharded clusters (round 6): across shards every queue travels as a list of (subject, key) and the owner
- * of a member applies what was delivered to it in the same canonical order -- the cluster equals the unsharded run.  Not combinable with
- * view_cap, gc_ticks, join_pull or pull_ticks (SWIMSIM_ERR_INVALID). */
+ * of a member applies what was delivered to it in the same canonical order -- the cluster equals the unsharded run.  Settling, the
+ * join-time pull and the periodic pull / push-pull combine with it (round 6): they are state transfer, not rumours -- a pulled or pushed
+ * entry follows the merge of the pull (the larger entry wins) in both modes, settling reconciles to the largest entry among the members
+ * that are up as always.  Not combinable with view_cap (SWIMSIM_ERR_INVALID). */
 
 /* Bounded member maps (view_cap = C > 0) -- what lets heavy message loss run at millions of members
  * per GPU (BASELINE config 5): there nearly every member is a subject of somebody's false suspicion all the time, and a

@@ -1184,8 +1184,8 @@ static int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, char*
   if (c->pull_ticks == 1) { snprintf(err, errn, "pull_ticks must be 0 (off) or >= 2"); return SWIMSIM_ERR_INVALID; }
   if (c->push_pull > 1 || (c->push_pull && !c->pull_ticks)) { snprintf(err, errn, "push_pull must be 0 or 1 and needs pull_ticks"); return SWIMSIM_ERR_INVALID; }
   if (c->strict_reference_rules > 1) { snprintf(err, errn, "strict_reference_rules must be 0 or 1"); return SWIMSIM_ERR_INVALID; }
-  if (c->strict_reference_rules && (c->view_cap || c->gc_ticks || c->join_pull || c->pull_ticks)) {
-    snprintf(err, errn, "strict_reference_rules cannot be combined with view_cap, gc_ticks, join_pull or pull_ticks"); return SWIMSIM_ERR_INVALID; }
+  if (c->strict_reference_rules && c->view_cap) {
+    snprintf(err, errn, "strict_reference_rules cannot be combined with view_cap"); return SWIMSIM_ERR_INVALID; }
   if (c->view_cap) {
     if (c->view_cap < SWIMSIM_VIEW_CAP_MIN || c->view_cap > SWIMSIM_VIEW_CAP_MAX) { snprintf(err, errn, "view_cap must be 0 (unbounded) or in [%u, %u]", SWIMSIM_VIEW_CAP_MIN, SWIMSIM_VIEW_CAP_MAX); return SWIMSIM_ERR_INVALID; }
     if (c->gc_ticks || c->join_pull || c->pull_ticks || c->target_scheme != SWIMSIM_TARGETS_RANDOM) {

@@ -27,8 +27,8 @@ while time.time()-t0 < BUDGET:
                  gcTicks=_abi.GC_AUTO if rng.random()<0.5 else 0, joinPull=1 if rng.random()<0.5 else 0,
                  pullTicks=rng.choice([0,0,2,5,17,60]) if shards==1 else rng.choice([0,0,0,3,17]))
     sc.pushPull = bool(sc.pullTicks) and rng.random() < 0.5                      # (on shards too since round 6)
-    if not sc.gcTicks and not sc.joinPull and not sc.pullTicks and rng.random() < 0.3:
-        sc.strictReferenceRules = True                                          # the literal rule, on shards too since round 6
+    if rng.random() < 0.25:
+        sc.strictReferenceRules = True                                          # the literal rule: on shards, with settling and state pulls too since round 6
     rk=rng.choice(["","0","1"])
     if rk: os.environ["SWIMSIM_RECORDS_KERNEL"]=rk
     else: os.environ.pop("SWIMSIM_RECORDS_KERNEL", None)

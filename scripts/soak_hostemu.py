@@ -45,7 +45,7 @@ def run_case(seed0, k, log=print):
     S = rng.choice([4, 7, 12])
     pt = rng.choice([0, 0, 2, 3, 9, 40])                          # periodic state pull (on shards: exchange round 0 in every tick)
     pp = bool(pt) and (rng.random() < 0.5 if shards == 1 else rng2.random() < 0.5)   # ... as a push-pull (on shards too since round 6: drawn from a generator of its own, so that the cases of earlier rounds replay as they were)
-    strict = not gc and not jp and not pt and (rng.random() < 0.5 if shards == 1 else rng2.random() < 0.5)   # the literal suspectOrDeadNode' (no other option with it; on shards too since round 6)
+    strict = (rng.random() < 0.5 if shards == 1 else rng2.random() < 0.5) if (not gc and not jp and not pt) else rng2.random() < 0.25   # the literal suspectOrDeadNode' (round 6: on shards, with settling and state pulls too -- those draws come from rng2)
     fold = rng.choice(["0", "1"])                                # plain ticks with / without begin_kernel
     ticks = rng.choice([200, 400, 800])
     sc = SimConfig(cfg=Config(numToGossip=p), nMembers=n, seed=rng.randrange(1, 1 << 30), lossPpm=loss, eventMask=0x1F,

@@ -167,8 +167,8 @@ int resolve_config(const swimsim_config_t* in, swimsim_config_t* c, std::string*
   if (c->push_pull > 1 || (c->push_pull && !c->pull_ticks)) { *err = "push_pull must be 0 or 1 and needs pull_ticks"; return SWIMSIM_ERR_INVALID; }
   if (c->strict_reference_rules > 1) { *err = "strict_reference_rules must be 0 or 1"; return SWIMSIM_ERR_INVALID; }
   if (c->n_shards > 1 && c->n_members > (1u << 27)) { *err = "sharded clusters: n_members must be <= 2^27"; return SWIMSIM_ERR_INVALID; }
-  if (c->strict_reference_rules && (c->view_cap || c->gc_ticks || c->join_pull || c->pull_ticks)) {
-    *err = "strict_reference_rules cannot be combined with view_cap, gc_ticks, join_pull or pull_ticks"; return SWIMSIM_ERR_INVALID; }
+  if (c->strict_reference_rules && c->view_cap) {
+    *err = "strict_reference_rules cannot be combined with view_cap"; return SWIMSIM_ERR_INVALID; }
   if (c->view_cap) {
     if (c->view_cap < SWIMSIM_VIEW_CAP_MIN || c->view_cap > SWIMSIM_VIEW_CAP_MAX) {
       *err = "view_cap must be 0 (unbounded) or in [" + std::to_string(SWIMSIM_VIEW_CAP_MIN) + ", " + std::to_string(SWIMSIM_VIEW_CAP_MAX) + "]"; return SWIMSIM_ERR_INVALID; }

@@ -388,6 +388,33 @@ def test_strict_reference_rules_on_sharded_clusters_on_one_gpu(oracle_abi, hip_a
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("n,shards,loss,T,push", [(3000, 1, 150000, 3, 1), (4096, 4, 100000, 5, 0), (65536, 1, 20000, 64, 0), (65536, 8, 20000, 0, 0)])
+def test_strict_reference_rules_with_settling_and_state_pulls_on_the_gpu(oracle_abi, hip_abi, n, shards, loss, T, push):
+    """The literal rule x settling x join pull x periodic (push-)pull x shards on MI355X (round 6): = the unsharded oracle's literal mode."""
+    from swim_amd import _abi
+    from swim_amd.shard import LocalFabric, ShardedSim
+    events = n <= 4096
+    sc = SimConfig(cfg=Config(numToGossip=3), nMembers=n, seed=77, lossPpm=loss, eventMask=0x1F if events else 0, suspicionTicks=6,
+                   maxSubjects=n if n <= 4096 else 16384, strictReferenceRules=True, gcTicks=_abi.GC_AUTO, joinPull=1, pullTicks=T, pushPull=bool(push),
+                   retransmitMult=1)
+    a = Sim.create(oracle_abi, sc)
+    b = Sim.create(hip_abi, sc) if shards == 1 else ShardedSim(hip_abi, sc, LocalFabric(shards), device="cuda:0")
+    _oracle_threads(a)
+    for s in (a, b):
+        for k in range(12):
+            s.crash((37 * k + 11) % n, 3 + 2 * k)
+            if k % 2 == 0:
+                s.scheduleFault(3 + 2 * k + 9 + k, (37 * k + 11) % n, True)
+    for _ in range(16):
+        a.step(5); b.step(5)
+        assert a.counters() == b.counters() and a.digest() == b.digest(), "tick %d" % a.tick
+        if events:
+            assert a.drainEventsRaw() == b.drainEventsRaw()
+    assert a.firstDetection() == b.firstDetection()
+    assert oracle_abi.lib.swimoracle_d13_hits(a._h) > 0 and a.counters()["settled"] > 0
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("fold,n", [("0", 4096), ("1", 4096), ("1", 65536)])
 def test_plain_ticks_with_and_without_begin_kernel_on_the_gpu(oracle_abi, hip_abi, monkeypatch, fold, n):
     """Ticks without scheduled changes run without begin_kernel (probe_kernel's workgroup 0 does its part on the side, merge_kernel's

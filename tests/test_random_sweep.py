@@ -31,6 +31,7 @@ def test_random_configurations(oracle_abi, block):
                        targetScheme=scheme, inboxCap=rng.choice([0, 0, 1, 2]), gcTicks=gc,
                        joinPull=seed % 2, pullTicks=(0, 0, 2, 5, 17)[(seed >> 3) % 5])
         sc.pushPull = bool(sc.pullTicks) and (seed >> 7) % 2 == 1            # (on shards too since round 6)
+        sc.strictReferenceRules = (seed >> 11) % 4 == 0                     # the literal rule with every option, on shards too (round 6)
         a = Sim.create(oracle_abi, sc)
         rm = shards > 1 and rng.random() < 0.5       # replicated queue masks instead of probe records (read at create)
         os.environ["SWIMSIM_CLUSTER_STEP"] = "0" if rm else "1"
