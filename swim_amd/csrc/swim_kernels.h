@@ -773,7 +773,10 @@ __device__ inline uint32_t find_rid(const DevState& s, uint32_t slot, uint32_t k
 // allocation number as find_rid reports it.
 __device__ inline uint32_t young_rid(uint32_t rid, uint32_t number, uint32_t H) {
   const uint32_t ahead = (number - H) & RT_SPAN_MASK;           // an id older than the head reads as a huge distance
-  return (ahead <= RID_MASK + 1u - KW_BITS || ahead > RT_SPAN_MASK / 2u) ? rid : RID_PARKED;
+  // (strictly below: the id H + 2^RID_BITS - KW_BITS has the low bits of H - KW_BITS, the OLDEST id of the wide window -- two rumours
+  // under one id, and a receiver's test-and-set dropped the second.  Round 6, soak case 832/8 on the 8-bit build: a shard handing out
+  // 192 ids in one tick; the product's 16-bit ids get there at 65 280)
+  return (ahead < RID_MASK + 1u - KW_BITS || ahead > RT_SPAN_MASK / 2u) ? rid : RID_PARKED;
 }
 
 // a rumour id that fell out of the (wide) known-ring window is replaced by RID_PARKED ("no id") at the next rewrite of
@@ -1427,9 +1430,15 @@ __global__ __launch_bounds__(BLOCK, SWIM_MERGE_WAVES) void merge_kernel(SWIM_STA
     // Suspect -> Dead by timeout; ... of a member that is up all the same (a false positive: ground truth, replicated)
     if (cause == 1u) timers_fired += 1u + ((uint32_t)(s.mb[subject] & MB_UP) << 16);
     if ((key & 3u) == ST_SUSPECT) tput(slot + 1);                     // deadline t + S (D4)
-    const uint32_t rid = (hasrid || ABL(ABL_FIND_RID)) ? rid_in : find_rid(s, slot, key);
+    uint32_t born = 0;                            // (find_rid: the id's allocation number, i.e. its exact age against the head)
+    const uint32_t rid = (hasrid || ABL(ABL_FIND_RID)) ? rid_in : find_rid(s, slot, key, &born);
 #ifndef SWIM_NO_OWN_KNOWN
-    if (stated && rid_in_ring(rid, H)) kn |= rid_bit(rid);           // a rumour I state under an id of the window: known from now on
+    // a rumour I state under an id of the window [H - 64, H): known from now on.  By the id's ALLOCATION NUMBER, not by the id: an id
+    // handed out in this very tick lies above the head, and past 2^RID_BITS - 64 new ids in one tick its low bits read as a position of
+    // the window -- a foreign bit in the ring, and the rumour that owns the position was filtered as known (8-bit test build, soak
+    // case 832/8: 1 500 members, robust scheme, 4 shards; the product's 16-bit ids get there at 65 472 new rumours in one tick).  An
+    // id the ring directory named (hasrid) is in the window by construction.
+    if (stated && (hasrid ? rid_in_ring(rid, H) : ((H - 1u - born) & RT_SPAN_MASK) < KN_BITS)) kn |= rid_bit(rid);
 #endif
     if (!ABL(ABL_GROUP)) {
     kill_slot(slot);

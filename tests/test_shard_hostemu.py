@@ -238,6 +238,16 @@ def test_soak_case_703_24_a_message_from_outside_opens_its_row_on_every_shard():
     assert ok, what
 
 
+def test_soak_case_832_8_an_id_exactly_one_window_short_of_a_turn():
+    """Round 6's soak (scripts/soak_hostemu.py 832, case 8; 8-bit rumour ids, 1 500 members on 4 shards, robust scheme, 2 % loss, settling,
+    pull_ticks = 3): a shard handed out 192 rumour ids within one tick; young_rid let the id H + 2^bits - KW_BITS travel with its id, whose
+    low bits are those of H - KW_BITS, the oldest id of the receivers' wide window -- Suspect@0 and Dead@0 about one member under ONE id, and
+    the receiver's test-and-set dropped the Dead.  An off-by-one since round 3 (`<=` for `<`), exposed when the ring directory changed
+    which ids a tick hands out; the product's 16-bit ids reach it at 65 280 new rumours in one tick."""
+    ok, what = _soak().run_case(832, 8, log=lambda *a, **k: None)
+    assert ok, what
+
+
 @pytest.mark.parametrize("shards,T,n", [(2, 3, 600), (4, 5, 1000), (3, 40, 300)])
 def test_messages_from_outside_with_state_pulls_and_settling_on_shards(oracle_abi, emu_abi, shards, T, n):
     """swimsim_inject_rumor x pull_ticks x settling x shards, deliberately dense in the combination that diverged: many messages from
