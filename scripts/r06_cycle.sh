@@ -95,12 +95,21 @@ h)  # batch sizes of merge_kernel's three loops of dependent view-cell loads (de
    echo "# 1 % loss, settling:"; LOSS=10000 GC=1 ROUNDS=5 CHUNK=20 timeout 900 python scripts/ab_time.py $L;
    for v in db7 tb4 db7tb4 w3all; do echo "# BASELINE.md row 3(s) as written: product | $v"; CPT=9.5 GC=1 MAXSUBJ=8192 WARM=200 CHUNK=20 ROUNDS=5 timeout 900 python scripts/ab_time.py $C/libswimsim_x_db4.so $C/libswimsim_x_$v.so; done) 2>&1 | grep -v amdgpu.ids | tee $O/r06h_ab_merge_batches.txt
   ;;
-fin4)  # after the last source change (the literal rule with settling and state pulls: swimsim.hip's configuration check): suite, PMC,
+fin4)  # (superseded by fin5) after a source change (the literal rule with settling and state pulls: swimsim.hip's configuration check): suite, PMC,
        # traces of both windows, traffic.json re-keyed, the driver's line, a random parity sweep with the new combinations
   bash scripts/gpu_cycle.sh r06fin4 tests pmc
   (cd /tmp && export TMPDIR=/tmp && bash $R/scripts/prof_timed_window.sh r06fin4 --steps 20 --warmup 5 && AS_WRITTEN=1 bash $R/scripts/prof_timed_window.sh r06fin4_as_written --steps 20 --warmup 5)
   python scripts/make_traffic_json.py $O/r06fin4_pmc/summary.txt r06fin4 > /dev/null && cp profiles/traffic.json $O/r06fin4_traffic.json
   timeout 900 python bench.py --steps 20 --warmup 5 > $O/r06fin4_bench_driver_flags.json 2> $O/r06fin4_bench_driver_flags.err; tail -c 300 $O/r06fin4_bench_driver_flags.json
   SEED=777 timeout 1500 python scripts/gpu_parity_sweep.py 2>&1 | grep -v amdgpu.ids | tail -8 | tee $O/r06fin4_gpu_parity_sweep.txt
+  ;;
+fin5)  # the round's LAST kernel sources (young_rid's bound, the own-known test by allocation number): suite, PMC, traces of both windows,
+       # traffic.json re-keyed, the driver's line and the default line, a random parity sweep
+  bash scripts/gpu_cycle.sh r06fin5 tests pmc
+  (cd /tmp && export TMPDIR=/tmp && bash $R/scripts/prof_timed_window.sh r06fin5 --steps 20 --warmup 5 && AS_WRITTEN=1 bash $R/scripts/prof_timed_window.sh r06fin5_as_written --steps 20 --warmup 5)
+  python scripts/make_traffic_json.py $O/r06fin5_pmc/summary.txt r06fin5 > /dev/null && cp profiles/traffic.json $O/r06fin5_traffic.json
+  timeout 900 python bench.py --steps 20 --warmup 5 > $O/r06fin5_bench_driver_flags.json 2> $O/r06fin5_bench_driver_flags.err; tail -c 300 $O/r06fin5_bench_driver_flags.json
+  timeout 900 python bench.py > $O/r06fin5_bench_default_flags.json 2> $O/r06fin5_bench_default_flags.err; tail -c 300 $O/r06fin5_bench_default_flags.json
+  SEED=4242 timeout 1500 python scripts/gpu_parity_sweep.py 2>&1 | grep -v amdgpu.ids | tail -4 | tee $O/r06fin5_gpu_parity_sweep.txt
   ;;
 esac
