@@ -411,7 +411,9 @@ def test_strict_reference_rules_with_settling_and_state_pulls_on_the_gpu(oracle_
         if events:
             assert a.drainEventsRaw() == b.drainEventsRaw()
     assert a.firstDetection() == b.firstDetection()
-    assert oracle_abi.lib.swimoracle_d13_hits(a._h) > 0 and a.counters()["settled"] > 0
+    if n <= 4096:      # (the small, lossy cases are runs where the two rules part and rows settle; at 65 536 members and 2 % loss 80 ticks need not get there)
+        assert oracle_abi.lib.swimoracle_d13_hits(a._h) > 0 and a.counters()["settled"] > 0
+    assert b.counters()["changes"] > n
     a.close(); b.close()
 
 
