@@ -45,6 +45,8 @@ def run(seed, cases):
         sc = SimConfig(cfg=Config(numToGossip=rng.choice([1, 3, 5])), nMembers=n, seed=rng.randrange(1, 1 << 30), lossPpm=rng.choice([0, 0, 20000, 200000]),
                        eventMask=0x1F, suspicionTicks=rng.choice([4, 7]), retransmitMult=rng.choice([1, 3]), maxSubjects=min(n, 1024),
                        gcTicks=_abi.GC_AUTO if rng.random() < 0.5 else 0, joinPull=int(rng.random() < 0.5), pullTicks=rng.choice([0, 0, 3, 9]), inboxCap=rng.choice([0, 2]))
+        sc.pushPull = bool(sc.pullTicks) and rng.random() < 0.5                 # (round 6: on shards too)
+        sc.strictReferenceRules = rng.random() < 0.25                         # (round 6: on shards, with settling and state pulls)
         os.environ["SWIMSIM_CLUSTER_STEP"] = rng.choice(["0", "1"])
         s = Sim.create(lib, sc) if shards == 1 else ShardedSim(lib, sc, LocalFabric(shards))
         for _ in range(n // 6):
