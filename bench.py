@@ -233,12 +233,25 @@ def main(argv=None, abi=None):
                 # the in-library exchange reads the peers' buffers over xGMI: it needs peer access between the devices.  Where the node
                 # cannot (or the first tick fails on the device), the same job is started again as one process per GPU under
                 # torch.distributed.run -- the other launch shape of this file -- instead of failing the line.
+                # The trial tick runs on a thread with a deadline: this path (peer reads over xGMI, events across devices) has never run
+                # on two devices (one GPU per box here), and a tick that never returns must not hang the line either.
                 from swim_amd.sim import SwimError
-                try:
-                    sim.step(1)
-                    for d in sorted(set(devices)):
-                        torch.cuda.synchronize(d)
-                except SwimError as e:
+                import threading
+                trial = {}
+
+                def _trial():
+                    try:
+                        sim.step(1)
+                        for d in sorted(set(devices)):
+                            torch.cuda.synchronize(d)
+                    except SwimError as e_:
+                        trial["err"] = e_
+                th = threading.Thread(target=_trial, daemon=True)
+                th.start(); th.join(float(os.environ.get("SWIM_BENCH_TRIAL_S", "180")))
+                if th.is_alive():
+                    trial["err"] = "no answer from the first tick within the deadline"
+                if "err" in trial:
+                    e = trial["err"]
                     import socket
                     sys.stderr.write("bench: one-process cluster step failed (%s): restarting as one process per GPU\n" % e)
                     with socket.socket() as so:
